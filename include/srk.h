@@ -1,0 +1,214 @@
+/* srk.h -- C ABI of libsrk_gfx950.so: the MI355X (gfx950) kernels for the SR convolutional hot path.
+ *
+ * The reference (george-gca/sr-pytorch-lightning) has no FFI layer: its hot path is
+ * `SRModel.forward()` (models/srmodel.py:156-171) calling stock torch.nn leaf modules
+ * (SURVEY.md section 8(b)).  The entry points below are what a binding for that path
+ * has to call; each one names the reference op it replaces.  The Python binding that
+ * ships with this repo is `sr-pytorch-lightning_amd/_lib.py` (ctypes), and
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers owned by the caller (torch tensors in practice).
+ *    The library allocates nothing persistent and never frees.
+ *  - Every launcher takes the HIP stream to enqueue on; it never synchronises and
+ *    never touches the null stream, so it can be captured into a hipGraph.
+ *  - Return value: 0 on success, otherwise a hipError_t or a negative SRK_E_* code;
+ *    `srk_last_error()` returns a thread-local message.  No exceptions cross the ABI.
+ *  - Launchers are re-entrant and hold no mutable global state (autograd calls
+ *    backward from another thread).
+ *  - Activations are NHWC with an explicit pixel pitch and channel offset (both in
+ *    elements) so that a conv can read / write a channel slice of a wider buffer
+ *    (RDN dense blocks, models/rdn.py:21).  Channel counts seen by the MFMA kernels are
+ *    padded to a multiple of 16 with ZERO-filled padding channels.
+ *  - dtype: SRK_BF16 / SRK_F16 storage with fp32 accumulate, or SRK_F32 (fp32 MFMA,
+ *    the parity mode: north_star "conv activations within 1e-3 fp32").
+ */
+#ifndef SRK_H
+#define SRK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* srk_stream_t; /* hipStream_t */
+
+enum { SRK_BF16 = 0, SRK_F16 = 1, SRK_F32 = 2 };
+
+enum {
+  SRK_E_BADARG = -1,   /* shape / alignment / mode not supported */
+  SRK_E_NODEV = -2     /* no gfx950 device / kernel image not loadable */
+};
+
+/* output / residual addressing modes of srk_conv2d */
+enum {
+  SRK_OUT_NHWC = 0,      /* out[n][y][x][coff + co], dtype = args.dtype                               */
+  SRK_OUT_NHWC_PS = 1,   /* conv followed by nn.PixelShuffle(r) (models/common.py:133), fused into the  */
+                         /* store: out[n][y*r+i][x*r+j][coff + c]; packed channel co' = (i*r+j)*C + c   */
+  SRK_OUT_PLANAR = 2     /* fp32 NCHW (the model boundary), optional PixelShuffle(r):                   */
+                         /* out[n][c][y*r+i][x*r+j], co = c*r*r + i*r + j (torch channel order)         */
+};
+
+/* ---- weight packing -------------------------------------------------------------------------
+ * Replaces nothing in the reference: it converts the parameters of record (OIHW fp32, the
+ * state_dict layout of nn.Conv2d) into the MFMA-friendly shadow layout
+ *     wpk[tap][Kin/CH][CoutP][CH]      CH = 16 bytes / sizeof(dtype)
+ * forward : Kin = Cin padded to 16,  rows = Cout padded to CoutP, tap = kh*KW+kw
+ * dgrad   : Kin = Cout padded to 16, rows = Cin padded to CoutP, tap flipped (conv transpose)
+ * `ps_r` > 1 applies the PixelShuffle channel permutation of SRK_OUT_NHWC_PS to the Cout axis.
+ * bias_pk (nullable) receives the fp32 bias padded/permuted to CoutP (forward only).           */
+typedef struct {
+  const float* w;      /* [Cout][Cin][KH][KW] fp32 */
+  const float* bias;   /* [Cout] or NULL */
+  void* wpk;           /* out */
+  float* bias_pk;      /* out [CoutP] or NULL */
+  int Cout, Cin, KH, KW;
+  int KinP;            /* padded reduction channels (multiple of 16) */
+  int CoutP;           /* padded rows */
+  int dgrad;           /* 0 forward layout, 1 dgrad layout */
+  int ps_r;            /* 0/1: none; r>1: NHWC pixel-shuffle permutation on the Cout axis */
+  int dtype;
+} srk_pack_args;
+int srk_pack_conv_weights(const srk_pack_args* a, srk_stream_t stream);
+
+/* ---- implicit-GEMM convolution (forward and dgrad) --------------------------------------------
+ * Replaces nn.Conv2d(stride 1, padding k//2) + the elementwise ops the reference issues after it:
+ * DefaultConv2d (models/common.py:7-30), ReLU (common.py:99-100), `* res_scale` and `res += x`
+ * (common.py:106-107, edsr.py:46-47, rcan.py:52-54,72-73,121-122, rdn.py:40,109, wdsr.py:25-26,
+ * 49-50,112), nn.PixelShuffle (common.py:133, rdn.py:81,89,92, wdsr.py:88,94), torch.cat slice
+ * writes (rdn.py:21,108) and the `add_mean` shift (common.py:58-71).  Epilogue order:
+ *     v = acc + bias[co];  if relu: v = max(v,0);  v *= scale;  v += res;
+ *     if mask and co >= mask_from: v = (mask > 0) ? v : 0;      (ReLU backward)
+ *     v += post_add[c]  (planar mode only);  store.
+ * The same kernel computes dgrad when given dgrad-packed weights.                                */
+typedef struct {
+  const void* x; int x_pitch, x_coff;  /* input NHWC, Cin channels starting at x_coff              */
+  int x_ps;                            /* 0/1: plain; r>1: x is stored pixel-shuffled by r, i.e. it is */
+                                       /* [N][H*r][W*r][Cin/(r*r)] and channel k = (i*r+j)*C + c     */
+  int N, H, W;                         /* conv-space dims ('same' conv: output dims = input dims)    */
+  int Cin;                             /* multiple of 16                                              */
+  const void* wpk; const float* bias;  /* packed weights [KH*KW][Cin/CH][CoutP][CH]; bias [CoutP]/NULL */
+  int CoutP;                           /* multiple of the channel tile chosen by srk_conv_tile()      */
+  int Cout;                            /* channels to store (NHWC: multiple of 4, <= CoutP; planar: real) */
+  int KH, KW;                          /* 1 or 3                                                      */
+  int relu; float scale;
+  const void* res; int res_pitch, res_coff;    /* same addressing mode and dtype as out; NULL = none */
+  const void* mask; int mask_pitch, mask_coff; int mask_from;  /* NHWC/NHWC_PS addressing, dtype     */
+  void* out; int out_pitch, out_coff; int out_mode; int ps_r;
+  const float* post_add;               /* planar: per output channel c, or NULL                      */
+  int dtype;
+} srk_conv_args;
+int srk_conv2d(const srk_conv_args* a, srk_stream_t stream);
+/* channel tile (32/64/128) the launcher uses for a given number of output channels */
+int srk_conv_tile(int Cout);
+
+/* ---- weight / bias gradient -------------------------------------------------------------------
+ * Replaces autograd's conv weight-gradient for the convs above:
+ *     dwp[tap][ci][co] += sum_{n,y,x} x[n][y+kh-ph][x+kw-pw][ci] * dy[n][y][x][co]   (fp32 atomics)
+ *     dbp[co]          += sum dy
+ * dwp/dbp are fp32 scratch the caller zeroes; srk_wgrad_finalize converts to OIHW.             */
+typedef struct {
+  const void* x; int x_pitch, x_coff; int x_ps;
+  const void* dy; int dy_pitch, dy_coff; int dy_ps;
+  int N, H, W;
+  int Cin, Cout;            /* both multiples of 16 (padded storage channels)                     */
+  int KH, KW;
+  float* dwp;               /* [KH*KW][Cin][Cout] fp32, zeroed by the caller                      */
+  float* dbp;               /* [Cout] fp32 zeroed, or NULL                                        */
+  int dtype;
+} srk_wgrad_args;
+int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream);
+
+typedef struct {
+  const float* dwp; const float* dbp;   /* from srk_conv2d_wgrad                                 */
+  float* dw; float* db;                 /* OIHW fp32 [Cout][Cin][KH][KW], [Cout]; db may be NULL */
+  int Cout, Cin, KH, KW;                /* real sizes                                            */
+  int CinP, CoutP;                      /* padded sizes used by dwp                              */
+  int ps_r;                             /* channel permutation of SRK_OUT_NHWC_PS on Cout        */
+  float scale;                          /* multiplies the result (res_scale, loss un-scaling)    */
+  int accumulate;                       /* 0: dw = v, 1: dw += v                                 */
+} srk_wgrad_fin_args;
+int srk_wgrad_finalize(const srk_wgrad_fin_args* a, srk_stream_t stream);
+
+/* ---- input unfold (model boundary) -----------------------------------------------------------------
+ * Head convs 3->F (edsr.py:21-22, rcan.py:92-93, rdn.py:57-58, wdsr.py:69-71) and WDSR's 5x5 skip conv
+ * (wdsr.py:90-94) have Cin <= 4: too thin for a 16-channel MFMA K-chunk.  The boundary kernel fuses the
+ * input mean shift (common.py:58-71 sign=-1, wdsr.py:103-105), the NCHW fp32 -> NHWC conversion and an
+ * im2col of the K x K window:
+ *     dst[n][y][x][ci*KH*KW + kh*KW + kw] = x[n][ci][y+kh-ph][x+kw-pw] - sub[ci]      (0 outside the image)
+ * so the conv becomes a 1x1 conv over Cin*KH*KW (padded to 16) channels whose weight matrix is
+ * w.reshape(Cout, Cin*KH*KW) -- the OIHW parameter itself -- and runs through srk_conv2d /
+ * srk_conv2d_wgrad like every other layer.                                                          */
+typedef struct {
+  const float* x;           /* NCHW fp32 [N][Cin][H][W]                                            */
+  const float* sub;         /* per-input-channel value subtracted before the conv, or NULL         */
+  void* dst; int dst_pitch, dst_coff;
+  int N, Cin, H, W, KH, KW;
+  int Kstore;               /* channels written: >= Cin*KH*KW, multiple of 16, extra are zero      */
+  int dtype;
+} srk_unfold_args;
+int srk_unfold_nchw(const srk_unfold_args* a, srk_stream_t stream);
+
+/* ---- layout conversion at the model boundary ------------------------------------------------------
+ * NCHW fp32 <-> NHWC dtype.  `ps_r` > 1 on to_nhwc un-shuffles: dst[n][y][x][c*r*r+i*r+j] =
+ * src[n][c][y*r+i][x*r+j] (the adjoint of the fused PixelShuffle store in planar mode).        */
+typedef struct {
+  const float* src; void* dst; int dst_pitch, dst_coff;
+  int N, C, H, W;           /* dst dims: C channels (padded with zeros up to Cstore), H x W      */
+  int Cstore; int ps_r; float scale; int dtype;
+} srk_to_nhwc_args;
+int srk_nchw_to_nhwc(const srk_to_nhwc_args* a, srk_stream_t stream);
+
+typedef struct {
+  const void* src; int src_pitch, src_coff; float* dst;
+  int N, C, H, W; int dtype;
+} srk_to_nchw_args;
+int srk_nhwc_to_nchw(const srk_to_nchw_args* a, srk_stream_t stream);
+
+/* ---- RCAN channel attention -----------------------------------------------------------------------
+ * CALayer.forward (models/rcan.py:10-29) fused with RCAB's `res += x` (rcan.py:52-54):
+ *   sums[n][c] = sum_{hw} t          (srk_ca_pool, wave reductions + fp32 atomics, caller zeroes sums)
+ *   z = relu(W1 mean + b1); s = sigmoid(W2 z + b2); out = t * s + res    (srk_ca_apply)
+ * and its backward (srk_ca_bwd_reduce / srk_ca_bwd_apply).  W1:[Cr][C], W2:[C][Cr] are the raw
+ * fp32 parameters conv_du.0.weight / conv_du.2.weight.                                         */
+typedef struct {
+  const void* t; int t_pitch, t_coff;
+  const void* u; int u_pitch, u_coff;   /* NULL: plain sum of t; else sum of t*u (backward)      */
+  float* sums;                          /* [N][C] fp32, caller-zeroed                            */
+  int N, HW, C; int dtype;
+} srk_ca_pool_args;
+int srk_ca_pool(const srk_ca_pool_args* a, srk_stream_t stream);
+
+typedef struct {
+  const void* t; int t_pitch, t_coff;
+  const void* res; int res_pitch, res_coff;     /* nullable */
+  const float* sums;                    /* [N][C] from srk_ca_pool                               */
+  const float* w1; const float* b1; const float* w2; const float* b2;
+  float* s_out; float* z_out;           /* [N][C], [N][Cr] saved for backward (nullable)         */
+  void* out; int out_pitch, out_coff;
+  int N, HW, C, Cr; int dtype;
+} srk_ca_apply_args;
+int srk_ca_apply(const srk_ca_apply_args* a, srk_stream_t stream);
+
+typedef struct {
+  const void* g; int g_pitch, g_coff;   /* gradient w.r.t. the CA output (t*s)                   */
+  const float* gsum;                    /* [N][C] = sum_hw g*t from srk_ca_pool(t,u=g)           */
+  const float* sums; const float* s; const float* z;   /* saved by forward                      */
+  const float* w1; const float* w2;
+  float* dw1; float* db1; float* dw2; float* db2;      /* fp32, caller-zeroed, atomically added  */
+  void* gt; int gt_pitch, gt_coff;      /* out: gradient w.r.t. t = g*s + dmean/HW               */
+  int N, HW, C, Cr; int dtype;
+} srk_ca_bwd_args;
+int srk_ca_bwd_apply(const srk_ca_bwd_args* a, srk_stream_t stream);
+
+/* ---- misc ------------------------------------------------------------------------------------------ */
+const char* srk_last_error(void);
+int srk_version(void);
+/* number of compute units of the current device (0 when no device) */
+int srk_device_cus(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRK_H */

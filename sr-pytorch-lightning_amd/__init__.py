@@ -1,0 +1,9 @@
+"""sr-pytorch-lightning_amd: the MI355X-native convolutional hot path of george-gca/sr-pytorch-lightning.
+
+The directory name is not a valid Python identifier; import it as `sr_amd` (the alias module at
+the repository root) or with `importlib.import_module("sr-pytorch-lightning_amd")`.
+"""
+from . import _lib, ops, models  # noqa: F401
+from .models import EDSR, RCAN, RDN, SRCNN, SRModel, WDSR  # noqa: F401
+
+__all__ = ["_lib", "ops", "models", "EDSR", "RCAN", "RDN", "SRCNN", "SRModel", "WDSR"]

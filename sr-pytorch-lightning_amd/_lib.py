@@ -1,0 +1,133 @@
+"""ctypes binding of libsrk_gfx950.so (the C ABI declared in include/srk.h).
+
+The structures below mirror include/srk.h field for field.  There is NO fallback:
+if the shared library is missing or a launcher returns non-zero, a RuntimeError
+is raised (the product path never routes through the CPU oracle).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrk_gfx950.so")
+
+SRK_BF16, SRK_F16, SRK_F32 = 0, 1, 2
+OUT_NHWC, OUT_NHWC_PS, OUT_PLANAR = 0, 1, 2
+
+_p, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+
+class PackArgs(C.Structure):
+    _fields_ = [("w", _p), ("bias", _p), ("wpk", _p), ("bias_pk", _p),
+                ("Cout", _i), ("Cin", _i), ("KH", _i), ("KW", _i),
+                ("KinP", _i), ("CoutP", _i), ("dgrad", _i), ("ps_r", _i), ("dtype", _i)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("x_ps", _i),
+                ("N", _i), ("H", _i), ("W", _i), ("Cin", _i),
+                ("wpk", _p), ("bias", _p), ("CoutP", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
+                ("relu", _i), ("scale", _f),
+                ("res", _p), ("res_pitch", _i), ("res_coff", _i),
+                ("mask", _p), ("mask_pitch", _i), ("mask_coff", _i), ("mask_from", _i),
+                ("out", _p), ("out_pitch", _i), ("out_coff", _i), ("out_mode", _i), ("ps_r", _i),
+                ("post_add", _p), ("dtype", _i)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("x_ps", _i),
+                ("dy", _p), ("dy_pitch", _i), ("dy_coff", _i), ("dy_ps", _i),
+                ("N", _i), ("H", _i), ("W", _i), ("Cin", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
+                ("dwp", _p), ("dbp", _p), ("dtype", _i)]
+
+
+class WgradFinArgs(C.Structure):
+    _fields_ = [("dwp", _p), ("dbp", _p), ("dw", _p), ("db", _p),
+                ("Cout", _i), ("Cin", _i), ("KH", _i), ("KW", _i), ("CinP", _i), ("CoutP", _i),
+                ("ps_r", _i), ("scale", _f), ("accumulate", _i)]
+
+
+class UnfoldArgs(C.Structure):
+    _fields_ = [("x", _p), ("sub", _p), ("dst", _p), ("dst_pitch", _i), ("dst_coff", _i),
+                ("N", _i), ("Cin", _i), ("H", _i), ("W", _i), ("KH", _i), ("KW", _i), ("Kstore", _i), ("dtype", _i)]
+
+
+class ToNhwcArgs(C.Structure):
+    _fields_ = [("src", _p), ("dst", _p), ("dst_pitch", _i), ("dst_coff", _i),
+                ("N", _i), ("C", _i), ("H", _i), ("W", _i), ("Cstore", _i), ("ps_r", _i), ("scale", _f), ("dtype", _i)]
+
+
+class ToNchwArgs(C.Structure):
+    _fields_ = [("src", _p), ("src_pitch", _i), ("src_coff", _i), ("dst", _p),
+                ("N", _i), ("C", _i), ("H", _i), ("W", _i), ("dtype", _i)]
+
+
+class CaPoolArgs(C.Structure):
+    _fields_ = [("t", _p), ("t_pitch", _i), ("t_coff", _i), ("u", _p), ("u_pitch", _i), ("u_coff", _i),
+                ("sums", _p), ("N", _i), ("HW", _i), ("C", _i), ("dtype", _i)]
+
+
+class CaApplyArgs(C.Structure):
+    _fields_ = [("t", _p), ("t_pitch", _i), ("t_coff", _i), ("res", _p), ("res_pitch", _i), ("res_coff", _i),
+                ("sums", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p), ("s_out", _p), ("z_out", _p),
+                ("out", _p), ("out_pitch", _i), ("out_coff", _i),
+                ("N", _i), ("HW", _i), ("C", _i), ("Cr", _i), ("dtype", _i)]
+
+
+class CaBwdArgs(C.Structure):
+    _fields_ = [("g", _p), ("g_pitch", _i), ("g_coff", _i), ("gsum", _p), ("sums", _p), ("s", _p), ("z", _p),
+                ("w1", _p), ("w2", _p), ("dw1", _p), ("db1", _p), ("dw2", _p), ("db2", _p),
+                ("gt", _p), ("gt_pitch", _i), ("gt_coff", _i),
+                ("N", _i), ("HW", _i), ("C", _i), ("Cr", _i), ("dtype", _i)]
+
+
+# every launcher declared in include/srk.h: name -> argument struct
+LAUNCHERS = {
+    "srk_pack_conv_weights": PackArgs,
+    "srk_conv2d": ConvArgs,
+    "srk_conv2d_wgrad": WgradArgs,
+    "srk_wgrad_finalize": WgradFinArgs,
+    "srk_unfold_nchw": UnfoldArgs,
+    "srk_nchw_to_nhwc": ToNhwcArgs,
+    "srk_nhwc_to_nchw": ToNchwArgs,
+    "srk_ca_pool": CaPoolArgs,
+    "srk_ca_apply": CaApplyArgs,
+    "srk_ca_bwd_apply": CaBwdArgs,
+}
+OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus")
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, st in LAUNCHERS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [C.POINTER(st), C.c_void_p]
+        fn.restype = C.c_int
+    lib.srk_conv_tile.argtypes = [C.c_int]
+    lib.srk_conv_tile.restype = C.c_int
+    lib.srk_last_error.restype = C.c_char_p
+    lib.srk_version.restype = C.c_int
+    lib.srk_device_cus.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def call(name, args, stream):
+    """Invoke launcher `name`; raise RuntimeError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(C.byref(args), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.srk_last_error().decode(errors='replace')}")
+
+
+def conv_tile(cout):
+    return load().srk_conv_tile(int(cout))

@@ -1,0 +1,286 @@
+// Weight / bias gradient of the 'same' convolution on gfx950 MFMA.
+//
+//   dWp[tap][ci][co] += sum_{n,y,x} X[n][y+kh-p][x+kw-p][ci] * dY[n][y][x][co]
+//
+// GEMM view: M = ci (A = X^T), N = co (B = dY), K = pixels.  Both operands live in LDS as
+// [pixel][channel] images (the same swizzled halo image the forward kernel uses), i.e. K-major, so the
+// 16-bit path fetches MFMA fragments with the gfx950 transposing LDS read `ds_read_b64_tr_b16`
+// (4 pixels x 16 channels per 16-lane group); the fp32 path reads one float per lane (32x32x2 MFMA).
+// One K-step = one 16-pixel tile row; the K*K taps are K*K accumulator tiles fed from shifted rows /
+// columns of the halo image.  A workgroup owns one (ci-block, co-block) pair of 128-byte channel
+// blocks, walks a strided set of 16x16 pixel tiles accumulating in registers, and adds its partial
+// result into the fp32 scratch with row-contiguous float atomics.
+//
+// Replaces: autograd's conv2d weight/bias gradient for models/common.py:7-30 convs.
+#include "srk_common.h"
+
+namespace {
+
+template <int DT, int KS> struct WgCfg {
+  typedef DTraits<DT> Tr;
+  static constexpr int CH = Tr::CH;
+  static constexpr int ESZ = 16 / CH;                 // bytes per element
+  static constexpr int CBLK = 128 / ESZ;              // channels per 128-byte block (64 / 32)
+  static constexpr int RB = CBLK / 32;                // 32-row MFMA blocks per channel block (2 / 1)
+  static constexpr int PAIRS = RB * RB;               // (ci32, co32) pairs per workgroup (4 / 1)
+  static constexpr int KGROUPS = 4 / PAIRS;           // waves that split the K (tile-row) loop (1 / 4)
+  static constexpr int NT = 256;
+  static constexpr int NTAPS = KS * KS;
+  static constexpr int PAD = KS / 2;
+  static constexpr int TIN = 16 + KS - 1;
+  static constexpr int PITCH = (TIN + 1) & ~1;
+  static constexpr int XS_BYTES = TIN * PITCH * 128;
+  static constexpr int DYS_BYTES = 256 * 128;
+  static constexpr int LDS_BYTES = XS_BYTES + DYS_BYTES;
+  static constexpr int XPIECES = TIN * TIN * 8;
+  static constexpr int DYPIECES = 256 * 8;
+};
+
+// element offset of chunk k0 (first channel) of conv-space pixel (n,gy,gx); r>1: tensor stored pixel-shuffled
+SRK_DEV size_t chunk_off(int n, int gy, int gx, int H, int W, int r, int Cs, int k0, int pitch, int coff) {
+  if (r == 1) return ((size_t)(n * H + gy) * W + gx) * pitch + coff + k0;
+  const int ij = k0 / Cs, c0 = k0 - ij * Cs;
+  const int si = ij / r, sj = ij - si * r;
+  return ((size_t)(n * H * r + gy * r + si) * (W * r) + gx * r + sj) * pitch + coff + c0;
+}
+
+// 16-bit operand fetch with the transposing LDS read.  For a 32x32x16 MFMA operand whose M/N index is a
+// channel (32 channels of 32-block ch32) and whose K index is 16 consecutive pixels of one image row,
+// lane l of 16-lane group G = l>>4 supplies the address of pixel k = 8*(G>>1) + 4*rd + q (q = (l&15)>>2),
+// channels 16*(G&1) + 4p .. +3 (p = l&3), and receives channel 16*(G&1) + (l&15) of pixels 8*(G>>1)+4*rd+0..3.
+// tr_lane_off() is the per-lane byte offset inside an image row for column shift col0 and read rd;
+// the row offset (row * pitch * 128) is a compile-time immediate in the unrolled K loop.
+SRK_DEV int tr_lane_off(int col0, int rd, int ch32, int lane) {
+  const int G = lane >> 4, hh = G >> 1, rowblk = G & 1, q = (lane & 15) >> 2, p = lane & 3;
+  const int chunk = ch32 * 4 + rowblk * 2 + (p >> 1);
+  const int col = col0 + 8 * hh + 4 * rd + q;
+  return (col << 7) + ((chunk ^ swz(col)) << 4) + ((p & 1) << 3);
+}
+
+SRK_DEV i32x4 tr_read2(const char* a0, const char* a1) {
+  typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+  const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(a0));
+  const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(a1));
+  const i32x2 l2 = __builtin_bit_cast(i32x2, lo), h2 = __builtin_bit_cast(i32x2, hi);
+  return i32x4{l2.x, l2.y, h2.x, h2.y};
+}
+
+SRK_DEV float lds_f32(const char* img, int pitch, int row, int col, int c) {
+  return *reinterpret_cast<const float*>(img + ((row * pitch + col) << 7) + (((c >> 2) ^ swz(col)) << 4) + ((c & 3) << 2));
+}
+
+template <int DT, int KS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int ntiles) {
+  typedef WgCfg<DT, KS> C;
+  typedef typename C::Tr Tr;
+  typedef typename Tr::elem elem;
+  constexpr int CH = C::CH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;
+  char* const Ds = smem + C::XS_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave % C::PAIRS, kgroup = wave / C::PAIRS;
+  const int rb = pair / C::RB, cbk = pair % C::RB;   // 32-blocks of ci (rows) and co (cols) inside the channel block
+  const int cib = blockIdx.y, cob = blockIdx.z;
+  const int H = a.H, W = a.W;
+  const int nch_x = a.Cin / CH, nch_d = a.Cout / CH;
+  const int rx = a.x_ps > 1 ? a.x_ps : 1, rd = a.dy_ps > 1 ? a.dy_ps : 1;
+  const int Csx = a.Cin / (rx * rx), Csd = a.Cout / (rd * rd);
+  const elem* const xg = reinterpret_cast<const elem*>(a.x);
+  const elem* const dg = reinterpret_cast<const elem*>(a.dy);
+
+  f32x16 acc[C::NTAPS];
+#pragma unroll
+  for (int t = 0; t < C::NTAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  float bsum = 0.f;
+  constexpr int BPARTS = C::NT / C::CBLK;                 // bias-grad: pixel partitions per channel
+  const int b_c = tid % C::CBLK, b_part = tid / C::CBLK;
+  int xoff[KS][2], doff[2];
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) {
+    xoff[kw][0] = tr_lane_off(kw, 0, rb, lane);
+    xoff[kw][1] = tr_lane_off(kw, 1, rb, lane);
+  }
+  doff[0] = tr_lane_off(0, 0, cbk, lane);
+  doff[1] = tr_lane_off(0, 1, cbk, lane);
+
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int pt = tile;
+    const int tX = pt % tilesX;
+    pt /= tilesX;
+    const int tY = pt % tilesY;
+    const int n = pt / tilesY;
+    const int y0 = tY * 16, x0 = tX * 16;
+
+    __syncthreads();   // previous tile's fragment reads are done
+    // ---- stage X halo tile (ci block) ------------------------------------------------------------
+#pragma unroll 1
+    for (int base = tid; base < C::XPIECES; base += 4 * C::NT) {
+      i32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * C::NT;
+        v[u] = i32x4{0, 0, 0, 0};
+        if (i < C::XPIECES) {
+          const int s = i & 7, p = i >> 3;
+          const int iy = p / C::TIN, ix = p - iy * C::TIN;
+          const int c = cib * 8 + (s ^ swz(ix));
+          const int gy = y0 + iy - C::PAD, gx = x0 + ix - C::PAD;
+          if (c < nch_x && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v[u] = gload16(xg + chunk_off(n, gy, gx, H, W, rx, Csx, c * CH, a.x_pitch, a.x_coff));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * C::NT;
+        if (i < C::XPIECES) {
+          const int s = i & 7, p = i >> 3;
+          const int iy = p / C::TIN, ix = p - iy * C::TIN;
+          lds_write16(Xs + ((iy * C::PITCH + ix) << 7) + (s << 4), v[u]);
+        }
+      }
+    }
+    // ---- stage dY tile (co block), zero outside the image ------------------------------------------
+#pragma unroll 1
+    for (int base = tid; base < C::DYPIECES; base += 4 * C::NT) {
+      i32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * C::NT;
+        const int s = i & 7, p = i >> 3;
+        const int iy = p >> 4, ix = p & 15;
+        const int c = cob * 8 + (s ^ swz(ix));
+        const int gy = y0 + iy, gx = x0 + ix;
+        v[u] = i32x4{0, 0, 0, 0};
+        if (c < nch_d && gy < H && gx < W)
+          v[u] = gload16(dg + chunk_off(n, gy, gx, H, W, rd, Csd, c * CH, a.dy_pitch, a.dy_coff));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) lds_write16(Ds + ((base + u * C::NT) << 4), v[u]);
+    }
+    __syncthreads();
+
+    // ---- bias gradient from the dY image ------------------------------------------------------------
+    if (a.dbp && cib == 0) {
+#pragma unroll 4
+      for (int p = b_part; p < 256; p += BPARTS) {
+        const char* ad = Ds + (p << 7) + ((((b_c / CH)) ^ swz(p & 15)) << 4) + (b_c % CH) * C::ESZ;
+        bsum += Tr::to_f32(*reinterpret_cast<const elem*>(ad));
+      }
+    }
+
+    // ---- K loop over tile rows ---------------------------------------------------------------------------
+    if constexpr (Tr::IS16) {
+      // fully unrolled: row offsets become ds_read immediates; the halo rows are rotated through
+      // registers so each K-step fetches only ONE new image row (KS fragments) plus the dY fragment
+      i32x4 xf[KS][KS];
+#pragma unroll
+      for (int rr = 0; rr < KS - 1; ++rr)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw)
+          xf[rr % KS][kw] = tr_read2(Xs + xoff[kw][0] + rr * (C::PITCH * 128), Xs + xoff[kw][1] + rr * (C::PITCH * 128));
+#pragma unroll
+      for (int y = 0; y < 16; ++y) {
+        const int nr = y + KS - 1;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw)
+          xf[nr % KS][kw] = tr_read2(Xs + xoff[kw][0] + nr * (C::PITCH * 128), Xs + xoff[kw][1] + nr * (C::PITCH * 128));
+        const i32x4 bf = tr_read2(Ds + doff[0] + y * (16 * 128), Ds + doff[1] + y * (16 * 128));
+#pragma unroll
+        for (int t = 0; t < C::NTAPS; ++t) {
+          const int kh = t / KS, kw = t - kh * KS;
+          acc[t] = Tr::mma(xf[(y + kh) % KS][kw], bf, acc[t]);
+        }
+      }
+    } else {
+      const int i = lane & 31, hk = lane >> 5;
+#pragma unroll 1
+      for (int y = kgroup; y < 16; y += C::KGROUPS) {
+#pragma unroll 2
+        for (int m = 0; m < 8; ++m) {
+          const int col = 2 * m + hk;
+          const float b = lds_f32(Ds, 16, y, col, i);
+#pragma unroll
+          for (int t = 0; t < C::NTAPS; ++t) {
+            const int kh = t / KS, kw = t - kh * KS;
+            const float av = lds_f32(Xs, C::PITCH, y + kh, col + kw, i);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- add the partial result into the fp32 scratch (row-contiguous float atomics) -------------------
+  const int co = cob * C::CBLK + cbk * 32 + (lane & 31);
+  const int hq = lane >> 5;
+  if (co < a.Cout) {
+#pragma unroll
+    for (int t = 0; t < C::NTAPS; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = cib * C::CBLK + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hq;
+        if (ci < a.Cin) atomicAdd(a.dwp + ((size_t)t * a.Cin + ci) * a.Cout + co, acc[t][e]);
+      }
+    }
+  }
+  if (a.dbp && cib == 0) {
+    const int c = cob * C::CBLK + b_c;
+    if (c < a.Cout) atomicAdd(a.dbp + c, bsum);
+  }
+}
+
+template <int DT, int KS> int launch(const srk_wgrad_args& a, hipStream_t st) {
+  typedef WgCfg<DT, KS> C;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<DT, KS>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  if (attr != hipSuccess) {
+    srk_set_error("srk_conv2d_wgrad: cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(attr));
+    return (int)attr;
+  }
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
+  const long long ntiles = (long long)a.N * tilesX * tilesY;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) {
+    srk_set_error("srk_conv2d_wgrad: bad tile count %lld", ntiles);
+    return SRK_E_BADARG;
+  }
+  const int cib = (a.Cin + C::CBLK - 1) / C::CBLK, cob = (a.Cout + C::CBLK - 1) / C::CBLK;
+  int slabs = 256 / (cib * cob);
+  if (slabs < 1) slabs = 1;
+  if (slabs > ntiles) slabs = (int)ntiles;
+  hipLaunchKernelGGL((conv_wgrad_kernel<DT, KS>), dim3(slabs, cib, cob), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY,
+                     (int)ntiles);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int DT> int dispatch(const srk_wgrad_args& a, hipStream_t st) {
+  return a.KH == 3 ? launch<DT, 3>(a, st) : launch<DT, 1>(a, st);
+}
+
+}  // namespace
+
+extern "C" int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->dy && a->dwp, "srk_conv2d_wgrad: null pointer");
+  SRK_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0, "srk_conv2d_wgrad: bad dims");
+  SRK_CHECK_ARG(a->KH == a->KW && (a->KH == 1 || a->KH == 3), "srk_conv2d_wgrad: kernel %dx%d not supported", a->KH, a->KW);
+  SRK_CHECK_ARG(a->Cin % 16 == 0 && a->Cout % 16 == 0 && a->Cin > 0 && a->Cout > 0, "srk_conv2d_wgrad: Cin=%d Cout=%d must be multiples of 16", a->Cin, a->Cout);
+  SRK_CHECK_ARG(a->dtype >= SRK_BF16 && a->dtype <= SRK_F32, "srk_conv2d_wgrad: dtype %d", a->dtype);
+  const int ch = a->dtype == SRK_F32 ? 4 : 8;
+  SRK_CHECK_ARG(a->x_pitch % ch == 0 && a->x_coff % ch == 0 && a->dy_pitch % ch == 0 && a->dy_coff % ch == 0,
+                "srk_conv2d_wgrad: pitch/offset must be 16-byte aligned");
+  const int rx = a->x_ps > 1 ? a->x_ps : 1, rd = a->dy_ps > 1 ? a->dy_ps : 1;
+  SRK_CHECK_ARG(a->Cin % (rx * rx) == 0 && (a->Cin / (rx * rx)) % ch == 0 && a->Cout % (rd * rd) == 0 && (a->Cout / (rd * rd)) % ch == 0,
+                "srk_conv2d_wgrad: pixel-shuffled operand incompatible with channel count");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (a->dtype) {
+    case SRK_BF16: return dispatch<SRK_BF16>(*a, st);
+    case SRK_F16: return dispatch<SRK_F16>(*a, st);
+    default: return dispatch<SRK_F32>(*a, st);
+  }
+}

@@ -1,0 +1,271 @@
+// Weight packing (OIHW fp32 -> MFMA shadow layout), weight-gradient unpacking, NCHW<->NHWC conversion,
+// and the library's error/introspection entry points.
+#include <stdarg.h>
+#include "srk_common.h"
+
+static thread_local char g_err[512] = "";
+
+void srk_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* srk_last_error(void) { return g_err; }
+extern "C" int srk_version(void) { return 100; }
+extern "C" int srk_device_cus(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+  return p.multiProcessorCount;
+}
+
+namespace {
+
+// PixelShuffle permutation on the output-channel axis: packed co' = (i*r+j)*C + c  <->  torch co = c*r*r + i*r + j
+__device__ __forceinline__ int ps_unperm(int cop, int Cout, int r) {
+  if (r <= 1) return cop;
+  const int r2 = r * r, Cc = Cout / r2;
+  const int ij = cop / Cc, c = cop - ij * Cc;
+  return c * r2 + ij;
+}
+
+template <int DT> __global__ void pack_kernel(const srk_pack_args a, long long total) {
+  typedef DTraits<DT> Tr;
+  constexpr int CH = Tr::CH;
+  typename Tr::elem* out = reinterpret_cast<typename Tr::elem*>(a.wpk);
+  const int nch = a.KinP / CH;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    // idx = ((tap*nch + cc)*CoutP + row)*CH + e
+    const int e = (int)(idx % CH);
+    long long t = idx / CH;
+    const int row = (int)(t % a.CoutP);
+    t /= a.CoutP;
+    const int cc = (int)(t % nch);
+    const int tap = (int)(t / nch);
+    const int k = cc * CH + e;           // reduction-channel index
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    float v = 0.f;
+    if (!a.dgrad) {
+      // rows = output channels (permuted for pixel shuffle), k = input channel
+      if (row < a.Cout && k < a.Cin) {
+        const int co = ps_unperm(row, a.Cout, a.ps_r);
+        v = a.w[(((size_t)co * a.Cin + k) * a.KH + kh) * a.KW + kw];
+      }
+    } else {
+      // rows = input channels, k = output channel in dy's storage order, taps flipped
+      if (row < a.Cin && k < a.Cout) {
+        const int co = ps_unperm(k, a.Cout, a.ps_r);
+        v = a.w[(((size_t)co * a.Cin + row) * a.KH + (a.KH - 1 - kh)) * a.KW + (a.KW - 1 - kw)];
+      }
+    }
+    out[idx] = Tr::from_f32(v);
+  }
+  if (a.bias_pk && !a.dgrad) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.CoutP; i += gridDim.x * blockDim.x) {
+      float b = 0.f;
+      if (a.bias && i < a.Cout) b = a.bias[ps_unperm(i, a.Cout, a.ps_r)];
+      a.bias_pk[i] = b;
+    }
+  }
+}
+
+__global__ void wgrad_finalize_kernel(const srk_wgrad_fin_args a) {
+  const int taps = a.KH * a.KW;
+  const long long total = (long long)a.Cout * a.Cin * taps;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(idx % taps);
+    long long t = idx / taps;
+    const int ci = (int)(t % a.Cin);
+    const int co = (int)(t / a.Cin);
+    int cop = co;
+    if (a.ps_r > 1) {
+      const int r2 = a.ps_r * a.ps_r, Cc = a.Cout / r2;
+      const int c = co / r2, ij = co - c * r2;
+      cop = ij * Cc + c;
+    }
+    const float v = a.scale * a.dwp[((size_t)tap * a.CinP + ci) * a.CoutP + cop];
+    if (a.accumulate) a.dw[idx] += v; else a.dw[idx] = v;
+  }
+  if (a.db && a.dbp) {
+    for (int co = blockIdx.x * blockDim.x + threadIdx.x; co < a.Cout; co += gridDim.x * blockDim.x) {
+      int cop = co;
+      if (a.ps_r > 1) {
+        const int r2 = a.ps_r * a.ps_r, Cc = a.Cout / r2;
+        const int c = co / r2, ij = co - c * r2;
+        cop = ij * Cc + c;
+      }
+      const float v = a.scale * a.dbp[cop];
+      if (a.accumulate) a.db[co] += v; else a.db[co] = v;
+    }
+  }
+}
+
+// NCHW fp32 -> NHWC dtype; one thread per (pixel, 4-channel group)
+template <int DT> __global__ void to_nhwc_kernel(const srk_to_nhwc_args a) {
+  typedef DTraits<DT> Tr;
+  typename Tr::elem* dst = reinterpret_cast<typename Tr::elem*>(a.dst);
+  const int r = a.ps_r > 1 ? a.ps_r : 1, r2 = r * r;
+  const int groups = a.Cstore / 4;
+  const long long total = (long long)a.N * a.H * a.W * groups;
+  const int Cs = a.C / r2;   // channels of the (shuffled) source
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % groups);
+    long long p = idx / groups;
+    const int x = (int)(p % a.W);
+    p /= a.W;
+    const int y = (int)(p % a.H);
+    const int n = (int)(p / a.H);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = g * 4 + e;
+      float s = 0.f;
+      if (c < a.C) {
+        const int cs = c / r2, ij = c - cs * r2;
+        const int si = ij / r, sj = ij - si * r;
+        s = a.scale * a.src[((size_t)(n * Cs + cs) * (a.H * r) + y * r + si) * (a.W * r) + x * r + sj];
+      }
+      v[e] = s;
+    }
+    store4<DT>(dst + ((size_t)(n * a.H + y) * a.W + x) * a.dst_pitch + a.dst_coff + g * 4, v);
+  }
+}
+
+template <int DT> __global__ void to_nchw_kernel(const srk_to_nchw_args a) {
+  typedef DTraits<DT> Tr;
+  const typename Tr::elem* src = reinterpret_cast<const typename Tr::elem*>(a.src);
+  const long long total = (long long)a.N * a.C * a.H * a.W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % a.W);
+    long long t = idx / a.W;
+    const int y = (int)(t % a.H);
+    t /= a.H;
+    const int c = (int)(t % a.C);
+    const int n = (int)(t / a.C);
+    a.dst[idx] = Tr::to_f32(src[((size_t)(n * a.H + y) * a.W + x) * a.src_pitch + a.src_coff + c]);
+  }
+}
+
+// boundary im2col: NCHW fp32 (- sub) -> NHWC dtype with K = Cin*KH*KW channels; one thread per (pixel, 4 k's)
+template <int DT> __global__ void unfold_kernel(const srk_unfold_args a) {
+  typedef DTraits<DT> Tr;
+  typename Tr::elem* dst = reinterpret_cast<typename Tr::elem*>(a.dst);
+  const int groups = a.Kstore / 4, taps = a.KH * a.KW, K = a.Cin * taps;
+  const int ph = a.KH / 2, pw = a.KW / 2;
+  const long long total = (long long)a.N * a.H * a.W * groups;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % groups);
+    long long p = idx / groups;
+    const int x = (int)(p % a.W);
+    p /= a.W;
+    const int y = (int)(p % a.H);
+    const int n = (int)(p / a.H);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = g * 4 + e;
+      float s = 0.f;
+      if (k < K) {
+        const int ci = k / taps, t = k - ci * taps;
+        const int kh = t / a.KW, kw = t - kh * a.KW;
+        const int yy = y + kh - ph, xx = x + kw - pw;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+          s = a.x[((size_t)(n * a.Cin + ci) * a.H + yy) * a.W + xx];
+          if (a.sub) s -= a.sub[ci];
+        }
+      }
+      v[e] = s;
+    }
+    store4<DT>(dst + ((size_t)(n * a.H + y) * a.W + x) * a.dst_pitch + a.dst_coff + g * 4, v);
+  }
+}
+
+inline int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  if (g > 2048) g = 2048;   // cap + grid-stride (guide G11)
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int srk_pack_conv_weights(const srk_pack_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->w && a->wpk, "srk_pack_conv_weights: null pointer");
+  SRK_CHECK_ARG(a->KinP % 16 == 0 && a->CoutP % 32 == 0, "srk_pack_conv_weights: KinP=%d CoutP=%d", a->KinP, a->CoutP);
+  SRK_CHECK_ARG(a->dgrad ? (a->KinP >= a->Cout && a->CoutP >= a->Cin) : (a->KinP >= a->Cin && a->CoutP >= a->Cout),
+                "srk_pack_conv_weights: padded sizes too small");
+  if (a->ps_r > 1) SRK_CHECK_ARG(a->Cout % (a->ps_r * a->ps_r) == 0, "srk_pack_conv_weights: Cout %% r^2");
+  const long long total = (long long)a->KH * a->KW * a->KinP * a->CoutP;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(total, 256);
+  switch (a->dtype) {
+    case SRK_BF16: hipLaunchKernelGGL(pack_kernel<SRK_BF16>, dim3(grid), dim3(256), 0, st, *a, total); break;
+    case SRK_F16: hipLaunchKernelGGL(pack_kernel<SRK_F16>, dim3(grid), dim3(256), 0, st, *a, total); break;
+    case SRK_F32: hipLaunchKernelGGL(pack_kernel<SRK_F32>, dim3(grid), dim3(256), 0, st, *a, total); break;
+    default: SRK_CHECK_ARG(false, "srk_pack_conv_weights: dtype %d", a->dtype);
+  }
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_wgrad_finalize(const srk_wgrad_fin_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->dwp && a->dw, "srk_wgrad_finalize: null pointer");
+  SRK_CHECK_ARG(a->CinP >= a->Cin && a->CoutP >= a->Cout, "srk_wgrad_finalize: padded sizes");
+  const long long total = (long long)a->Cout * a->Cin * a->KH * a->KW;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(grid_for(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_nchw_to_nhwc(const srk_to_nhwc_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->src && a->dst, "srk_nchw_to_nhwc: null pointer");
+  const int r = a->ps_r > 1 ? a->ps_r : 1;
+  SRK_CHECK_ARG(a->Cstore % 4 == 0 && a->Cstore >= a->C && a->C % (r * r) == 0 && a->dst_pitch % 4 == 0 && a->dst_coff % 4 == 0,
+                "srk_nchw_to_nhwc: C=%d Cstore=%d r=%d", a->C, a->Cstore, r);
+  const long long total = (long long)a->N * a->H * a->W * (a->Cstore / 4);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(total, 256);
+  switch (a->dtype) {
+    case SRK_BF16: hipLaunchKernelGGL(to_nhwc_kernel<SRK_BF16>, dim3(grid), dim3(256), 0, st, *a); break;
+    case SRK_F16: hipLaunchKernelGGL(to_nhwc_kernel<SRK_F16>, dim3(grid), dim3(256), 0, st, *a); break;
+    case SRK_F32: hipLaunchKernelGGL(to_nhwc_kernel<SRK_F32>, dim3(grid), dim3(256), 0, st, *a); break;
+    default: SRK_CHECK_ARG(false, "srk_nchw_to_nhwc: dtype %d", a->dtype);
+  }
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_nhwc_to_nchw(const srk_to_nchw_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->src && a->dst, "srk_nhwc_to_nchw: null pointer");
+  const long long total = (long long)a->N * a->C * a->H * a->W;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(total, 256);
+  switch (a->dtype) {
+    case SRK_BF16: hipLaunchKernelGGL(to_nchw_kernel<SRK_BF16>, dim3(grid), dim3(256), 0, st, *a); break;
+    case SRK_F16: hipLaunchKernelGGL(to_nchw_kernel<SRK_F16>, dim3(grid), dim3(256), 0, st, *a); break;
+    case SRK_F32: hipLaunchKernelGGL(to_nchw_kernel<SRK_F32>, dim3(grid), dim3(256), 0, st, *a); break;
+    default: SRK_CHECK_ARG(false, "srk_nhwc_to_nchw: dtype %d", a->dtype);
+  }
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_unfold_nchw(const srk_unfold_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->dst, "srk_unfold_nchw: null pointer");
+  SRK_CHECK_ARG(a->Kstore % 16 == 0 && a->Kstore >= a->Cin * a->KH * a->KW && a->dst_pitch % 4 == 0 && a->dst_coff % 4 == 0,
+                "srk_unfold_nchw: Kstore=%d for Cin=%d %dx%d", a->Kstore, a->Cin, a->KH, a->KW);
+  const long long total = (long long)a->N * a->H * a->W * (a->Kstore / 4);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(total, 256);
+  switch (a->dtype) {
+    case SRK_BF16: hipLaunchKernelGGL(unfold_kernel<SRK_BF16>, dim3(grid), dim3(256), 0, st, *a); break;
+    case SRK_F16: hipLaunchKernelGGL(unfold_kernel<SRK_F16>, dim3(grid), dim3(256), 0, st, *a); break;
+    case SRK_F32: hipLaunchKernelGGL(unfold_kernel<SRK_F32>, dim3(grid), dim3(256), 0, st, *a); break;
+    default: SRK_CHECK_ARG(false, "srk_unfold_nchw: dtype %d", a->dtype);
+  }
+  SRK_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,136 @@
+// Device-side helpers shared by the gfx950 kernels (wave64, MFMA 32x32, 16-byte LDS chunks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/srk.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;      // one 16-byte chunk
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+
+#define SRK_DEV __device__ __forceinline__
+
+// thread-local error text (host)
+void srk_set_error(const char* fmt, ...);
+#define SRK_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      srk_set_error(__VA_ARGS__);           \
+      return SRK_E_BADARG;                  \
+    }                                       \
+  } while (0)
+#define SRK_LAUNCH_CHECK()                                   \
+  do {                                                       \
+    hipError_t e_ = hipGetLastError();                       \
+    if (e_ != hipSuccess) {                                  \
+      srk_set_error("%s: %s", __func__, hipGetErrorString(e_)); \
+      return (int)e_;                                        \
+    }                                                        \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// dtype traits.  CH = elements per 16-byte chunk.  A "chunk" is the unit of the K dimension:
+// lane half h of a 32x32 MFMA consumes chunk (2*kstep + h) of both operands.
+// ---------------------------------------------------------------------------------------------
+template <int DT> struct DTraits;
+
+template <> struct DTraits<SRK_BF16> {
+  typedef uint16_t elem;
+  static constexpr int CH = 8;
+  static constexpr bool IS16 = true;
+  static SRK_DEV float to_f32(elem v) { return __uint_as_float(((uint32_t)v) << 16); }
+  static SRK_DEV elem from_f32(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(uint16_t, b);
+  }
+  static SRK_DEV f32x16 mma(i32x4 a, i32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <> struct DTraits<SRK_F16> {
+  typedef uint16_t elem;
+  static constexpr int CH = 8;
+  static constexpr bool IS16 = true;
+  static SRK_DEV float to_f32(elem v) { return (float)__builtin_bit_cast(_Float16, v); }
+  static SRK_DEV elem from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+  static SRK_DEV f32x16 mma(i32x4 a, i32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <> struct DTraits<SRK_F32> {
+  typedef float elem;
+  static constexpr int CH = 4;
+  static constexpr bool IS16 = false;
+  static SRK_DEV float to_f32(elem v) { return v; }
+  static SRK_DEV elem from_f32(float f) { return f; }
+  // one chunk = 4 floats -> four 32x32x2 MFMAs; lane half h supplies k = h of each
+  static SRK_DEV f32x16 mma(i32x4 a, i32x4 b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.x), __int_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.y), __int_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.z), __int_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.w), __int_as_float(b.w), c, 0, 0, 0);
+    return c;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// LDS activation image: [row][col] pixels, 128 bytes (8 chunks) per pixel, chunk slot XOR-swizzled
+// by the pixel's column so that (a) the 32-pixel ds_read_b128 operand reads of the implicit GEMM
+// (2 tile rows x 16 columns, any tap shift) and (b) the 4-pixel x 4-chunk ds_read_b64_tr_b16
+// blocks of the weight-gradient kernel are both bank-conflict free (DESIGN.md "LDS image").
+//   slot = chunk ^ g(col),  g(col) = ((u & 1) << 2) | (u >> 1),  u = (col >> 1) & 7
+// The row pitch (in pixels) must be even so that the 256-byte bank-row half is col & 1.
+// ---------------------------------------------------------------------------------------------
+SRK_DEV int swz(int col) {
+  int u = (col >> 1) & 7;
+  return ((u & 1) << 2) | (u >> 1);
+}
+
+SRK_DEV i32x4 lds_read16(const char* p) { return *reinterpret_cast<const i32x4*>(p); }
+SRK_DEV void lds_write16(char* p, i32x4 v) { *reinterpret_cast<i32x4*>(p) = v; }
+
+SRK_DEV i32x4 gload16(const void* p) { return *reinterpret_cast<const i32x4*>(p); }
+
+// XCD-contiguous block remap: blocks b and b+8 share an XCD under round-robin dispatch, so give each
+// XCD a contiguous range of the linear work index (neighbouring tiles then share that XCD's L2).
+// Bijective for every grid size; placement only affects speed, never results.
+SRK_DEV int xcd_remap(int bid, int nb) {
+  int q = nb >> 3, rem = nb & 7, xcd = bid & 7, k = bid >> 3;
+  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+}
+
+// element <-> float helpers on 4-element groups (8 B for 16-bit types, 16 B for fp32)
+template <int DT> SRK_DEV void load4(const typename DTraits<DT>::elem* p, float v[4]) {
+  typedef DTraits<DT> Tr;
+  if constexpr (Tr::IS16) {
+    i32x2 raw = *reinterpret_cast<const i32x2*>(p);
+    uint32_t a = (uint32_t)raw.x, b = (uint32_t)raw.y;
+    v[0] = Tr::to_f32((uint16_t)(a & 0xffff));
+    v[1] = Tr::to_f32((uint16_t)(a >> 16));
+    v[2] = Tr::to_f32((uint16_t)(b & 0xffff));
+    v[3] = Tr::to_f32((uint16_t)(b >> 16));
+  } else {
+    f32x4 raw = *reinterpret_cast<const f32x4*>(p);
+    v[0] = raw.x; v[1] = raw.y; v[2] = raw.z; v[3] = raw.w;
+  }
+}
+
+template <int DT> SRK_DEV void store4(typename DTraits<DT>::elem* p, const float v[4]) {
+  typedef DTraits<DT> Tr;
+  if constexpr (Tr::IS16) {
+    uint32_t a = (uint32_t)Tr::from_f32(v[0]) | ((uint32_t)Tr::from_f32(v[1]) << 16);
+    uint32_t b = (uint32_t)Tr::from_f32(v[2]) | ((uint32_t)Tr::from_f32(v[3]) << 16);
+    i32x2 raw; raw.x = (int)a; raw.y = (int)b;
+    *reinterpret_cast<i32x2*>(p) = raw;
+  } else {
+    f32x4 raw; raw.x = v[0]; raw.y = v[1]; raw.z = v[2]; raw.w = v[3];
+    *reinterpret_cast<f32x4*>(p) = raw;
+  }
+}

@@ -1,0 +1,38 @@
+"""EDSR on the HIP path.  Reference: models/edsr.py:9-54 (same ctor, same state_dict keys)."""
+from typing import Any
+
+import torch.nn as nn
+
+from .. import ops
+from .common import DefaultConv2d, MeanShift, ResBlock, UpscaleBlock
+from .srmodel import SRModel
+
+
+class EDSR(SRModel):
+    def __init__(self, n_feats: int = 64, n_resblocks: int = 16, res_scale: int = 1, **kwargs: dict[str, Any]):
+        super().__init__(**kwargs)
+        kernel_size = 3
+        if self._channels == 3:
+            self.sub_mean = MeanShift()
+            self.add_mean = MeanShift(sign=1)
+        m_head = [DefaultConv2d(in_channels=self._channels, out_channels=n_feats, kernel_size=kernel_size)]
+        m_body = [ResBlock(n_feats=n_feats, kernel_size=kernel_size, res_scale=res_scale) for _ in range(n_resblocks)]
+        m_body.append(DefaultConv2d(in_channels=n_feats, out_channels=n_feats, kernel_size=kernel_size))
+        m_tail = [UpscaleBlock(self._scale_factor, n_feats),
+                  DefaultConv2d(in_channels=n_feats, out_channels=self._channels, kernel_size=kernel_size)]
+        self.head = nn.Sequential(*m_head)
+        self.body = nn.Sequential(*m_body)
+        self.tail = nn.Sequential(*m_tail)
+
+    def forward(self, x):
+        """NCHW float in [0,1] -> NCHW fp32, x scale_factor (edsr.py:40-54)."""
+        rgb = self._channels == 3
+        f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, -self.sub_mean.shift() if rgb else None,
+                          self.compute_dtype)
+        r = f
+        for blk in list(self.body)[:-1]:
+            r = blk(r)
+        r = self.body[-1](r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
+        r = self.tail[0](r)                              # upsampler, PixelShuffle fused into the conv store
+        t = self.tail[1]
+        return ops.tail_conv(r, t.weight, t.bias, post_add=self.add_mean.shift() if rgb else None)

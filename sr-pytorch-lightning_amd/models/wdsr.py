@@ -1,0 +1,82 @@
+"""WDSR on the HIP path.  Reference: models/wdsr.py:9-117 (same ctor, same state_dict keys)."""
+from typing import Any
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .srmodel import SRModel
+
+
+def _wn_weight(m):
+    """Legacy nn.utils.weight_norm re-parametrisation w = g * v / ||v|| (wdsr.py:62), kept in PyTorch
+    (parameter-sized work); the resulting OIHW weight feeds the HIP conv and receives its gradient."""
+    return torch._weight_norm(m.weight_v, m.weight_g, 0)
+
+
+class _Block_A(nn.Module):
+    """3x3 (F -> 4F) -> ReLU -> 3x3 (4F -> F), * res_scale, += x (wdsr.py:9-27)."""
+
+    def __init__(self, n_feats, kernel_size, wn, act=nn.ReLU(True), res_scale=1):
+        super().__init__()
+        self.res_scale = res_scale
+        block_feats = 4 * n_feats
+        self.body = nn.Sequential(wn(nn.Conv2d(n_feats, block_feats, kernel_size, padding=kernel_size // 2)), act,
+                                  wn(nn.Conv2d(block_feats, n_feats, kernel_size, padding=kernel_size // 2)))
+
+    def forward(self, x):
+        c1, c2 = self.body[0], self.body[2]
+        return ops.conv_chain(x, [(_wn_weight(c1), c1.bias), (_wn_weight(c2), c2.bias)], [True, False], scale=self.res_scale)
+
+
+class _Block_B(nn.Module):
+    """1x1 (F -> 6F) -> ReLU -> 1x1 (6F -> int(.8F)) -> 3x3 (-> F), * res_scale, += x (wdsr.py:30-51)."""
+
+    def __init__(self, n_feats, kernel_size, wn, act=nn.ReLU(True), res_scale=1):
+        super().__init__()
+        self.res_scale = res_scale
+        expand, linear = 6, 0.8
+        self.body = nn.Sequential(wn(nn.Conv2d(n_feats, n_feats * expand, 1, padding=1 // 2)), act,
+                                  wn(nn.Conv2d(n_feats * expand, int(n_feats * linear), 1, padding=1 // 2)),
+                                  wn(nn.Conv2d(int(n_feats * linear), n_feats, kernel_size, padding=kernel_size // 2)))
+
+    def forward(self, x):
+        c1, c2, c3 = self.body[0], self.body[2], self.body[3]
+        return ops.conv_chain(x, [(_wn_weight(c1), c1.bias), (_wn_weight(c2), c2.bias), (_wn_weight(c3), c3.bias)],
+                              [True, False, False], scale=self.res_scale)
+
+
+class WDSR(SRModel):
+    def __init__(self, type: str = 'B', n_feats: int = 128, n_resblocks: int = 16, res_scale: int = 1, **kwargs: dict[str, Any]):
+        super().__init__(**kwargs)
+        kernel_size = 3
+
+        def wn(x):
+            return nn.utils.weight_norm(x)
+
+        if self._channels == 3:
+            # plain attribute, not a buffer, as in the reference (wdsr.py:66-67)
+            self.rgb_mean = torch.FloatTensor([0.4488, 0.4371, 0.4040]).view([1, 3, 1, 1])
+        head = [wn(nn.Conv2d(self._channels, n_feats, 3, padding=3 // 2))]
+        block = _Block_A if type == 'A' else _Block_B
+        body = [block(n_feats, kernel_size, act=nn.ReLU(True), res_scale=res_scale, wn=wn) for _ in range(n_resblocks)]
+        out_feats = self._scale_factor * self._scale_factor * self._channels
+        tail = [wn(nn.Conv2d(n_feats, out_feats, 3, padding=3 // 2)), nn.PixelShuffle(self._scale_factor)]
+        skip = [wn(nn.Conv2d(3, out_feats, 5, padding=5 // 2)), nn.PixelShuffle(self._scale_factor)]
+        self.head = nn.Sequential(*head)
+        self.body = nn.Sequential(*body)
+        self.tail = nn.Sequential(*tail)
+        self.skip = nn.Sequential(*skip)
+
+    def forward(self, x):
+        """wdsr.py:102-117: x - mean; s = PS(skip(x)); x = PS(tail(body(head(x)))); x += s; x + mean."""
+        mean = None
+        if self._channels == 3:
+            self.rgb_mean = self.rgb_mean.to(x.device)
+            mean = self.rgb_mean.view(3).contiguous()
+        r = self._scale_factor
+        s = ops.skip_conv(x, _wn_weight(self.skip[0]), self.skip[0].bias, mean, r, self.compute_dtype)
+        f = ops.head_conv(x, _wn_weight(self.head[0]), self.head[0].bias, mean, self.compute_dtype)
+        for blk in self.body:
+            f = blk(f)
+        return ops.tail_conv(f, _wn_weight(self.tail[0]), self.tail[0].bias, res=s, post_add=mean, ps_r=r)

@@ -1,0 +1,591 @@
+"""Host side of the HIP hot path: thin launch wrappers + block-level `torch.autograd.Function`s.
+
+Activations between ops are NHWC tensors `[N, H, W, Cp]` in the compute dtype
+(bf16 / fp16 / fp32), Cp = channels padded to a multiple of 16 with zero padding
+channels; NCHW fp32 exists only at the model boundary (`head_conv` in,
+`tail_conv` out), exactly where the reference's `forward(x)` contract is
+(models/srmodel.py:156-171).  Parameters of record stay OIHW fp32
+(state_dict-compatible); packed MFMA layouts are shadow copies
+cached per parameter version.
+
+Nothing here falls back to PyTorch arithmetic: every op raises if the tensors are
+not on a GPU or the HIP library is missing.
+"""
+import torch
+
+from . import _lib as L
+
+_DT = {torch.bfloat16: L.SRK_BF16, torch.float16: L.SRK_F16, torch.float32: L.SRK_F32}
+
+
+def pad16(c):
+    return (int(c) + 15) // 16 * 16
+
+
+def _roundup(a, b):
+    return (a + b - 1) // b * b
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("the sr_amd HIP ops run on an MI355X ('cuda') device only; there is no CPU fallback "
+                           "(use oracle/ for a CPU reference in tests)")
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _pitch(t):
+    """Pixel pitch (elements) of an NHWC tensor / channel-slice view; validates the layout."""
+    n, h, w, c = t.shape
+    p = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else (t.stride(0) if n > 1 else c))
+    if w > 1 and h > 1:
+        assert t.stride(1) == w * p, "NHWC view must be dense in W"
+    if h > 1 and n > 1:
+        assert t.stride(0) == h * w * p, "NHWC view must be dense in H"
+    assert c == 1 or t.stride(3) == 1, "channels must be innermost"
+    return p
+
+
+# --------------------------------------------------------------------------------------------
+# weight packing (cached on the parameter object, keyed by its in-place version counter)
+# --------------------------------------------------------------------------------------------
+class Packed:
+    __slots__ = ("wpk", "bias", "KinP", "CoutP", "k", "ps_r")
+
+
+def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True):
+    """OIHW fp32 `w` (+ bias) -> packed shadow layout for srk_conv2d (forward or dgrad)."""
+    _need_gpu(w)
+    key = (dtype, bool(dgrad), int(ps_r))
+    ver = (w._version, -1 if b is None else b._version, w.data_ptr())
+    store = None
+    if cache and isinstance(w, torch.nn.Parameter):
+        store = w.__dict__.setdefault("_srk_pack", {})
+        hit = store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+    cout, cin, kh, kw = w.shape
+    assert kh == kw
+    p = Packed()
+    p.k, p.ps_r = kh, int(ps_r)
+    if not dgrad:
+        p.KinP, p.CoutP = pad16(cin), _roundup(cout, L.conv_tile(cout))
+    else:
+        p.KinP, p.CoutP = pad16(cout), _roundup(cin, L.conv_tile(cin))
+    wf = w.detach()
+    if wf.dtype != torch.float32 or not wf.is_contiguous():
+        wf = wf.float().contiguous()
+    p.wpk = torch.empty(kh * kw * p.KinP * p.CoutP, dtype=dtype, device=w.device)
+    p.bias = None
+    bf = None
+    if not dgrad:
+        p.bias = torch.empty(p.CoutP, dtype=torch.float32, device=w.device)
+        if b is not None:
+            bf = b.detach().float().contiguous()
+    a = L.PackArgs(w=wf.data_ptr(), bias=_ptr(bf), wpk=p.wpk.data_ptr(), bias_pk=_ptr(p.bias),
+                   Cout=cout, Cin=cin, KH=kh, KW=kw, KinP=p.KinP, CoutP=p.CoutP,
+                   dgrad=int(dgrad), ps_r=int(ps_r), dtype=_DT[dtype])
+    L.call("srk_pack_conv_weights", a, _stream())
+    if store is not None:
+        store[key] = (ver, p)
+    return p
+
+
+# --------------------------------------------------------------------------------------------
+# raw launch wrappers
+# --------------------------------------------------------------------------------------------
+def conv_raw(x, pk, *, N, H, W, Cin, Cout, out, out_mode=L.OUT_NHWC, ps_r=0, relu=False, scale=1.0,
+             res=None, mask=None, mask_from=0, post_add=None, x_ps=0, use_bias=True):
+    """One srk_conv2d launch.  `x`, `out`, `res`, `mask` are NHWC tensors or channel-slice views
+    (planar mode: `out`/`res` are NCHW fp32).  (N,H,W) are the conv-space dims."""
+    _need_gpu(x)
+    dt = x.dtype
+    planar = out_mode == L.OUT_PLANAR
+    a = L.ConvArgs(
+        x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(x_ps), N=N, H=H, W=W, Cin=Cin,
+        wpk=pk.wpk.data_ptr(), bias=_ptr(pk.bias) if use_bias else 0, CoutP=pk.CoutP, Cout=Cout, KH=pk.k, KW=pk.k,
+        relu=int(relu), scale=float(scale),
+        res=_ptr(res), res_pitch=0 if (res is None or planar) else _pitch(res), res_coff=0,
+        mask=_ptr(mask), mask_pitch=0 if mask is None else _pitch(mask), mask_coff=0, mask_from=int(mask_from),
+        out=out.data_ptr(), out_pitch=0 if planar else _pitch(out), out_coff=0, out_mode=out_mode, ps_r=int(ps_r),
+        post_add=_ptr(post_add), dtype=_DT[dt])
+    L.call("srk_conv2d", a, _stream())
+    return out
+
+
+def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=0, dy_ps=0, want_bias=True):
+    """dW (OIHW fp32) and db for a conv whose input was `x` and output gradient is `dy`.
+    Cin/Cout are the padded storage channel counts of x / dy; w_shape the real OIHW shape."""
+    _need_gpu(x)
+    dev = x.device
+    cout, cin, kh, kw = w_shape
+    dwp = torch.zeros(k * k * Cin * Cout + Cout, dtype=torch.float32, device=dev)
+    dbp = dwp[k * k * Cin * Cout:]
+    a = L.WgradArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(x_ps),
+                    dy=dy.data_ptr(), dy_pitch=_pitch(dy), dy_coff=0, dy_ps=int(dy_ps),
+                    N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k,
+                    dwp=dwp.data_ptr(), dbp=dbp.data_ptr() if want_bias else 0, dtype=_DT[x.dtype])
+    L.call("srk_conv2d_wgrad", a, _stream())
+    dw = torch.empty(w_shape, dtype=torch.float32, device=dev)
+    db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+    # the unfolded head conv presents its OIHW weight as a 1x1 conv over Cin*KH*KW channels
+    f = L.WgradFinArgs(dwp=dwp.data_ptr(), dbp=dbp.data_ptr() if want_bias else 0, dw=dw.data_ptr(), db=_ptr(db),
+                       Cout=cout, Cin=(cin * kh * kw) // (k * k), KH=k, KW=k, CinP=Cin, CoutP=Cout,
+                       ps_r=int(ps_r), scale=float(scale), accumulate=0)
+    L.call("srk_wgrad_finalize", f, _stream())
+    return dw, db
+
+
+def unfold_raw(x, sub, k, dtype):
+    """NCHW fp32 -> NHWC im2col [N,H,W,pad16(C*k*k)] (- sub[c]), the head-conv input."""
+    _need_gpu(x)
+    n, c, h, w = x.shape
+    xs = x.detach()
+    if xs.dtype != torch.float32 or not xs.is_contiguous():
+        xs = xs.float().contiguous()
+    ks = pad16(c * k * k)
+    dst = torch.empty((n, h, w, ks), dtype=dtype, device=x.device)
+    a = L.UnfoldArgs(x=xs.data_ptr(), sub=_ptr(sub), dst=dst.data_ptr(), dst_pitch=ks, dst_coff=0,
+                     N=n, Cin=c, H=h, W=w, KH=k, KW=k, Kstore=ks, dtype=_DT[dtype])
+    L.call("srk_unfold_nchw", a, _stream())
+    return dst
+
+
+def to_nhwc(src, dtype, *, ps_r=0, scale=1.0):
+    """NCHW fp32 -> NHWC dtype (channels padded to 16).  ps_r>1 un-shuffles:
+    dst[n,y,x,c*r*r+i*r+j] = src[n,c,y*r+i,x*r+j]."""
+    _need_gpu(src)
+    r = ps_r if ps_r > 1 else 1
+    n, cs, hs, ws = src.shape
+    c, h, w = cs * r * r, hs // r, ws // r
+    s = src.detach()
+    if s.dtype != torch.float32 or not s.is_contiguous():
+        s = s.float().contiguous()
+    dst = torch.empty((n, h, w, pad16(c)), dtype=dtype, device=src.device)
+    a = L.ToNhwcArgs(src=s.data_ptr(), dst=dst.data_ptr(), dst_pitch=dst.shape[3], dst_coff=0,
+                     N=n, C=c, H=h, W=w, Cstore=dst.shape[3], ps_r=int(ps_r), scale=float(scale), dtype=_DT[dtype])
+    L.call("srk_nchw_to_nhwc", a, _stream())
+    return dst
+
+
+def to_nchw(src, C=None):
+    """NHWC dtype -> NCHW fp32 (first C channels)."""
+    _need_gpu(src)
+    n, h, w, cp = src.shape
+    C = cp if C is None else C
+    dst = torch.empty((n, C, h, w), dtype=torch.float32, device=src.device)
+    a = L.ToNchwArgs(src=src.data_ptr(), src_pitch=_pitch(src), src_coff=0, dst=dst.data_ptr(),
+                     N=n, C=C, H=h, W=w, dtype=_DT[src.dtype])
+    L.call("srk_nhwc_to_nchw", a, _stream())
+    return dst
+
+
+def _f32c(t):
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# autograd Functions
+# --------------------------------------------------------------------------------------------
+class ConvFn(torch.autograd.Function):
+    """y = conv_same(x, w, b) * scale (+ res), optional fused PixelShuffle(ps_r) store.
+
+    forward : DefaultConv2d (models/common.py:7-30) [+ nn.PixelShuffle, common.py:133] [+ `res += x`,
+              edsr.py:46-47, rcan.py:72-73,121-122, rdn.py:109]
+    backward: dgrad = the same kernel on flipped/transposed weights reading dy through the
+              pixel-shuffle addressing; wgrad = srk_conv2d_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, scale, ps_r):
+        _need_gpu(x)
+        n, h, wd, cinp = x.shape
+        cout, cin, k, _ = w.shape
+        assert cinp == pad16(cin), f"input has {cinp} channels, conv expects pad16({cin})"
+        pk = pack_conv(w, b, x.dtype, ps_r=ps_r)
+        if ps_r > 1:
+            c = cout // (ps_r * ps_r)
+            assert c % 16 == 0, "fused PixelShuffle store needs C % 16 == 0"
+            out = torch.empty((n, h * ps_r, wd * ps_r, c), dtype=x.dtype, device=x.device)
+            conv_raw(x, pk, N=n, H=h, W=wd, Cin=cinp, Cout=cout, out=out, out_mode=L.OUT_NHWC_PS, ps_r=ps_r,
+                     scale=scale, res=res)
+        else:
+            out = torch.empty((n, h, wd, pad16(cout)), dtype=x.dtype, device=x.device)
+            conv_raw(x, pk, N=n, H=h, W=wd, Cin=cinp, Cout=out.shape[3], out=out, scale=scale, res=res)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (scale, ps_r, b is not None, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        scale, ps_r, has_b, has_res = ctx.cfg
+        g = g.contiguous()
+        n, h, wd, cinp = x.shape
+        cout, cin, k, _ = w.shape
+        coutp = pad16(cout)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            pkd = pack_conv(w, None, x.dtype, dgrad=True, ps_r=ps_r)
+            gx = torch.empty_like(x)
+            conv_raw(g, pkd, N=n, H=h, W=wd, Cin=coutp, Cout=cinp, out=gx, scale=scale, x_ps=ps_r, use_bias=False)
+        if ctx.needs_input_grad[1]:
+            gw, gb = wgrad_raw(x, g, N=n, H=h, W=wd, Cin=cinp, Cout=coutp, k=k, w_shape=tuple(w.shape),
+                               ps_r=ps_r, scale=scale, dy_ps=ps_r, want_bias=has_b)
+        return gx, gw, gb, (g if has_res else None), None, None
+
+
+def conv(x, w, b, *, res=None, scale=1.0, ps_r=0):
+    return ConvFn.apply(x, w, b, res, float(scale), int(ps_r))
+
+
+class HeadConvFn(torch.autograd.Function):
+    """NCHW fp32 image -> NHWC features: (x - sub) conv_same w + b, via boundary im2col + 1x1 MFMA conv.
+
+    sub_mean + head conv: models/common.py:58-71 (sign=-1), edsr.py:41-44, rcan.py:116-119;
+    SFENet1: rdn.py:100; WDSR head: wdsr.py:103-108.  The input image gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, sub, dtype):
+        _need_gpu(x)
+        cout, cin, k, _ = w.shape
+        n, c, h, wd = x.shape
+        assert c == cin
+        xu = unfold_raw(x, sub, k, dtype)
+        pk = _pack_head(w, b, dtype)
+        out = torch.empty((n, h, wd, pad16(cout)), dtype=dtype, device=x.device)
+        conv_raw(xu, pk, N=n, H=h, W=wd, Cin=xu.shape[3], Cout=out.shape[3], out=out)
+        ctx.save_for_backward(xu, w)
+        ctx.has_b = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xu, w = ctx.saved_tensors
+        g = g.contiguous()
+        n, h, wd, kp = xu.shape
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gw, gb = wgrad_raw(xu, g, N=n, H=h, W=wd, Cin=kp, Cout=g.shape[3], k=1, w_shape=tuple(w.shape),
+                               want_bias=ctx.has_b)
+        return None, gw, gb, None, None
+
+
+def _pack_head(w, b, dtype):
+    """Pack an OIHW weight as the 1x1 conv over Cin*KH*KW unfolded channels (cached on the parameter)."""
+    key = ("head", dtype)
+    ver = (w._version, -1 if b is None else b._version, w.data_ptr())
+    store = w.__dict__.setdefault("_srk_pack", {}) if isinstance(w, torch.nn.Parameter) else None
+    if store is not None:
+        hit = store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+    cout = w.shape[0]
+    pk = pack_conv(w.detach().reshape(cout, -1, 1, 1), b, dtype, cache=False)
+    if store is not None:
+        store[key] = (ver, pk)
+    return pk
+
+
+def head_conv(x, w, b, sub, dtype):
+    return HeadConvFn.apply(x, w, b, sub, dtype)
+
+
+class TailConvFn(torch.autograd.Function):
+    """NHWC features -> NCHW fp32 image: conv_same [+ PixelShuffle(r)] [+ res] + post_add.
+
+    EDSR/RCAN tail conv + add_mean (edsr.py:49-52, common.py:58-71 sign=+1); RDN UPNet last conv
+    (rdn.py:94); WDSR tail conv + PixelShuffle + `x += s` + mean (wdsr.py:110-115)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, post_add, ps_r):
+        _need_gpu(x)
+        n, h, wd, cinp = x.shape
+        cout, cin, k, _ = w.shape
+        r = ps_r if ps_r > 1 else 1
+        pk = pack_conv(w, b, x.dtype)          # planar store keeps torch's channel order
+        out = torch.empty((n, cout // (r * r), h * r, wd * r), dtype=torch.float32, device=x.device)
+        resc = None if res is None else _f32c(res)
+        conv_raw(x, pk, N=n, H=h, W=wd, Cin=cinp, Cout=cout, out=out, out_mode=L.OUT_PLANAR, ps_r=ps_r,
+                 res=resc, post_add=post_add)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (ps_r, b is not None, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        ps_r, has_b, has_res = ctx.cfg
+        n, h, wd, cinp = x.shape
+        cout, cin, k, _ = w.shape
+        dy = to_nhwc(g, x.dtype, ps_r=ps_r)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            pkd = pack_conv(w, None, x.dtype, dgrad=True)
+            gx = torch.empty_like(x)
+            conv_raw(dy, pkd, N=n, H=h, W=wd, Cin=dy.shape[3], Cout=cinp, out=gx, use_bias=False)
+        if ctx.needs_input_grad[1]:
+            gw, gb = wgrad_raw(x, dy, N=n, H=h, W=wd, Cin=cinp, Cout=dy.shape[3], k=k, w_shape=tuple(w.shape),
+                               want_bias=has_b)
+        return gx, gw, gb, (g if has_res else None), None, None
+
+
+def tail_conv(x, w, b, *, res=None, post_add=None, ps_r=0):
+    return TailConvFn.apply(x, w, b, res, post_add, int(ps_r))
+
+
+class SkipConvFn(torch.autograd.Function):
+    """NCHW fp32 image -> NCHW fp32 image: (x - sub) conv_same(k x k) + PixelShuffle(r), WDSR's skip
+    branch (models/wdsr.py:90-94,107): boundary im2col + 1x1 MFMA conv with the planar shuffle store."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, sub, ps_r, dtype):
+        _need_gpu(x)
+        cout, cin, k, _ = w.shape
+        n, c, h, wd = x.shape
+        r = ps_r if ps_r > 1 else 1
+        xu = unfold_raw(x, sub, k, dtype)
+        pk = _pack_head(w, b, dtype)
+        out = torch.empty((n, cout // (r * r), h * r, wd * r), dtype=torch.float32, device=x.device)
+        conv_raw(xu, pk, N=n, H=h, W=wd, Cin=xu.shape[3], Cout=cout, out=out, out_mode=L.OUT_PLANAR, ps_r=ps_r)
+        ctx.save_for_backward(xu, w)
+        ctx.cfg = (ps_r, b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xu, w = ctx.saved_tensors
+        ps_r, has_b = ctx.cfg
+        n, h, wd, kp = xu.shape
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            dy = to_nhwc(g, xu.dtype, ps_r=ps_r)
+            gw, gb = wgrad_raw(xu, dy, N=n, H=h, W=wd, Cin=kp, Cout=dy.shape[3], k=1, w_shape=tuple(w.shape),
+                               want_bias=has_b)
+        return None, gw, gb, None, None, None
+
+
+def skip_conv(x, w, b, sub, ps_r, dtype):
+    return SkipConvFn.apply(x, w, b, sub, int(ps_r), dtype)
+
+
+class ConvChainFn(torch.autograd.Function):
+    """out = chain(x) * scale + x, chain = conv_1 [ReLU] conv_2 [ReLU] ... conv_L  (residual blocks).
+
+    ResBlock (models/common.py:74-109), WDSR _Block_A (wdsr.py:9-27) and _Block_B (wdsr.py:30-51).
+    `relus[i]` says whether a ReLU follows conv i (never after the last).  Saved for backward: x and
+    the post-ReLU activations; the ReLU backward is the `mask` epilogue of the dgrad that produces
+    the gradient of that activation, `* scale` and `+ g` are dgrad epilogues too."""
+
+    @staticmethod
+    def forward(ctx, x, scale, relus, *params):
+        _need_gpu(x)
+        L_ = len(relus)
+        ws, bs = params[0::2], params[1::2]
+        n, h, wd, _ = x.shape
+        acts = [x]
+        a = x
+        for i in range(L_):
+            w = ws[i]
+            cout, cin, k, _ = w.shape
+            pk = pack_conv(w, bs[i], x.dtype)
+            out = torch.empty((n, h, wd, pad16(cout)), dtype=x.dtype, device=x.device)
+            last = i == L_ - 1
+            conv_raw(a, pk, N=n, H=h, W=wd, Cin=a.shape[3], Cout=out.shape[3], out=out, relu=relus[i],
+                     scale=scale if last else 1.0, res=x if last else None)
+            a = out
+            if not last:
+                acts.append(a)
+        ctx.save_for_backward(*acts, *ws)
+        ctx.cfg = (scale, tuple(relus), tuple(b is not None for b in bs))
+        return a
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, relus, has_b = ctx.cfg
+        L_ = len(relus)
+        acts, ws = ctx.saved_tensors[:L_], ctx.saved_tensors[L_:]
+        g = g.contiguous()
+        n, h, wd, _ = g.shape
+        grads = [None] * (2 * L_)
+        dy = g
+        for i in range(L_ - 1, -1, -1):
+            w = ws[i]
+            a_in = acts[i]
+            k = w.shape[2]
+            sc = scale if i == L_ - 1 else 1.0
+            if ctx.needs_input_grad[3 + 2 * i]:
+                gw, gb = wgrad_raw(a_in, dy, N=n, H=h, W=wd, Cin=a_in.shape[3], Cout=dy.shape[3], k=k,
+                                   w_shape=tuple(w.shape), scale=sc, want_bias=has_b[i])
+                grads[2 * i], grads[2 * i + 1] = gw, gb
+            pkd = pack_conv(w, None, g.dtype, dgrad=True)
+            gin = torch.empty_like(a_in)
+            conv_raw(dy, pkd, N=n, H=h, W=wd, Cin=dy.shape[3], Cout=a_in.shape[3], out=gin, scale=sc,
+                     res=g if i == 0 else None,
+                     mask=a_in if (i > 0 and relus[i - 1]) else None, use_bias=False)
+            dy = gin
+        return (dy, None, None, *grads)
+
+
+def conv_chain(x, convs, relus, scale=1.0):
+    """convs: list of (weight, bias) ; relus: list of bool (ReLU after conv i)."""
+    flat = []
+    for w, b in convs:
+        flat += [w, b]
+    return ConvChainFn.apply(x, float(scale), tuple(bool(r) for r in relus), *flat)
+
+
+class RCABFn(torch.autograd.Function):
+    """RCAB (models/rcan.py:33-55): conv -> ReLU -> conv -> CALayer (rcan.py:10-29), += x.
+
+    forward : 2 convs, srk_ca_pool (sum over HxW), srk_ca_apply (MLP + sigmoid scale + residual)
+    backward: srk_ca_pool(t*g), srk_ca_bwd_apply, dgrad2 (ReLU mask), dgrad1 (+g), 2 wgrads."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, cw1, cb1, cw2, cb2):
+        _need_gpu(x)
+        n, h, wd, cp = x.shape
+        dt = x.dtype
+        c = w2.shape[0]
+        cr = cw1.shape[0]
+        y1 = torch.empty_like(x)
+        conv_raw(x, pack_conv(w1, b1, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=y1, relu=True)
+        t = torch.empty_like(x)
+        conv_raw(y1, pack_conv(w2, b2, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=t)
+        sums = torch.zeros((n, cp), dtype=torch.float32, device=x.device)
+        L.call("srk_ca_pool", L.CaPoolArgs(t=t.data_ptr(), t_pitch=cp, t_coff=0, u=0, u_pitch=0, u_coff=0,
+                                           sums=sums.data_ptr(), N=n, HW=h * wd, C=cp, dtype=_DT[dt]), _stream())
+        s = torch.empty((n, cp), dtype=torch.float32, device=x.device)
+        z = torch.empty((n, cr), dtype=torch.float32, device=x.device)
+        out = torch.empty_like(x)
+        w1f, b1f, w2f, b2f = _ca_params(cw1, cb1, cw2, cb2, cp)
+        L.call("srk_ca_apply", L.CaApplyArgs(
+            t=t.data_ptr(), t_pitch=cp, t_coff=0, res=x.data_ptr(), res_pitch=cp, res_coff=0, sums=sums.data_ptr(),
+            w1=w1f.data_ptr(), b1=b1f.data_ptr(), w2=w2f.data_ptr(), b2=b2f.data_ptr(),
+            s_out=s.data_ptr(), z_out=z.data_ptr(), out=out.data_ptr(), out_pitch=cp, out_coff=0,
+            N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt]), _stream())
+        ctx.save_for_backward(x, y1, t, sums, s, z, w1, w2, cw1, cw2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y1, t, sums, s, z, w1, w2, cw1, cw2 = ctx.saved_tensors
+        g = g.contiguous()
+        n, h, wd, cp = x.shape
+        dt = x.dtype
+        c, cr = w2.shape[0], cw1.shape[0]
+        dev = x.device
+        gsum = torch.zeros((n, cp), dtype=torch.float32, device=dev)
+        L.call("srk_ca_pool", L.CaPoolArgs(t=t.data_ptr(), t_pitch=cp, t_coff=0, u=g.data_ptr(), u_pitch=_pitch(g), u_coff=0,
+                                           sums=gsum.data_ptr(), N=n, HW=h * wd, C=cp, dtype=_DT[dt]), _stream())
+        w1f, _, w2f, _ = _ca_params(cw1, None, cw2, None, cp)
+        scratch = torch.zeros(2 * cr * cp + cr + cp, dtype=torch.float32, device=dev)
+        dw1, db1 = scratch[:cr * cp], scratch[cr * cp:cr * cp + cr]
+        dw2, db2 = scratch[cr * cp + cr:2 * cr * cp + cr], scratch[2 * cr * cp + cr:]
+        gt = torch.empty_like(x)
+        L.call("srk_ca_bwd_apply", L.CaBwdArgs(
+            g=g.data_ptr(), g_pitch=_pitch(g), g_coff=0, gsum=gsum.data_ptr(), sums=sums.data_ptr(), s=s.data_ptr(),
+            z=z.data_ptr(), w1=w1f.data_ptr(), w2=w2f.data_ptr(), dw1=dw1.data_ptr(), db1=db1.data_ptr(),
+            dw2=dw2.data_ptr(), db2=db2.data_ptr(), gt=gt.data_ptr(), gt_pitch=cp, gt_coff=0,
+            N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt]), _stream())
+        gw2, gb2 = wgrad_raw(y1, gt, N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w2.shape[2], w_shape=tuple(w2.shape))
+        g1 = torch.empty_like(x)
+        conv_raw(gt, pack_conv(w2, None, dt, dgrad=True), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1, use_bias=False)
+        gw1, gb1 = wgrad_raw(x, g1, N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w1.shape[2], w_shape=tuple(w1.shape))
+        gx = torch.empty_like(x)
+        conv_raw(g1, pack_conv(w1, None, dt, dgrad=True), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=gx, res=g, use_bias=False)
+        # un-pad the CA parameter gradients (rows/cols beyond the real C are zero)
+        gcw1 = dw1.view(cr, cp)[:, :c].reshape(cr, c, 1, 1).contiguous()
+        gcw2 = dw2.view(cp, cr)[:c].reshape(c, cr, 1, 1).contiguous()
+        return gx, gw1, gb1, gw2, gb2, gcw1, db1.clone(), gcw2, db2[:c].clone()
+
+
+def _ca_params(cw1, cb1, cw2, cb2, cp):
+    """fp32 [Cr][Cp] / [Cp][Cr] views of conv_du.{0,2} padded to the activation's channel count."""
+    cr, c = cw1.shape[0], cw1.shape[1]
+    w1 = _f32c(cw1).view(cr, c)
+    w2 = _f32c(cw2).view(c, cr)
+    b1 = None if cb1 is None else _f32c(cb1)
+    b2 = None if cb2 is None else _f32c(cb2)
+    if cp != c:
+        w1 = torch.nn.functional.pad(w1, (0, cp - c)).contiguous()
+        w2 = torch.nn.functional.pad(w2, (0, 0, 0, cp - c)).contiguous()
+        if b2 is not None:
+            b2 = torch.nn.functional.pad(b2, (0, cp - c)).contiguous()
+    return w1, b1, w2, b2
+
+
+def rcab(x, w1, b1, w2, b2, cw1, cb1, cw2, cb2):
+    return RCABFn.apply(x, w1, b1, w2, b2, cw1, cb1, cw2, cb2)
+
+
+class RDBFn(torch.autograd.Function):
+    """Residual dense block (models/rdn.py:9-40): C x [relu(conv3x3(feat)) appended to feat], 1x1 LFF, + x.
+
+    The reference re-copies the growing tensor with torch.cat at every layer (rdn.py:21); here all
+    layers write their G channels into a slice of ONE pre-allocated [N,H,W,G0+C*G] NHWC buffer and read
+    the prefix of it (pitch = full width).  Backward walks the chain in reverse on a gradient buffer
+    of the same shape: every dgrad accumulates into the prefix (res = out) and applies the ReLU mask
+    of the newest slice it completes."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        _need_gpu(x)
+        n, h, wd, g0 = x.shape
+        nconv = (len(params) - 2) // 2
+        ws, bs = params[0:2 * nconv:2], params[1:2 * nconv:2]
+        wl, bl = params[-2], params[-1]
+        g = ws[0].shape[0]
+        assert g0 % 16 == 0 and g % 16 == 0, "dense-block widths must be multiples of 16"
+        ctot = g0 + nconv * g
+        feat = torch.empty((n, h, wd, ctot), dtype=x.dtype, device=x.device)
+        feat[..., :g0].copy_(x)
+        for c in range(nconv):
+            cin = g0 + c * g
+            conv_raw(feat[..., :cin], pack_conv(ws[c], bs[c], x.dtype), N=n, H=h, W=wd, Cin=cin, Cout=g,
+                     out=feat[..., cin:cin + g], relu=True)
+        out = torch.empty_like(x)
+        conv_raw(feat, pack_conv(wl, bl, x.dtype), N=n, H=h, W=wd, Cin=ctot, Cout=g0, out=out, res=x)
+        ctx.save_for_backward(feat, *ws, wl)
+        ctx.cfg = (nconv, g0, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        nconv, g0, g = ctx.cfg
+        feat = ctx.saved_tensors[0]
+        ws, wl = ctx.saved_tensors[1:1 + nconv], ctx.saved_tensors[-1]
+        gout = gout.contiguous()
+        n, h, wd, ctot = feat.shape
+        dt = feat.dtype
+        grads = [None] * (2 * nconv + 2)
+        gwl, gbl = wgrad_raw(feat, gout, N=n, H=h, W=wd, Cin=ctot, Cout=g0, k=1, w_shape=tuple(wl.shape))
+        grads[-2], grads[-1] = gwl, gbl
+        gfeat = torch.empty_like(feat)
+        # LFF dgrad fills the whole gradient buffer; the top slice (output of the last dense conv) gets its ReLU mask
+        conv_raw(gout, pack_conv(wl, None, dt, dgrad=True), N=n, H=h, W=wd, Cin=g0, Cout=ctot, out=gfeat,
+                 mask=feat, mask_from=ctot - g, use_bias=False)
+        for c in range(nconv - 1, -1, -1):
+            cin = g0 + c * g
+            dy = gfeat[..., cin:cin + g]
+            gw, gb = wgrad_raw(feat[..., :cin], dy, N=n, H=h, W=wd, Cin=cin, Cout=g, k=ws[c].shape[2],
+                               w_shape=tuple(ws[c].shape))
+            grads[2 * c], grads[2 * c + 1] = gw, gb
+            pref = gfeat[..., :cin]
+            conv_raw(dy, pack_conv(ws[c], None, dt, dgrad=True), N=n, H=h, W=wd, Cin=g, Cout=cin, out=pref, res=pref,
+                     mask=feat[..., :cin] if c > 0 else None, mask_from=cin - g if c > 0 else 0, use_bias=False)
+        gx = gfeat[..., :g0] + gout
+        return (gx, *grads)
+
+
+def rdb(x, convs, lff):
+    flat = []
+    for w, b in convs:
+        flat += [w, b]
+    return RDBFn.apply(x, *flat, lff[0], lff[1])
