@@ -55,11 +55,14 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(model_name, scale, patch, seconds=12.0, max_steps=8):
+def cpu_baseline(model_name, scale, patch, seconds=15.0, max_steps=8):
     """The CPU oracle's training step (fp32, torch CPU, all host cores) on a bounded sample."""
     from oracle import train as OT
     cls, kw, _, _ = MODELS[model_name]
-    cores = os.cpu_count() or 1
+    # torch's CPU conv scales to ~32 threads on the GPU node's host and collapses beyond (measured: 4x64x48x48
+    # conv 0.20 ms at 32 threads, 4.0 ms at 128), so the baseline uses min(32, available cores)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(32, avail))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = OT.OracleModel(cls, scale_factor=scale, **kw)

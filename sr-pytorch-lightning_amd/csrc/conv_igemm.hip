@@ -13,6 +13,7 @@
 //
 // Replaces (reference file:line): DefaultConv2d models/common.py:7-30 and the fused elementwise ops
 // listed in include/srk.h.  The same kernel is the data-gradient when given dgrad-packed weights.
+#include <stdlib.h>
 #include "srk_common.h"
 
 namespace {
@@ -36,9 +37,269 @@ template <int DT, int TC, int KS> struct ConvCfg {
   static constexpr int WPT = (8 * TC) / NT;           // weight pieces per thread
 };
 
+
+// ---- epilogue shared by the streaming and the weight-stationary kernels ---------------------------------
+// lane = one output pixel (gy,gx); acc[cb][pb] register e = channel co0 + cb*32 + (e&3) + 8*(e>>2) + 4*h.
+// The bias is already in the accumulators (acc_init_bias).  Mode branches are taken once per tile, the
+// residual / mask loads of all channel groups are issued back to back before their first use, and the
+// per-group channel offsets are compile-time immediates.
+template <int CB_W, int PB_W>
+SRK_DEV void acc_init_bias(f32x16 (&acc)[CB_W][PB_W], const float* bias, int co_lane) {
+  // co_lane = first channel of this lane's register group 0 (co0 + 4*h)
+#pragma unroll
+  for (int cb = 0; cb < CB_W; ++cb) {
+    f32x4 b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = bias ? *reinterpret_cast<const f32x4*>(bias + co_lane + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pb = 0; pb < PB_W; ++pb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[cb][pb][4 * i + 0] = b[i].x; acc[cb][pb][4 * i + 1] = b[i].y;
+        acc[cb][pb][4 * i + 2] = b[i].z; acc[cb][pb][4 * i + 3] = b[i].w;
+      }
+  }
+}
+
+template <int DT, int CB_W, int PB_W>
+SRK_DEV void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], int n, int y0, int x0, int co0,
+                           const int (&pyb)[PB_W], int px, int h) {
+  typedef DTraits<DT> Tr;
+  typedef typename Tr::elem elem;
+  constexpr int NG = CB_W * 4;                 // 4-channel groups per lane: group g -> channel offset (g>>2)*32 + (g&3)*8
+  const int H = a.H, W = a.W;
+  const int mode = a.out_mode;
+  const int rr = a.ps_r > 1 ? a.ps_r : 1;
+  const float scale = a.scale;
+  const bool relu = a.relu != 0;
+  const int col = co0 + 4 * h;                 // this lane's first channel
+#pragma unroll
+  for (int pb = 0; pb < PB_W; ++pb) {
+    const int gy = y0 + pyb[pb], gx = x0 + px;
+    if (gy >= H || gx >= W) continue;
+    float v[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = acc[g >> 2][pb][4 * (g & 3) + e];
+        if (relu) t = fmaxf(t, 0.f);
+        v[g][e] = t * scale;
+      }
+
+    if (mode == SRK_OUT_NHWC) {
+      const size_t pix = (size_t)(n * H + gy) * W + gx;
+      if (a.res) {
+        const elem* rp = reinterpret_cast<const elem*>(a.res) + pix * a.res_pitch + a.res_coff + col;
+        float q[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int off = (g >> 2) * 32 + (g & 3) * 8;
+          if (col + off < a.Cout) load4<DT>(rp + off, q[g]);
+          else q[g][0] = q[g][1] = q[g][2] = q[g][3] = 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[g][e] += q[g][e];
+      }
+      if (a.mask) {
+        const elem* mp = reinterpret_cast<const elem*>(a.mask) + pix * a.mask_pitch + a.mask_coff + col;
+        float q[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int off = (g >> 2) * 32 + (g & 3) * 8;
+          if (col + off < a.Cout && col + off >= a.mask_from) load4<DT>(mp + off, q[g]);
+          else q[g][0] = q[g][1] = q[g][2] = q[g][3] = 1.f;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[g][e] = q[g][e] > 0.f ? v[g][e] : 0.f;
+      }
+      elem* op = reinterpret_cast<elem*>(a.out) + pix * a.out_pitch + a.out_coff + col;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int off = (g >> 2) * 32 + (g & 3) * 8;
+        if (col + off < a.Cout) store4<DT>(op + off, v[g]);
+      }
+    } else if (mode == SRK_OUT_NHWC_PS) {
+      // out[n][gy*r+i][gx*r+j][c], packed channel co' = (i*r+j)*Cc + c ; Cc % 4 == 0 keeps a group in one pixel
+      const int Cc = a.Cout / (rr * rr);
+      const bool pow2 = (Cc & (Cc - 1)) == 0;
+      const int sh = 31 - __builtin_clz(Cc);
+      const size_t rowpix = (size_t)(n * H * rr + gy * rr) * (W * rr) + gx * rr;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int co = col + (g >> 2) * 32 + (g & 3) * 8;
+        if (co >= a.Cout) continue;
+        const int ij = pow2 ? (co >> sh) : (co / Cc);
+        const int c = co - ij * Cc;
+        const int si = ij / rr, sj = ij - si * rr;
+        const size_t pix = rowpix + (size_t)si * (W * rr) + sj;
+        if (a.res) {
+          float q[4];
+          load4<DT>(reinterpret_cast<const elem*>(a.res) + pix * a.res_pitch + a.res_coff + c, q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[g][e] += q[e];
+        }
+        if (a.mask && co >= a.mask_from) {
+          float q[4];
+          load4<DT>(reinterpret_cast<const elem*>(a.mask) + pix * a.mask_pitch + a.mask_coff + c, q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[g][e] = q[e] > 0.f ? v[g][e] : 0.f;
+        }
+        store4<DT>(reinterpret_cast<elem*>(a.out) + pix * a.out_pitch + a.out_coff + c, v[g]);
+      }
+    } else {
+      // fp32 NCHW (model boundary), optional PixelShuffle: out[n][c][gy*r+i][gx*r+j], co = c*r*r + i*r + j
+      const int r2 = rr * rr, Cc = a.Cout / r2;
+      float* const o = reinterpret_cast<float*>(a.out);
+      const float* const rs = reinterpret_cast<const float*>(a.res);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ce = col + (g >> 2) * 32 + (g & 3) * 8 + e;
+          if (ce < a.Cout) {
+            const int c = ce / r2, ij = ce - c * r2;
+            const int si = ij / rr, sj = ij - si * rr;
+            const size_t idx = ((size_t)(n * Cc + c) * (H * rr) + gy * rr + si) * (W * rr) + gx * rr + sj;
+            float val = v[g][e];
+            if (rs) val += rs[idx];
+            if (a.post_add) val += a.post_add[c];
+            o[idx] = val;
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// ---- fast epilogue: NHWC / NHWC_PS stores of a FULL 64-channel tile through buffer instructions ----------
+// One 32-bit byte offset per (lane, pixel block); the 8 channel groups of a lane are instruction immediates;
+// out-of-image pixels get an out-of-range offset (loads return 0, stores are dropped), so there is no
+// per-group predicate, branch or 64-bit address arithmetic.  Preconditions are checked by the launcher
+// (conv_fast_ok): tensors < 2 GiB, stored channels a multiple of 64, PixelShuffle planes a multiple of 64.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr unsigned SRK_OOB = 0x80000000u;
+
+SRK_DEV __amdgpu_buffer_rsrc_t big_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int DT> SRK_DEV void buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int imm_bytes, float q[4]) {
+  typedef DTraits<DT> Tr;
+  if constexpr (Tr::IS16) {
+    const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + imm_bytes, 0, 0);
+    q[0] = Tr::to_f32((uint16_t)(raw.x & 0xffff)); q[1] = Tr::to_f32((uint16_t)(raw.x >> 16));
+    q[2] = Tr::to_f32((uint16_t)(raw.y & 0xffff)); q[3] = Tr::to_f32((uint16_t)(raw.y >> 16));
+  } else {
+    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes, 0, 0);
+    q[0] = __uint_as_float(raw.x); q[1] = __uint_as_float(raw.y); q[2] = __uint_as_float(raw.z); q[3] = __uint_as_float(raw.w);
+  }
+}
+
+template <int DT> SRK_DEV void buf_store4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int imm_bytes, const float v[4]) {
+  typedef DTraits<DT> Tr;
+  if constexpr (Tr::IS16) {
+    u32x2 raw;
+    raw.x = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+    raw.y = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+    __builtin_amdgcn_raw_buffer_store_b64(raw, rs, voff + imm_bytes, 0, 0);
+  } else {
+    u32x4 raw;
+    raw.x = __float_as_uint(v[0]); raw.y = __float_as_uint(v[1]); raw.z = __float_as_uint(v[2]); raw.w = __float_as_uint(v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff + imm_bytes, 0, 0);
+  }
+}
+
+// opix[pb]: destination pixel index of this lane (or -1), cdst: destination channel of the lane's group 0,
+// cfirst: conv output channel of group 0 (for mask_from)
+template <int DT, int CB_W, int PB_W>
+SRK_DEV void conv_epilogue_fast(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], const int (&opix)[PB_W], int cdst, int cfirst) {
+  typedef DTraits<DT> Tr;
+  constexpr int ESZ = 16 / Tr::CH;
+  constexpr int NG = CB_W * 4;
+  const __amdgpu_buffer_rsrc_t ro = big_rsrc(a.out);
+  const bool has_res = a.res != nullptr, has_mask = a.mask != nullptr, relu = a.relu != 0;
+  const float scale = a.scale;
+#pragma unroll
+  for (int pb = 0; pb < PB_W; ++pb) {
+    const bool ok = opix[pb] >= 0;
+    float v[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[g][e] = acc[g >> 2][pb][4 * (g & 3) + e];
+    if (relu) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+    }
+    if (scale != 1.f) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[g][e] *= scale;
+    }
+    if (has_res) {
+      const __amdgpu_buffer_rsrc_t rr = big_rsrc(a.res);
+      const unsigned vr = ok ? (unsigned)((opix[pb] * a.res_pitch + a.res_coff + cdst) * ESZ) : SRK_OOB;
+      float q[NG][4];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) buf_load4<DT>(rr, vr, ((g >> 2) * 32 + (g & 3) * 8) * ESZ, q[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[g][e] += q[g][e];
+    }
+    if (has_mask) {
+      const __amdgpu_buffer_rsrc_t rm = big_rsrc(a.mask);
+      const unsigned vm = ok ? (unsigned)((opix[pb] * a.mask_pitch + a.mask_coff + cdst) * ESZ) : SRK_OOB;
+      float q[NG][4];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) buf_load4<DT>(rm, vm, ((g >> 2) * 32 + (g & 3) * 8) * ESZ, q[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const bool use = cfirst + (g >> 2) * 32 + (g & 3) * 8 >= a.mask_from;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[g][e] = (!use || q[g][e] > 0.f) ? v[g][e] : 0.f;
+      }
+    }
+    const unsigned vo = ok ? (unsigned)((opix[pb] * a.out_pitch + a.out_coff + cdst) * ESZ) : SRK_OOB;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) buf_store4<DT>(ro, vo, ((g >> 2) * 32 + (g & 3) * 8) * ESZ, v[g]);
+  }
+}
+
+// destination pixel / channel of a 64-aligned channel tile starting at conv channel c0 (wave-uniform part)
+struct FastDst { int si, sj, rr, cbase; };
+SRK_DEV FastDst fast_dst(const srk_conv_args& a, int c0) {
+  FastDst d;
+  d.rr = (a.out_mode == SRK_OUT_NHWC_PS && a.ps_r > 1) ? a.ps_r : 1;
+  if (d.rr > 1) {
+    const int Cc = a.Cout / (d.rr * d.rr);
+    const int ij = c0 / Cc;
+    d.cbase = c0 - ij * Cc;
+    d.si = ij / d.rr;
+    d.sj = ij - d.si * d.rr;
+  } else {
+    d.cbase = c0; d.si = 0; d.sj = 0;
+  }
+  return d;
+}
+SRK_DEV int fast_opix(const srk_conv_args& a, const FastDst& d, int n, int gy, int gx) {
+  if (gy >= a.H || gx >= a.W) return -1;
+  return (n * a.H * d.rr + gy * d.rr + d.si) * (a.W * d.rr) + gx * d.rr + d.sj;
+}
+
 template <int DT, int TC, int KS>
 __global__ __launch_bounds__((ConvCfg<DT, TC, KS>::NT)) void conv_igemm_kernel(const srk_conv_args a, int tilesX,
-                                                                              int tilesY, int ctiles) {
+                                                                              int tilesY, int ctiles, int fast) {
   typedef ConvCfg<DT, TC, KS> C;
   typedef typename C::Tr Tr;
   typedef typename Tr::elem elem;
@@ -134,12 +395,7 @@ __global__ __launch_bounds__((ConvCfg<DT, TC, KS>::NT)) void conv_igemm_kernel(c
 
   // ---- accumulators ------------------------------------------------------------------------------
   f32x16 acc[C::CB_W][C::PB_W];
-#pragma unroll
-  for (int cb = 0; cb < C::CB_W; ++cb)
-#pragma unroll
-    for (int pb = 0; pb < C::PB_W; ++pb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[cb][pb][e] = 0.f;
+  acc_init_bias<C::CB_W, C::PB_W>(acc, a.bias, ctile * TC + wco0 + 4 * h);
 
   const int px = r & 15;
   int pyb[C::PB_W];
@@ -196,81 +452,252 @@ __global__ __launch_bounds__((ConvCfg<DT, TC, KS>::NT)) void conv_igemm_kernel(c
     }
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------------
-  const int mode = a.out_mode;
-  const int rr = a.ps_r > 1 ? a.ps_r : 1;
-  const float scale = a.scale;
-  const bool relu = a.relu != 0;
+  if constexpr (TC >= 64) {
+    if (fast) {
+      const FastDst d = fast_dst(a, ctile * TC + wco0);
+      int opix[C::PB_W];
 #pragma unroll
-  for (int pb = 0; pb < C::PB_W; ++pb) {
-    const int gy = y0 + pyb[pb], gx = x0 + px;
-    if (gy >= H || gx >= W) continue;
-#pragma unroll
-    for (int cb = 0; cb < C::CB_W; ++cb) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int co = ctile * TC + wco0 + cb * 32 + 8 * i + 4 * h;   // first of 4 consecutive channels
-        if (co >= a.Cout) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[cb][pb][4 * i + e];
-        if (a.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + co);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
-        if (relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= scale;
-
-        if (mode == SRK_OUT_PLANAR) {
-          const int r2 = rr * rr, Cc = a.Cout / r2;
-          float* const o = reinterpret_cast<float*>(a.out);
-          const float* const rs = reinterpret_cast<const float*>(a.res);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int ce = co + e;
-            if (ce < a.Cout) {
-              const int c = ce / r2, ij = ce - c * r2;
-              const int si = ij / rr, sj = ij - si * rr;
-              const size_t idx = ((size_t)(n * Cc + c) * (H * rr) + gy * rr + si) * (W * rr) + gx * rr + sj;
-              float val = v[e];
-              if (rs) val += rs[idx];
-              if (a.post_add) val += a.post_add[c];
-              o[idx] = val;
-            }
-          }
-        } else {
-          size_t pix;   // pixel index in the output tensor
-          int c = co;
-          if (mode == SRK_OUT_NHWC_PS) {
-            const int Cc = a.Cout / (rr * rr);
-            const int ij = co / Cc;
-            c = co - ij * Cc;
-            const int si = ij / rr, sj = ij - si * rr;
-            pix = (size_t)(n * H * rr + gy * rr + si) * (W * rr) + gx * rr + sj;
-          } else {
-            pix = (size_t)(n * H + gy) * W + gx;
-          }
-          if (a.res) {
-            float q[4];
-            load4<DT>(reinterpret_cast<const elem*>(a.res) + pix * a.res_pitch + a.res_coff + c, q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += q[e];
-          }
-          if (a.mask && co >= a.mask_from) {
-            float q[4];
-            load4<DT>(reinterpret_cast<const elem*>(a.mask) + pix * a.mask_pitch + a.mask_coff + c, q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = q[e] > 0.f ? v[e] : 0.f;
-          }
-          store4<DT>(reinterpret_cast<elem*>(a.out) + pix * a.out_pitch + a.out_coff + c, v);
-        }
-      }
+      for (int pb = 0; pb < C::PB_W; ++pb) opix[pb] = fast_opix(a, d, n, y0 + pyb[pb], x0 + px);
+      conv_epilogue_fast<DT, C::CB_W, C::PB_W>(a, acc, opix, d.cbase + 4 * h, ctile * TC + wco0 + 4 * h);
+      return;
     }
   }
+  conv_epilogue<DT, C::CB_W, C::PB_W>(a, acc, n, y0, x0, ctile * TC + wco0, pyb, px, h);
+}
+
+
+// =================================================================================================
+// Weight-stationary persistent variant: 3x3, Cin <= 64 (ONE 128-byte input block), 16-bit dtypes.
+//
+// The streaming kernel above is latency-bound on the 64->64 layers that carry EDSR-baseline / RCAN
+// (a tap's 16 MFMAs are far shorter than the weight slab's load latency).  Here all 9 taps of a
+// 64-channel output tile (73.7 KB) are loaded into LDS ONCE per workgroup, the workgroup is persistent
+// (one per CU) and walks a contiguous range of 16x16 pixel tiles, and the halo tile of tile t+1 is fetched
+// by LDS-DMA (global_load_lds_dwordx4: no staging registers, no wait) into the second halo buffer while
+// the 144 MFMAs per wave of tile t run with NO barrier inside:
+//     LDS = 73,728 (weights) + 2 x 41,472 (halo images) = 156,672 B of the CU's 160 KiB.
+// Out-of-image halo pixels are DMA'd from a 16-byte zero page, so no lane ever skips its LDS slot.
+// =================================================================================================
+__device__ __attribute__((aligned(16), used)) unsigned int srk_zero_page[4] = {0u, 0u, 0u, 0u};
+
+struct WsCfg {
+  static constexpr int NT = 512;
+  static constexpr int TIN = 18, PITCH = 18;
+  static constexpr int WS_BYTES = 9 * 8 * 64 * 16;     // 73,728
+  static constexpr int XS_BYTES = TIN * PITCH * 128;   // 41,472
+  static constexpr int LDS_BYTES = WS_BYTES + 2 * XS_BYTES;
+  static constexpr int XPIECES = TIN * TIN * 8;        // 2,592
+  static constexpr int WPIECES = 9 * 8 * 64;           // 4,608
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+SRK_DEV void dma16(const void* gsrc, char* lds_wave_base) {
+  // lane l writes LDS[lds_wave_base + 16*l] <- 16 bytes at its own global address
+  __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
+                                                          int nptiles, unsigned x_bytes, int tq, int trem) {
+  // 8 waves = two groups of 4.  A group owns every other tile of the workgroup's range and ONE halo buffer; it
+  // alternates an MFMA phase (144 MFMAs per wave, LDS reads only) with an epilogue phase (issue the DMA of its
+  // next halo tile, then convert/store the finished tile).  The groups run one phase apart, so each SIMD always
+  // holds one wave in its matrix phase and one in its memory/VALU phase; one workgroup barrier per phase.
+  typedef DTraits<DT> Tr;
+  typedef typename Tr::elem elem;
+  typedef WsCfg C;
+  constexpr int CH = Tr::CH;   // 8
+  constexpr int GT = 256;                                  // threads per group
+  constexpr int NPK = (C::XPIECES + GT - 1) / GT;          // 11 halo pieces per lane
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Wl = smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3;
+  const int gtid = tid & (GT - 1);
+  const int r = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W;
+  const elem* const xg = reinterpret_cast<const elem*>(a.x);
+  const elem* const wg = reinterpret_cast<const elem*>(a.wpk);
+  char* const Xg = smem + C::WS_BYTES + grp * C::XS_BYTES;
+
+  // (tq, trem) = divmod(nptiles, slots) from the host: slot s owns tq tiles, +1 for the first trem slots
+  const unsigned slot = blockIdx.x / (unsigned)ctiles;
+  const int ctile = (int)(blockIdx.x - slot * (unsigned)ctiles);
+  const int t0 = (int)slot * tq + min((int)slot, trem);
+  const int nt = tq + ((int)slot < trem ? 1 : 0);
+  if (nt <= 0) return;
+  const int nj = (nt - grp + 1) >> 1;          // tiles of this group: t0 + 2j + grp
+  const int nph = 2 * ((nt + 1) >> 1) + 1;     // phases (group 0 has the most tiles)
+
+  // ---- halo-tile DMA: everything that does not depend on the tile is computed ONCE per lane ------------------
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem*>(xg), 0, x_bytes, 0x00020000);
+  int pconst[NPK], pyx[NPK];
+#pragma unroll
+  for (int k = 0; k < NPK; ++k) {
+    const int i = gtid + k * GT;
+    const int sl = i & 7, p = i >> 3;
+    const int iy = p / C::TIN, ix = p - iy * C::TIN;
+    const int c = sl ^ swz(ix);
+    pconst[k] = (((iy - 1) * W + (ix - 1)) * a.x_pitch + a.x_coff + c * CH) * (int)sizeof(elem);
+    pyx[k] = (i < C::XPIECES) ? (((iy - 1) & 0xffff) | ((ix - 1) << 16)) : (int)0x7fff7fff;   // beyond the tile: never valid
+  }
+  auto tile_of = [&](int j, int& n, int& y0, int& x0) {
+    const int pt = t0 + 2 * j + grp;
+    const int tX = pt % tilesX;
+    const int q = pt / tilesX;
+    const int tY = q % tilesY;
+    n = q / tilesY;
+    y0 = tY * 16;
+    x0 = tX * 16;
+  };
+  auto dma_x = [&](int j) {
+    int n, y0, x0;
+    tile_of(j, n, y0, x0);
+    const int tbase = (((n * H + y0) * W + x0) * a.x_pitch) * (int)sizeof(elem);   // wave-uniform (SALU)
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      const int gy = y0 + (int)(short)(pyx[k] & 0xffff), gx = x0 + (pyx[k] >> 16);
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned voff = ok ? (unsigned)(tbase + pconst[k]) : 0x80000000u;
+      if (k < NPK - 1 || gtid + k * GT < C::XPIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void*)(Xg + ((k * GT + w4 * 64) << 4)), 16, voff, 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: all 9 taps of this channel tile (both groups), then each group's first halo tile ---------------
+#pragma unroll 1
+  for (int k = 0; k < C::WPIECES / 512; ++k) {
+    const int i = tid + k * 512;              // i = (tap*8 + c)*64 + co
+    const int co = i & 63, c = (i >> 6) & 7, tap = i >> 9;
+    const size_t off = ((size_t)(tap * 8 + c) * a.CoutP + ctile * 64 + co) * CH;
+    dma16(wg + off, Wl + ((k * 512 + wave * 64) << 4));
+  }
+  if (nj > 0) dma_x(0);
+
+  const int px = r & 15;
+  int pyb[2];
+  pyb[0] = w4 * 4 + (r >> 4);
+  pyb[1] = w4 * 4 + 2 + (r >> 4);
+  int gsw[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) gsw[kw] = swz(px + kw);
+  const char* const wlane = Wl + ((h * 64 + r) << 4);
+  const char* const xl0 = Xg + ((pyb[0] * C::PITCH + px) << 7);
+  const char* const xl1 = Xg + ((pyb[1] * C::PITCH + px) << 7);
+
+  // bias as the C operand of the first MFMA of every tile (no accumulator initialisation pass)
+  f32x16 bias16[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ctile * 64 + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bias16[cb][4 * i + 0] = b.x; bias16[cb][4 * i + 1] = b.y; bias16[cb][4 * i + 2] = b.z; bias16[cb][4 * i + 3] = b.w;
+    }
+  const FastDst fdst = fast_dst(a, ctile * 64);
+
+  f32x16 acc[2][2];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weights + first halo tiles
+  __builtin_amdgcn_s_barrier();
+
+#pragma unroll 1
+  for (int p = 0; p < nph; ++p) {
+    const int q = p - grp;            // this group's own phase counter
+    const int j = q >> 1;
+    if (q >= 0 && j < nj) {
+      if ((q & 1) == 0) {
+        // ---------------- MFMA phase: 36 K-steps (9 taps x 4 chunk pairs), fragments fetched two steps ahead ----
+        auto frag = [&](int s, i32x4& a0, i32x4& a1, i32x4& b0, i32x4& b1) {
+          const int tap = s >> 2, ks = s & 3;
+          const int kh = tap / 3, kw = tap - kh * 3;
+          const int kc2 = 2 * ks;
+          a0 = lds_read16(wlane + (((tap * 8 + kc2) * 64) << 4));
+          a1 = lds_read16(wlane + (((tap * 8 + kc2) * 64 + 32) << 4));
+          const int so = (((kc2 + h) ^ gsw[kw]) << 4) + ((kh * C::PITCH + kw) << 7);
+          b0 = lds_read16(xl0 + so);
+          b1 = lds_read16(xl1 + so);
+        };
+        i32x4 fa0[3], fa1[3], fb0[3], fb1[3];
+        frag(0, fa0[0], fa1[0], fb0[0], fb1[0]);
+        frag(1, fa0[1], fa1[1], fb0[1], fb1[1]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+          const int c0 = s % 3, c2 = (s + 2) % 3;
+          if (s + 2 < 36) frag(s + 2, fa0[c2], fa1[c2], fb0[c2], fb1[c2]);
+          if (s == 0) {
+            acc[0][0] = Tr::mma(fa0[c0], fb0[c0], bias16[0]);
+            acc[0][1] = Tr::mma(fa0[c0], fb1[c0], bias16[0]);
+            acc[1][0] = Tr::mma(fa1[c0], fb0[c0], bias16[1]);
+            acc[1][1] = Tr::mma(fa1[c0], fb1[c0], bias16[1]);
+          } else {
+            acc[0][0] = Tr::mma(fa0[c0], fb0[c0], acc[0][0]);
+            acc[0][1] = Tr::mma(fa0[c0], fb1[c0], acc[0][1]);
+            acc[1][0] = Tr::mma(fa1[c0], fb0[c0], acc[1][0]);
+            acc[1][1] = Tr::mma(fa1[c0], fb1[c0], acc[1][1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        // ---------------- epilogue phase: next halo tile's DMA first (this group's MFMAs on the buffer are done),
+        // then the finished tile; the counted wait leaves the 16 stores per lane in flight, the DMA is older ----
+        if (j + 1 < nj) dma_x(j + 1);
+        int n, y0, x0;
+        tile_of(j, n, y0, x0);
+        int opix[2];
+        opix[0] = fast_opix(a, fdst, n, y0 + pyb[0], x0 + px);
+        opix[1] = fast_opix(a, fdst, n, y0 + pyb[1], x0 + px);
+        conv_epilogue_fast<DT, 2, 2>(a, acc, opix, fdst.cbase + 4 * h, ctile * 64 + 4 * h);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+// launcher-side preconditions of conv_epilogue_fast
+static bool conv_fast_ok(const srk_conv_args& a, int esz) {
+  if (a.out_mode == SRK_OUT_PLANAR) return false;
+  if (a.Cout % 64 != 0) return false;
+  const int rr = (a.out_mode == SRK_OUT_NHWC_PS && a.ps_r > 1) ? a.ps_r : 1;
+  if (rr > 1 && (a.Cout / (rr * rr)) % 64 != 0) return false;
+  const long long px = (long long)a.N * a.H * a.W * rr * rr;
+  long long mx = px * a.out_pitch;
+  if (a.res && px * a.res_pitch > mx) mx = px * a.res_pitch;
+  if (a.mask && px * a.mask_pitch > mx) mx = px * a.mask_pitch;
+  return mx * esz < 0x7fff0000LL;
+}
+
+template <int DT> int launch_ws(const srk_conv_args& a, hipStream_t st) {
+  typedef WsCfg C;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<DT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  if (attr != hipSuccess) {
+    srk_set_error("srk_conv2d(ws): cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(attr));
+    return (int)attr;
+  }
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16, ctiles = a.CoutP / 64;
+  const long long nptiles = (long long)a.N * tilesX * tilesY;
+  if (nptiles <= 0 || nptiles > 0x7fffffffLL) {
+    srk_set_error("srk_conv2d(ws): bad tile count %lld", nptiles);
+    return SRK_E_BADARG;
+  }
+  long long slots = cus / ctiles;            // workgroups per channel tile
+  if (slots < 1) slots = 1;
+  if (slots > nptiles) slots = nptiles;
+  const unsigned grid = (unsigned)(slots * ctiles);
+  const long long xb = ((long long)a.N * a.H * a.W * a.x_pitch) * (long long)sizeof(typename DTraits<DT>::elem);
+  hipLaunchKernelGGL((conv_ws_kernel<DT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY, ctiles, (int)nptiles,
+                     (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots));
+  SRK_LAUNCH_CHECK();
+  return 0;
 }
 
 template <int DT, int TC, int KS> int launch(const srk_conv_args& a, hipStream_t st) {
@@ -288,12 +715,19 @@ template <int DT, int TC, int KS> int launch(const srk_conv_args& a, hipStream_t
     return SRK_E_BADARG;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<DT, TC, KS>), dim3((unsigned)nb), dim3(C::NT), C::LDS_BYTES, st, a, tilesX,
-                     tilesY, ctiles);
+                     tilesY, ctiles, (int)conv_fast_ok(a, 16 / C::CH));
   SRK_LAUNCH_CHECK();
   return 0;
 }
 
 template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
+  if constexpr (DTraits<DT>::IS16) {
+    // 3x3, one input block, 64-channel output tiles: weights stay in LDS, persistent workgroups
+    const long long xbytes = ((long long)a.N * a.H * a.W * a.x_pitch) * 2;
+    if (a.KH == 3 && a.Cin == 64 && a.CoutP % 64 == 0 && a.x_ps <= 1 && xbytes < 0x7fffffffLL && conv_fast_ok(a, 2) &&
+        getenv("SRK_NO_WS") == nullptr)
+      return launch_ws<DT>(a, st);
+  }
   const int tc = (a.CoutP % 128 == 0) ? 128 : (a.CoutP % 64 == 0) ? 64 : 32;
   if (a.KH == 3) {
     if (tc == 128) return launch<DT, 128, 3>(a, st);
