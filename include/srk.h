@@ -114,14 +114,21 @@ typedef struct {
   int N, H, W;
   int Cin, Cout;            /* both multiples of 16 (padded storage channels)                     */
   int KH, KW;
-  float* dwp;               /* [KH*KW][Cin][Cout] fp32, zeroed by the caller                      */
-  float* dbp;               /* [Cout] fp32 zeroed, or NULL                                        */
+  float* dwp;               /* fp32 scratch: nslabs x [KH*KW][Cin][Cout]                          */
+  float* dbp;               /* fp32 scratch: nslabs x [Cout], or NULL                             */
+  int nslabs;               /* value returned by srk_wgrad_slabs() for these arguments:           */
+                            /*  >0: slab mode, every workgroup stores its partial sum to its own  */
+                            /*      slab (no atomics, no zeroing, bitwise reproducible);          */
+                            /*   0: atomic mode, ONE slab that the caller has zeroed              */
   int dtype;
 } srk_wgrad_args;
 int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream);
+/* number of slabs srk_conv2d_wgrad will write for these arguments (0 = atomic mode, see nslabs) */
+int srk_wgrad_slabs(const srk_wgrad_args* a);
 
 typedef struct {
   const float* dwp; const float* dbp;   /* from srk_conv2d_wgrad                                 */
+  int nslabs;                           /* slabs to sum (0 or 1: a single slab)                  */
   float* dw; float* db;                 /* OIHW fp32 [Cout][Cin][KH][KW], [Cout]; db may be NULL */
   int Cout, Cin, KH, KW;                /* real sizes                                            */
   int CinP, CoutP;                      /* padded sizes used by dwp                              */

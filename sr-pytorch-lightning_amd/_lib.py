@@ -37,11 +37,11 @@ class WgradArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("x_ps", _i),
                 ("dy", _p), ("dy_pitch", _i), ("dy_coff", _i), ("dy_ps", _i),
                 ("N", _i), ("H", _i), ("W", _i), ("Cin", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
-                ("dwp", _p), ("dbp", _p), ("dtype", _i)]
+                ("dwp", _p), ("dbp", _p), ("nslabs", _i), ("dtype", _i)]
 
 
 class WgradFinArgs(C.Structure):
-    _fields_ = [("dwp", _p), ("dbp", _p), ("dw", _p), ("db", _p),
+    _fields_ = [("dwp", _p), ("dbp", _p), ("nslabs", _i), ("dw", _p), ("db", _p),
                 ("Cout", _i), ("Cin", _i), ("KH", _i), ("KW", _i), ("CinP", _i), ("CoutP", _i),
                 ("ps_r", _i), ("scale", _f), ("accumulate", _i)]
 
@@ -93,7 +93,7 @@ LAUNCHERS = {
     "srk_ca_apply": CaApplyArgs,
     "srk_ca_bwd_apply": CaBwdArgs,
 }
-OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus")
+OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs")
 
 _lib = None
 
@@ -114,6 +114,8 @@ def load():
         fn.restype = C.c_int
     lib.srk_conv_tile.argtypes = [C.c_int]
     lib.srk_conv_tile.restype = C.c_int
+    lib.srk_wgrad_slabs.argtypes = [C.POINTER(WgradArgs)]
+    lib.srk_wgrad_slabs.restype = C.c_int
     lib.srk_last_error.restype = C.c_char_p
     lib.srk_version.restype = C.c_int
     lib.srk_device_cus.restype = C.c_int

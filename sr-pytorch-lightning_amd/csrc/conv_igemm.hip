@@ -500,7 +500,8 @@ SRK_DEV void dma16(const void* gsrc, char* lds_wave_base) {
 
 template <int DT>
 __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
-                                                          int nptiles, unsigned x_bytes, int tq, int trem) {
+                                                          int nptiles, unsigned x_bytes, int tq, int trem, int dbg) {
+  // dbg (SRK_WS_DBG, timing ablations only, results are wrong): 1 = skip MFMAs, 2 = skip epilogue, 4 = skip halo DMA
   // 8 waves = two groups of 4.  A group owns every other tile of the workgroup's range and ONE halo buffer; it
   // alternates an MFMA phase (144 MFMAs per wave, LDS reads only) with an epilogue phase (issue the DMA of its
   // next halo tile, then convert/store the finished tile).  The groups run one phase apart, so each SIMD always
@@ -611,6 +612,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     const int j = q >> 1;
     if (q >= 0 && j < nj) {
       if ((q & 1) == 0) {
+        if (dbg & 1) {
+          acc[0][0] = bias16[0]; acc[0][1] = bias16[0]; acc[1][0] = bias16[1]; acc[1][1] = bias16[1];
+        } else {
         // ---------------- MFMA phase: 36 K-steps (9 taps x 4 chunk pairs), fragments fetched two steps ahead ----
         auto frag = [&](int s, i32x4& a0, i32x4& a1, i32x4& b0, i32x4& b1) {
           const int tap = s >> 2, ks = s & 3;
@@ -644,17 +648,23 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
+        }
       } else {
         // ---------------- epilogue phase: next halo tile's DMA first (this group's MFMAs on the buffer are done),
         // then the finished tile; the counted wait leaves the 16 stores per lane in flight, the DMA is older ----
-        if (j + 1 < nj) dma_x(j + 1);
-        int n, y0, x0;
-        tile_of(j, n, y0, x0);
-        int opix[2];
-        opix[0] = fast_opix(a, fdst, n, y0 + pyb[0], x0 + px);
-        opix[1] = fast_opix(a, fdst, n, y0 + pyb[1], x0 + px);
-        conv_epilogue_fast<DT, 2, 2>(a, acc, opix, fdst.cbase + 4 * h, ctile * 64 + 4 * h);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (j + 1 < nj && !(dbg & 4)) dma_x(j + 1);
+        if (!(dbg & 2)) {
+          int n, y0, x0;
+          tile_of(j, n, y0, x0);
+          int opix[2];
+          opix[0] = fast_opix(a, fdst, n, y0 + pyb[0], x0 + px);
+          opix[1] = fast_opix(a, fdst, n, y0 + pyb[1], x0 + px);
+          conv_epilogue_fast<DT, 2, 2>(a, acc, opix, fdst.cbase + 4 * h, ctile * 64 + 4 * h);
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+          asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][5]), "v"(acc[1][0][9]), "v"(acc[1][1][15]));
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
       }
     }
     __builtin_amdgcn_s_barrier();
@@ -695,7 +705,7 @@ template <int DT> int launch_ws(const srk_conv_args& a, hipStream_t st) {
   const unsigned grid = (unsigned)(slots * ctiles);
   const long long xb = ((long long)a.N * a.H * a.W * a.x_pitch) * (long long)sizeof(typename DTraits<DT>::elem);
   hipLaunchKernelGGL((conv_ws_kernel<DT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY, ctiles, (int)nptiles,
-                     (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots));
+                     (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), getenv("SRK_WS_DBG") ? atoi(getenv("SRK_WS_DBG")) : 0);
   SRK_LAUNCH_CHECK();
   return 0;
 }

@@ -12,6 +12,7 @@
 // result into the fp32 scratch with row-contiguous float atomics.
 //
 // Replaces: autograd's conv2d weight/bias gradient for models/common.py:7-30 convs.
+#include <stdlib.h>
 #include "srk_common.h"
 
 namespace {
@@ -235,6 +236,230 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const srk_wgrad_args
   }
 }
 
+
+// =================================================================================================
+// Slab-mode kernel (16-bit dtypes, 3x3): same MFMA core, but
+//  * halo / dY tiles arrive by LDS-DMA (buffer_load ... lds; out-of-image pieces use an out-of-range offset and
+//    are zero-filled by the hardware), with all per-lane address constants computed once per kernel;
+//  * the (X, dY) image pair is double-buffered: the DMA of tile t+1 is in flight during the 144 MFMAs per wave
+//    of tile t; there is no per-tile epilogue, so one wave per SIMD with the whole 512-register file
+//    (144 accumulators + 9 rotating X fragments) keeps the matrix pipe busy; one barrier per tile;
+//  * every workgroup STORES its partial sum to its own slab: no atomics, nothing to zero, bitwise
+//    reproducible; srk_wgrad_finalize sums the slabs.
+// =================================================================================================
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int DT>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int ntiles,
+                                                                unsigned x_bytes, unsigned dy_bytes, int tq, int trem) {
+  typedef WgCfg<DT, 3> C;
+  typedef typename C::Tr Tr;
+  typedef typename Tr::elem elem;
+  constexpr int CH = C::CH, KS = 3, GT = 256, ESZ = C::ESZ;
+  constexpr int NPK = (C::XPIECES + GT - 1) / GT;      // 11 halo pieces per lane
+  constexpr int NDK = C::DYPIECES / GT;                // 8 dY pieces per lane
+  constexpr int BUF_BYTES = C::XS_BYTES + C::DYS_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = wave >> 1, cbk = wave & 1;
+  const int slot = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
+  const int H = a.H, W = a.W;
+  const int nch_x = a.Cin / CH, nch_d = a.Cout / CH;
+
+  const int t0 = slot * tq + min(slot, trem);
+  const int nt = tq + (slot < trem ? 1 : 0);
+
+  // ---- per-lane DMA constants --------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, dy_bytes, 0x00020000);
+  int pconst[NPK], pyx[NPK];
+#pragma unroll
+  for (int k = 0; k < NPK; ++k) {
+    const int i = tid + k * GT;
+    const int sl = i & 7, p = i >> 3;
+    const int iy = p / C::TIN, ix = p - iy * C::TIN;
+    const int c = cib * 8 + (sl ^ swz(ix));
+    pconst[k] = (((iy - 1) * W + (ix - 1)) * a.x_pitch + a.x_coff + c * CH) * ESZ;
+    pyx[k] = (i < C::XPIECES && c < nch_x) ? (((iy - 1) & 0xffff) | ((ix - 1) << 16)) : (int)0x7fff7fff;
+  }
+  // dY piece i = tid + 256k: slot, column and channel chunk do not depend on k, the row advances by 2 per k
+  const int rd = a.dy_ps > 1 ? a.dy_ps : 1;
+  const int d_ix = (tid >> 3) & 15, d_iy0 = tid >> 7;
+  const int d_c = cob * 8 + ((tid & 7) ^ swz(d_ix));
+  const bool d_cok = d_c < nch_d;
+  int dconst, dkstride;
+  {
+    const int Csd = a.Cout / (rd * rd);
+    const int k0 = d_c * CH;
+    const int ij = k0 / Csd, c0 = k0 - ij * Csd;
+    const int si = ij / rd, sj = ij - si * rd;
+    dconst = (((d_iy0 * rd + si) * (W * rd) + d_ix * rd + sj) * a.dy_pitch + a.dy_coff + c0) * ESZ;
+    dkstride = 2 * rd * (W * rd) * a.dy_pitch * ESZ;
+  }
+  auto dma_tile = [&](int pt, char* Xb) {
+    const int tX = pt % tilesX;
+    const int q = pt / tilesX;
+    const int tY = q % tilesY, n = q / tilesY;
+    const int y0 = tY * 16, x0 = tX * 16;
+    char* const Db = Xb + C::XS_BYTES;
+    const int xbase = (((n * H + y0) * W + x0) * a.x_pitch) * ESZ;
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      const int gy = y0 + (int)(short)(pyx[k] & 0xffff), gx = x0 + (pyx[k] >> 16);
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned voff = ok ? (unsigned)(xbase + pconst[k]) : 0x80000000u;
+      if (k < NPK - 1 || tid + k * GT < C::XPIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(Xb + ((k * GT + wave * 64) << 4)), 16, voff, 0, 0, 0);
+    }
+    const int dbase = (((n * H * rd + y0 * rd) * (W * rd) + x0 * rd) * a.dy_pitch) * ESZ;
+    const bool colok = d_cok && (x0 + d_ix < W);
+#pragma unroll
+    for (int k = 0; k < NDK; ++k) {
+      const bool ok = colok && (y0 + d_iy0 + 2 * k < H);
+      const unsigned voff = ok ? (unsigned)(dbase + dconst + k * dkstride) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void_t*)(Db + ((k * GT + wave * 64) << 4)), 16, voff, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  float bsum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = a.dbp != nullptr && cib == 0;
+  int xoff[KS][2], doff[2];
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) {
+    xoff[kw][0] = tr_lane_off(kw, 0, rb, lane);
+    xoff[kw][1] = tr_lane_off(kw, 1, rb, lane);
+  }
+  doff[0] = tr_lane_off(0, 0, cbk, lane);
+  doff[1] = tr_lane_off(0, 1, cbk, lane);
+
+  dma_tile(t0, smem);
+#pragma unroll 1
+  for (int it = 0; it < nt; ++it) {
+    char* const Xs = smem + (it & 1) * BUF_BYTES;
+    char* const Ds = Xs + C::XS_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile `it` landed
+    __builtin_amdgcn_s_barrier();                         // ... for every wave; the other buffer is free
+    if (it + 1 < nt) dma_tile(t0 + it + 1, smem + ((it + 1) & 1) * BUF_BYTES);
+
+    if (do_bias) {
+      // bias gradient: lane owns LDS slot (tid&7) of pixels (tid>>3) + 32k; the slot's channel chunk is the same
+      // for all 8 of them (the swizzle depends on the column, and 32 pixels = 2 full rows)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const i32x4 raw = lds_read16(Ds + ((tid + 256 * k) << 4));
+        const uint32_t w4[4] = {(uint32_t)raw.x, (uint32_t)raw.y, (uint32_t)raw.z, (uint32_t)raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bsum8[2 * i] += Tr::to_f32((uint16_t)(w4[i] & 0xffff));
+          bsum8[2 * i + 1] += Tr::to_f32((uint16_t)(w4[i] >> 16));
+        }
+      }
+    }
+    // K loop over the 16 tile rows; the fragments of step y+1 (one new halo row, one dY row) are fetched while
+    // the 9 MFMAs of step y run (4 rotating halo-row slots), sched_barrier keeps the groups apart
+    i32x4 xf[4][KS];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw)
+        xf[rr][kw] = tr_read2(Xs + xoff[kw][0] + rr * (C::PITCH * 128), Xs + xoff[kw][1] + rr * (C::PITCH * 128));
+    i32x4 bf = tr_read2(Ds + doff[0], Ds + doff[1]);
+#pragma unroll
+    for (int y = 0; y < 16; ++y) {
+      i32x4 bfn = bf;
+      if (y + 1 < 16) {
+        const int nr = y + 3;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw)
+          xf[nr & 3][kw] = tr_read2(Xs + xoff[kw][0] + nr * (C::PITCH * 128), Xs + xoff[kw][1] + nr * (C::PITCH * 128));
+        bfn = tr_read2(Ds + doff[0] + (y + 1) * (16 * 128), Ds + doff[1] + (y + 1) * (16 * 128));
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int kh = t / KS, kw = t - kh * KS;
+        acc[t] = Tr::mma(xf[(y + kh) & 3][kw], bf, acc[t]);
+      }
+      bf = bfn;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- store the workgroup's slab (row-contiguous 128-byte segments per half wave) ------------------------
+  {
+    const int co = cob * 64 + cbk * 32 + (lane & 31);
+    const int hq = lane >> 5;
+    float* const slab = a.dwp + (size_t)slot * 9 * a.Cin * a.Cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = cib * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hq;
+        if (ci < a.Cin && co < a.Cout) slab[((size_t)t * a.Cin + ci) * a.Cout + co] = acc[t][e];
+      }
+    }
+  }
+  if (do_bias) {
+    // fixed-order reduction of the per-lane chunk sums: channel c lives in chunk c>>3, held by the 32 lanes
+    // (hi, q16) with slot (c>>3) ^ swz(q16)
+    float* const bred = reinterpret_cast<float*>(smem);      // [256][8]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bred[tid * 8 + e] = bsum8[e];
+    __syncthreads();
+    if (tid < 64) {
+      const int ch = tid >> 3, e = tid & 7;
+      float t = 0.f;
+      for (int p0 = 0; p0 < 32; ++p0) t += bred[((p0 << 3) + (ch ^ swz(p0 & 15))) * 8 + e];
+      const int c = cob * 64 + tid;
+      if (c < a.Cout) a.dbp[(size_t)slot * a.Cout + c] = t;
+    }
+  }
+}
+
+// pixel slabs used by the slab-mode kernel for these arguments (0: atomic-mode kernel)
+static int wgrad_ws_slabs(const srk_wgrad_args& a) {
+  if (a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3 || a.x_ps > 1) return 0;
+  if (getenv("SRK_NO_WS")) return 0;
+  const int rd = a.dy_ps > 1 ? a.dy_ps : 1;
+  const long long xb = (long long)a.N * a.H * a.W * a.x_pitch * 2, db = (long long)a.N * a.H * a.W * rd * rd * a.dy_pitch * 2;
+  if (xb >= 0x7fff0000LL || db >= 0x7fff0000LL) return 0;
+  const long long ntiles = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+  const int cib = (a.Cin + 63) / 64, cob = (a.Cout + 63) / 64;
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  long long slabs = cus / (cib * cob);
+  if (slabs < 1) slabs = 1;
+  if (slabs > ntiles) slabs = ntiles;
+  return (int)slabs;
+}
+
+template <int DT> int launch_ws(const srk_wgrad_args& a, hipStream_t st, int slabs) {
+  typedef WgCfg<DT, 3> C;
+  constexpr int LDS = 2 * (C::XS_BYTES + C::DYS_BYTES);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ws_kernel<DT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr != hipSuccess) {
+    srk_set_error("srk_conv2d_wgrad(ws): cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
+    return (int)attr;
+  }
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
+  const long long ntiles = (long long)a.N * tilesX * tilesY;
+  const int cib = (a.Cin + 63) / 64, cob = (a.Cout + 63) / 64;
+  const int rd = a.dy_ps > 1 ? a.dy_ps : 1;
+  const unsigned xb = (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2);
+  const unsigned db = (unsigned)((long long)a.N * a.H * a.W * rd * rd * a.dy_pitch * 2);
+  hipLaunchKernelGGL((conv_wgrad_ws_kernel<DT>), dim3(slabs, cib, cob), dim3(256), LDS, st, a, tilesX, tilesY, (int)ntiles, xb, db,
+                     (int)(ntiles / slabs), (int)(ntiles % slabs));
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int DT, int KS> int launch(const srk_wgrad_args& a, hipStream_t st) {
   typedef WgCfg<DT, KS> C;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<DT, KS>),
@@ -278,9 +503,14 @@ extern "C" int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a->Cin % (rx * rx) == 0 && (a->Cin / (rx * rx)) % ch == 0 && a->Cout % (rd * rd) == 0 && (a->Cout / (rd * rd)) % ch == 0,
                 "srk_conv2d_wgrad: pixel-shuffled operand incompatible with channel count");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int slabs = wgrad_ws_slabs(*a);
+  SRK_CHECK_ARG(a->nslabs == slabs, "srk_conv2d_wgrad: nslabs=%d but srk_wgrad_slabs() is %d for these arguments", a->nslabs, slabs);
+  if (slabs > 0) return a->dtype == SRK_BF16 ? launch_ws<SRK_BF16>(*a, st, slabs) : launch_ws<SRK_F16>(*a, st, slabs);
   switch (a->dtype) {
     case SRK_BF16: return dispatch<SRK_BF16>(*a, st);
     case SRK_F16: return dispatch<SRK_F16>(*a, st);
     default: return dispatch<SRK_F32>(*a, st);
   }
 }
+
+extern "C" int srk_wgrad_slabs(const srk_wgrad_args* a) { return a ? wgrad_ws_slabs(*a) : 0; }

@@ -72,33 +72,80 @@ template <int DT> __global__ void pack_kernel(const srk_pack_args a, long long t
   }
 }
 
-__global__ void wgrad_finalize_kernel(const srk_wgrad_fin_args a) {
+// Sums the per-workgroup slabs and converts [tap][ci][co'] -> OIHW.  Block = 128 consecutive slab elements x 8 waves;
+// wave w sums slabs w, w+8, ... with float2 loads (512 contiguous bytes per wave instruction, 8 loads in flight),
+// the 8 partial sums meet in LDS in a fixed order (bitwise reproducible).
+__global__ __launch_bounds__(512) void wgrad_finalize_kernel(const srk_wgrad_fin_args a) {
+  __shared__ float red[8][128];
   const int taps = a.KH * a.KW;
-  const long long total = (long long)a.Cout * a.Cin * taps;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int tap = (int)(idx % taps);
-    long long t = idx / taps;
-    const int ci = (int)(t % a.Cin);
-    const int co = (int)(t / a.Cin);
-    int cop = co;
-    if (a.ps_r > 1) {
-      const int r2 = a.ps_r * a.ps_r, Cc = a.Cout / r2;
-      const int c = co / r2, ij = co - c * r2;
-      cop = ij * Cc + c;
-    }
-    const float v = a.scale * a.dwp[((size_t)tap * a.CinP + ci) * a.CoutP + cop];
-    if (a.accumulate) a.dw[idx] += v; else a.dw[idx] = v;
-  }
-  if (a.db && a.dbp) {
-    for (int co = blockIdx.x * blockDim.x + threadIdx.x; co < a.Cout; co += gridDim.x * blockDim.x) {
-      int cop = co;
-      if (a.ps_r > 1) {
-        const int r2 = a.ps_r * a.ps_r, Cc = a.Cout / r2;
-        const int c = co / r2, ij = co - c * r2;
-        cop = ij * Cc + c;
+  const int ns = a.nslabs > 1 ? a.nslabs : 1;
+  const size_t per = (size_t)taps * a.CinP * a.CoutP;       // multiple of 256 (CinP, CoutP multiples of 16)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long nchunks = ((long long)per + 127) / 128;
+  for (long long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const size_t e0 = (size_t)ch * 128 + 2 * lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (e0 < per) {
+      const float* p = a.dwp + e0;
+#pragma unroll 8
+      for (int sl = wv; sl < ns; sl += 8) {
+        const float2 v = *reinterpret_cast<const float2*>(p + (size_t)sl * per);
+        s0 += v.x;
+        s1 += v.y;
       }
-      const float v = a.scale * a.dbp[cop];
-      if (a.accumulate) a.db[co] += v; else a.db[co] = v;
+    }
+    red[wv][2 * lane] = s0;
+    red[wv][2 * lane + 1] = s1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const size_t e = (size_t)ch * 128 + threadIdx.x;
+      if (e < per) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+        const int cop = (int)(e % a.CoutP);
+        const size_t r2 = e / a.CoutP;
+        const int ci = (int)(r2 % a.CinP), tap = (int)(r2 / a.CinP);
+        if (cop < a.Cout && ci < a.Cin) {
+          int co = cop;
+          if (a.ps_r > 1) {          // packed co' = ij*Cc + c  ->  torch co = c*r*r + ij
+            const int r2p = a.ps_r * a.ps_r, Cc = a.Cout / r2p;
+            const int ij = cop / Cc, c = cop - ij * Cc;
+            co = c * r2p + ij;
+          }
+          const size_t o = ((size_t)co * a.Cin + ci) * taps + tap;
+          const float v = a.scale * t;
+          if (a.accumulate) a.dw[o] += v; else a.dw[o] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (a.db && a.dbp && blockIdx.x == 0) {
+    // bias: 64 channels per pass, wave w sums slabs w, w+8, ... (loads in flight), fixed-order LDS reduce
+    for (int c0 = 0; c0 < a.CoutP; c0 += 64) {
+      const int cop = c0 + lane;
+      float t = 0.f;
+      if (cop < a.CoutP) {
+#pragma unroll 8
+        for (int sl = wv; sl < ns; sl += 8) t += a.dbp[(size_t)sl * a.CoutP + cop];
+      }
+      red[wv][lane] = t;
+      __syncthreads();
+      if (threadIdx.x < 64 && cop < a.Cout) {
+        float u = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) u += red[g][lane];
+        int co = cop;
+        if (a.ps_r > 1) {
+          const int r2p = a.ps_r * a.ps_r, Cc = a.Cout / r2p;
+          const int ij = cop / Cc, c = cop - ij * Cc;
+          co = c * r2p + ij;
+        }
+        const float v = a.scale * u;
+        if (a.accumulate) a.db[co] += v; else a.db[co] = v;
+      }
+      __syncthreads();
     }
   }
 }
@@ -214,8 +261,9 @@ extern "C" int srk_pack_conv_weights(const srk_pack_args* a, srk_stream_t stream
 extern "C" int srk_wgrad_finalize(const srk_wgrad_fin_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a && a->dwp && a->dw, "srk_wgrad_finalize: null pointer");
   SRK_CHECK_ARG(a->CinP >= a->Cin && a->CoutP >= a->Cout, "srk_wgrad_finalize: padded sizes");
-  const long long total = (long long)a->Cout * a->Cin * a->KH * a->KW;
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(grid_for(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  const long long rows = ((long long)a->KH * a->KW * a->CinP * a->CoutP + 127) / 128;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)(rows > 2048 ? 2048 : (rows < 1 ? 1 : rows))), dim3(512), 0,
+                     reinterpret_cast<hipStream_t>(stream), *a);
   SRK_LAUNCH_CHECK();
   return 0;
 }

@@ -125,17 +125,23 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
     _need_gpu(x)
     dev = x.device
     cout, cin, kh, kw = w_shape
-    dwp = torch.zeros(k * k * Cin * Cout + Cout, dtype=torch.float32, device=dev)
-    dbp = dwp[k * k * Cin * Cout:]
     a = L.WgradArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(x_ps),
                     dy=dy.data_ptr(), dy_pitch=_pitch(dy), dy_coff=0, dy_ps=int(dy_ps),
-                    N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k,
-                    dwp=dwp.data_ptr(), dbp=dbp.data_ptr() if want_bias else 0, dtype=_DT[x.dtype])
+                    N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, dwp=0, dbp=0, nslabs=0, dtype=_DT[x.dtype])
+    nslabs = L.load().srk_wgrad_slabs(a)
+    per = k * k * Cin * Cout
+    if nslabs > 0:      # slab mode: every workgroup writes its own slab, nothing to zero
+        scratch = torch.empty(nslabs * (per + Cout), dtype=torch.float32, device=dev)
+    else:               # atomic mode: one zeroed slab
+        scratch = torch.zeros(per + Cout, dtype=torch.float32, device=dev)
+    ns = max(nslabs, 1)
+    dbp = scratch[ns * per:]
+    a.dwp, a.dbp, a.nslabs = scratch.data_ptr(), (dbp.data_ptr() if want_bias else 0), nslabs
     L.call("srk_conv2d_wgrad", a, _stream())
     dw = torch.empty(w_shape, dtype=torch.float32, device=dev)
     db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
     # the unfolded head conv presents its OIHW weight as a 1x1 conv over Cin*KH*KW channels
-    f = L.WgradFinArgs(dwp=dwp.data_ptr(), dbp=dbp.data_ptr() if want_bias else 0, dw=dw.data_ptr(), db=_ptr(db),
+    f = L.WgradFinArgs(dwp=scratch.data_ptr(), dbp=dbp.data_ptr() if want_bias else 0, nslabs=nslabs, dw=dw.data_ptr(), db=_ptr(db),
                        Cout=cout, Cin=(cin * kh * kw) // (k * k), KH=k, KW=k, CinP=Cin, CoutP=Cout,
                        ps_r=int(ps_r), scale=float(scale), accumulate=0)
     L.call("srk_wgrad_finalize", f, _stream())

@@ -27,9 +27,17 @@ else:
     dy = (torch.rand(a.n, a.hw, a.hw, A.ops.pad16(a.cout), device=dev) - 0.5).to(dt)
     f = lambda: A.ops.wgrad_raw(x, dy, N=a.n, H=a.hw, W=a.hw, Cin=a.cin, Cout=dy.shape[3], k=a.k, w_shape=tuple(w.shape))
 for _ in range(3): f()
-torch.cuda.synchronize(); e0.record()
-for _ in range(a.iters): f()
-e1.record(); torch.cuda.synchronize()
+torch.cuda.synchronize()
+# replay the launches from ONE hipGraph so that the Python/ctypes launch rate (~10 us) does not bound the timing
+st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(st):
+    f()
+torch.cuda.current_stream().wait_stream(st); torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    for _ in range(a.iters): f()
+g.replay(); torch.cuda.synchronize()
+e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / a.iters
 fl = 2.0 * a.n * a.hw * a.hw * a.cin * a.cout * a.k * a.k
 print(f"{a.mode} {a.dtype} n={a.n} {a.hw}x{a.hw} {a.cin}->{a.cout} k{a.k}: {us:.2f} us/iter  {fl/us/1e6:.1f} TFLOP/s  ws={'off' if os.environ.get('SRK_NO_WS') else 'on'}")
