@@ -500,7 +500,12 @@ SRK_DEV void dma16(const void* gsrc, char* lds_wave_base) {
 
 template <int DT>
 __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
-                                                          int nptiles, unsigned x_bytes, int tq, int trem, int dbg) {
+                                                          int nptiles, unsigned x_bytes, int tq, int trem, int dbg,
+                                                          int xs_img, int xs_row, int xs_col, int wtap) {
+  // wtap: 16-byte chunks per tap in the packed weight buffer (8 for Cin = 64; 8*r*r when this launch handles one
+  // 64-channel K-block of a wider reduction, a.wpk then points at that block's first chunk)
+  // xs_img / xs_row / xs_col: element strides of the input between images, rows and columns of the conv-space grid
+  // (plain NHWC: H*W*pitch, W*pitch, pitch; one sub-pixel lattice of a pixel-shuffled tensor: r*W*r*pitch, r*pitch)
   // dbg (SRK_WS_DBG, timing ablations only, results are wrong): 1 = skip MFMAs, 2 = skip epilogue, 4 = skip halo DMA
   // 8 waves = two groups of 4.  A group owns every other tile of the workgroup's range and ONE halo buffer; it
   // alternates an MFMA phase (144 MFMAs per wave, LDS reads only) with an epilogue phase (issue the DMA of its
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     const int sl = i & 7, p = i >> 3;
     const int iy = p / C::TIN, ix = p - iy * C::TIN;
     const int c = sl ^ swz(ix);
-    pconst[k] = (((iy - 1) * W + (ix - 1)) * a.x_pitch + a.x_coff + c * CH) * (int)sizeof(elem);
+    pconst[k] = ((iy - 1) * xs_row + (ix - 1) * xs_col + a.x_coff + c * CH) * (int)sizeof(elem);
     pyx[k] = (i < C::XPIECES) ? (((iy - 1) & 0xffff) | ((ix - 1) << 16)) : (int)0x7fff7fff;   // beyond the tile: never valid
   }
   auto tile_of = [&](int j, int& n, int& y0, int& x0) {
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   auto dma_x = [&](int j) {
     int n, y0, x0;
     tile_of(j, n, y0, x0);
-    const int tbase = (((n * H + y0) * W + x0) * a.x_pitch) * (int)sizeof(elem);   // wave-uniform (SALU)
+    const int tbase = (n * xs_img + y0 * xs_row + x0 * xs_col) * (int)sizeof(elem);   // wave-uniform (SALU)
 #pragma unroll
     for (int k = 0; k < NPK; ++k) {
       const int gy = y0 + (int)(short)(pyx[k] & 0xffff), gx = x0 + (pyx[k] >> 16);
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   for (int k = 0; k < C::WPIECES / 512; ++k) {
     const int i = tid + k * 512;              // i = (tap*8 + c)*64 + co
     const int co = i & 63, c = (i >> 6) & 7, tap = i >> 9;
-    const size_t off = ((size_t)(tap * 8 + c) * a.CoutP + ctile * 64 + co) * CH;
+    const size_t off = ((size_t)(tap * wtap + c) * a.CoutP + ctile * 64 + co) * CH;
     dma16(wg + off, Wl + ((k * 512 + wave * 64) << 4));
   }
   if (nj > 0) dma_x(0);
@@ -703,10 +708,38 @@ template <int DT> int launch_ws(const srk_conv_args& a, hipStream_t st) {
   if (slots < 1) slots = 1;
   if (slots > nptiles) slots = nptiles;
   const unsigned grid = (unsigned)(slots * ctiles);
-  const long long xb = ((long long)a.N * a.H * a.W * a.x_pitch) * (long long)sizeof(typename DTraits<DT>::elem);
-  hipLaunchKernelGGL((conv_ws_kernel<DT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY, ctiles, (int)nptiles,
-                     (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), getenv("SRK_WS_DBG") ? atoi(getenv("SRK_WS_DBG")) : 0);
-  SRK_LAUNCH_CHECK();
+  const int dbg = getenv("SRK_WS_DBG") ? atoi(getenv("SRK_WS_DBG")) : 0;
+  const int rin = a.x_ps > 1 ? a.x_ps : 1;
+  const long long xb = ((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2;
+  if (rin == 1) {
+    hipLaunchKernelGGL((conv_ws_kernel<DT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY, ctiles, (int)nptiles,
+                       (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), dbg, a.H * a.W * a.x_pitch, a.W * a.x_pitch,
+                       a.x_pitch, 8);
+    SRK_LAUNCH_CHECK();
+    return 0;
+  }
+  // Input stored pixel-shuffled (the dgrad of a conv + PixelShuffle(r)): channel k = (i*r+j)*64 + c lives at sub-pixel
+  // (i,j), so the K = r*r*64 reduction is r*r weight-stationary 64->64 convs, one per sub-pixel lattice of x, each
+  // with its own 9x64x64 weight slab (K-block ij of every tap of the packed weights), accumulating into `out`:
+  //   launch 0: out = scale*conv_0 + res ; launch ij>0: out = scale*conv_ij + out ; the mask runs on the last one.
+  const int r2 = rin * rin;
+  for (int ij = 0; ij < r2; ++ij) {
+    srk_conv_args b = a;
+    const int si = ij / rin, sj = ij - si * rin;
+    b.x = reinterpret_cast<const char*>(a.x) + ((size_t)si * (a.W * rin) + sj) * a.x_pitch * 2;
+    b.x_ps = 0;
+    b.Cin = 64;
+    b.wpk = reinterpret_cast<const char*>(a.wpk) + (size_t)ij * 8 * a.CoutP * 8 * 2;
+    if (ij > 0) {
+      b.bias = nullptr;
+      b.res = a.out; b.res_pitch = a.out_pitch; b.res_coff = a.out_coff;
+    }
+    if (ij < r2 - 1) b.mask = nullptr;
+    hipLaunchKernelGGL((conv_ws_kernel<DT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, st, b, tilesX, tilesY, ctiles, (int)nptiles,
+                       (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), dbg,
+                       a.H * rin * a.W * rin * a.x_pitch, rin * a.W * rin * a.x_pitch, rin * a.x_pitch, 8 * r2);
+    SRK_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -734,7 +767,9 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
   if constexpr (DTraits<DT>::IS16) {
     // 3x3, one input block, 64-channel output tiles: weights stay in LDS, persistent workgroups
     const long long xbytes = ((long long)a.N * a.H * a.W * a.x_pitch) * 2;
-    if (a.KH == 3 && a.Cin == 64 && a.CoutP % 64 == 0 && a.x_ps <= 1 && xbytes < 0x7fffffffLL && conv_fast_ok(a, 2) &&
+    const int rin = a.x_ps > 1 ? a.x_ps : 1;
+    const bool shape_ok = rin == 1 ? a.Cin == 64 : (a.Cin == 64 * rin * rin && !a.relu && a.out_mode == SRK_OUT_NHWC);
+    if (a.KH == 3 && shape_ok && a.CoutP % 64 == 0 && xbytes * rin * rin < 0x7fffffffLL && conv_fast_ok(a, 2) &&
         getenv("SRK_NO_WS") == nullptr)
       return launch_ws<DT>(a, st);
   }
