@@ -487,7 +487,6 @@ struct WsCfg {
   static constexpr int XS_BYTES = TIN * PITCH * 128;   // 41,472
   static constexpr int LDS_BYTES = WS_BYTES + 2 * XS_BYTES;
   static constexpr int XPIECES = TIN * TIN * 8;        // 2,592
-  static constexpr int WPIECES = 9 * 8 * 64;           // 4,608
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -498,7 +497,7 @@ SRK_DEV void dma16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int DT>
+template <int DT, int CBW, int NKS, bool FAST>
 __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
                                                           int nptiles, unsigned x_bytes, int tq, int trem, int dbg,
                                                           int xs_img, int xs_row, int xs_col, int wtap) {
@@ -515,6 +514,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   typedef typename Tr::elem elem;
   typedef WsCfg C;
   constexpr int CH = Tr::CH;   // 8
+  constexpr int TCW = CBW * 32;                            // output channels per workgroup tile
+  constexpr int NSTEP = 9 * NKS;                           // K-steps per tile
+  constexpr int WPIECES = 9 * 2 * NKS * TCW;               // 16-byte pieces of the weight slab
   constexpr int GT = 256;                                  // threads per group
   constexpr int NPK = (C::XPIECES + GT - 1) / GT;          // 11 halo pieces per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   const int H = a.H, W = a.W;
   const elem* const xg = reinterpret_cast<const elem*>(a.x);
   const elem* const wg = reinterpret_cast<const elem*>(a.wpk);
-  char* const Xg = smem + C::WS_BYTES + grp * C::XS_BYTES;
+  char* const Xg = smem + WPIECES * 16 + grp * C::XS_BYTES;
 
   // (tq, trem) = divmod(nptiles, slots) from the host: slot s owns tq tiles, +1 for the first trem slots
   const unsigned slot = blockIdx.x / (unsigned)ctiles;
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     const int iy = p / C::TIN, ix = p - iy * C::TIN;
     const int c = sl ^ swz(ix);
     pconst[k] = ((iy - 1) * xs_row + (ix - 1) * xs_col + a.x_coff + c * CH) * (int)sizeof(elem);
-    pyx[k] = (i < C::XPIECES) ? (((iy - 1) & 0xffff) | ((ix - 1) << 16)) : (int)0x7fff7fff;   // beyond the tile: never valid
+    pyx[k] = (i < C::XPIECES && c < 2 * NKS) ? (((iy - 1) & 0xffff) | ((ix - 1) << 16)) : (int)0x7fff7fff;   // never valid
   }
   auto tile_of = [&](int j, int& n, int& y0, int& x0) {
     const int pt = t0 + 2 * j + grp;
@@ -577,11 +579,13 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
 
   // ---- prologue: all 9 taps of this channel tile (both groups), then each group's first halo tile ---------------
 #pragma unroll 1
-  for (int k = 0; k < C::WPIECES / 512; ++k) {
-    const int i = tid + k * 512;              // i = (tap*8 + c)*64 + co
-    const int co = i & 63, c = (i >> 6) & 7, tap = i >> 9;
-    const size_t off = ((size_t)(tap * wtap + c) * a.CoutP + ctile * 64 + co) * CH;
-    dma16(wg + off, Wl + ((k * 512 + wave * 64) << 4));
+  for (int k = 0; k < (WPIECES + 511) / 512; ++k) {
+    const int i = tid + k * 512;              // i = (tap*2*NKS + c)*TCW + co
+    if (i < WPIECES) {
+      const int co = i % TCW, c = (i / TCW) % (2 * NKS), tap = i / (TCW * 2 * NKS);
+      const size_t off = ((size_t)(tap * wtap + c) * a.CoutP + ctile * TCW + co) * CH;
+      dma16(wg + off, Wl + ((k * 512 + wave * 64) << 4));
+    }
   }
   if (nj > 0) dma_x(0);
 
@@ -592,22 +596,22 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   int gsw[3];
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) gsw[kw] = swz(px + kw);
-  const char* const wlane = Wl + ((h * 64 + r) << 4);
+  const char* const wlane = Wl + ((h * TCW + r) << 4);
   const char* const xl0 = Xg + ((pyb[0] * C::PITCH + px) << 7);
   const char* const xl1 = Xg + ((pyb[1] * C::PITCH + px) << 7);
 
   // bias as the C operand of the first MFMA of every tile (no accumulator initialisation pass)
-  f32x16 bias16[2];
+  f32x16 bias16[CBW];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+  for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ctile * 64 + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ctile * TCW + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
       bias16[cb][4 * i + 0] = b.x; bias16[cb][4 * i + 1] = b.y; bias16[cb][4 * i + 2] = b.z; bias16[cb][4 * i + 3] = b.w;
     }
-  const FastDst fdst = fast_dst(a, ctile * 64);
+  const FastDst fdst = fast_dst(a, ctile * TCW);
 
-  f32x16 acc[2][2];
+  f32x16 acc[CBW][2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weights + first halo tiles
   __builtin_amdgcn_s_barrier();
 
@@ -618,37 +622,32 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     if (q >= 0 && j < nj) {
       if ((q & 1) == 0) {
         if (dbg & 1) {
-          acc[0][0] = bias16[0]; acc[0][1] = bias16[0]; acc[1][0] = bias16[1]; acc[1][1] = bias16[1];
+#pragma unroll
+          for (int cb = 0; cb < CBW; ++cb) { acc[cb][0] = bias16[cb]; acc[cb][1] = bias16[cb]; }
         } else {
-        // ---------------- MFMA phase: 36 K-steps (9 taps x 4 chunk pairs), fragments fetched two steps ahead ----
-        auto frag = [&](int s, i32x4& a0, i32x4& a1, i32x4& b0, i32x4& b1) {
-          const int tap = s >> 2, ks = s & 3;
+        // ---------------- MFMA phase: 9*NKS K-steps, fragments fetched two steps ahead ---------------------------
+        auto frag = [&](int s, i32x4 (&af)[CBW], i32x4& b0, i32x4& b1) {
+          const int tap = s / NKS, ks = s - tap * NKS;
           const int kh = tap / 3, kw = tap - kh * 3;
           const int kc2 = 2 * ks;
-          a0 = lds_read16(wlane + (((tap * 8 + kc2) * 64) << 4));
-          a1 = lds_read16(wlane + (((tap * 8 + kc2) * 64 + 32) << 4));
+#pragma unroll
+          for (int cb = 0; cb < CBW; ++cb) af[cb] = lds_read16(wlane + (((tap * 2 * NKS + kc2) * TCW + cb * 32) << 4));
           const int so = (((kc2 + h) ^ gsw[kw]) << 4) + ((kh * C::PITCH + kw) << 7);
           b0 = lds_read16(xl0 + so);
           b1 = lds_read16(xl1 + so);
         };
-        i32x4 fa0[3], fa1[3], fb0[3], fb1[3];
-        frag(0, fa0[0], fa1[0], fb0[0], fb1[0]);
-        frag(1, fa0[1], fa1[1], fb0[1], fb1[1]);
+        i32x4 fa[3][CBW], fb0[3], fb1[3];
+        frag(0, fa[0], fb0[0], fb1[0]);
+        frag(1, fa[1], fb0[1], fb1[1]);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int s = 0; s < 36; ++s) {
+        for (int s = 0; s < NSTEP; ++s) {
           const int c0 = s % 3, c2 = (s + 2) % 3;
-          if (s + 2 < 36) frag(s + 2, fa0[c2], fa1[c2], fb0[c2], fb1[c2]);
-          if (s == 0) {
-            acc[0][0] = Tr::mma(fa0[c0], fb0[c0], bias16[0]);
-            acc[0][1] = Tr::mma(fa0[c0], fb1[c0], bias16[0]);
-            acc[1][0] = Tr::mma(fa1[c0], fb0[c0], bias16[1]);
-            acc[1][1] = Tr::mma(fa1[c0], fb1[c0], bias16[1]);
-          } else {
-            acc[0][0] = Tr::mma(fa0[c0], fb0[c0], acc[0][0]);
-            acc[0][1] = Tr::mma(fa0[c0], fb1[c0], acc[0][1]);
-            acc[1][0] = Tr::mma(fa1[c0], fb0[c0], acc[1][0]);
-            acc[1][1] = Tr::mma(fa1[c0], fb1[c0], acc[1][1]);
+          if (s + 2 < NSTEP) frag(s + 2, fa[c2], fb0[c2], fb1[c2]);
+#pragma unroll
+          for (int cb = 0; cb < CBW; ++cb) {
+            acc[cb][0] = Tr::mma(fa[c0][cb], fb0[c0], s == 0 ? bias16[cb] : acc[cb][0]);
+            acc[cb][1] = Tr::mma(fa[c0][cb], fb1[c0], s == 0 ? bias16[cb] : acc[cb][1]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -661,11 +660,16 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
         if (!(dbg & 2)) {
           int n, y0, x0;
           tile_of(j, n, y0, x0);
-          int opix[2];
-          opix[0] = fast_opix(a, fdst, n, y0 + pyb[0], x0 + px);
-          opix[1] = fast_opix(a, fdst, n, y0 + pyb[1], x0 + px);
-          conv_epilogue_fast<DT, 2, 2>(a, acc, opix, fdst.cbase + 4 * h, ctile * 64 + 4 * h);
-          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          if constexpr (FAST) {
+            int opix[2];
+            opix[0] = fast_opix(a, fdst, n, y0 + pyb[0], x0 + px);
+            opix[1] = fast_opix(a, fdst, n, y0 + pyb[1], x0 + px);
+            conv_epilogue_fast<DT, CBW, 2>(a, acc, opix, fdst.cbase + 4 * h, ctile * TCW + 4 * h);
+          } else {
+            conv_epilogue<DT, CBW, 2>(a, acc, n, y0, x0, ctile * TCW, pyb, px, h);
+          }
+          if constexpr (FAST && CBW == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
           asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][5]), "v"(acc[1][0][9]), "v"(acc[1][1][15]));
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -689,16 +693,18 @@ static bool conv_fast_ok(const srk_conv_args& a, int esz) {
   return mx * esz < 0x7fff0000LL;
 }
 
-template <int DT> int launch_ws(const srk_conv_args& a, hipStream_t st) {
+template <int DT, int CBW, int NKS, bool FAST> int launch_ws(const srk_conv_args& a, hipStream_t st) {
   typedef WsCfg C;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<DT>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  constexpr int TCW = CBW * 32;
+  constexpr int LDS = 9 * 2 * NKS * TCW * 16 + 2 * C::XS_BYTES;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<DT, CBW, NKS, FAST>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) {
-    srk_set_error("srk_conv2d(ws): cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(attr));
+    srk_set_error("srk_conv2d(ws): cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
     return (int)attr;
   }
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
-  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16, ctiles = a.CoutP / 64;
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16, ctiles = a.CoutP / TCW;
   const long long nptiles = (long long)a.N * tilesX * tilesY;
   if (nptiles <= 0 || nptiles > 0x7fffffffLL) {
     srk_set_error("srk_conv2d(ws): bad tile count %lld", nptiles);
@@ -712,9 +718,9 @@ template <int DT> int launch_ws(const srk_conv_args& a, hipStream_t st) {
   const int rin = a.x_ps > 1 ? a.x_ps : 1;
   const long long xb = ((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2;
   if (rin == 1) {
-    hipLaunchKernelGGL((conv_ws_kernel<DT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY, ctiles, (int)nptiles,
+    hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST>), dim3(grid), dim3(C::NT), LDS, st, a, tilesX, tilesY, ctiles, (int)nptiles,
                        (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), dbg, a.H * a.W * a.x_pitch, a.W * a.x_pitch,
-                       a.x_pitch, 8);
+                       a.x_pitch, 2 * NKS);
     SRK_LAUNCH_CHECK();
     return 0;
   }
@@ -735,7 +741,7 @@ template <int DT> int launch_ws(const srk_conv_args& a, hipStream_t st) {
       b.res = a.out; b.res_pitch = a.out_pitch; b.res_coff = a.out_coff;
     }
     if (ij < r2 - 1) b.mask = nullptr;
-    hipLaunchKernelGGL((conv_ws_kernel<DT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, st, b, tilesX, tilesY, ctiles, (int)nptiles,
+    hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST>), dim3(grid), dim3(C::NT), LDS, st, b, tilesX, tilesY, ctiles, (int)nptiles,
                        (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), dbg,
                        a.H * rin * a.W * rin * a.x_pitch, rin * a.W * rin * a.x_pitch, rin * a.x_pitch, 8 * r2);
     SRK_LAUNCH_CHECK();
@@ -765,13 +771,17 @@ template <int DT, int TC, int KS> int launch(const srk_conv_args& a, hipStream_t
 
 template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
   if constexpr (DTraits<DT>::IS16) {
-    // 3x3, one input block, 64-channel output tiles: weights stay in LDS, persistent workgroups
-    const long long xbytes = ((long long)a.N * a.H * a.W * a.x_pitch) * 2;
+    // 3x3 with ONE 128-byte input block: weights stay in LDS, persistent workgroups (conv_ws_kernel)
     const int rin = a.x_ps > 1 ? a.x_ps : 1;
-    const bool shape_ok = rin == 1 ? a.Cin == 64 : (a.Cin == 64 * rin * rin && !a.relu && a.out_mode == SRK_OUT_NHWC);
-    if (a.KH == 3 && shape_ok && a.CoutP % 64 == 0 && xbytes * rin * rin < 0x7fffffffLL && conv_fast_ok(a, 2) &&
-        getenv("SRK_NO_WS") == nullptr)
-      return launch_ws<DT>(a, st);
+    const long long xbytes = ((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2;
+    if (a.KH == 3 && xbytes < 0x7fffffffLL && getenv("SRK_NO_WS") == nullptr) {
+      if (a.CoutP % 64 == 0 && conv_fast_ok(a, 2)) {
+        if (rin == 1 && a.Cin == 64) return launch_ws<DT, 2, 4, true>(a, st);
+        if (rin == 1 && a.Cin == 16) return launch_ws<DT, 2, 1, true>(a, st);          // e.g. dgrad of the 3-channel tail conv
+        if (rin > 1 && a.Cin == 64 * rin * rin && !a.relu && a.out_mode == SRK_OUT_NHWC) return launch_ws<DT, 2, 4, true>(a, st);
+      }
+      if (a.CoutP == 32 && rin == 1 && a.Cin == 64) return launch_ws<DT, 1, 4, false>(a, st);   // e.g. the 64->3 tail conv
+    }
   }
   const int tc = (a.CoutP % 128 == 0) ? 128 : (a.CoutP % 64 == 0) ? 64 : 32;
   if (a.KH == 3) {
