@@ -45,7 +45,7 @@ template <int DT, int TC, int KS> struct ConvCfg {
 // per-group channel offsets are compile-time immediates.
 template <int CB_W, int PB_W>
 SRK_DEV void acc_init_bias(f32x16 (&acc)[CB_W][PB_W], const float* bias, int co_lane) {
-  // co_lane = first channel of this lane's register group 0 (co0 + 4*h)
+  // bias is stored in MFMA-row order; co_lane = first ROW of this lane's register group 0 (row0 + 4*h)
 #pragma unroll
   for (int cb = 0; cb < CB_W; ++cb) {
     f32x4 b[4];
@@ -61,18 +61,20 @@ SRK_DEV void acc_init_bias(f32x16 (&acc)[CB_W][PB_W], const float* bias, int co_
   }
 }
 
+// GOFF(g): channel offset (relative to the lane's first channel) of 4-channel group g = 4*cb + i
+#define SRK_GOFF(g) (CB_W == 2 ? ((g) >> 2) * 16 + ((g) & 3) * 4 : ((g) & 3) * 4)
 template <int DT, int CB_W, int PB_W>
 SRK_DEV void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], int n, int y0, int x0, int co0,
                            const int (&pyb)[PB_W], int px, int h) {
   typedef DTraits<DT> Tr;
   typedef typename Tr::elem elem;
-  constexpr int NG = CB_W * 4;                 // 4-channel groups per lane: group g -> channel offset (g>>2)*32 + (g&3)*8
+  constexpr int NG = CB_W * 4;                 // 4-channel groups per lane (row permutation: srk_common.h row_to_chan)
   const int H = a.H, W = a.W;
   const int mode = a.out_mode;
   const int rr = a.ps_r > 1 ? a.ps_r : 1;
   const float scale = a.scale;
   const bool relu = a.relu != 0;
-  const int col = co0 + 4 * h;                 // this lane's first channel
+  const int col = co0 + (CB_W == 2 ? 32 : 16) * h;   // this lane's first channel (its 16*CB_W channels are contiguous)
 #pragma unroll
   for (int pb = 0; pb < PB_W; ++pb) {
     const int gy = y0 + pyb[pb], gx = x0 + px;
@@ -94,7 +96,7 @@ SRK_DEV void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], in
         float q[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          const int off = (g >> 2) * 32 + (g & 3) * 8;
+          const int off = SRK_GOFF(g);
           if (col + off < a.Cout) load4<DT>(rp + off, q[g]);
           else q[g][0] = q[g][1] = q[g][2] = q[g][3] = 0.f;
         }
@@ -108,7 +110,7 @@ SRK_DEV void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], in
         float q[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          const int off = (g >> 2) * 32 + (g & 3) * 8;
+          const int off = SRK_GOFF(g);
           if (col + off < a.Cout && col + off >= a.mask_from) load4<DT>(mp + off, q[g]);
           else q[g][0] = q[g][1] = q[g][2] = q[g][3] = 1.f;
         }
@@ -120,7 +122,7 @@ SRK_DEV void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], in
       elem* op = reinterpret_cast<elem*>(a.out) + pix * a.out_pitch + a.out_coff + col;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        const int off = (g >> 2) * 32 + (g & 3) * 8;
+        const int off = SRK_GOFF(g);
         if (col + off < a.Cout) store4<DT>(op + off, v[g]);
       }
     } else if (mode == SRK_OUT_NHWC_PS) {
@@ -131,7 +133,7 @@ SRK_DEV void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], in
       const size_t rowpix = (size_t)(n * H * rr + gy * rr) * (W * rr) + gx * rr;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        const int co = col + (g >> 2) * 32 + (g & 3) * 8;
+        const int co = col + SRK_GOFF(g);
         if (co >= a.Cout) continue;
         const int ij = pow2 ? (co >> sh) : (co / Cc);
         const int c = co - ij * Cc;
@@ -160,7 +162,7 @@ SRK_DEV void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], in
       for (int g = 0; g < NG; ++g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int ce = col + (g >> 2) * 32 + (g & 3) * 8 + e;
+          const int ce = col + SRK_GOFF(g) + e;
           if (ce < a.Cout) {
             const int c = ce / r2, ij = ce - c * r2;
             const int si = ij / rr, sj = ij - si * rr;
@@ -190,89 +192,101 @@ SRK_DEV __amdgpu_buffer_rsrc_t big_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int DT> SRK_DEV void buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int imm_bytes, float q[4]) {
+// 16 contiguous channels of one lane <-> 16 floats, as 16-byte buffer accesses (2 for 16-bit types, 4 for fp32)
+template <int DT> SRK_DEV void buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int imm_bytes, float q[16]) {
   typedef DTraits<DT> Tr;
   if constexpr (Tr::IS16) {
-    const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + imm_bytes, 0, 0);
-    q[0] = Tr::to_f32((uint16_t)(raw.x & 0xffff)); q[1] = Tr::to_f32((uint16_t)(raw.x >> 16));
-    q[2] = Tr::to_f32((uint16_t)(raw.y & 0xffff)); q[3] = Tr::to_f32((uint16_t)(raw.y >> 16));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, 0);
+      unpack2<DT>(raw.x, q[8 * t + 0], q[8 * t + 1]);
+      unpack2<DT>(raw.y, q[8 * t + 2], q[8 * t + 3]);
+      unpack2<DT>(raw.z, q[8 * t + 4], q[8 * t + 5]);
+      unpack2<DT>(raw.w, q[8 * t + 6], q[8 * t + 7]);
+    }
   } else {
-    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes, 0, 0);
-    q[0] = __uint_as_float(raw.x); q[1] = __uint_as_float(raw.y); q[2] = __uint_as_float(raw.z); q[3] = __uint_as_float(raw.w);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, 0);
+      q[4 * t + 0] = __uint_as_float(raw.x); q[4 * t + 1] = __uint_as_float(raw.y);
+      q[4 * t + 2] = __uint_as_float(raw.z); q[4 * t + 3] = __uint_as_float(raw.w);
+    }
   }
 }
 
-template <int DT> SRK_DEV void buf_store4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int imm_bytes, const float v[4]) {
+template <int DT> SRK_DEV void buf_store16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int imm_bytes, const float v[16], bool relu_packed) {
   typedef DTraits<DT> Tr;
   if constexpr (Tr::IS16) {
-    u32x2 raw;
-    raw.x = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-    raw.y = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
-    __builtin_amdgcn_raw_buffer_store_b64(raw, rs, voff + imm_bytes, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      u32x4 raw;
+      raw.x = pack2<DT>(v[8 * t + 0], v[8 * t + 1]);
+      raw.y = pack2<DT>(v[8 * t + 2], v[8 * t + 3]);
+      raw.z = pack2<DT>(v[8 * t + 4], v[8 * t + 5]);
+      raw.w = pack2<DT>(v[8 * t + 6], v[8 * t + 7]);
+      if (relu_packed) { raw.x = relu_pk16(raw.x); raw.y = relu_pk16(raw.y); raw.z = relu_pk16(raw.z); raw.w = relu_pk16(raw.w); }
+      __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff + imm_bytes + 16 * t, 0, 0);
+    }
   } else {
-    u32x4 raw;
-    raw.x = __float_as_uint(v[0]); raw.y = __float_as_uint(v[1]); raw.z = __float_as_uint(v[2]); raw.w = __float_as_uint(v[3]);
-    __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff + imm_bytes, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      u32x4 raw;
+      raw.x = __float_as_uint(v[4 * t + 0]); raw.y = __float_as_uint(v[4 * t + 1]);
+      raw.z = __float_as_uint(v[4 * t + 2]); raw.w = __float_as_uint(v[4 * t + 3]);
+      __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff + imm_bytes + 16 * t, 0, 0);
+    }
   }
 }
 
-// opix[pb]: destination pixel index of this lane (or -1), cdst: destination channel of the lane's group 0,
-// cfirst: conv output channel of group 0 (for mask_from)
+// opix[pb]: destination pixel index of this lane (or -1); cdst: destination channel of the lane's first channel
+// (its 16*CB_W channels are contiguous: accumulator cb, register e <-> channel cdst + 16*cb + e);
+// cfirst: conv output channel of that first channel (for mask_from)
 template <int DT, int CB_W, int PB_W>
 SRK_DEV void conv_epilogue_fast(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], const int (&opix)[PB_W], int cdst, int cfirst) {
   typedef DTraits<DT> Tr;
   constexpr int ESZ = 16 / Tr::CH;
-  constexpr int NG = CB_W * 4;
   const __amdgpu_buffer_rsrc_t ro = big_rsrc(a.out);
   const bool has_res = a.res != nullptr, has_mask = a.mask != nullptr, relu = a.relu != 0;
   const float scale = a.scale;
+  const bool simple = !has_res && !has_mask && scale == 1.f;     // conv (+ReLU): convert, packed ReLU, store
 #pragma unroll
   for (int pb = 0; pb < PB_W; ++pb) {
     const bool ok = opix[pb] >= 0;
-    float v[NG][4];
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[g][e] = acc[g >> 2][pb][4 * (g & 3) + e];
-    if (relu) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
-    }
-    if (scale != 1.f) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[g][e] *= scale;
-    }
-    if (has_res) {
-      const __amdgpu_buffer_rsrc_t rr = big_rsrc(a.res);
-      const unsigned vr = ok ? (unsigned)((opix[pb] * a.res_pitch + a.res_coff + cdst) * ESZ) : SRK_OOB;
-      float q[NG][4];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) buf_load4<DT>(rr, vr, ((g >> 2) * 32 + (g & 3) * 8) * ESZ, q[g]);
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[g][e] += q[g][e];
-    }
-    if (has_mask) {
-      const __amdgpu_buffer_rsrc_t rm = big_rsrc(a.mask);
-      const unsigned vm = ok ? (unsigned)((opix[pb] * a.mask_pitch + a.mask_coff + cdst) * ESZ) : SRK_OOB;
-      float q[NG][4];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) buf_load4<DT>(rm, vm, ((g >> 2) * 32 + (g & 3) * 8) * ESZ, q[g]);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const bool use = cfirst + (g >> 2) * 32 + (g & 3) * 8 >= a.mask_from;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[g][e] = (!use || q[g][e] > 0.f) ? v[g][e] : 0.f;
-      }
-    }
     const unsigned vo = ok ? (unsigned)((opix[pb] * a.out_pitch + a.out_coff + cdst) * ESZ) : SRK_OOB;
+    const unsigned vr = (ok && has_res) ? (unsigned)((opix[pb] * a.res_pitch + a.res_coff + cdst) * ESZ) : SRK_OOB;
+    const unsigned vm = (ok && has_mask) ? (unsigned)((opix[pb] * a.mask_pitch + a.mask_coff + cdst) * ESZ) : SRK_OOB;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) buf_store4<DT>(ro, vo, ((g >> 2) * 32 + (g & 3) * 8) * ESZ, v[g]);
+    for (int cb = 0; cb < CB_W; ++cb) {
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = acc[cb][pb][e];
+      if (simple && Tr::IS16) {
+        buf_store16<DT>(ro, vo, cb * 16 * ESZ, v, relu);
+        continue;
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (scale != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] *= scale;
+      }
+      if (has_res) {
+        float q[16];
+        buf_load16<DT>(big_rsrc(a.res), vr, cb * 16 * ESZ, q);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += q[e];
+      }
+      if (has_mask) {
+        float q[16];
+        buf_load16<DT>(big_rsrc(a.mask), vm, cb * 16 * ESZ, q);
+        const bool use = cfirst + cb * 16 >= a.mask_from;      // mask_from is a multiple of 16
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = (!use || q[e] > 0.f) ? v[e] : 0.f;
+      }
+      buf_store16<DT>(ro, vo, cb * 16 * ESZ, v, false);
+    }
   }
 }
 
@@ -458,7 +472,7 @@ __global__ __launch_bounds__((ConvCfg<DT, TC, KS>::NT)) void conv_igemm_kernel(c
       int opix[C::PB_W];
 #pragma unroll
       for (int pb = 0; pb < C::PB_W; ++pb) opix[pb] = fast_opix(a, d, n, y0 + pyb[pb], x0 + px);
-      conv_epilogue_fast<DT, C::CB_W, C::PB_W>(a, acc, opix, d.cbase + 4 * h, ctile * TC + wco0 + 4 * h);
+      conv_epilogue_fast<DT, C::CB_W, C::PB_W>(a, acc, opix, d.cbase + 32 * h, ctile * TC + wco0 + 32 * h);
       return;
     }
   }
@@ -615,10 +629,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weights + first halo tiles
   __builtin_amdgcn_s_barrier();
 
+  // diagnostic stamps (dbg & 8, never in a timed build): s_memtime at the start and end of each phase body
+  unsigned long long* const stamp = (dbg & 8) && blockIdx.x == 0 && (tid & 255) == 0
+                                        ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.post_add)) + grp * 128 : nullptr;
 #pragma unroll 1
   for (int p = 0; p < nph; ++p) {
     const int q = p - grp;            // this group's own phase counter
     const int j = q >> 1;
+    if (stamp) stamp[2 * p] = __builtin_amdgcn_s_memtime();
     if (q >= 0 && j < nj) {
       if ((q & 1) == 0) {
         if (dbg & 1) {
@@ -664,18 +682,19 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
             int opix[2];
             opix[0] = fast_opix(a, fdst, n, y0 + pyb[0], x0 + px);
             opix[1] = fast_opix(a, fdst, n, y0 + pyb[1], x0 + px);
-            conv_epilogue_fast<DT, CBW, 2>(a, acc, opix, fdst.cbase + 4 * h, ctile * TCW + 4 * h);
+            conv_epilogue_fast<DT, CBW, 2>(a, acc, opix, fdst.cbase + 32 * h, ctile * TCW + 32 * h);
           } else {
             conv_epilogue<DT, CBW, 2>(a, acc, n, y0, x0, ctile * TCW, pyb, px, h);
           }
-          if constexpr (FAST && CBW == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          if constexpr (FAST && CBW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // 8 dwordx4 stores per lane
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-          asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][5]), "v"(acc[1][0][9]), "v"(acc[1][1][15]));
+          asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][5]), "v"(acc[CBW - 1][0][9]), "v"(acc[CBW - 1][1][15]));
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
     }
+    if (stamp) stamp[2 * p + 1] = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();
   }
 }
@@ -684,6 +703,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
 static bool conv_fast_ok(const srk_conv_args& a, int esz) {
   if (a.out_mode == SRK_OUT_PLANAR) return false;
   if (a.Cout % 64 != 0) return false;
+  const int al = 16 / esz;                       // 16-byte accesses
+  if (a.out_pitch % al || a.out_coff % al) return false;
+  if (a.res && (a.res_pitch % al || a.res_coff % al)) return false;
+  if (a.mask && (a.mask_pitch % al || a.mask_coff % al || a.mask_from % 16)) return false;
   const int rr = (a.out_mode == SRK_OUT_NHWC_PS && a.ps_r > 1) ? a.ps_r : 1;
   if (rr > 1 && (a.Cout / (rr * rr)) % 64 != 0) return false;
   const long long px = (long long)a.N * a.H * a.W * rr * rr;

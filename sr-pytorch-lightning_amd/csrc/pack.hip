@@ -47,26 +47,32 @@ template <int DT> __global__ void pack_kernel(const srk_pack_args a, long long t
     const int tap = (int)(t / nch);
     const int k = cc * CH + e;           // reduction-channel index
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    // MFMA row -> stored output channel (srk_common.h row_to_chan): per 64-row block, or per 32-row block when
+    // the padded row count is not a multiple of 64 (the 32-row kernel tile)
+    const int blk = (a.CoutP % 64 == 0) ? 64 : 32;
+    const int chan = (row / blk) * blk + row_to_chan(row % blk, blk);
     float v = 0.f;
     if (!a.dgrad) {
       // rows = output channels (permuted for pixel shuffle), k = input channel
-      if (row < a.Cout && k < a.Cin) {
-        const int co = ps_unperm(row, a.Cout, a.ps_r);
+      if (chan < a.Cout && k < a.Cin) {
+        const int co = ps_unperm(chan, a.Cout, a.ps_r);
         v = a.w[(((size_t)co * a.Cin + k) * a.KH + kh) * a.KW + kw];
       }
     } else {
       // rows = input channels, k = output channel in dy's storage order, taps flipped
-      if (row < a.Cin && k < a.Cout) {
+      if (chan < a.Cin && k < a.Cout) {
         const int co = ps_unperm(k, a.Cout, a.ps_r);
-        v = a.w[(((size_t)co * a.Cin + row) * a.KH + (a.KH - 1 - kh)) * a.KW + (a.KW - 1 - kw)];
+        v = a.w[(((size_t)co * a.Cin + chan) * a.KH + (a.KH - 1 - kh)) * a.KW + (a.KW - 1 - kw)];
       }
     }
     out[idx] = Tr::from_f32(v);
   }
   if (a.bias_pk && !a.dgrad) {
+    const int blk = (a.CoutP % 64 == 0) ? 64 : 32;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.CoutP; i += gridDim.x * blockDim.x) {
+      const int chan = (i / blk) * blk + row_to_chan(i % blk, blk);     // bias_pk is indexed by MFMA row
       float b = 0.f;
-      if (a.bias && i < a.Cout) b = a.bias[ps_unperm(i, a.Cout, a.ps_r)];
+      if (a.bias && chan < a.Cout) b = a.bias[ps_unperm(chan, a.Cout, a.ps_r)];
       a.bias_pk[i] = b;
     }
   }

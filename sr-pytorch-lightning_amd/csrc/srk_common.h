@@ -106,6 +106,49 @@ SRK_DEV int xcd_remap(int bid, int nb) {
   return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Output-channel (MFMA row) permutation of the packed weights.  A 32x32 MFMA leaves lane half h with rows
+// {8i + 4h + e}: four 4-row groups 8 rows apart.  Packing the weights so that MFMA row rho of a channel block
+// carries channel  c = 32h + 16cb + 4i + e  (64-channel blocks: rho = 32cb + 8i + 4h + e)  or
+// c = 16h + 4i + e  (32-channel blocks)  makes the 16 accumulator registers of a lane 16 CONTIGUOUS channels
+// (register index = channel offset), so the epilogue moves 16-byte pieces: 4x fewer store instructions than
+// 4-channel groups (the store tail is issue-bound, guide T21).
+// ---------------------------------------------------------------------------------------------
+SRK_DEV int row_to_chan(int rho, int blk) {   // rho in [0, blk), blk = 64 or 32
+  const int e = rho & 3, hh = (rho >> 2) & 1, i = (rho >> 3) & 3;
+  if (blk == 64) return 32 * hh + 16 * (rho >> 5) + 4 * i + e;
+  return 16 * hh + 4 * i + e;
+}
+
+// packed pair conversion: two floats -> one dword of two 16-bit elements (ONE v_cvt_pk instruction, RNE)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+template <int DT> SRK_DEV uint32_t pack2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  if constexpr (DT == SRK_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// one dword of two 16-bit elements -> two floats (bf16: one shift, one and)
+template <int DT> SRK_DEV void unpack2(uint32_t w, float& lo, float& hi) {
+  if constexpr (DT == SRK_BF16) {
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xffff0000u);
+  } else {
+    const f16x2 h = __builtin_bit_cast(f16x2, w);
+    lo = (float)h.x;
+    hi = (float)h.y;
+  }
+}
+// ReLU on a packed pair of 16-bit floats: negative <=> sign bit <=> negative as int16 (-0.0 -> +0.0... stays -0.0
+// only for max(-0.0, 0) = 0 as integers: 0x8000 is negative, so it becomes +0.0)
+SRK_DEV uint32_t relu_pk16(uint32_t w) {
+  typedef __attribute__((ext_vector_type(2))) short i16x2;
+  const i16x2 v = __builtin_bit_cast(i16x2, w);
+  const i16x2 z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, z));
+}
+
 // element <-> float helpers on 4-element groups (8 B for 16-bit types, 16 B for fp32)
 template <int DT> SRK_DEV void load4(const typename DTraits<DT>::elem* p, float v[4]) {
   typedef DTraits<DT> Tr;

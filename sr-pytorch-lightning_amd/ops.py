@@ -59,13 +59,36 @@ class Packed:
     __slots__ = ("wpk", "bias", "KinP", "CoutP", "k", "ps_r")
 
 
+_PACK_CACHE_ENABLED = False
+
+
+class pack_cache:
+    """Context manager: reuse packed weights across calls while the parameters are FROZEN (inference loops).
+
+    Off by default: an optimizer may update parameters without touching their autograd version counter
+    (torch's fused Adam does), so a version-keyed cache cannot be trusted while training -- every forward /
+    backward repacks (one small kernel per conv)."""
+
+    def __init__(self, enabled=True):
+        self.enabled, self.prev = enabled, None
+
+    def __enter__(self):
+        global _PACK_CACHE_ENABLED
+        self.prev, _PACK_CACHE_ENABLED = _PACK_CACHE_ENABLED, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_CACHE_ENABLED
+        _PACK_CACHE_ENABLED = self.prev
+
+
 def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True):
     """OIHW fp32 `w` (+ bias) -> packed shadow layout for srk_conv2d (forward or dgrad)."""
     _need_gpu(w)
     key = (dtype, bool(dgrad), int(ps_r))
     ver = (w._version, -1 if b is None else b._version, w.data_ptr())
     store = None
-    if cache and isinstance(w, torch.nn.Parameter):
+    if cache and _PACK_CACHE_ENABLED and isinstance(w, torch.nn.Parameter):
         store = w.__dict__.setdefault("_srk_pack", {})
         hit = store.get(key)
         if hit is not None and hit[0] == ver:
@@ -287,7 +310,7 @@ def _pack_head(w, b, dtype):
     """Pack an OIHW weight as the 1x1 conv over Cin*KH*KW unfolded channels (cached on the parameter)."""
     key = ("head", dtype)
     ver = (w._version, -1 if b is None else b._version, w.data_ptr())
-    store = w.__dict__.setdefault("_srk_pack", {}) if isinstance(w, torch.nn.Parameter) else None
+    store = w.__dict__.setdefault("_srk_pack", {}) if (_PACK_CACHE_ENABLED and isinstance(w, torch.nn.Parameter)) else None
     if store is not None:
         hit = store.get(key)
         if hit is not None and hit[0] == ver:

@@ -215,3 +215,33 @@ def test_validation_and_predict_steps(A):
     assert tuple(sr.shape) == (1, 3, 84, 148) and float(sr.min()) >= 0 and float(sr.max()) <= 1
     u8 = m.to_uint8(sr)
     assert u8.dtype == torch.uint8
+
+
+def test_fused_adam_training_sees_updated_weights(A):
+    """Packed shadow weights must follow optimizers that update parameters without bumping the autograd
+    version counter (torch's fused Adam): the loss must move from step to step exactly as in the oracle."""
+    from oracle import train as OT
+    kw = dict(n_feats=16, n_resblocks=2, res_scale=0.1, scale_factor=4)
+    torch.manual_seed(0)
+    m = A.EDSR(precision=32, **kw)
+    ref = OT.OracleModel("EDSR", **kw)
+    ref.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    m = m.cuda()
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-2, fused=True)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(5)
+    lr_, hr = torch.rand(2, 3, 12, 12, generator=g), torch.rand(2, 3, 48, 48, generator=g)
+    losses, rlosses = [], []
+    for _ in range(4):
+        opt.zero_grad(set_to_none=True)
+        loss = m.training_step({"lr": lr_.cuda(), "hr": hr.cuda()}, 0)["loss"]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        ropt.zero_grad()
+        rl = ref.training_step({"lr": lr_, "hr": hr})["loss"]
+        rl.backward()
+        ropt.step()
+        rlosses.append(float(rl))
+    assert abs(losses[0] - losses[-1]) > 1e-3, "loss does not move: stale weights?"
+    np.testing.assert_allclose(losses, rlosses, rtol=2e-3)

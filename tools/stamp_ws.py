@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase s_memtime stamps of the two wave groups of workgroup 0 of conv_ws_kernel (SRK_WS_DBG=8)."""
+import os, sys
+os.environ["SRK_WS_DBG"] = "8"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, sr_amd as A
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dev = torch.device("cuda"); dt = torch.bfloat16
+x = (torch.rand(n, 48, 48, 64, device=dev) - 0.5).to(dt)
+w = torch.nn.Parameter((torch.rand(64, 64, 3, 3, device=dev) - 0.5) * 0.05); b = torch.nn.Parameter(torch.zeros(64, device=dev))
+pk = A.ops.pack_conv(w, b, dt)
+out = torch.empty_like(x)
+stamps = torch.zeros(256, dtype=torch.int64, device=dev)
+for _ in range(20):
+    A.ops.conv_raw(x, pk, N=n, H=48, W=48, Cin=64, Cout=64, out=out, relu=True, post_add=stamps.view(torch.float32))
+torch.cuda.synchronize()
+st = stamps.cpu().numpy()
+for g in (0, 1):
+    t = st[g * 128:(g + 1) * 128]
+    t0 = st[0]
+    print(f"group {g}: (start,end) cycles rel. to first stamp, per phase")
+    for p in range(12):
+        if t[2 * p] == 0: break
+        print(f"   phase {p:2d}: start {t[2*p]-t0:7d}  end {t[2*p+1]-t0:7d}  body {t[2*p+1]-t[2*p]:6d}")
