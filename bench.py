@@ -44,7 +44,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--batch", type=int, default=64, help="LR patches per GPU per step (weak scaling)")
+    p.add_argument("--batch", type=int, default=256, help="LR patches per GPU per step (weak scaling)")
     p.add_argument("--model", default="edsr_baseline", choices=sorted(MODELS))
     p.add_argument("--dtype", default="bf16", choices=sorted(PREC))
     p.add_argument("--patch", type=int, default=48, help="LR patch edge")
@@ -86,9 +86,10 @@ def cpu_baseline(model_name, scale, patch, seconds=15.0, max_steps=8):
             "sample": f"{k} training steps of batch {n} ({cls} fp32, torch {torch.__version__} CPU, {cores} threads), {dt:.1f} s"}
 
 
-def dominant_kernel_roofline(A, batch, patch, feats, dtype, iters=200):
-    """Average duration of ONE launch of the dominant kernel (F->F 3x3 conv on [batch, patch, patch, F]) via
-    HIP events on the launch stream; achieved = algorithmic FLOPs per launch / duration."""
+def dominant_kernel_roofline(A, batch, patch, feats, dtype, iters=100):
+    """Average duration of ONE launch of the dominant kernel (F->F 3x3 conv + bias + ReLU on [batch, patch, patch, F]).
+    `iters` launches are captured into one hipGraph and replayed between two HIP events on the launch stream, so
+    the Python launch rate (~10 us) does not enter; achieved = algorithmic FLOPs per launch / duration."""
     dt = TDT[dtype]
     dev = torch.device("cuda", torch.cuda.current_device())
     x = (torch.rand(batch, patch, patch, feats, device=dev) - 0.5).to(dt)
@@ -97,22 +98,45 @@ def dominant_kernel_roofline(A, batch, patch, feats, dtype, iters=200):
     pk = A.ops.pack_conv(w, b, dt)
     out = torch.empty_like(x)
     kw = dict(N=batch, H=patch, W=patch, Cin=feats, Cout=feats, out=out, relu=True)
-    for _ in range(10):
+    for _ in range(5):
         A.ops.conv_raw(x, pk, **kw)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        A.ops.conv_raw(x, pk, **kw)
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            A.ops.conv_raw(x, pk, **kw)
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        A.ops.conv_raw(x, pk, **kw)
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     flops = 2.0 * batch * patch * patch * feats * feats * 9
     ach = flops / (us * 1e-6) / 1e12
     peak = PEAK_TFLOPS[dtype]
-    return {"bound": "mfma", "kernel": f"conv_igemm 3x3 {feats}->{feats} @{patch}x{patch} x{batch} ({dtype})",
+    esz = 4 if dtype == "f32" else 2
+    alg_bytes = 2.0 * batch * patch * patch * feats * esz            # one read + one write of the activation
+    return {"bound": "mfma", "kernel": f"conv_ws_kernel 3x3 {feats}->{feats} @{patch}x{patch} x{batch} ({dtype}), fwd = dgrad kernel",
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "us_per_launch": round(us, 2), "flops_per_launch": flops, "traffic": None}
+            "us_per_launch": round(us, 2), "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": round(alg_bytes / (us * 1e-6) / 1e9, 1),
+            "traffic": TRAFFIC_PMC.get((feats, patch, batch, dtype))}
+
+
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> B;
+# MI355X_MICROARCH.md "HBM"), measured with tools/pmc_conv.sh and committed under profiles/; None where not measured
+TRAFFIC_PMC = {
+    (64, 48, 64, "bf16"): (10796.8 * 2 + 18432.0) * 1024,
+    (64, 48, 256, "bf16"): (39654.2 * 2 + 73729.0) * 1024,
+}
 
 
 def main():
@@ -128,19 +152,21 @@ def main():
     import sr_amd as A
     from sr_amd import trainer as T
     A._lib.load()
-    if world > 1:
-        T.init_distributed("cuda")
+    force_ddp = os.environ.get("SRK_FORCE_DDP") == "1"      # 1-rank process group: exercises the DDP path on one GPU
+    if world > 1 or force_ddp:
+        T.init_distributed("cuda", force=force_ddp)
 
     cls, kw, gflop_fwd, feats = MODELS[a.model]
     torch.manual_seed(0)                                  # identical weights on every rank
     model = getattr(A, cls)(scale_factor=a.scale, precision=PREC[a.dtype], **kw).to(dev)
-    net = T.wrap_ddp(model, dev)
+    net = T.wrap_ddp(model, dev, force=force_ddp)
     batch = T.synthetic_batch(a.batch, 3, a.patch, a.scale, 1234 + rank, dev)
     params = [p for p in model.parameters() if p.requires_grad]
     # reference optimizer: Adam at torch defaults (srmodel.py:145-154,602-603).  Same update rule, torch's fused
     # multi-tensor implementation (one kernel for all 74 tensors instead of ~150 tiny per-tensor launches),
     # capturable so the step counter lives on the device for hipGraph replay
-    opt = torch.optim.Adam(params, fused=True, capturable=not a.no_graph)
+    want_graph = not a.no_graph and ((world == 1 and not force_ddp) or os.environ.get("SRK_BENCH_GRAPH_DDP") == "1")
+    opt = torch.optim.Adam(params, fused=True, capturable=want_graph)
 
     def train_step():
         opt.zero_grad(set_to_none=True)
@@ -155,9 +181,13 @@ def main():
             return net(batch["lr"])
 
     step = infer_step if a.inference else train_step
+    last = {}
     graph = None
     used_graph = False
-    if not a.no_graph:
+    # N > 1: DDP's bucketed all-reduce runs on RCCL's own stream; capturing it into a hipGraph could not be validated
+    # on a multi-GPU node from this build environment, so the data-parallel run launches eagerly (at the default
+    # batch the step is GPU-bound: ~11 ms of kernels vs ~3 ms of launch calls) unless SRK_BENCH_GRAPH_DDP=1.
+    if not a.no_graph and ((world == 1 and not force_ddp) or os.environ.get("SRK_BENCH_GRAPH_DDP") == "1"):
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -168,7 +198,7 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                step()
+                last["out"] = step()
             used_graph = True
         except Exception as e:  # noqa: BLE001
             if rank == 0:
@@ -180,11 +210,12 @@ def main():
         if graph is not None:
             graph.replay()
         else:
-            step()
+            last["out"] = step()
 
     for _ in range(a.warmup):
         run_one()
     torch.cuda.synchronize()
+    loss_first = float(last["out"].detach().float().mean()) if not a.inference and "out" in last else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -201,6 +232,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    loss_last = float(last["out"].detach().float().mean()) if not a.inference and "out" in last else None
     if rank == 0:
         total = a.batch * world * a.steps
         value = total / el
@@ -213,7 +245,8 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{a.model} x{a.scale}, {a.patch}x{a.patch} LR patches, batch {a.batch}/GPU, "
                                    f"{'forward only' if a.inference else 'train step (L1 + Adam)'}",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": used_graph},
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": used_graph,
+                       "loss_after_warmup": loss_first, "loss_after_timed_steps": loss_last},
             "model_mfma_frac": round(value / world * flop_per_patch / 1e3 / PEAK_TFLOPS[a.dtype], 4),
         }
         try:
@@ -226,7 +259,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

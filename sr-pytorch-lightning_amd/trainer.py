@@ -19,9 +19,13 @@ def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init_distributed(device_type):
+def init_distributed(device_type, force=False):
+    """Create the process group when WORLD_SIZE > 1 (or `force`: a 1-rank group, used to exercise the DDP path on
+    a single GPU)."""
     rank, world, local = dist_env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -33,9 +37,9 @@ def init_distributed(device_type):
     return rank, world, local
 
 
-def wrap_ddp(model, device):
+def wrap_ddp(model, device, force=False):
     """DDP wrapper tuned for this path: one bucket (all grads), bucket views, no unused-parameter scan."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return model
     nbytes = sum(p.numel() * 4 for p in model.parameters() if p.requires_grad)
     cap_mb = max(1, int(nbytes / 2 ** 20) + 1)
