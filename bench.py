@@ -134,8 +134,8 @@ def dominant_kernel_roofline(A, batch, patch, feats, dtype, iters=100):
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> B;
 # MI355X_MICROARCH.md "HBM"), measured with tools/pmc_conv.sh and committed under profiles/; None where not measured
 TRAFFIC_PMC = {
-    (64, 48, 64, "bf16"): (10796.8 * 2 + 18432.0) * 1024,
-    (64, 48, 256, "bf16"): (39654.2 * 2 + 73729.0) * 1024,
+    (64, 48, 64, "bf16"): (10656.0 * 2 + 18432.0) * 1024,      # profiles/r1_pmc_n64_summary.txt
+    (64, 48, 256, "bf16"): (39629.7 * 2 + 73734.4) * 1024,     # profiles/r1_pmc_n256_summary.txt
 }
 
 
