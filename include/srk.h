@@ -71,6 +71,9 @@ typedef struct {
   int dtype;
 } srk_pack_args;
 int srk_pack_conv_weights(const srk_pack_args* a, srk_stream_t stream);
+/* Same, for `n` convolutions in ONE launch: `table` is a DEVICE array of srk_pack_args (a training step re-packs
+ * the forward and dgrad layouts of every conv of the model from the updated fp32 parameters).              */
+int srk_pack_conv_weights_group(const srk_pack_args* table, int n, srk_stream_t stream);
 
 /* ---- implicit-GEMM convolution (forward and dgrad) --------------------------------------------
  * Replaces nn.Conv2d(stride 1, padding k//2) + the elementwise ops the reference issues after it:

@@ -93,7 +93,8 @@ LAUNCHERS = {
     "srk_ca_apply": CaApplyArgs,
     "srk_ca_bwd_apply": CaBwdArgs,
 }
-OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs")
+OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
+                 "srk_pack_conv_weights_group")
 
 _lib = None
 
@@ -116,6 +117,8 @@ def load():
     lib.srk_conv_tile.restype = C.c_int
     lib.srk_wgrad_slabs.argtypes = [C.POINTER(WgradArgs)]
     lib.srk_wgrad_slabs.restype = C.c_int
+    lib.srk_pack_conv_weights_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.srk_pack_conv_weights_group.restype = C.c_int
     lib.srk_last_error.restype = C.c_char_p
     lib.srk_version.restype = C.c_int
     lib.srk_device_cus.restype = C.c_int

@@ -32,12 +32,13 @@ __device__ __forceinline__ int ps_unperm(int cop, int Cout, int r) {
   return c * r2 + ij;
 }
 
-template <int DT> __global__ void pack_kernel(const srk_pack_args a, long long total) {
+template <int DT> __device__ void pack_body(const srk_pack_args& a, long long total, long long first, long long stride) {
   typedef DTraits<DT> Tr;
   constexpr int CH = Tr::CH;
   typename Tr::elem* out = reinterpret_cast<typename Tr::elem*>(a.wpk);
   const int nch = a.KinP / CH;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+  const int blk = (a.CoutP % 64 == 0) ? 64 : 32;
+  for (long long idx = first; idx < total; idx += stride) {
     // idx = ((tap*nch + cc)*CoutP + row)*CH + e
     const int e = (int)(idx % CH);
     long long t = idx / CH;
@@ -49,7 +50,6 @@ template <int DT> __global__ void pack_kernel(const srk_pack_args a, long long t
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
     // MFMA row -> stored output channel (srk_common.h row_to_chan): per 64-row block, or per 32-row block when
     // the padded row count is not a multiple of 64 (the 32-row kernel tile)
-    const int blk = (a.CoutP % 64 == 0) ? 64 : 32;
     const int chan = (row / blk) * blk + row_to_chan(row % blk, blk);
     float v = 0.f;
     if (!a.dgrad) {
@@ -68,13 +68,28 @@ template <int DT> __global__ void pack_kernel(const srk_pack_args a, long long t
     out[idx] = Tr::from_f32(v);
   }
   if (a.bias_pk && !a.dgrad) {
-    const int blk = (a.CoutP % 64 == 0) ? 64 : 32;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.CoutP; i += gridDim.x * blockDim.x) {
-      const int chan = (i / blk) * blk + row_to_chan(i % blk, blk);     // bias_pk is indexed by MFMA row
+    for (long long i = first; i < a.CoutP; i += stride) {
+      const int chan = (int)(i / blk) * blk + row_to_chan((int)(i % blk), blk);     // bias_pk is indexed by MFMA row
       float b = 0.f;
       if (a.bias && chan < a.Cout) b = a.bias[ps_unperm(chan, a.Cout, a.ps_r)];
       a.bias_pk[i] = b;
     }
+  }
+}
+
+template <int DT> __global__ void pack_kernel(const srk_pack_args a, long long total) {
+  pack_body<DT>(a, total, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+
+// one launch for a whole model: blockIdx.y = table entry, blockIdx.x strides over its elements
+__global__ void pack_group_kernel(const srk_pack_args* __restrict__ table) {
+  const srk_pack_args a = table[blockIdx.y];
+  const long long total = (long long)a.KH * a.KW * a.KinP * a.CoutP;
+  const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+  switch (a.dtype) {
+    case SRK_BF16: pack_body<SRK_BF16>(a, total, first, stride); break;
+    case SRK_F16: pack_body<SRK_F16>(a, total, first, stride); break;
+    default: pack_body<SRK_F32>(a, total, first, stride); break;
   }
 }
 
@@ -260,6 +275,13 @@ extern "C" int srk_pack_conv_weights(const srk_pack_args* a, srk_stream_t stream
     case SRK_F32: hipLaunchKernelGGL(pack_kernel<SRK_F32>, dim3(grid), dim3(256), 0, st, *a, total); break;
     default: SRK_CHECK_ARG(false, "srk_pack_conv_weights: dtype %d", a->dtype);
   }
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_pack_conv_weights_group(const srk_pack_args* table, int n, srk_stream_t stream) {
+  SRK_CHECK_ARG(table && n > 0 && n <= 65535, "srk_pack_conv_weights_group: bad table / n=%d", n);
+  hipLaunchKernelGGL(pack_group_kernel, dim3(16, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table);
   SRK_LAUNCH_CHECK();
   return 0;
 }

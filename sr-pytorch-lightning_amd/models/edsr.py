@@ -26,6 +26,7 @@ class EDSR(SRModel):
 
     def forward(self, x):
         """NCHW float in [0,1] -> NCHW fp32, x scale_factor (edsr.py:40-54)."""
+        ops.begin_forward(self._pack_group())
         rgb = self._channels == 3
         f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, -self.sub_mean.shift() if rgb else None,
                           self.compute_dtype)

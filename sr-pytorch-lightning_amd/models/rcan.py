@@ -81,6 +81,7 @@ class RCAN(SRModel):
 
     def forward(self, x):
         """rcan.py:115-129"""
+        ops.begin_forward(self._pack_group())
         rgb = self._channels == 3
         f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, -self.sub_mean.shift() if rgb else None,
                           self.compute_dtype)

@@ -58,6 +58,7 @@ class RDN(SRModel):
 
     def forward(self, x):
         """rdn.py:99-111.  No MeanShift in this model."""
+        ops.begin_forward(self._pack_group())
         f1 = ops.head_conv(x, self.SFENet1.weight, self.SFENet1.bias, None, self.compute_dtype)
         x = ops.conv(f1, self.SFENet2.weight, self.SFENet2.bias)
         outs = []

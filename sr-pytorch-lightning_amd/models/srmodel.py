@@ -178,6 +178,14 @@ class SRModel(_Base):
     def forward(self, x):  # srmodel.py:156-158 (abstract)
         raise NotImplementedError
 
+    def _pack_group(self):
+        """Lazily created `ops.PackGroup`: one launch per step re-packs every conv's shadow weights."""
+        g = self.__dict__.get("_srk_packs")
+        if g is None:
+            from .. import ops
+            g = self.__dict__["_srk_packs"] = ops.PackGroup()
+        return g
+
     # -- srmodel.py:160-171 ---------------------------------------------------------------------------
     def training_step(self, batch, batch_idx):
         img_sr = self.forward(batch['lr'])

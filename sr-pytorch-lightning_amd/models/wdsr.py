@@ -70,6 +70,7 @@ class WDSR(SRModel):
 
     def forward(self, x):
         """wdsr.py:102-117: x - mean; s = PS(skip(x)); x = PS(tail(body(head(x)))); x += s; x + mean."""
+        ops.begin_forward(None)      # weight-norm weights are fresh tensors every step: packed per use
         mean = None
         if self._channels == 3:
             self.rgb_mean = self.rgb_mean.to(x.device)

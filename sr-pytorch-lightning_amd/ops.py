@@ -82,19 +82,87 @@ class pack_cache:
         _PACK_CACHE_ENABLED = self.prev
 
 
-def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True):
-    """OIHW fp32 `w` (+ bias) -> packed shadow layout for srk_conv2d (forward or dgrad)."""
+class PackGroup:
+    """The packed shadow weights of ONE model, re-packed by a single kernel launch per step.
+
+    `begin_forward(group)` (called at the top of a model's forward) launches `srk_pack_conv_weights_group` over a
+    device-side table of every (parameter, layout) pair the model has used so far -- forward and dgrad layouts --
+    so the ~2 pack launches per conv per training step collapse into one.  Entries are discovered on the first
+    step (packed individually then).  Buffers are persistent, so the launch is hipGraph-capturable."""
+
+    def __init__(self):
+        self.entries = {}       # key -> [PackArgs, Packed, w, b]
+        self.table = None
+        self.dirty = False
+        self.fresh = False      # packed buffers correspond to the current parameter values
+
+    def lookup(self, key):
+        e = self.entries.get(key)
+        return e[1] if (e is not None and self.fresh) else None
+
+    def add(self, key, args, packed, w, b):
+        self.entries[key] = [args, packed, w, b]
+        self.dirty = True
+
+    def refresh(self):
+        if not self.entries:
+            self.fresh = True
+            return
+        for e in self.entries.values():          # parameters moved / re-allocated since the table was built?
+            a, _, w, b = e
+            bp = 0 if b is None else b.data_ptr()
+            if a.w != w.data_ptr() or (a.bias or 0) != bp:
+                a.w, a.bias = w.data_ptr(), bp
+                self.dirty = True
+        if self.dirty:
+            import ctypes as C
+            arr = (L.PackArgs * len(self.entries))(*[e[0] for e in self.entries.values()])
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            dev = next(iter(self.entries.values()))[2].device
+            self.table = raw.to(dev)
+            self.dirty = False
+        rc = L.load().srk_pack_conv_weights_group(self.table.data_ptr(), len(self.entries), _stream())
+        if rc != 0:
+            raise RuntimeError(f"srk_pack_conv_weights_group failed (rc={rc}): {L.load().srk_last_error().decode()}")
+        self.fresh = True
+
+
+import threading
+_TLS = threading.local()
+
+
+def begin_forward(group):
+    """Refresh `group` (one launch) and make it the group that new (parameter, layout) pairs register with."""
+    _TLS.group = group
+    if group is not None:
+        group.refresh()
+
+
+def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False):
+    """OIHW fp32 `w` (+ bias) -> packed shadow layout for srk_conv2d (forward or dgrad).
+    as_1x1: present the OIHW weight as the 1x1 conv over Cin*KH*KW unfolded channels (head / skip convs)."""
     _need_gpu(w)
-    key = (dtype, bool(dgrad), int(ps_r))
+    is_param = isinstance(w, torch.nn.Parameter)
+    key = (id(w), dtype, bool(dgrad), int(ps_r), bool(as_1x1))
+    group = None
+    if is_param:
+        gref = w.__dict__.get("_srk_group")
+        group = gref() if gref is not None else getattr(_TLS, "group", None)
+        if group is not None:
+            hit = group.lookup(key)
+            if hit is not None:
+                return hit
     ver = (w._version, -1 if b is None else b._version, w.data_ptr())
     store = None
-    if cache and _PACK_CACHE_ENABLED and isinstance(w, torch.nn.Parameter):
+    if cache and _PACK_CACHE_ENABLED and is_param:
         store = w.__dict__.setdefault("_srk_pack", {})
         hit = store.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
     cout, cin, kh, kw = w.shape
     assert kh == kw
+    if as_1x1:
+        cin, kh, kw = cin * kh * kw, 1, 1
     p = Packed()
     p.k, p.ps_r = kh, int(ps_r)
     if not dgrad:
@@ -110,13 +178,19 @@ def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True):
     if not dgrad:
         p.bias = torch.empty(p.CoutP, dtype=torch.float32, device=w.device)
         if b is not None:
-            bf = b.detach().float().contiguous()
+            bf = b.detach()
+            if bf.dtype != torch.float32 or not bf.is_contiguous():
+                bf = bf.float().contiguous()
     a = L.PackArgs(w=wf.data_ptr(), bias=_ptr(bf), wpk=p.wpk.data_ptr(), bias_pk=_ptr(p.bias),
                    Cout=cout, Cin=cin, KH=kh, KW=kw, KinP=p.KinP, CoutP=p.CoutP,
                    dgrad=int(dgrad), ps_r=int(ps_r), dtype=_DT[dtype])
     L.call("srk_pack_conv_weights", a, _stream())
     if store is not None:
         store[key] = (ver, p)
+    if group is not None and wf.data_ptr() == w.data_ptr() and (bf is None or bf.data_ptr() == b.data_ptr()):
+        import weakref
+        group.add(key, a, p, w, b if not dgrad else None)
+        w.__dict__["_srk_group"] = weakref.ref(group)
     return p
 
 
@@ -307,19 +381,8 @@ class HeadConvFn(torch.autograd.Function):
 
 
 def _pack_head(w, b, dtype):
-    """Pack an OIHW weight as the 1x1 conv over Cin*KH*KW unfolded channels (cached on the parameter)."""
-    key = ("head", dtype)
-    ver = (w._version, -1 if b is None else b._version, w.data_ptr())
-    store = w.__dict__.setdefault("_srk_pack", {}) if (_PACK_CACHE_ENABLED and isinstance(w, torch.nn.Parameter)) else None
-    if store is not None:
-        hit = store.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
-    cout = w.shape[0]
-    pk = pack_conv(w.detach().reshape(cout, -1, 1, 1), b, dtype, cache=False)
-    if store is not None:
-        store[key] = (ver, pk)
-    return pk
+    """Pack an OIHW weight as the 1x1 conv over Cin*KH*KW unfolded channels."""
+    return pack_conv(w, b, dtype, as_1x1=True)
 
 
 def head_conv(x, w, b, sub, dtype):
