@@ -392,16 +392,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_a
   }
 
   // ---- store the workgroup's slab (row-contiguous 128-byte segments per half wave) ------------------------
+  // buffer stores: one 32-bit offset per lane, the (tap, row) part is uniform; rows / columns beyond the real
+  // channel counts get an out-of-range offset (dropped by the hardware) instead of a branch
   {
     const int co = cob * 64 + cbk * 32 + (lane & 31);
     const int hq = lane >> 5;
-    float* const slab = a.dwp + (size_t)slot * 9 * a.Cin * a.Cout;
+    const size_t slab_elems = (size_t)9 * a.Cin * a.Cout;
+    const __amdgpu_buffer_rsrc_t srs =
+        __builtin_amdgcn_make_buffer_rsrc(a.dwp + (size_t)slot * slab_elems, 0, (unsigned)(slab_elems * 4), 0x00020000);
+    const int ci0 = cib * 64 + rb * 32 + 4 * hq;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int ci = cib * 64 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hq;
-        if (ci < a.Cin && co < a.Cout) slab[((size_t)t * a.Cin + ci) * a.Cout + co] = acc[t][e];
+        const int ci = ci0 + (e & 3) + 8 * (e >> 2);
+        const unsigned voff = (ci < a.Cin && co < a.Cout) ? (unsigned)(((t * a.Cin + ci) * a.Cout + co) * 4) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][e]), srs, voff, 0, 0);
       }
     }
   }

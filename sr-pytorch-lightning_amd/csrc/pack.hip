@@ -202,6 +202,36 @@ template <int DT> __global__ void to_nhwc_kernel(const srk_to_nhwc_args a) {
   }
 }
 
+// Cstore == 16 (the 3-channel image gradient): one thread per pixel, plane reads coalesced across x, ONE 32-byte
+// (16-bit) / 64-byte (fp32) contiguous store per pixel
+template <int DT> __global__ void to_nhwc16_kernel(const srk_to_nhwc_args a) {
+  typedef DTraits<DT> Tr;
+  typename Tr::elem* dst = reinterpret_cast<typename Tr::elem*>(a.dst);
+  const int r = a.ps_r > 1 ? a.ps_r : 1, r2 = r * r;
+  const int Cs = a.C / r2;
+  const long long total = (long long)a.N * a.H * a.W;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(p % a.W);
+    long long q = p / a.W;
+    const int y = (int)(q % a.H);
+    const int n = (int)(q / a.H);
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float s = 0.f;
+      if (c < a.C) {
+        const int cs = c / r2, ij = c - cs * r2;
+        const int si = ij / r, sj = ij - si * r;
+        s = a.scale * a.src[((size_t)(n * Cs + cs) * (a.H * r) + y * r + si) * (a.W * r) + x * r + sj];
+      }
+      v[c] = s;
+    }
+    typename Tr::elem* o = dst + (size_t)p * a.dst_pitch + a.dst_coff;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) store4<DT>(o + 4 * g, v + 4 * g);
+  }
+}
+
 template <int DT> __global__ void to_nchw_kernel(const srk_to_nchw_args a) {
   typedef DTraits<DT> Tr;
   const typename Tr::elem* src = reinterpret_cast<const typename Tr::elem*>(a.src);
@@ -301,8 +331,20 @@ extern "C" int srk_nchw_to_nhwc(const srk_to_nhwc_args* a, srk_stream_t stream) 
   const int r = a->ps_r > 1 ? a->ps_r : 1;
   SRK_CHECK_ARG(a->Cstore % 4 == 0 && a->Cstore >= a->C && a->C % (r * r) == 0 && a->dst_pitch % 4 == 0 && a->dst_coff % 4 == 0,
                 "srk_nchw_to_nhwc: C=%d Cstore=%d r=%d", a->C, a->Cstore, r);
-  const long long total = (long long)a->N * a->H * a->W * (a->Cstore / 4);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->Cstore == 16) {
+    const long long px = (long long)a->N * a->H * a->W;
+    const int g16 = (int)((px + 255) / 256 > 8192 ? 8192 : (px + 255) / 256);
+    switch (a->dtype) {
+      case SRK_BF16: hipLaunchKernelGGL(to_nhwc16_kernel<SRK_BF16>, dim3(g16), dim3(256), 0, st, *a); break;
+      case SRK_F16: hipLaunchKernelGGL(to_nhwc16_kernel<SRK_F16>, dim3(g16), dim3(256), 0, st, *a); break;
+      case SRK_F32: hipLaunchKernelGGL(to_nhwc16_kernel<SRK_F32>, dim3(g16), dim3(256), 0, st, *a); break;
+      default: SRK_CHECK_ARG(false, "srk_nchw_to_nhwc: dtype %d", a->dtype);
+    }
+    SRK_LAUNCH_CHECK();
+    return 0;
+  }
+  const long long total = (long long)a->N * a->H * a->W * (a->Cstore / 4);
   const int grid = grid_for(total, 256);
   switch (a->dtype) {
     case SRK_BF16: hipLaunchKernelGGL(to_nhwc_kernel<SRK_BF16>, dim3(grid), dim3(256), 0, st, *a); break;
