@@ -245,3 +245,25 @@ def test_fused_adam_training_sees_updated_weights(A):
         rlosses.append(float(rl))
     assert abs(losses[0] - losses[-1]) > 1e-3, "loss does not move: stale weights?"
     np.testing.assert_allclose(losses, rlosses, rtol=2e-3)
+
+
+@pytest.mark.parametrize("dt,min_psnr", [(torch.float32, 90.0), (torch.bfloat16, 50.0)])
+def test_full_image_inference_vs_oracle(A, dt, min_psnr):
+    """validation/predict path (srmodel.py:214-232,375-433): batch 1, arbitrary H x W (not multiples of the 16x16
+    tile), clamp + uint8 rounding; EDSR-baseline at default init against the fp32 CPU oracle."""
+    ent = MANIFEST["edsr_baseline_x4"]
+    torch.manual_seed(0)
+    m = A.EDSR(precision=PREC[dt], **ent["kwargs"])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    x = torch.rand(1, 3, 85, 123, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        y_ref = OF.forward("EDSR", sd, x, **ent["kwargs"]).clamp(0, 1)
+        y = m.predict_step({"lr": x.cuda()}, 0)
+    assert tuple(y.shape) == (1, 3, 340, 492)
+    mse = float(((y.cpu().double() - y_ref.double()) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
+    assert psnr > min_psnr, f"PSNR(build, oracle) = {psnr:.1f} dB"
+    # uint8 rounding (torchvision.utils.save_image): identical except where the fp32 values straddle x.5/255
+    d = (m.to_uint8(y).cpu().int() - m.to_uint8(y_ref).int()).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < (1e-3 if dt == torch.float32 else 0.08)
