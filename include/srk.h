@@ -94,7 +94,8 @@ typedef struct {
   const void* wpk; const float* bias;  /* packed weights [KH*KW][Cin/CH][CoutP][CH]; bias [CoutP]/NULL */
   int CoutP;                           /* multiple of the channel tile chosen by srk_conv_tile()      */
   int Cout;                            /* channels to store (NHWC: multiple of 4, <= CoutP; planar: real) */
-  int KH, KW;                          /* 1 or 3                                                      */
+  int KH, KW;                          /* 1 or 3 (3x3 with one 64-channel input block in bf16/fp16 runs on   */
+                                       /* the weight-stationary persistent kernel, everything else streams)   */
   int relu; float scale;
   const void* res; int res_pitch, res_coff;    /* same addressing mode and dtype as out; NULL = none */
   const void* mask; int mask_pitch, mask_coff; int mask_from;  /* NHWC/NHWC_PS addressing, dtype     */

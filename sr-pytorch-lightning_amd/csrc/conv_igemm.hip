@@ -481,18 +481,19 @@ __global__ __launch_bounds__((ConvCfg<DT, TC, KS>::NT)) void conv_igemm_kernel(c
 
 
 // =================================================================================================
-// Weight-stationary persistent variant: 3x3, Cin <= 64 (ONE 128-byte input block), 16-bit dtypes.
+// Weight-stationary persistent variant: 3x3, ONE 128-byte input block (Cin <= 64), 16-bit dtypes.
 //
 // The streaming kernel above is latency-bound on the 64->64 layers that carry EDSR-baseline / RCAN
 // (a tap's 16 MFMAs are far shorter than the weight slab's load latency).  Here all 9 taps of a
 // 64-channel output tile (73.7 KB) are loaded into LDS ONCE per workgroup, the workgroup is persistent
-// (one per CU) and walks a contiguous range of 16x16 pixel tiles, and the halo tile of tile t+1 is fetched
-// by LDS-DMA (global_load_lds_dwordx4: no staging registers, no wait) into the second halo buffer while
-// the 144 MFMAs per wave of tile t run with NO barrier inside:
-//     LDS = 73,728 (weights) + 2 x 41,472 (halo images) = 156,672 B of the CU's 160 KiB.
-// Out-of-image halo pixels are DMA'd from a 16-byte zero page, so no lane ever skips its LDS slot.
+// (one per CU) and walks a contiguous range of 16x16 pixel tiles, and halo tiles are fetched by LDS-DMA
+// (buffer_load ... lds: no staging registers, no wait) while the other wave group runs its MFMAs:
+//     LDS = 73,728 (weights) + 2 x 41,472 (one halo image per wave group) = 156,672 B of the CU's 160 KiB.
+// Out-of-image halo pixels use an out-of-range buffer offset, for which the hardware writes zeros, so no
+// lane ever skips its LDS slot.  Environment knobs (diagnostics only): SRK_NO_WS=1 routes everything to the
+// streaming kernel; SRK_WS_DBG bit 1/2/4 skip MFMAs / epilogue / halo DMA (timing ablations, wrong results),
+// bit 8 writes s_memtime phase stamps to the buffer passed as `post_add` (tools/stamp_ws.py).
 // =================================================================================================
-__device__ __attribute__((aligned(16), used)) unsigned int srk_zero_page[4] = {0u, 0u, 0u, 0u};
 
 struct WsCfg {
   static constexpr int NT = 512;
