@@ -213,6 +213,39 @@ typedef struct {
 } srk_ca_bwd_args;
 int srk_ca_bwd_apply(const srk_ca_bwd_args* a, srk_stream_t stream);
 
+/* ---- data step feeding the path ------------------------------------------------
+ * _SRDataset._get_item / _get_patch in 'train' mode (srdata.py:64-91,137-169): crop an LR patch and the matching
+ * HR patch, rotate both counter-clockwise by rot*90 degrees, horizontal flip, vertical flip, uint8 -> float / 255,
+ * HWC -> CHW.  One launch for a whole batch: `table` is a DEVICE array of per-sample descriptors (images stay on
+ * the GPU as uint8 HWC), outputs are the NCHW fp32 batch tensors that SRModel.training_step consumes.        */
+typedef struct {
+  const uint8_t* lr; const uint8_t* hr;   /* uint8 [H][W][C] images of this sample (device)               */
+  int lr_h, lr_w, hr_h, hr_w;
+  int top, left;                          /* LR patch origin (row, column); the HR origin is scale * that  */
+  int rot;                                /* 0..3 quarter turns counter-clockwise                          */
+  int hflip, vflip;
+} srk_patch_desc;
+typedef struct {
+  const srk_patch_desc* table; int N; int C; int patch_lr; int scale;
+  float* lr_out;                          /* [N][C][patch_lr][patch_lr]                                    */
+  float* hr_out;                          /* [N][C][patch_lr*scale][patch_lr*scale]                        */
+} srk_patch_args;
+int srk_sample_patches(const srk_patch_args* a, srk_stream_t stream);
+
+/* ---- metric core on the device ---------------------------------------------------
+ * validation_step clamps both images to [0,1] and calls piq.psnr (srmodel.py:224-232,582).  This reduction
+ * returns per image the sum of squared differences of the clamped images and the element count, either over all
+ * channels (RGB PSNR, the reference's definition) or over the BT.601 luma with a `shave`-pixel border removed
+ * (PSNR-Y, the convention BASELINE.json names).  PSNR = 10 log10(count / sse) is left to the caller.        */
+typedef struct {
+  const float* sr; const float* hr;       /* NCHW fp32                                                     */
+  int N, C, H, W;
+  int luma;                               /* 0: all channels; 1: BT.601 Y of the 3 channels                */
+  int shave;                              /* border removed on every side (luma or not)                    */
+  double* sse;                            /* [N] sums, caller-zeroed                                       */
+} srk_sse_args;
+int srk_image_sse(const srk_sse_args* a, srk_stream_t stream);
+
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* srk_last_error(void);
 int srk_version(void);

@@ -16,4 +16,4 @@ modules in the build container (`tests/golden/generate_golden.py`);
 PSNR/SSIM (`oracle.metrics`) restate piq's published defaults but piq is not
 installable here: that part is "parity unpinned" (see DESIGN.md).
 """
-from . import fill, functional, init, metrics, conv_np, train  # noqa: F401
+from . import fill, functional, init, metrics, conv_np, train, data  # noqa: F401

@@ -3,7 +3,7 @@
 The directory name is not a valid Python identifier; import it as `sr_amd` (the alias module at
 the repository root) or with `importlib.import_module("sr-pytorch-lightning_amd")`.
 """
-from . import _lib, ops, models  # noqa: F401
+from . import _lib, ops, models, data  # noqa: F401
 from .models import EDSR, RCAN, RDN, SRCNN, SRModel, WDSR  # noqa: F401
 
-__all__ = ["_lib", "ops", "models", "EDSR", "RCAN", "RDN", "SRCNN", "SRModel", "WDSR"]
+__all__ = ["_lib", "ops", "models", "data", "EDSR", "RCAN", "RDN", "SRCNN", "SRModel", "WDSR"]

@@ -80,6 +80,19 @@ class CaBwdArgs(C.Structure):
                 ("N", _i), ("HW", _i), ("C", _i), ("Cr", _i), ("dtype", _i)]
 
 
+class PatchDesc(C.Structure):
+    _fields_ = [("lr", _p), ("hr", _p), ("lr_h", _i), ("lr_w", _i), ("hr_h", _i), ("hr_w", _i),
+                ("top", _i), ("left", _i), ("rot", _i), ("hflip", _i), ("vflip", _i)]
+
+
+class PatchArgs(C.Structure):
+    _fields_ = [("table", _p), ("N", _i), ("C", _i), ("patch_lr", _i), ("scale", _i), ("lr_out", _p), ("hr_out", _p)]
+
+
+class SseArgs(C.Structure):
+    _fields_ = [("sr", _p), ("hr", _p), ("N", _i), ("C", _i), ("H", _i), ("W", _i), ("luma", _i), ("shave", _i), ("sse", _p)]
+
+
 # every launcher declared in include/srk.h: name -> argument struct
 LAUNCHERS = {
     "srk_pack_conv_weights": PackArgs,
@@ -92,6 +105,8 @@ LAUNCHERS = {
     "srk_ca_pool": CaPoolArgs,
     "srk_ca_apply": CaApplyArgs,
     "srk_ca_bwd_apply": CaBwdArgs,
+    "srk_sample_patches": PatchArgs,
+    "srk_image_sse": SseArgs,
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group")

@@ -64,7 +64,11 @@ _out_of_scope_optimizers = {"Ranger", "RangerVA", "RangerQH"}
 
 
 def _psnr(x, y):
-    """RGB PSNR, data_range 1, per image then batch mean (piq.psnr defaults; srmodel.py:52,582)."""
+    """RGB PSNR, data_range 1, per image then batch mean (piq.psnr defaults; srmodel.py:52,582).
+    On the GPU the squared-error reduction is the HIP kernel srk_image_sse (no D2H sync per image)."""
+    if x.is_cuda:
+        from .. import ops
+        return ops.psnr(x, y)
     mse = ((x.float() - y.float()) ** 2).flatten(1).mean(dim=1)
     return (10.0 * torch.log10(1.0 / (mse + 1e-8))).mean()
 
@@ -101,7 +105,15 @@ def _psnr_y(x, y, shave):
     return (10.0 * torch.log10(1.0 / mse.clamp_min(1e-12))).mean()
 
 
-_supported_metrics = {"PSNR": _psnr, "SSIM": _ssim}   # srmodel.py:47-54 (the torch-only ones)
+def _psnr_y_metric(x, y):
+    """PSNR-Y (BT.601 luma, border = 4 px): the quantity BASELINE.json names; NOT in the reference's table."""
+    if x.is_cuda and x.shape[1] == 3:
+        from .. import ops
+        return ops.psnr(x, y, luma=True, shave=4, eps=0.0)
+    return _psnr_y(x, y, 4)
+
+
+_supported_metrics = {"PSNR": _psnr, "SSIM": _ssim, "PSNR-Y": _psnr_y_metric}   # srmodel.py:47-54 (+ PSNR-Y)
 
 
 def _dtype_from_precision(precision):

@@ -681,3 +681,25 @@ def rdb(x, convs, lff):
     for w, b in convs:
         flat += [w, b]
     return RDBFn.apply(x, *flat, lff[0], lff[1])
+
+
+# --------------------------------------------------------------------------------------------
+# metric core on the device
+# --------------------------------------------------------------------------------------------
+def image_sse(sr, hr, *, luma=False, shave=0):
+    """Per-image sum of squared differences of clamp(sr,0,1) and clamp(hr,0,1) (all channels, or BT.601 luma) with a
+    `shave`-pixel border removed, and the element count per image.  srmodel.py:224-232,582 (piq.psnr core)."""
+    _need_gpu(sr)
+    n, c, h, w = sr.shape
+    s32, h32 = _f32c(sr), _f32c(hr)
+    sse = torch.zeros(n, dtype=torch.float64, device=sr.device)
+    a = L.SseArgs(sr=s32.data_ptr(), hr=h32.data_ptr(), N=n, C=c, H=h, W=w, luma=int(luma), shave=int(shave), sse=sse.data_ptr())
+    L.call("srk_image_sse", a, _stream())
+    count = (h - 2 * shave) * (w - 2 * shave) * (1 if luma else c)
+    return sse, count
+
+
+def psnr(sr, hr, *, luma=False, shave=0, eps=1e-8):
+    """10 log10(1 / (MSE + eps)) per image, batch mean (piq.psnr defaults: data_range 1, EPS 1e-8)."""
+    sse, count = image_sse(sr, hr, luma=luma, shave=shave)
+    return (10.0 * torch.log10(1.0 / (sse / count + eps))).mean().float()

@@ -1,0 +1,62 @@
+"""GPU parity of the steps either side of the path against the oracle:
+srk_sample_patches vs oracle.data (itself pinned to PIL), srk_image_sse vs oracle.metrics."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data as OD, metrics as OM
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scale,patch,channels", [(4, 48, 3), (2, 32, 3), (3, 24, 1), (4, 192, 3)])
+def test_patch_sampler_bit_exact(scale, patch, channels):
+    import sr_amd as A
+    rng = np.random.default_rng(5)
+    pairs = []
+    for h, w in ((70, 96), (64, 64), (51, 83)):
+        h, w = max(h, patch // scale + 3), max(w, patch // scale + 5)
+        pairs.append((rng.integers(0, 256, (h, w, channels), dtype=np.uint8),
+                      rng.integers(0, 256, (h * scale, w * scale, channels), dtype=np.uint8)))
+    s = A.data.PatchSampler(pairs, scale, patch, augment=True)
+    pyrng = random.Random(11)
+    idx = [pyrng.randrange(len(pairs)) for _ in range(24)]
+    params = [s.draw(i, pyrng) for i in idx]
+    assert {p[2] for p in params} == {0, 90, 180, 270} and {p[3] for p in params} == {True, False}
+    out = s.batch(idx, params)
+    torch.cuda.synchronize()
+    assert out["lr"].dtype == torch.float32 and tuple(out["hr"].shape) == (24, channels, patch, patch)
+    for k, (i, (top, left, angle, hf, vf)) in enumerate(zip(idx, params)):
+        lo, ho = OD.get_patch_pair(pairs[i][0], pairs[i][1], top, left, patch // scale, scale, angle, hf, vf)
+        np.testing.assert_array_equal(out["lr"][k].cpu().numpy(), lo)
+        np.testing.assert_array_equal(out["hr"][k].cpu().numpy(), ho)
+
+
+def test_patch_sampler_feeds_training_step():
+    import sr_amd as A
+    rng = np.random.default_rng(1)
+    pairs = [(rng.integers(0, 256, (40, 40, 3), dtype=np.uint8), rng.integers(0, 256, (160, 160, 3), dtype=np.uint8))]
+    s = A.data.PatchSampler(pairs, 4, 96)
+    m = A.EDSR(n_feats=16, n_resblocks=1, precision="bf16").cuda()
+    res = m.training_step(s.batch([0, 0, 0, 0], rng=random.Random(2)), 0)
+    res["loss"].backward()
+    assert torch.isfinite(res["loss"])
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 37, 53), (3, 192, 192), (2, 340, 492)])
+def test_psnr_reductions(n, h, w):
+    import sr_amd as A
+    g = torch.Generator().manual_seed(3)
+    hr = torch.rand(n, 3, h, w, generator=g) * 1.2 - 0.1           # some values outside [0,1]: the clamp matters
+    sr = hr + 0.05 * torch.randn(n, 3, h, w, generator=g)
+    got = float(A.ops.psnr(sr.cuda(), hr.cuda()))
+    ref = float(OM.psnr(sr.clamp(0, 1), hr.clamp(0, 1)))
+    assert abs(got - ref) < 1e-4, (got, ref)
+    goty = float(A.ops.psnr(sr.cuda(), hr.cuda(), luma=True, shave=4, eps=0.0))
+    refy = float(OM.psnr_y(sr.clamp(0, 1), hr.clamp(0, 1), 4))
+    assert abs(goty - refy) < 1e-3, (goty, refy)
+    m = A.EDSR(n_feats=16, n_resblocks=1, metrics=["PSNR", "SSIM", "PSNR-Y"])
+    out = m._calculate_metrics(sr.clamp(0, 1).cuda(), hr.clamp(0, 1).cuda(), 1)
+    assert abs(float(out["Set5/PSNR"]) - ref) < 1e-4 and abs(float(out["Set5/PSNR-Y"]) - refy) < 1e-3
