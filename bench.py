@@ -15,6 +15,7 @@ conv, timed with HIP events on its own stream inside this process) and, at N=1, 
 oracle's training step timed on this host's cores over a bounded sample).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -159,14 +160,24 @@ def main():
     cls, kw, gflop_fwd, feats = MODELS[a.model]
     torch.manual_seed(0)                                  # identical weights on every rank
     model = getattr(A, cls)(scale_factor=a.scale, precision=PREC[a.dtype], **kw).to(dev)
-    net = T.wrap_ddp(model, dev, force=force_ddp)
     batch = T.synthetic_batch(a.batch, 3, a.patch, a.scale, 1234 + rank, dev)
     params = [p for p in model.parameters() if p.requires_grad]
-    # reference optimizer: Adam at torch defaults (srmodel.py:145-154,602-603).  Same update rule, torch's fused
-    # multi-tensor implementation (one kernel for all 74 tensors instead of ~150 tiny per-tensor launches),
-    # capturable so the step counter lives on the device for hipGraph replay
-    want_graph = not a.no_graph and ((world == 1 and not force_ddp) or os.environ.get("SRK_BENCH_GRAPH_DDP") == "1")
-    opt = torch.optim.Adam(params, fused=True, capturable=want_graph)
+    ddp = world > 1 or force_ddp
+    # hipGraph: one graph per training step.  With DDP the documented recipe applies (torch "CUDA graphs" notes): build
+    # DDP and run >= 11 warm-up iterations on the side stream that also captures, so that RCCL's all-reduce and the
+    # reducer's AccumulateGrad hooks are bound to it.  That works on a 1-rank RCCL group
+    # (SRK_FORCE_DDP=1 SRK_BENCH_GRAPH_DDP=1: 21.5k patches/s vs 21.7k eager -- at batch 256 the GPU is the bottleneck either way), but an N > 1 capture cannot be tried on the 1-GPU
+    # development box, so N > 1 launches eagerly unless SRK_BENCH_GRAPH_DDP=1.
+    want_graph = not a.no_graph and (not ddp or os.environ.get("SRK_BENCH_GRAPH_DDP") == "1")
+    side = torch.cuda.Stream() if want_graph else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        net = T.wrap_ddp(model, dev, force=force_ddp)
+        # reference optimizer: Adam at torch defaults (srmodel.py:145-154,602-603).  Same update rule, torch's fused
+        # multi-tensor implementation (one kernel for all 74 tensors instead of ~150 tiny per-tensor launches),
+        # capturable so the step counter lives on the device for hipGraph replay
+        opt = torch.optim.Adam(params, fused=True, capturable=want_graph)
 
     def train_step():
         opt.zero_grad(set_to_none=True)
@@ -184,20 +195,16 @@ def main():
     last = {}
     graph = None
     used_graph = False
-    # N > 1: DDP's bucketed all-reduce runs on RCCL's own stream; capturing it into a hipGraph could not be validated
-    # on a multi-GPU node from this build environment, so the data-parallel run launches eagerly (at the default
-    # batch the step is GPU-bound: ~11 ms of kernels vs ~3 ms of launch calls) unless SRK_BENCH_GRAPH_DDP=1.
-    if not a.no_graph and ((world == 1 and not force_ddp) or os.environ.get("SRK_BENCH_GRAPH_DDP") == "1"):
+    if want_graph:
         try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(3):
+            with torch.cuda.stream(side):
+                for _ in range(11 if ddp else 3):
                     step()
-            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: RCCL's watchdog thread polls events while this thread captures
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if ddp else "global"):
                 last["out"] = step()
             used_graph = True
         except Exception as e:  # noqa: BLE001
@@ -258,6 +265,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(a.model, a.scale, a.patch)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        # RCCL prints a version banner through C stdio (buffered until exit when stdout is a pipe): flush it first so
+        # that the JSON line is the last line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
