@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrk_gfx950.so")
+# SRK_LIB_PATH: A/B timing of two builds of the same library (tools/); never a different implementation
+LIB_PATH = os.environ.get("SRK_LIB_PATH") or os.path.join(_HERE, "libsrk_gfx950.so")
 
 SRK_BF16, SRK_F16, SRK_F32 = 0, 1, 2
 OUT_NHWC, OUT_NHWC_PS, OUT_PLANAR = 0, 1, 2

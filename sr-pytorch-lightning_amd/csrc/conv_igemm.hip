@@ -311,6 +311,130 @@ SRK_DEV int fast_opix(const srk_conv_args& a, const FastDst& d, int n, int gy, i
   return (n * a.H * d.rr + gy * d.rr + d.si) * (a.W * d.rr) + gx * d.rr + d.sj;
 }
 
+// ---- quad-transposed epilogue (weight-stationary kernel, 16-bit types, full 64-channel tile) --------------------
+// With lane = pixel, one dwordx4 store instruction drops 64 pieces of 16 bytes into 64 different 128-byte lines, and
+// the memory path pays per line touched, not per byte: measured (tools/ubench/store_patterns.hip, 32 CUs active)
+// 15 B/clk/CU for that pattern, 31 for 32-byte runs, 50 for 64-byte runs, 58 for whole lines; chip-wide the 16-byte
+// pattern saturates the L2 request rate at 3.0-3.5 TB/s.  A lane holds 64 contiguous bytes of its pixel (4 pieces),
+// so a 4x4 transpose of pieces inside each quad of lanes (4 x-adjacent pixels; two v_mov_dpp quad_perm stages) turns
+// "instruction k = piece k of 64 pixels" into "instruction j = pixel j of every quad, 4 lanes covering its 64
+// contiguous bytes": 4x fewer line touches for the stores and for the residual / mask loads, which are issued
+// directly in the transposed layout.  Arithmetic is unchanged (the fp32 values are transposed before the
+// bias/ReLU/scale/residual/mask sequence, or, for conv(+ReLU) alone, the packed 16-bit results are).
+SRK_DEV uint32_t dpp_quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }   // [1,0,3,2]
+SRK_DEV uint32_t dpp_quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }   // [2,3,0,1]
+// in: R[k] = item k of this lane; out: R[j] = item (lane & 3) of lane (quad base + j)
+SRK_DEV void quad_transpose4(uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3, bool b0, bool b1) {
+  {
+    const uint32_t s01 = b0 ? r0 : r1, s23 = b0 ? r2 : r3;
+    const uint32_t g01 = dpp_quad_xor1(s01), g23 = dpp_quad_xor1(s23);
+    r0 = b0 ? g01 : r0; r1 = b0 ? r1 : g01;
+    r2 = b0 ? g23 : r2; r3 = b0 ? r3 : g23;
+  }
+  {
+    const uint32_t s02 = b1 ? r0 : r2, s13 = b1 ? r1 : r3;
+    const uint32_t g02 = dpp_quad_xor2(s02), g13 = dpp_quad_xor2(s13);
+    r0 = b1 ? g02 : r0; r2 = b1 ? r2 : g02;
+    r1 = b1 ? g13 : r1; r3 = b1 ? r3 : g13;
+  }
+}
+
+template <int DT>
+SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int pbase0, int pbase1, int okmask0, int okmask1,
+                                int pstep, int cl, bool use_mask, int qi) {
+  // pbaseX: destination pixel index of the quad's first pixel for pixel block X; okmaskX bit j: pixel j of the quad
+  // is inside the image; pstep: destination pixel stride between x-neighbours (r for a pixel-shuffled store);
+  // cl: destination channel of this lane's 8-channel piece AFTER the transpose; qi = lane & 3
+  static_assert(DTraits<DT>::IS16, "16-bit types only");
+  const __amdgpu_buffer_rsrc_t ro = big_rsrc(a.out);
+  const bool has_res = a.res != nullptr, has_mask = a.mask != nullptr, relu = a.relu != 0;
+  const float scale = a.scale;
+  const bool simple = !has_res && !has_mask && scale == 1.f;
+  const bool b0 = qi & 1, b1 = qi & 2;
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const int pbase = pb ? pbase1 : pbase0, okm = pb ? okmask1 : okmask0;
+    unsigned vo[4], vr[4], vm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = (okm >> j) & 1;
+      const int pix = pbase + j * pstep;
+      vo[j] = ok ? (unsigned)((pix * a.out_pitch + a.out_coff + cl) * 2) : SRK_OOB;
+      vr[j] = (ok && has_res) ? (unsigned)((pix * a.res_pitch + a.res_coff + cl) * 2) : SRK_OOB;
+      vm[j] = (ok && has_mask) ? (unsigned)((pix * a.mask_pitch + a.mask_coff + cl) * 2) : SRK_OOB;
+    }
+    if (simple) {
+      uint32_t P[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          P[k][d] = pack2<DT>(acc[k >> 1][pb][8 * (k & 1) + 2 * d], acc[k >> 1][pb][8 * (k & 1) + 2 * d + 1]);
+          if (relu) P[k][d] = relu_pk16(P[k][d]);
+        }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) quad_transpose4(P[0][d], P[1][d], P[2][d], P[3][d], b0, b1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 raw = {P[j][0], P[j][1], P[j][2], P[j][3]};
+        __builtin_amdgcn_raw_buffer_store_b128(raw, ro, vo[j], 0, 0);
+      }
+      continue;
+    }
+    // residual / mask pieces, already in the transposed layout (issued first: their latency hides behind the transposes)
+    u32x4 rq[4], mq[4];
+    if (has_res) {
+      const __amdgpu_buffer_rsrc_t rr = big_rsrc(a.res);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rq[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, vr[j], 0, 0);
+    }
+    if (has_mask) {
+      const __amdgpu_buffer_rsrc_t rm = big_rsrc(a.mask);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mq[j] = __builtin_amdgcn_raw_buffer_load_b128(rm, vm[j], 0, 0);
+    }
+    uint32_t F[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) F[k][e] = __float_as_uint(acc[k >> 1][pb][8 * (k & 1) + e]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) quad_transpose4(F[0][e], F[1][e], F[2][e], F[3][e], b0, b1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(F[j][e]);
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (scale != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= scale;
+      }
+      if (has_res) {
+        float q[8];
+        unpack2<DT>(rq[j].x, q[0], q[1]); unpack2<DT>(rq[j].y, q[2], q[3]);
+        unpack2<DT>(rq[j].z, q[4], q[5]); unpack2<DT>(rq[j].w, q[6], q[7]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += q[e];
+      }
+      if (has_mask) {
+        float q[8];
+        unpack2<DT>(mq[j].x, q[0], q[1]); unpack2<DT>(mq[j].y, q[2], q[3]);
+        unpack2<DT>(mq[j].z, q[4], q[5]); unpack2<DT>(mq[j].w, q[6], q[7]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (!use_mask || q[e] > 0.f) ? v[e] : 0.f;
+      }
+      u32x4 raw;
+      raw.x = pack2<DT>(v[0], v[1]); raw.y = pack2<DT>(v[2], v[3]);
+      raw.z = pack2<DT>(v[4], v[5]); raw.w = pack2<DT>(v[6], v[7]);
+      __builtin_amdgcn_raw_buffer_store_b128(raw, ro, vo[j], 0, 0);
+    }
+  }
+}
+
 template <int DT, int TC, int KS>
 __global__ __launch_bounds__((ConvCfg<DT, TC, KS>::NT)) void conv_igemm_kernel(const srk_conv_args a, int tilesX,
                                                                               int tilesY, int ctiles, int fast) {
@@ -536,6 +660,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   constexpr int NPK = (C::XPIECES + GT - 1) / GT;          // 11 halo pieces per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Wl = smem;
+  const unsigned long long t_entry = (dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -592,14 +717,33 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     }
   };
 
+  // bias as the C operand of the first MFMA of every tile (no accumulator initialisation pass); loaded FIRST so
+  // that the counted wait of group 1 below covers it
+  f32x16 bias16[CBW];
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ctile * TCW + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bias16[cb][4 * i + 0] = b.x; bias16[cb][4 * i + 1] = b.y; bias16[cb][4 * i + 2] = b.z; bias16[cb][4 * i + 3] = b.w;
+    }
+  asm volatile("" ::: "memory");
   // ---- prologue: all 9 taps of this channel tile (both groups), then each group's first halo tile ---------------
+  // every workgroup needs the SAME weight bytes at the same moment: walking them in the same order would send all
+  // CUs of an XCD to one L2 channel at a time, so each workgroup starts at its own 1-KB block (SRK_WS_DBG bit 16: off)
+  static_assert(WPIECES % 64 == 0, "weight slab is a whole number of 1-KB blocks");
+  constexpr int NBLK = WPIECES / 64;
+  const int rot = (dbg & 16) ? 0 : (int)((blockIdx.x * 11u) % (unsigned)NBLK);
 #pragma unroll 1
-  for (int k = 0; k < (WPIECES + 511) / 512; ++k) {
-    const int i = tid + k * 512;              // i = (tap*2*NKS + c)*TCW + co
-    if (i < WPIECES) {
+  for (int k = 0; k < (NBLK + 7) / 8; ++k) {
+    const int blk = k * 8 + wave;
+    if (blk < NBLK) {
+      int rb = blk + rot;
+      if (rb >= NBLK) rb -= NBLK;
+      const int i = rb * 64 + lane;             // i = (tap*2*NKS + c)*TCW + co
       const int co = i % TCW, c = (i / TCW) % (2 * NKS), tap = i / (TCW * 2 * NKS);
       const size_t off = ((size_t)(tap * wtap + c) * a.CoutP + ctile * TCW + co) * CH;
-      dma16(wg + off, Wl + ((k * 512 + wave * 64) << 4));
+      dma16(wg + off, Wl + (rb << 10));
     }
   }
   if (nj > 0) dma_x(0);
@@ -615,19 +759,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   const char* const xl0 = Xg + ((pyb[0] * C::PITCH + px) << 7);
   const char* const xl1 = Xg + ((pyb[1] * C::PITCH + px) << 7);
 
-  // bias as the C operand of the first MFMA of every tile (no accumulator initialisation pass)
-  f32x16 bias16[CBW];
-#pragma unroll
-  for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ctile * TCW + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      bias16[cb][4 * i + 0] = b.x; bias16[cb][4 * i + 1] = b.y; bias16[cb][4 * i + 2] = b.z; bias16[cb][4 * i + 3] = b.w;
-    }
   const FastDst fdst = fast_dst(a, ctile * TCW);
 
   f32x16 acc[CBW][2];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weights + first halo tiles
+  // group 0 needs the weights and its halo tile now; group 1 idles through phase 0, so it only has to have landed its
+  // share of the weights here (its 10-11 halo pieces are the youngest operations) and waits for its halo tile at the
+  // end of phase 0: 41.5 KB less in the all-CUs-at-once prologue burst (~12-14 B/clk/CU)
+  if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   // diagnostic stamps (dbg & 8, never in a timed build): s_memtime at the start and end of each phase body
@@ -645,15 +784,22 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           for (int cb = 0; cb < CBW; ++cb) { acc[cb][0] = bias16[cb]; acc[cb][1] = bias16[cb]; }
         } else {
         // ---------------- MFMA phase: 9*NKS K-steps, fragments fetched two steps ahead ---------------------------
-        auto frag = [&](int s, i32x4 (&af)[CBW], i32x4& b0, i32x4& b1) {
+        // fragment piece q of K-step s: q < CBW -> weights of channel block q, q = CBW / CBW+1 -> pixel block 0 / 1
+        auto frag1 = [&](int s, int q, i32x4 (&af)[CBW], i32x4& b0, i32x4& b1) {
           const int tap = s / NKS, ks = s - tap * NKS;
           const int kh = tap / 3, kw = tap - kh * 3;
           const int kc2 = 2 * ks;
+          if (q < CBW) {
+            af[q] = lds_read16(wlane + (((tap * 2 * NKS + kc2) * TCW + q * 32) << 4));
+          } else {
+            const int so = (((kc2 + h) ^ gsw[kw]) << 4) + ((kh * C::PITCH + kw) << 7);
+            if (q == CBW) b0 = lds_read16(xl0 + so);
+            else b1 = lds_read16(xl1 + so);
+          }
+        };
+        auto frag = [&](int s, i32x4 (&af)[CBW], i32x4& b0, i32x4& b1) {
 #pragma unroll
-          for (int cb = 0; cb < CBW; ++cb) af[cb] = lds_read16(wlane + (((tap * 2 * NKS + kc2) * TCW + cb * 32) << 4));
-          const int so = (((kc2 + h) ^ gsw[kw]) << 4) + ((kh * C::PITCH + kw) << 7);
-          b0 = lds_read16(xl0 + so);
-          b1 = lds_read16(xl1 + so);
+          for (int q = 0; q < CBW + 2; ++q) frag1(s, q, af, b0, b1);
         };
         i32x4 fa[3][CBW], fb0[3], fb1[3];
         frag(0, fa[0], fb0[0], fb1[0]);
@@ -662,13 +808,20 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
           const int c0 = s % 3, c2 = (s + 2) % 3;
-          if (s + 2 < NSTEP) frag(s + 2, fa[c2], fb0[c2], fb1[c2]);
+          // ONE LDS read per MFMA gap (four waves x one ds_read_b128 = 16 of the gap's 32 LDS-array cycles); a burst of
+          // 4 reads per wave in one gap oversubscribes the array while the waves run in step
+          int q = 0;
 #pragma unroll
           for (int cb = 0; cb < CBW; ++cb) {
+            if (s + 2 < NSTEP && q < CBW + 2) { frag1(s + 2, q, fa[c2], fb0[c2], fb1[c2]); ++q; }
             acc[cb][0] = Tr::mma(fa[c0][cb], fb0[c0], s == 0 ? bias16[cb] : acc[cb][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < NSTEP && q < CBW + 2) { frag1(s + 2, q, fa[c2], fb0[c2], fb1[c2]); ++q; }
+            if (cb == CBW - 1)
+              for (; s + 2 < NSTEP && q < CBW + 2; ++q) frag1(s + 2, q, fa[c2], fb0[c2], fb1[c2]);
             acc[cb][1] = Tr::mma(fa[c0][cb], fb1[c0], s == 0 ? bias16[cb] : acc[cb][1]);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
         }
@@ -679,7 +832,18 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
         if (!(dbg & 2)) {
           int n, y0, x0;
           tile_of(j, n, y0, x0);
-          if constexpr (FAST) {
+          if constexpr (FAST && CBW == 2) {
+            // quad-transposed stores: lane (quad q, position i) ends up with piece i (8 channels) of the quad's pixels
+            const int gxb = x0 + (px & ~3), qi = px & 3;
+            const int xm = min(max(W - gxb, 0), 4);
+            const int xmask = (1 << xm) - 1;
+            const int gy0 = y0 + pyb[0], gy1 = y0 + pyb[1];
+            const int pb0 = (n * H * fdst.rr + gy0 * fdst.rr + fdst.si) * (W * fdst.rr) + gxb * fdst.rr + fdst.sj;
+            const int pb1 = pb0 + 2 * fdst.rr * (W * fdst.rr);            // pyb[1] = pyb[0] + 2
+            const int cq = 32 * h + 8 * qi;
+            conv_epilogue_quad<DT>(a, acc, pb0, pb1, gy0 < H ? xmask : 0, gy1 < H ? xmask : 0, fdst.rr, fdst.cbase + cq,
+                                   ctile * TCW + (cq & ~15) >= a.mask_from, qi);
+          } else if constexpr (FAST) {
             int opix[2];
             opix[0] = fast_opix(a, fdst, n, y0 + pyb[0], x0 + px);
             opix[1] = fast_opix(a, fdst, n, y0 + pyb[1], x0 + px);
@@ -695,8 +859,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
         }
       }
     }
+    if (q < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 1, phase 0: its first halo tile
     if (stamp) stamp[2 * p + 1] = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();
+  }
+  if (stamp) {                       // [100] entry of the FIRST stamped launch, [101] entry / [102] exit of the last one
+    if (stamp[100] == 0) stamp[100] = t_entry;
+    stamp[101] = t_entry;
+    stamp[102] = __builtin_amdgcn_s_memtime();
   }
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase s_memtime stamps of the two wave groups of workgroup 0 of conv_ws_kernel (SRK_WS_DBG=8)."""
 import os, sys
-os.environ["SRK_WS_DBG"] = "8"
+os.environ["SRK_WS_DBG"] = os.environ.get("STAMP_DBG", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sr_amd as A
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -11,10 +11,22 @@ w = torch.nn.Parameter((torch.rand(64, 64, 3, 3, device=dev) - 0.5) * 0.05); b =
 pk = A.ops.pack_conv(w, b, dt)
 out = torch.empty_like(x)
 stamps = torch.zeros(256, dtype=torch.int64, device=dev)
-for _ in range(20):
-    A.ops.conv_raw(x, pk, N=n, H=48, W=48, Cin=64, Cout=64, out=out, relu=True, post_add=stamps.view(torch.float32))
+NL = 20
+A.ops.conv_raw(x, pk, N=n, H=48, W=48, Cin=64, Cout=64, out=out, relu=True, post_add=stamps.view(torch.float32))
+stamps.zero_()
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    for _ in range(NL):
+        A.ops.conv_raw(x, pk, N=n, H=48, W=48, Cin=64, Cout=64, out=out, relu=True, post_add=stamps.view(torch.float32))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); g.replay(); e1.record()
 torch.cuda.synchronize()
 st = stamps.cpu().numpy()
+us = e0.elapsed_time(e1) * 1e3 / NL
+ticks = (st[102] - st[100]) / NL
+print(f"{us:.2f} us per launch (events), {ticks:.0f} s_memtime ticks per launch period -> {ticks/us:.1f} ticks/us")
+print(f"last launch: entry->first phase {st[0]-st[101]} ticks, entry->exit {st[102]-st[101]} ticks")
 for g in (0, 1):
     t = st[g * 128:(g + 1) * 128]
     t0 = st[0]
