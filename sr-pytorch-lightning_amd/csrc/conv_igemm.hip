@@ -311,6 +311,44 @@ SRK_DEV int fast_opix(const srk_conv_args& a, const FastDst& d, int n, int gy, i
   return (n * a.H * d.rr + gy * d.rr + d.si) * (a.W * d.rr) + gx * d.rr + d.sj;
 }
 
+// ---- planar epilogue for <= 4 output channels without PixelShuffle: the EDSR / RCAN / RDN tail conv (Cout = 3) -------
+// fp32 NCHW store (+ planar fp32 residual, + per-channel post_add).  Only the h = 0 lanes hold real channels
+// (registers 0..3 of channel block 0).  The generic epilogue walks all 16 padded channels of a lane behind
+// per-channel branches and issues each post_add / residual load right before its use (one exposed memory latency
+// per channel: 8-10k cycles per tile, 3x the tile's MFMA time); here post_add arrives in registers (loaded once
+// per kernel), the residual loads are issued together, and padding lanes are dropped by out-of-range offsets.
+template <int DT, int PB_W>
+SRK_DEV void conv_epilogue_planar4(const srk_conv_args& a, f32x16 (&acc)[1][PB_W], int n, int y0, int x0,
+                                   const int (&pyb)[PB_W], int px, int h, const float (&pa)[4]) {
+  const int H = a.H, W = a.W, plane = H * W;
+  const __amdgpu_buffer_rsrc_t ro = big_rsrc(a.out), rres = big_rsrc(a.res ? a.res : a.out);
+  const bool has_res = a.res != nullptr, relu = a.relu != 0;
+  const float scale = a.scale;
+  unsigned vo[PB_W][4];
+  float q[PB_W][4];
+#pragma unroll
+  for (int pb = 0; pb < PB_W; ++pb) {
+    const int gy = y0 + pyb[pb], gx = x0 + px;
+    const bool ok = h == 0 && gy < H && gx < W;
+    const int base = (n * a.Cout * H + gy) * W + gx;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      vo[pb][e] = (ok && e < a.Cout) ? (unsigned)(base + e * plane) * 4u : SRK_OOB;
+      q[pb][e] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vo[pb][e], 0, 0)) : 0.f;
+    }
+  }
+#pragma unroll
+  for (int pb = 0; pb < PB_W; ++pb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[0][pb][e];
+      if (relu) v = fmaxf(v, 0.f);
+      v = v * scale + q[pb][e];
+      v += pa[e];
+      if (e < a.Cout) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vo[pb][e], 0, 0);
+    }
+}
+
 // ---- quad-transposed epilogue (weight-stationary kernel, 16-bit types, full 64-channel tile) --------------------
 // With lane = pixel, one dwordx4 store instruction drops 64 pieces of 16 bytes into 64 different 128-byte lines, and
 // the memory path pays per line touched, not per byte: measured (tools/ubench/store_patterns.hip, 32 CUs active)
@@ -760,6 +798,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   const char* const xl1 = Xg + ((pyb[1] * C::PITCH + px) << 7);
 
   const FastDst fdst = fast_dst(a, ctile * TCW);
+  // tail-conv case (see conv_epilogue_planar4): wave-uniform, post_add in (scalar) registers for the whole kernel
+  const bool planar4 = !FAST && CBW == 1 && a.out_mode == SRK_OUT_PLANAR && a.ps_r <= 1 && a.Cout <= 4 &&
+                       (long long)a.N * a.Cout * H * W < (1ll << 29);
+  float pa4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (planar4 && a.post_add && !(dbg & 8)) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pa4[e] = e < a.Cout ? a.post_add[e] : 0.f;
+  }
 
   f32x16 acc[CBW][2];
   // group 0 needs the weights and its halo tile now; group 1 idles through phase 0, so it only has to have landed its
@@ -848,6 +894,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
             opix[0] = fast_opix(a, fdst, n, y0 + pyb[0], x0 + px);
             opix[1] = fast_opix(a, fdst, n, y0 + pyb[1], x0 + px);
             conv_epilogue_fast<DT, CBW, 2>(a, acc, opix, fdst.cbase + 32 * h, ctile * TCW + 32 * h);
+          } else if constexpr (CBW == 1) {
+            if (planar4) conv_epilogue_planar4<DT, 2>(a, acc, n, y0, x0, pyb, px, h, pa4);
+            else conv_epilogue<DT, CBW, 2>(a, acc, n, y0, x0, ctile * TCW, pyb, px, h);
           } else {
             conv_epilogue<DT, CBW, 2>(a, acc, n, y0, x0, ctile * TCW, pyb, px, h);
           }

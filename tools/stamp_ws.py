@@ -6,19 +6,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sr_amd as A
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = torch.device("cuda"); dt = torch.bfloat16
-x = (torch.rand(n, 48, 48, 64, device=dev) - 0.5).to(dt)
-w = torch.nn.Parameter((torch.rand(64, 64, 3, 3, device=dev) - 0.5) * 0.05); b = torch.nn.Parameter(torch.zeros(64, device=dev))
+HW = int(os.environ.get("STAMP_HW", "48")); COUT = int(os.environ.get("STAMP_COUT", "64"))
+x = (torch.rand(n, HW, HW, 64, device=dev) - 0.5).to(dt)
+w = torch.nn.Parameter((torch.rand(COUT, 64, 3, 3, device=dev) - 0.5) * 0.05); b = torch.nn.Parameter(torch.zeros(COUT, device=dev))
 pk = A.ops.pack_conv(w, b, dt)
-out = torch.empty_like(x)
+PLANAR = COUT < 16
+out = torch.empty(n, COUT, HW, HW, device=dev) if PLANAR else torch.empty(n, HW, HW, COUT, device=dev, dtype=dt)
+KW = dict(N=n, H=HW, W=HW, Cin=64, Cout=COUT, out=out, relu=not PLANAR, out_mode=A._lib.OUT_PLANAR if PLANAR else A._lib.OUT_NHWC)
 stamps = torch.zeros(256, dtype=torch.int64, device=dev)
 NL = 20
-A.ops.conv_raw(x, pk, N=n, H=48, W=48, Cin=64, Cout=64, out=out, relu=True, post_add=stamps.view(torch.float32))
+A.ops.conv_raw(x, pk, post_add=stamps.view(torch.float32), **KW)
 stamps.zero_()
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     for _ in range(NL):
-        A.ops.conv_raw(x, pk, N=n, H=48, W=48, Cin=64, Cout=64, out=out, relu=True, post_add=stamps.view(torch.float32))
+        A.ops.conv_raw(x, pk, post_add=stamps.view(torch.float32), **KW)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); g.replay(); e1.record()
 torch.cuda.synchronize()
