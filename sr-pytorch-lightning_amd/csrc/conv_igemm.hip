@@ -16,6 +16,11 @@
 #include <stdlib.h>
 #include "srk_common.h"
 
+// timing-experiment knob (separate builds only; measured: sc1 / nt stores do not beat plain stores here)
+#ifndef SRK_ST_AUX
+#define SRK_ST_AUX 0          // cache policy of the quad epilogue's stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+
 namespace {
 
 template <int DT, int TC, int KS> struct ConvCfg {
@@ -415,7 +420,7 @@ SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32x4 raw = {P[j][0], P[j][1], P[j][2], P[j][3]};
-        __builtin_amdgcn_raw_buffer_store_b128(raw, ro, vo[j], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(raw, ro, vo[j], 0, SRK_ST_AUX);
       }
       continue;
     }
@@ -468,7 +473,7 @@ SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int
       u32x4 raw;
       raw.x = pack2<DT>(v[0], v[1]); raw.y = pack2<DT>(v[2], v[3]);
       raw.z = pack2<DT>(v[4], v[5]); raw.w = pack2<DT>(v[6], v[7]);
-      __builtin_amdgcn_raw_buffer_store_b128(raw, ro, vo[j], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(raw, ro, vo[j], 0, SRK_ST_AUX);
     }
   }
 }
@@ -666,6 +671,9 @@ struct WsCfg {
   static constexpr int XPIECES = TIN * TIN * 8;        // 2,592
 };
 
+#ifndef SRK_WS_NOREAD
+#define SRK_WS_NOREAD 0      // timing ablation (separate build only): drop 1 of 4 fragment reads per K-step
+#endif
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           int q = 0;
 #pragma unroll
           for (int cb = 0; cb < CBW; ++cb) {
-            if (s + 2 < NSTEP && q < CBW + 2) { frag1(s + 2, q, fa[c2], fb0[c2], fb1[c2]); ++q; }
+            if (s + 2 < NSTEP && q < CBW + 2 && !SRK_WS_NOREAD) { frag1(s + 2, q, fa[c2], fb0[c2], fb1[c2]); ++q; }
             acc[cb][0] = Tr::mma(fa[c0][cb], fb0[c0], s == 0 ? bias16[cb] : acc[cb][0]);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < NSTEP && q < CBW + 2) { frag1(s + 2, q, fa[c2], fb0[c2], fb1[c2]); ++q; }

@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_a
   const int nt = tq + (slot < trem ? 1 : 0);
 
   // ---- per-lane DMA constants --------------------------------------------------------------------------
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, dy_bytes, 0x00020000);
+  const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
   int pconst[NPK], pyx[NPK];
 #pragma unroll
   for (int k = 0; k < NPK; ++k) {
@@ -298,29 +298,40 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_a
     dconst = (((d_iy0 * rd + si) * (W * rd) + d_ix * rd + sj) * a.dy_pitch + a.dy_coff + c0) * ESZ;
     dkstride = 2 * rd * (W * rd) * a.dy_pitch * ESZ;
   }
-  auto dma_tile = [&](int pt, char* Xb) {
+  // one tile's DMA = 11 halo pieces + 8 dY pieces per lane.  The pieces are issued one or two per K-step from inside
+  // the MFMA loop of the previous tile (an LDS-DMA issue costs 60-100 cycles of the wave's time in front of the loop,
+  // with the matrix pipe idle: one wave per SIMD; between MFMAs most of that hides behind the running MFMA)
+  struct TileAddr { int y0, x0, xbase, dbase; bool colok; unsigned Xb; };   // Xb: LDS byte address of the buffer
+  auto tile_addr = [&](int pt, char* Xb) {
+    TileAddr t;
     const int tX = pt % tilesX;
     const int q = pt / tilesX;
     const int tY = q % tilesY, n = q / tilesY;
-    const int y0 = tY * 16, x0 = tX * 16;
-    char* const Db = Xb + C::XS_BYTES;
-    const int xbase = (((n * H + y0) * W + x0) * a.x_pitch) * ESZ;
+    t.y0 = tY * 16; t.x0 = tX * 16;
+    t.xbase = (((n * H + t.y0) * W + t.x0) * a.x_pitch) * ESZ;
+    t.dbase = (((n * H * rd + t.y0 * rd) * (W * rd) + t.x0 * rd) * a.dy_pitch) * ESZ;
+    t.colok = d_cok && (t.x0 + d_ix < W);
+    t.Xb = lds0 + (unsigned)(Xb - smem);
+    return t;
+  };
+  auto dma_x_piece = [&](const TileAddr& t, int k) {
+    const int gy = t.y0 + (int)(short)(pyx[k] & 0xffff), gx = t.x0 + (pyx[k] >> 16);
+    const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const unsigned voff = ok ? (unsigned)(t.xbase + pconst[k]) : 0x80000000u;
+    if (k < NPK - 1 || tid + k * GT < C::XPIECES)
+      dma16_hidden(xrs, voff, __builtin_amdgcn_readfirstlane(t.Xb + ((k * GT + wave * 64) << 4)));
+  };
+  auto dma_d_piece = [&](const TileAddr& t, int k) {
+    const bool ok = t.colok && (t.y0 + d_iy0 + 2 * k < H);
+    const unsigned voff = ok ? (unsigned)(t.dbase + dconst + k * dkstride) : 0x80000000u;
+    dma16_hidden(drs, voff, __builtin_amdgcn_readfirstlane(t.Xb + C::XS_BYTES + ((k * GT + wave * 64) << 4)));
+  };
+  auto dma_tile = [&](int pt, char* Xb) {
+    const TileAddr t = tile_addr(pt, Xb);
 #pragma unroll
-    for (int k = 0; k < NPK; ++k) {
-      const int gy = y0 + (int)(short)(pyx[k] & 0xffff), gx = x0 + (pyx[k] >> 16);
-      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      const unsigned voff = ok ? (unsigned)(xbase + pconst[k]) : 0x80000000u;
-      if (k < NPK - 1 || tid + k * GT < C::XPIECES)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(Xb + ((k * GT + wave * 64) << 4)), 16, voff, 0, 0, 0);
-    }
-    const int dbase = (((n * H * rd + y0 * rd) * (W * rd) + x0 * rd) * a.dy_pitch) * ESZ;
-    const bool colok = d_cok && (x0 + d_ix < W);
+    for (int k = 0; k < NPK; ++k) dma_x_piece(t, k);
 #pragma unroll
-    for (int k = 0; k < NDK; ++k) {
-      const bool ok = colok && (y0 + d_iy0 + 2 * k < H);
-      const unsigned voff = ok ? (unsigned)(dbase + dconst + k * dkstride) : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void_t*)(Db + ((k * GT + wave * 64) << 4)), 16, voff, 0, 0, 0);
-    }
+    for (int k = 0; k < NDK; ++k) dma_d_piece(t, k);
   };
 
   f32x16 acc[9];
@@ -346,7 +357,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_a
     char* const Ds = Xs + C::XS_BYTES;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile `it` landed
     __builtin_amdgcn_s_barrier();                         // ... for every wave; the other buffer is free
-    if (it + 1 < nt) dma_tile(t0 + it + 1, smem + ((it + 1) & 1) * BUF_BYTES);
+    const bool more = it + 1 < nt;
+    const TileAddr nxt = tile_addr(more ? t0 + it + 1 : t0 + it, smem + ((it + 1) & 1) * BUF_BYTES);
 
     if (do_bias) {
       // bias gradient: lane owns LDS slot (tid&7) of pixels (tid>>3) + 32k; the slot's channel chunk is the same
@@ -385,6 +397,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_a
       for (int t = 0; t < 9; ++t) {
         const int kh = t / KS, kw = t - kh * KS;
         acc[t] = Tr::mma(xf[(y + kh) & 3][kw], bf, acc[t]);
+        // next tile's DMA: halo piece y after the 3rd MFMA of this step, dY piece y/2 after the 6th of the even steps
+        if (t == 2 && y < NPK && more) dma_x_piece(nxt, y);
+        if (t == 5 && (y & 1) == 0 && (y >> 1) < NDK && more) dma_d_piece(nxt, y >> 1);
       }
       bf = bfn;
       __builtin_amdgcn_sched_barrier(0);

@@ -98,6 +98,32 @@ SRK_DEV void lds_write16(char* p, i32x4 v) { *reinterpret_cast<i32x4*>(p) = v; }
 
 SRK_DEV i32x4 gload16(const void* p) { return *reinterpret_cast<const i32x4*>(p); }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA the compiler does not see.  hipcc treats `buffer_load ... lds` (the builtin) as a store to LDS that
+// may alias EVERY later LDS read, and puts `s_waitcnt vmcnt(0)` in front of the next ds_read: a tile prefetched into
+// the other half of a double buffer is then waited for before the current tile's MFMA loop starts (no overlap at
+// all).  Issued from inline asm, the transfer is invisible to that pass; the kernel orders it by hand
+// (`s_waitcnt vmcnt(0)` + s_barrier before the buffer is read).  The compiler's own vmcnt bookkeeping stays safe:
+// the counter retires in order, so operations it does not know about can only make its waits stricter.
+//   rsrc: buffer descriptor in SGPRs (make_rsrc4), voff: per-lane byte offset (out of range -> zero fill),
+//   lds_addr: wave-uniform LDS byte address; lane l lands at lds_addr + 16*l.
+// ---------------------------------------------------------------------------------------------
+SRK_DEV i32x4 make_rsrc4(const void* base, unsigned bytes) {
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uintptr_t)base);
+  r.y = __builtin_amdgcn_readfirstlane((int)(((uintptr_t)base >> 32) & 0xffff));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+SRK_DEV unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+SRK_DEV void dma16_hidden(i32x4 rsrc, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+               :: "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory", "m0");
+}
+
 // XCD-contiguous block remap: blocks b and b+8 share an XCD under round-robin dispatch, so give each
 // XCD a contiguous range of the linear work index (neighbouring tiles then share that XCD's L2).
 // Bijective for every grid size; placement only affects speed, never results.
