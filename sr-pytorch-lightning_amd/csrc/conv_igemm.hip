@@ -17,6 +17,12 @@
 #include "srk_common.h"
 
 // timing-experiment knob (separate builds only; measured: sc1 / nt stores do not beat plain stores here)
+#ifndef SRK_WS_STAMPS
+#define SRK_WS_STAMPS 0
+#endif
+#ifndef SRK_WS_ABLATE
+#define SRK_WS_ABLATE 0        // timing ablations (wrong results): 1 = skip MFMAs, 2 = skip epilogue, 4 = skip halo DMA, 16 = no weight-order rotation
+#endif
 #ifndef SRK_ST_AUX
 #define SRK_ST_AUX 0          // cache policy of the quad epilogue's stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
@@ -478,6 +484,123 @@ SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int
   }
 }
 
+// ---- the same epilogue with PREFETCHED residual / mask (conv_ws_kernel<..., EARLY = true>) ----------------------------
+// vmcnt retires in order.  A residual load issued in the epilogue phase sits behind the 11 DMA pieces of the next halo
+// tile, so its data only becomes usable when that whole tile has landed (3-5k cycles: s_memtime stamps showed the
+// first pixel block's arithmetic finishing 5.8k cycles into a 9.3k-cycle phase with the data long there, because the
+// compiler's own wait in front of the first use is vmcnt(0) whenever the loads come from an earlier loop iteration).
+// So: the pieces of tile j are requested at the START of tile j's MFMA phase, from inline asm (the compiler neither
+// sinks them nor waits for them) and completed by an explicit s_waitcnt at the END of that phase, when they have long
+// landed; the epilogue phase then runs   DMA of the next tile | compute(0) | store(0) | compute(1) | store(1)
+// on registers that are already valid.
+// "early" loads the residual if there is one, else the mask (4 x 16 bytes per lane and pixel block).
+struct QuadGeo {          // where this lane's quad lands: see conv_ws_kernel
+  int pbase[2];           // destination pixel index of the quad's first pixel, per pixel block
+  int okmask[2];          // bit j: pixel j of the quad is inside the image
+  int pstep;              // destination pixel stride between x-neighbours (r for a pixel-shuffled store)
+  int cl;                 // destination channel of this lane's 8-channel piece AFTER the transpose
+};
+struct QuadRegs { u32x4 r[4]; };
+
+SRK_DEV unsigned quad_off(const QuadGeo& g, int pb, int j, int pitch, int coff) {
+  return ((g.okmask[pb] >> j) & 1) ? (unsigned)(((g.pbase[pb] + j * g.pstep) * pitch + coff + g.cl) * 2) : SRK_OOB;
+}
+
+SRK_DEV u32x4 buf_load16_hidden(i32x4 rsrc, unsigned voff) {
+  u32x4 r;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
+  return r;      // NOT valid until the caller's own s_waitcnt (quad_early_wait)
+}
+// Prefetch in the NATURAL accumulator layout: piece k = channels 8k..8k+7 of this lane's own 32 channels of its own
+// pixel (pixel qi of the quad).  The arithmetic then runs before the transpose, on 16-bit-packed results, which halves
+// the transpose work (64 instead of 128 cross-lane moves+selects per pixel block): the epilogue phase is bound by
+// vector-instruction issue next to the other group's MFMA wave (stamps: 2.4-3.1k cycles per pixel block with the fp32
+// transposes, all operands already in registers).  The 16-byte-per-line load pattern this needs is the slow one for
+// the memory path, but it is issued in the MFMA phase, where this group has no other memory traffic.
+struct QuadPre { i32x4 rs; unsigned base[2]; };
+SRK_DEV QuadPre quad_early_setup(const srk_conv_args& a, const QuadGeo& g, int qi) {
+  QuadPre p;
+  const bool has_res = a.res != nullptr, has_mask = a.mask != nullptr;
+  p.rs = make_rsrc4(has_res ? a.res : a.mask, 0x7fffffffu);
+  const int pitch = has_res ? a.res_pitch : a.mask_pitch, coff = has_res ? a.res_coff : a.mask_coff;
+  const int c0 = g.cl - 8 * qi;                 // destination channel of this lane's first channel (g.cl is post-transpose)
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const bool ok = (g.okmask[pb] >> qi) & 1;
+    p.base[pb] = ok ? (unsigned)(((g.pbase[pb] + qi * g.pstep) * pitch + coff + c0) * 2) : SRK_OOB;
+  }
+  return p;
+}
+// piece k of pixel block pb (out-of-image pixels: base is out of range and stays so with +16k)
+SRK_DEV void quad_early_piece(const QuadPre& p, int pb, int k, QuadRegs& e) {
+  e.r[k] = buf_load16_hidden(p.rs, p.base[pb] + 16u * k);     // unconditional: EARLY is only dispatched with a residual or a mask
+}
+// all vector-memory operations of this wave older than its `younger` most recent ones have completed; ties the
+// prefetched registers to the wait so that no use can be scheduled in front of it
+template <int YOUNGER>
+SRK_DEV void quad_early_wait(QuadRegs& e0, QuadRegs& e1) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(e0.r[0]), "+v"(e0.r[1]), "+v"(e0.r[2]), "+v"(e0.r[3]), "+v"(e1.r[0]), "+v"(e1.r[1]), "+v"(e1.r[2]), "+v"(e1.r[3])
+               : "n"(YOUNGER) : "memory");
+}
+
+// accumulators of pixel block pb -> the 4 packed 16-byte pieces this lane stores (out.r[j]: pixel j of the quad)
+// accumulators of pixel block pb (+ prefetched residual OR mask, natural layout) -> the 4 packed 16-byte pieces this
+// lane stores after the quad transpose (out.r[j]: pixel j of the quad).  No memory operation in here: a compiler-visible
+// load would put `s_waitcnt vmcnt(0)` at the merge point of every path, i.e. make every tile wait for the halo DMA issued
+// just before (measured: 4.6k of a 9.4k-cycle phase); the dispatcher sends residual + mask to the plain variant.
+template <int DT>
+SRK_DEV void quad_compute(const srk_conv_args& a, f32x16 (&acc)[2][2], int pb, const QuadRegs& e, bool use_mask_lo,
+                          bool use_mask_hi, int qi, QuadRegs& out) {
+  static_assert(DTraits<DT>::IS16, "16-bit types only");
+  const bool has_res = a.res != nullptr, has_mask = a.mask != nullptr && !has_res, relu = a.relu != 0;
+  const float scale = a.scale;
+  const bool b0 = qi & 1, b1 = qi & 2;
+  uint32_t P[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = acc[k >> 1][pb][8 * (k & 1) + x];
+    if (relu) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) v[x] = fmaxf(v[x], 0.f);
+    }
+    if (scale != 1.f) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) v[x] *= scale;
+    }
+    if (has_res) {
+      float r8[8];
+      unpack2<DT>(e.r[k].x, r8[0], r8[1]); unpack2<DT>(e.r[k].y, r8[2], r8[3]);
+      unpack2<DT>(e.r[k].z, r8[4], r8[5]); unpack2<DT>(e.r[k].w, r8[6], r8[7]);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) v[x] += r8[x];
+    }
+    if (has_mask) {
+      const bool use = (k >> 1) ? use_mask_hi : use_mask_lo;      // channel block of piece k: 16 * (k >> 1)
+      float m8[8];
+      unpack2<DT>(e.r[k].x, m8[0], m8[1]); unpack2<DT>(e.r[k].y, m8[2], m8[3]);
+      unpack2<DT>(e.r[k].z, m8[4], m8[5]); unpack2<DT>(e.r[k].w, m8[6], m8[7]);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) v[x] = (!use || m8[x] > 0.f) ? v[x] : 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) P[k][d] = pack2<DT>(v[2 * d], v[2 * d + 1]);
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) quad_transpose4(P[0][d], P[1][d], P[2][d], P[3][d], b0, b1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out.r[j] = u32x4{P[j][0], P[j][1], P[j][2], P[j][3]};
+}
+
+SRK_DEV void quad_store(const srk_conv_args& a, const QuadGeo& g, int pb, const QuadRegs& out) {
+  const __amdgpu_buffer_rsrc_t ro = big_rsrc(a.out);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    __builtin_amdgcn_raw_buffer_store_b128(out.r[j], ro, quad_off(g, pb, j, a.out_pitch, a.out_coff), 0, SRK_ST_AUX);
+}
+
 template <int DT, int TC, int KS>
 __global__ __launch_bounds__((ConvCfg<DT, TC, KS>::NT)) void conv_igemm_kernel(const srk_conv_args a, int tilesX,
                                                                               int tilesY, int ctiles, int fast) {
@@ -657,9 +780,9 @@ __global__ __launch_bounds__((ConvCfg<DT, TC, KS>::NT)) void conv_igemm_kernel(c
 // (buffer_load ... lds: no staging registers, no wait) while the other wave group runs its MFMAs:
 //     LDS = 73,728 (weights) + 2 x 41,472 (one halo image per wave group) = 156,672 B of the CU's 160 KiB.
 // Out-of-image halo pixels use an out-of-range buffer offset, for which the hardware writes zeros, so no
-// lane ever skips its LDS slot.  Environment knobs (diagnostics only): SRK_NO_WS=1 routes everything to the
-// streaming kernel; SRK_WS_DBG bit 1/2/4 skip MFMAs / epilogue / halo DMA (timing ablations, wrong results),
-// bit 8 writes s_memtime phase stamps to the buffer passed as `post_add` (tools/stamp_ws.py).
+// lane ever skips its LDS slot.  Diagnostics: SRK_NO_WS=1 (environment) routes everything to the streaming kernel;
+// -DSRK_WS_ABLATE=<bits> and -DSRK_WS_STAMPS=1 (separate builds, `make stamp`) skip MFMAs / epilogue / halo DMA for
+// timing ablations and write s_memtime phase stamps through `post_add` (tools/stamp_ws.py).
 // =================================================================================================
 
 struct WsCfg {
@@ -682,9 +805,9 @@ SRK_DEV void dma16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int DT, int CBW, int NKS, bool FAST>
+template <int DT, int CBW, int NKS, bool FAST, bool EARLY>
 __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
-                                                          int nptiles, unsigned x_bytes, int tq, int trem, int dbg,
+                                                          int nptiles, unsigned x_bytes, int tq, int trem, int dbg_rt,
                                                           int xs_img, int xs_row, int xs_col, int wtap) {
   // wtap: 16-byte chunks per tap in the packed weight buffer (8 for Cin = 64; 8*r*r when this launch handles one
   // 64-channel K-block of a wider reduction, a.wpk then points at that block's first chunk)
@@ -706,7 +829,11 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   constexpr int NPK = (C::XPIECES + GT - 1) / GT;          // 11 halo pieces per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Wl = smem;
-  const unsigned long long t_entry = (dbg & 8) ? __builtin_amdgcn_s_memtime() : 0ull;
+  constexpr int dbg = SRK_WS_ABLATE;      // compile-time: a run-time knob costs registers and branches in the hot loops
+  (void)dbg_rt;
+#if SRK_WS_STAMPS
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -764,15 +891,23 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   };
 
   // bias as the C operand of the first MFMA of every tile (no accumulator initialisation pass); loaded FIRST so
-  // that the counted wait of group 1 below covers it
-  f32x16 bias16[CBW];
+  // that the counted wait of group 1 below covers it.  EARLY: the 16*CBW bias registers are needed for the prefetched
+  // residual / mask pieces, so the bias is parked in LDS behind the halo buffers and re-read per tile (8 broadcast
+  // ds_read_b128 per lane)
+  static_assert(!EARLY || (FAST && CBW == 2), "EARLY is a variant of the quad epilogue");
+  f32x16 bias16[EARLY ? 1 : CBW];
+  float* const Bl = reinterpret_cast<float*>(smem + WPIECES * 16 + 2 * C::XS_BYTES);
+  if constexpr (EARLY) {
+    if (tid < TCW) Bl[tid] = a.bias ? a.bias[ctile * TCW + tid] : 0.f;
+  } else {
 #pragma unroll
-  for (int cb = 0; cb < CBW; ++cb)
+    for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ctile * TCW + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      bias16[cb][4 * i + 0] = b.x; bias16[cb][4 * i + 1] = b.y; bias16[cb][4 * i + 2] = b.z; bias16[cb][4 * i + 3] = b.w;
-    }
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ctile * TCW + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias16[cb][4 * i + 0] = b.x; bias16[cb][4 * i + 1] = b.y; bias16[cb][4 * i + 2] = b.z; bias16[cb][4 * i + 3] = b.w;
+      }
+  }
   asm volatile("" ::: "memory");
   // ---- prologue: all 9 taps of this channel tile (both groups), then each group's first halo tile ---------------
   // every workgroup needs the SAME weight bytes at the same moment: walking them in the same order would send all
@@ -810,7 +945,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   const bool planar4 = !FAST && CBW == 1 && a.out_mode == SRK_OUT_PLANAR && a.ps_r <= 1 && a.Cout <= 4 &&
                        (long long)a.N * a.Cout * H * W < (1ll << 29);
   float pa4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (planar4 && a.post_add && !(dbg & 8)) {
+  if (planar4 && a.post_add && !SRK_WS_STAMPS) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) pa4[e] = e < a.Cout ? a.post_add[e] : 0.f;
   }
@@ -823,21 +958,53 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  // diagnostic stamps (dbg & 8, never in a timed build): s_memtime at the start and end of each phase body
-  unsigned long long* const stamp = (dbg & 8) && blockIdx.x == 0 && (tid & 255) == 0
+  // diagnostic stamps (separate -DSRK_WS_STAMPS=1 build, `make stamp` + tools/stamp_ws.py): s_memtime at the start and
+  // end of each phase body of workgroup 0, written through the post_add pointer
+#if SRK_WS_STAMPS
+  unsigned long long* const stamp = blockIdx.x == 0 && (tid & 255) == 0
                                         ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.post_add)) + grp * 128 : nullptr;
+#define SRK_STAMP(i) do { if (stamp) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SRK_STAMP(i) do { } while (0)
+#endif
+  // EARLY: geometry of this lane's quad for tile j, and the prefetched residual / mask pieces of the tile in flight
+  const int qi = px & 3;
+  const int cq = 32 * h + 8 * qi;
+  auto quad_geo = [&](int j) {
+    int n, y0, x0;
+    tile_of(j, n, y0, x0);
+    const int gxb = x0 + (px & ~3);
+    const int xm = min(max(W - gxb, 0), 4);
+    const int xmask = (1 << xm) - 1;
+    const int gy0 = y0 + pyb[0], gy1 = y0 + pyb[1];
+    QuadGeo g;
+    g.pbase[0] = (n * H * fdst.rr + gy0 * fdst.rr + fdst.si) * (W * fdst.rr) + gxb * fdst.rr + fdst.sj;
+    g.pbase[1] = g.pbase[0] + 2 * fdst.rr * (W * fdst.rr);            // pyb[1] = pyb[0] + 2
+    g.okmask[0] = gy0 < H ? xmask : 0;
+    g.okmask[1] = gy1 < H ? xmask : 0;
+    g.pstep = fdst.rr;
+    g.cl = fdst.cbase + cq;
+    return g;
+  };
+  QuadRegs e0, e1;
 #pragma unroll 1
   for (int p = 0; p < nph; ++p) {
     const int q = p - grp;            // this group's own phase counter
     const int j = q >> 1;
-    if (stamp) stamp[2 * p] = __builtin_amdgcn_s_memtime();
+    SRK_STAMP(2 * p);
     if (q >= 0 && j < nj) {
       if ((q & 1) == 0) {
         if (dbg & 1) {
 #pragma unroll
-          for (int cb = 0; cb < CBW; ++cb) { acc[cb][0] = bias16[cb]; acc[cb][1] = bias16[cb]; }
+          for (int cb = 0; cb < CBW; ++cb) { acc[cb][0] = bias16[EARLY ? 0 : cb]; acc[cb][1] = bias16[EARLY ? 0 : cb]; }
         } else {
         // ---------------- MFMA phase: 9*NKS K-steps, fragments fetched two steps ahead ---------------------------
+        // EARLY: the 12 swizzled operand addresses are rebuilt per tile (opaque copy of h): hoisted out of the tile loop
+        // they would stay live through the epilogue phase, which needs the registers
+        int hx = h;
+        if constexpr (EARLY) {
+          asm volatile("" : "+v"(hx));
+        }
         // fragment piece q of K-step s: q < CBW -> weights of channel block q, q = CBW / CBW+1 -> pixel block 0 / 1
         auto frag1 = [&](int s, int q, i32x4 (&af)[CBW], i32x4& b0, i32x4& b1) {
           const int tap = s / NKS, ks = s - tap * NKS;
@@ -846,7 +1013,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           if (q < CBW) {
             af[q] = lds_read16(wlane + (((tap * 2 * NKS + kc2) * TCW + q * 32) << 4));
           } else {
-            const int so = (((kc2 + h) ^ gsw[kw]) << 4) + ((kh * C::PITCH + kw) << 7);
+            const int so = (((kc2 + hx) ^ gsw[kw]) << 4) + ((kh * C::PITCH + kw) << 7);
             if (q == CBW) b0 = lds_read16(xl0 + so);
             else b1 = lds_read16(xl1 + so);
           }
@@ -856,8 +1023,20 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           for (int q = 0; q < CBW + 2; ++q) frag1(s, q, af, b0, b1);
         };
         i32x4 fa[3][CBW], fb0[3], fb1[3];
+        if constexpr (EARLY) {
+#pragma unroll
+          for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const f32x4 b = *reinterpret_cast<const f32x4*>(Bl + 4 * h + cb * 32 + 8 * i);
+              acc[cb][0][4 * i + 0] = b.x; acc[cb][0][4 * i + 1] = b.y; acc[cb][0][4 * i + 2] = b.z; acc[cb][0][4 * i + 3] = b.w;
+              acc[cb][1][4 * i + 0] = b.x; acc[cb][1][4 * i + 1] = b.y; acc[cb][1][4 * i + 2] = b.z; acc[cb][1][4 * i + 3] = b.w;
+            }
+        }
         frag(0, fa[0], fb0[0], fb1[0]);
         frag(1, fa[1], fb0[1], fb1[1]);
+        QuadPre pre;
+        if constexpr (EARLY) pre = quad_early_setup(a, quad_geo(j), qi);     // behind the first LDS reads: overlaps their latency
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
@@ -865,23 +1044,61 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           // ONE LDS read per MFMA gap (four waves x one ds_read_b128 = 16 of the gap's 32 LDS-array cycles); a burst of
           // 4 reads per wave in one gap oversubscribes the array while the waves run in step
           int q = 0;
+          if constexpr (EARLY) {
+            // one prefetch piece every 4th K-step: a 16-byte-per-line load keeps the address path busy for ~64 cycles,
+            // and eight of them back to back stall the wave's (in-order) issue for ~1k cycles with the matrix pipe idle
+            if (s % 4 == 1 && s / 4 < 8 && !(dbg & 2)) quad_early_piece(pre, (s / 4) >> 2, (s / 4) & 3, (s / 4) < 4 ? e0 : e1);
+          }
 #pragma unroll
           for (int cb = 0; cb < CBW; ++cb) {
             if (s + 2 < NSTEP && q < CBW + 2 && !SRK_WS_NOREAD) { frag1(s + 2, q, fa[c2], fb0[c2], fb1[c2]); ++q; }
-            acc[cb][0] = Tr::mma(fa[c0][cb], fb0[c0], s == 0 ? bias16[cb] : acc[cb][0]);
+            acc[cb][0] = Tr::mma(fa[c0][cb], fb0[c0], (!EARLY && s == 0) ? bias16[EARLY ? 0 : cb] : acc[cb][0]);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < NSTEP && q < CBW + 2) { frag1(s + 2, q, fa[c2], fb0[c2], fb1[c2]); ++q; }
             if (cb == CBW - 1)
               for (; s + 2 < NSTEP && q < CBW + 2; ++q) frag1(s + 2, q, fa[c2], fb0[c2], fb1[c2]);
-            acc[cb][1] = Tr::mma(fa[c0][cb], fb1[c0], s == 0 ? bias16[cb] : acc[cb][1]);
+            acc[cb][1] = Tr::mma(fa[c0][cb], fb1[c0], (!EARLY && s == 0) ? bias16[EARLY ? 0 : cb] : acc[cb][1]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
         __builtin_amdgcn_s_setprio(0);
+        // the pieces requested 5k cycles ago are the wave's only outstanding vector-memory operations: make them
+        // architecturally complete HERE, in the straight-line code that issued them.  (Waiting in the epilogue phase
+        // instead lets the compiler place its loop-carried register copies of e0 / e1 in front of the wait.)
+        if constexpr (EARLY) quad_early_wait<0>(e0, e1);
         }
       } else {
         // ---------------- epilogue phase: next halo tile's DMA first (this group's MFMAs on the buffer are done),
         // then the finished tile; the counted wait leaves the 16 stores per lane in flight, the DMA is older ----
+        if constexpr (EARLY) {
+          const bool more = j + 1 < nj;
+          if (more && !(dbg & 4)) dma_x(j + 1);
+          if (p == 3) SRK_STAMP(30);
+          if (!(dbg & 2)) {
+            const QuadGeo geo = quad_geo(j);
+            const bool um_lo = ctile * TCW + 32 * h >= a.mask_from, um_hi = ctile * TCW + 32 * h + 16 >= a.mask_from;
+            QuadRegs o0, o1;
+            quad_compute<DT>(a, acc, 0, e0, um_lo, um_hi, qi, o0);
+#if SRK_WS_STAMPS
+            asm volatile("" :: "v"(o0.r[0].x), "v"(o0.r[3].w));
+            if (p == 3) SRK_STAMP(31);
+#endif
+            quad_store(a, geo, 0, o0);
+            if (p == 3) SRK_STAMP(32);
+            quad_compute<DT>(a, acc, 1, e1, um_lo, um_hi, qi, o1);
+#if SRK_WS_STAMPS
+            asm volatile("" :: "v"(o1.r[0].x), "v"(o1.r[3].w));
+            if (p == 3) SRK_STAMP(33);
+#endif
+            quad_store(a, geo, 1, o1);
+            if (p == 3) SRK_STAMP(34);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the 8 dwordx4 stores per lane stay in flight
+            if (p == 3) SRK_STAMP(35);
+          } else {
+            asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][5]), "v"(acc[CBW - 1][0][9]), "v"(acc[CBW - 1][1][15]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        } else {
         if (j + 1 < nj && !(dbg & 4)) dma_x(j + 1);
         if (!(dbg & 2)) {
           int n, y0, x0;
@@ -914,17 +1131,20 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][5]), "v"(acc[CBW - 1][0][9]), "v"(acc[CBW - 1][1][15]));
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        }
       }
     }
     if (q < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 1, phase 0: its first halo tile
-    if (stamp) stamp[2 * p + 1] = __builtin_amdgcn_s_memtime();
+    SRK_STAMP(2 * p + 1);
     __builtin_amdgcn_s_barrier();
   }
+#if SRK_WS_STAMPS
   if (stamp) {                       // [100] entry of the FIRST stamped launch, [101] entry / [102] exit of the last one
     if (stamp[100] == 0) stamp[100] = t_entry;
     stamp[101] = t_entry;
     stamp[102] = __builtin_amdgcn_s_memtime();
   }
+#endif
 }
 
 // launcher-side preconditions of conv_epilogue_fast
@@ -944,11 +1164,11 @@ static bool conv_fast_ok(const srk_conv_args& a, int esz) {
   return mx * esz < 0x7fff0000LL;
 }
 
-template <int DT, int CBW, int NKS, bool FAST> int launch_ws(const srk_conv_args& a, hipStream_t st) {
+template <int DT, int CBW, int NKS, bool FAST, bool EARLY = false> int launch_ws(const srk_conv_args& a, hipStream_t st) {
   typedef WsCfg C;
   constexpr int TCW = CBW * 32;
-  constexpr int LDS = 9 * 2 * NKS * TCW * 16 + 2 * C::XS_BYTES;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<DT, CBW, NKS, FAST>),
+  constexpr int LDS = 9 * 2 * NKS * TCW * 16 + 2 * C::XS_BYTES + (EARLY ? TCW * 4 : 0);      // weights, two halo buffers (, bias)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<DT, CBW, NKS, FAST, EARLY>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) {
     srk_set_error("srk_conv2d(ws): cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
@@ -969,7 +1189,7 @@ template <int DT, int CBW, int NKS, bool FAST> int launch_ws(const srk_conv_args
   const int rin = a.x_ps > 1 ? a.x_ps : 1;
   const long long xb = ((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2;
   if (rin == 1) {
-    hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST>), dim3(grid), dim3(C::NT), LDS, st, a, tilesX, tilesY, ctiles, (int)nptiles,
+    hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST, EARLY>), dim3(grid), dim3(C::NT), LDS, st, a, tilesX, tilesY, ctiles, (int)nptiles,
                        (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), dbg, a.H * a.W * a.x_pitch, a.W * a.x_pitch,
                        a.x_pitch, 2 * NKS);
     SRK_LAUNCH_CHECK();
@@ -992,7 +1212,7 @@ template <int DT, int CBW, int NKS, bool FAST> int launch_ws(const srk_conv_args
       b.res = a.out; b.res_pitch = a.out_pitch; b.res_coff = a.out_coff;
     }
     if (ij < r2 - 1) b.mask = nullptr;
-    hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST>), dim3(grid), dim3(C::NT), LDS, st, b, tilesX, tilesY, ctiles, (int)nptiles,
+    hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST, EARLY>), dim3(grid), dim3(C::NT), LDS, st, b, tilesX, tilesY, ctiles, (int)nptiles,
                        (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), dbg,
                        a.H * rin * a.W * rin * a.x_pitch, rin * a.W * rin * a.x_pitch, rin * a.x_pitch, 8 * r2);
     SRK_LAUNCH_CHECK();
@@ -1027,7 +1247,12 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
     const long long xbytes = ((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2;
     if (a.KH == 3 && xbytes < 0x7fffffffLL && getenv("SRK_NO_WS") == nullptr) {
       if (a.CoutP % 64 == 0 && conv_fast_ok(a, 2)) {
-        if (rin == 1 && a.Cin == 64) return launch_ws<DT, 2, 4, true>(a, st);
+        if (rin == 1 && a.Cin == 64) {
+          // residual OR ReLU mask in the epilogue (not both): the variant that prefetches it during the MFMA phase
+          static const bool no_early = getenv("SRK_NO_EARLY") != nullptr;
+          if (((a.res != nullptr) != (a.mask != nullptr)) && !no_early) return launch_ws<DT, 2, 4, true, true>(a, st);
+          return launch_ws<DT, 2, 4, true>(a, st);
+        }
         if (rin == 1 && a.Cin == 16) return launch_ws<DT, 2, 1, true>(a, st);          // e.g. dgrad of the 3-channel tail conv
         if (rin > 1 && a.Cin == 64 * rin * rin && !a.relu && a.out_mode == SRK_OUT_NHWC) return launch_ws<DT, 2, 4, true>(a, st);
       }

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase s_memtime stamps of the two wave groups of workgroup 0 of conv_ws_kernel (SRK_WS_DBG=8)."""
+"""Diagnostic: per-phase s_memtime stamps of the two wave groups of workgroup 0 of conv_ws_kernel.
+Needs the stamp build of the library: `make -C sr-pytorch-lightning_amd/csrc stamp` (optionally
+STAMP_DEFS=-DSRK_WS_ABLATE=<bits> for the timing ablations)."""
 import os, sys
-os.environ["SRK_WS_DBG"] = os.environ.get("STAMP_DBG", "8")
+os.environ.setdefault("SRK_LIB_PATH", os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "libsrk_stamp.so"))   # make -C .../csrc stamp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sr_amd as A
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -12,7 +14,9 @@ w = torch.nn.Parameter((torch.rand(COUT, 64, 3, 3, device=dev) - 0.5) * 0.05); b
 pk = A.ops.pack_conv(w, b, dt)
 PLANAR = COUT < 16
 out = torch.empty(n, COUT, HW, HW, device=dev) if PLANAR else torch.empty(n, HW, HW, COUT, device=dev, dtype=dt)
-KW = dict(N=n, H=HW, W=HW, Cin=64, Cout=COUT, out=out, relu=not PLANAR, out_mode=A._lib.OUT_PLANAR if PLANAR else A._lib.OUT_NHWC)
+RES = torch.zeros_like(out) if os.environ.get('STAMP_RES') else None
+MASK = torch.ones_like(out) if os.environ.get('STAMP_MASK') else None
+KW = dict(res=RES, mask=MASK, N=n, H=HW, W=HW, Cin=64, Cout=COUT, out=out, relu=(not PLANAR) and RES is None and MASK is None, out_mode=A._lib.OUT_PLANAR if PLANAR else A._lib.OUT_NHWC)
 stamps = torch.zeros(256, dtype=torch.int64, device=dev)
 NL = 20
 A.ops.conv_raw(x, pk, post_add=stamps.view(torch.float32), **KW)
@@ -37,3 +41,12 @@ for g in (0, 1):
     for p in range(12):
         if t[2 * p] == 0: break
         print(f"   phase {p:2d}: start {t[2*p]-t0:7d}  end {t[2*p+1]-t0:7d}  body {t[2*p+1]-t[2*p]:6d}")
+
+
+
+
+t = st[0:128]
+if t[30]:
+    b = t[6]
+    names = ["DMA issued", "compute(0) done", "store(0) issued", "compute(1) done", "store(1) issued", "final wait done"]
+    print("group 0, phase 3 (epilogue, prefetch variant) sub-stamps, ticks from phase start: " + "; ".join(f"{nm} {t[30+i]-b}" for i, nm in enumerate(names)))
