@@ -807,7 +807,7 @@ SRK_DEV void dma16(const void* gsrc, char* lds_wave_base) {
 
 template <int DT, int CBW, int NKS, bool FAST, bool EARLY>
 __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
-                                                          int nptiles, unsigned x_bytes, int tq, int trem, int dbg_rt,
+                                                          int nptiles, unsigned x_bytes, int tq, int trem, int /*unused*/,
                                                           int xs_img, int xs_row, int xs_col, int wtap) {
   // wtap: 16-byte chunks per tap in the packed weight buffer (8 for Cin = 64; 8*r*r when this launch handles one
   // 64-channel K-block of a wider reduction, a.wpk then points at that block's first chunk)
@@ -830,7 +830,6 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Wl = smem;
   constexpr int dbg = SRK_WS_ABLATE;      // compile-time: a run-time knob costs registers and branches in the hot loops
-  (void)dbg_rt;
 #if SRK_WS_STAMPS
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -1045,9 +1044,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           // 4 reads per wave in one gap oversubscribes the array while the waves run in step
           int q = 0;
           if constexpr (EARLY) {
-            // one prefetch piece every 4th K-step: a 16-byte-per-line load keeps the address path busy for ~64 cycles,
+            // one prefetch piece every 4th K-step (every step when the loop is short): a 16-byte-per-line load keeps the address path busy for ~64 cycles,
             // and eight of them back to back stall the wave's (in-order) issue for ~1k cycles with the matrix pipe idle
-            if (s % 4 == 1 && s / 4 < 8 && !(dbg & 2)) quad_early_piece(pre, (s / 4) >> 2, (s / 4) & 3, (s / 4) < 4 ? e0 : e1);
+            constexpr int PST = NSTEP >= 33 ? 4 : 1;       // all 8 pieces must fit: steps 1, 1+PST, ..., 1+7*PST < NSTEP
+            static_assert(1 + 7 * PST < NSTEP, "prefetch schedule does not fit the K loop");
+            if (s >= 1 && (s - 1) % PST == 0 && (s - 1) / PST < 8 && !(dbg & 2)) {
+              const int pi = (s - 1) / PST;
+              quad_early_piece(pre, pi >> 2, pi & 3, pi < 4 ? e0 : e1);
+            }
           }
 #pragma unroll
           for (int cb = 0; cb < CBW; ++cb) {
@@ -1164,7 +1168,10 @@ static bool conv_fast_ok(const srk_conv_args& a, int esz) {
   return mx * esz < 0x7fff0000LL;
 }
 
-template <int DT, int CBW, int NKS, bool FAST, bool EARLY = false> int launch_ws(const srk_conv_args& a, hipStream_t st) {
+// one launch; `early` picks the variant that prefetches the residual / mask (see quad_compute)
+template <int DT, int CBW, int NKS, bool FAST, bool EARLY>
+static int launch_ws_one(const srk_conv_args& b, hipStream_t st, unsigned grid, int tilesX, int tilesY, int ctiles, int nptiles,
+                         unsigned xb, int tq, int trem, int xs_img, int xs_row, int xs_col, int wtap) {
   typedef WsCfg C;
   constexpr int TCW = CBW * 32;
   constexpr int LDS = 9 * 2 * NKS * TCW * 16 + 2 * C::XS_BYTES + (EARLY ? TCW * 4 : 0);      // weights, two halo buffers (, bias)
@@ -1174,7 +1181,16 @@ template <int DT, int CBW, int NKS, bool FAST, bool EARLY = false> int launch_ws
     srk_set_error("srk_conv2d(ws): cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
     return (int)attr;
   }
+  hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST, EARLY>), dim3(grid), dim3(C::NT), LDS, st, b, tilesX, tilesY, ctiles, nptiles,
+                     xb, tq, trem, 0, xs_img, xs_row, xs_col, wtap);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int DT, int CBW, int NKS, bool FAST> int launch_ws(const srk_conv_args& a, hipStream_t st) {
+  constexpr int TCW = CBW * 32;
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  static const bool no_early = getenv("SRK_NO_EARLY") != nullptr;
   const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16, ctiles = a.CoutP / TCW;
   const long long nptiles = (long long)a.N * tilesX * tilesY;
   if (nptiles <= 0 || nptiles > 0x7fffffffLL) {
@@ -1185,16 +1201,18 @@ template <int DT, int CBW, int NKS, bool FAST, bool EARLY = false> int launch_ws
   if (slots < 1) slots = 1;
   if (slots > nptiles) slots = nptiles;
   const unsigned grid = (unsigned)(slots * ctiles);
-  const int dbg = getenv("SRK_WS_DBG") ? atoi(getenv("SRK_WS_DBG")) : 0;
+  const int tq = (int)(nptiles / slots), trem = (int)(nptiles % slots);
   const int rin = a.x_ps > 1 ? a.x_ps : 1;
-  const long long xb = ((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2;
-  if (rin == 1) {
-    hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST, EARLY>), dim3(grid), dim3(C::NT), LDS, st, a, tilesX, tilesY, ctiles, (int)nptiles,
-                       (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), dbg, a.H * a.W * a.x_pitch, a.W * a.x_pitch,
-                       a.x_pitch, 2 * NKS);
-    SRK_LAUNCH_CHECK();
-    return 0;
-  }
+  const unsigned xb = (unsigned)(((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2);
+  // residual OR ReLU mask in the epilogue (not both): the variant that prefetches it during the MFMA phase
+  auto one = [&](const srk_conv_args& b, int xs_img, int xs_row, int xs_col, int wtap) -> int {
+    if constexpr (FAST && CBW == 2) {
+      if (((b.res != nullptr) != (b.mask != nullptr)) && !no_early)
+        return launch_ws_one<DT, CBW, NKS, FAST, true>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
+    }
+    return launch_ws_one<DT, CBW, NKS, FAST, false>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
+  };
+  if (rin == 1) return one(a, a.H * a.W * a.x_pitch, a.W * a.x_pitch, a.x_pitch, 2 * NKS);
   // Input stored pixel-shuffled (the dgrad of a conv + PixelShuffle(r)): channel k = (i*r+j)*64 + c lives at sub-pixel
   // (i,j), so the K = r*r*64 reduction is r*r weight-stationary 64->64 convs, one per sub-pixel lattice of x, each
   // with its own 9x64x64 weight slab (K-block ij of every tap of the packed weights), accumulating into `out`:
@@ -1212,10 +1230,8 @@ template <int DT, int CBW, int NKS, bool FAST, bool EARLY = false> int launch_ws
       b.res = a.out; b.res_pitch = a.out_pitch; b.res_coff = a.out_coff;
     }
     if (ij < r2 - 1) b.mask = nullptr;
-    hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST, EARLY>), dim3(grid), dim3(C::NT), LDS, st, b, tilesX, tilesY, ctiles, (int)nptiles,
-                       (unsigned)xb, (int)(nptiles / slots), (int)(nptiles % slots), dbg,
-                       a.H * rin * a.W * rin * a.x_pitch, rin * a.W * rin * a.x_pitch, rin * a.x_pitch, 8 * r2);
-    SRK_LAUNCH_CHECK();
+    const int rc = one(b, a.H * rin * a.W * rin * a.x_pitch, rin * a.W * rin * a.x_pitch, rin * a.x_pitch, 8 * r2);
+    if (rc != 0) return rc;
   }
   return 0;
 }
@@ -1247,12 +1263,7 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
     const long long xbytes = ((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2;
     if (a.KH == 3 && xbytes < 0x7fffffffLL && getenv("SRK_NO_WS") == nullptr) {
       if (a.CoutP % 64 == 0 && conv_fast_ok(a, 2)) {
-        if (rin == 1 && a.Cin == 64) {
-          // residual OR ReLU mask in the epilogue (not both): the variant that prefetches it during the MFMA phase
-          static const bool no_early = getenv("SRK_NO_EARLY") != nullptr;
-          if (((a.res != nullptr) != (a.mask != nullptr)) && !no_early) return launch_ws<DT, 2, 4, true, true>(a, st);
-          return launch_ws<DT, 2, 4, true>(a, st);
-        }
+        if (rin == 1 && a.Cin == 64) return launch_ws<DT, 2, 4, true>(a, st);
         if (rin == 1 && a.Cin == 16) return launch_ws<DT, 2, 1, true>(a, st);          // e.g. dgrad of the 3-channel tail conv
         if (rin > 1 && a.Cin == 64 * rin * rin && !a.relu && a.out_mode == SRK_OUT_NHWC) return launch_ws<DT, 2, 4, true>(a, st);
       }

@@ -38,16 +38,17 @@ def asm(tmp_path_factory):
     return out.read_text()
 
 
+@pytest.mark.parametrize("nks", [4, 1])
 @pytest.mark.parametrize("dt", [0, 1])
-def test_prefetch_registers_untouched_until_wait(asm, dt):
-    name = f"_ZN12_GLOBAL__N_114conv_ws_kernelILi{dt}ELi2ELi4ELb1ELb1EEEv13srk_conv_args"
+def test_prefetch_registers_untouched_until_wait(asm, dt, nks):
+    name = f"_ZN12_GLOBAL__N_114conv_ws_kernelILi{dt}ELi2ELi{nks}ELb1ELb1EEEv13srk_conv_args"
     start = asm.index(name + "iiiijiiiiiii:")
     body = asm[start:asm.index(".Lfunc_end", start)].split("\n")
     loads = [k for k, l in enumerate(body)
              if "buffer_load_dwordx4" in l and " lds" not in l and "ASMSTART" in body[k - 1]]
     assert len(loads) == 8, "4 pieces x 2 pixel blocks"
     mfma = [k for k, l in enumerate(body) if "v_mfma" in l]
-    assert len(mfma) == 144
+    assert len(mfma) == 36 * nks
     waits = [k for k, l in enumerate(body) if "s_waitcnt vmcnt(0)" in l and "ASMSTART" in body[k - 1] and k > mfma[-1]]
     assert waits, "the closing wait of the MFMA phase"
     wait = waits[0]
