@@ -397,9 +397,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_a
       for (int t = 0; t < 9; ++t) {
         const int kh = t / KS, kw = t - kh * KS;
         acc[t] = Tr::mma(xf[(y + kh) & 3][kw], bf, acc[t]);
-        // next tile's DMA: halo piece y after the 3rd MFMA of this step, dY piece y/2 after the 6th of the even steps
-        if (t == 2 && y < NPK && more) dma_x_piece(nxt, y);
-        if (t == 5 && (y & 1) == 0 && (y >> 1) < NDK && more) dma_d_piece(nxt, y >> 1);
+        // next tile's DMA, front-loaded (3 pieces per step in steps 0-5, the rest by step 7): a piece takes 3-5k cycles
+        // to land under load and the whole tile must be there when this loop (5.3k cycles) ends
+        if (t == 1 && 2 * y < NPK && more) dma_x_piece(nxt, 2 * y);
+        if (t == 4 && 2 * y + 1 < NPK && more) dma_x_piece(nxt, 2 * y + 1);
+        if (t == 7 && y < NDK && more) dma_d_piece(nxt, y);
       }
       bf = bfn;
       __builtin_amdgcn_sched_barrier(0);
