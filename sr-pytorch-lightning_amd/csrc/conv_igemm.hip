@@ -1037,8 +1037,15 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
         QuadPre pre;
         if constexpr (EARLY) pre = quad_early_setup(a, quad_geo(j), qi);     // behind the first LDS reads: overlaps their latency
         __builtin_amdgcn_s_setprio(1);
+#if SRK_WS_STAMPS
+        if (p == 2) SRK_STAMP(40);
+#endif
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
+#if SRK_WS_STAMPS
+          if (p == 2 && s == 1) SRK_STAMP(41);
+          if (p == 2 && s == NSTEP - 1) SRK_STAMP(42);
+#endif
           const int c0 = s % 3, c2 = (s + 2) % 3;
           // ONE LDS read per MFMA gap (four waves x one ds_read_b128 = 16 of the gap's 32 LDS-array cycles); a burst of
           // 4 reads per wave in one gap oversubscribes the array while the waves run in step
@@ -1066,6 +1073,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           }
         }
         __builtin_amdgcn_s_setprio(0);
+#if SRK_WS_STAMPS
+        if (p == 2) SRK_STAMP(43);
+#endif
         // the pieces requested 5k cycles ago are the wave's only outstanding vector-memory operations: make them
         // architecturally complete HERE, in the straight-line code that issued them.  (Waiting in the epilogue phase
         // instead lets the compiler place its loop-carried register copies of e0 / e1 in front of the wait.)

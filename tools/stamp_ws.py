@@ -18,7 +18,7 @@ RES = torch.zeros_like(out) if os.environ.get('STAMP_RES') else None
 MASK = torch.ones_like(out) if os.environ.get('STAMP_MASK') else None
 KW = dict(res=RES, mask=MASK, N=n, H=HW, W=HW, Cin=64, Cout=COUT, out=out, relu=(not PLANAR) and RES is None and MASK is None, out_mode=A._lib.OUT_PLANAR if PLANAR else A._lib.OUT_NHWC)
 stamps = torch.zeros(256, dtype=torch.int64, device=dev)
-NL = 20
+NL = int(os.environ.get('STAMP_NL', '20'))
 A.ops.conv_raw(x, pk, post_add=stamps.view(torch.float32), **KW)
 stamps.zero_()
 torch.cuda.synchronize()
@@ -27,6 +27,8 @@ with torch.cuda.graph(g):
     for _ in range(NL):
         A.ops.conv_raw(x, pk, post_add=stamps.view(torch.float32), **KW)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(int(os.environ.get('STAMP_WARM', '0'))): g.replay()
+torch.cuda.synchronize(); stamps.zero_(); torch.cuda.synchronize()
 e0.record(); g.replay(); e1.record()
 torch.cuda.synchronize()
 st = stamps.cpu().numpy()
@@ -50,3 +52,8 @@ if t[30]:
     b = t[6]
     names = ["DMA issued", "compute(0) done", "store(0) issued", "compute(1) done", "store(1) issued", "final wait done"]
     print("group 0, phase 3 (epilogue, prefetch variant) sub-stamps, ticks from phase start: " + "; ".join(f"{nm} {t[30+i]-b}" for i, nm in enumerate(names)))
+
+if t[40]:
+    b = t[4]
+    print(f"group 0, phase 2 (MFMA) sub-stamps, ticks from phase start: first fragments requested {t[40]-b}; K-step 1 reached {t[41]-b}; last K-step reached {t[42]-b} "
+          f"({(t[42]-t[41])/ (4*34):.2f} cycles per MFMA over steps 1..34); loop left {t[43]-b}")
