@@ -813,7 +813,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   // 64-channel K-block of a wider reduction, a.wpk then points at that block's first chunk)
   // xs_img / xs_row / xs_col: element strides of the input between images, rows and columns of the conv-space grid
   // (plain NHWC: H*W*pitch, W*pitch, pitch; one sub-pixel lattice of a pixel-shuffled tensor: r*W*r*pitch, r*pitch)
-  // dbg (SRK_WS_DBG, timing ablations only, results are wrong): 1 = skip MFMAs, 2 = skip epilogue, 4 = skip halo DMA
+  // dbg = SRK_WS_ABLATE (compile-time timing ablations, results are wrong): 1 = skip MFMAs, 2 = skip epilogue, 4 = skip halo DMA
   // 8 waves = two groups of 4.  A group owns every other tile of the workgroup's range and ONE halo buffer; it
   // alternates an MFMA phase (144 MFMAs per wave, LDS reads only) with an epilogue phase (issue the DMA of its
   // next halo tile, then convert/store the finished tile).  The groups run one phase apart, so each SIMD always
@@ -910,7 +910,8 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   asm volatile("" ::: "memory");
   // ---- prologue: all 9 taps of this channel tile (both groups), then each group's first halo tile ---------------
   // every workgroup needs the SAME weight bytes at the same moment: walking them in the same order would send all
-  // CUs of an XCD to one L2 channel at a time, so each workgroup starts at its own 1-KB block (SRK_WS_DBG bit 16: off)
+  // CUs of an XCD to one L2 channel at a time, so each workgroup starts at its own 1-KB block (SRK_WS_ABLATE bit 16: off;
+  // measured: no difference, the burst is bandwidth-bound)
   static_assert(WPIECES % 64 == 0, "weight slab is a whole number of 1-KB blocks");
   constexpr int NBLK = WPIECES / 64;
   const int rot = (dbg & 16) ? 0 : (int)((blockIdx.x * 11u) % (unsigned)NBLK);
