@@ -446,8 +446,183 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_a
   }
 }
 
+// =================================================================================================
+// 1x1 weight gradient, slab mode (16-bit):  dW[ci][co] = sum_p X[p][ci] * dY[p][co],  a plain GEMM with K = pixels.
+// Used by WDSR's 1x1 expand / reduce convs, RDN's local / global feature fusion and the unfolded 3-channel head conv.
+// Arithmetic intensity is M*N/(M+N) FLOP per byte of 16-bit operand (110 for 128 x 768): HBM-bound, so the kernel is
+// built around re-reading as little as possible rather than around the matrix pipe:
+//  * a workgroup owns CIB x COB channel blocks of 64 (128 x 256 or 256 x 128, the larger side on the larger channel
+//    count), i.e. the activations are read Cout/256 (resp. Cin/256) times instead of Cout/64: the v1 atomic kernel
+//    (64 x 64 per workgroup) moved 908 MB for WDSR-B's 128 -> 768 layer at batch 64, this one 340 MB;
+//  * K tiles of 64 consecutive pixels (NHWC: contiguous), each channel block a 64 x 128 B LDS plane in the swizzled
+//    4 x 16-pixel image format of the 3x3 kernel, so both operands are fetched with ds_read_b64_tr_b16;
+//    planes double-buffered by hidden LDS-DMA (dma16_hidden), 12 pieces per lane and tile issued between the MFMAs;
+//  * wave (rb, cbk) owns the (32 x 32) quadrant of every block pair: CIB*COB accumulator tiles (128 registers);
+//  * partial sums go to the workgroup's own slab, the bias gradient is summed from the dY planes on the side
+//    (ci-tile 0 only): same scratch layout and srk_wgrad_finalize as the 3x3 slab kernel (bitwise reproducible).
+// =================================================================================================
+template <int DT, int CIB, int COB>
+__global__ __launch_bounds__(256, 1) void wgrad1x1_ws_kernel(const srk_wgrad_args a, int ntiles, unsigned x_bytes, unsigned dy_bytes,
+                                                              int tq, int trem) {
+  typedef DTraits<DT> Tr;
+  constexpr int CH = Tr::CH, ESZ = 2;
+  constexpr int NPL = CIB + COB;                  // planes per buffer
+  constexpr int PLANE = 64 * 128;                 // 64 pixels x 128 bytes
+  constexpr int BUF_BYTES = NPL * PLANE;
+  constexpr int NPK = NPL * 2;                    // pieces per lane and tile: plane k >> 1, pixel (tid >> 3) + 32 (k & 1)
+  static_assert(Tr::IS16, "16-bit types only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = wave >> 1, cbk = wave & 1;
+  const int slot = blockIdx.x, cit = blockIdx.y, cot = blockIdx.z;
+  const long long P = (long long)a.N * a.H * a.W;
+  const int nch_x = a.Cin / CH, nch_d = a.Cout / CH;
+  const int t0 = slot * tq + min(slot, trem);
+  const int nt = tq + (slot < trem ? 1 : 0);
+
+  const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+  // per-lane piece constants: LDS slot sl, pixel column (px & 15) fixes the swizzle, so the channel chunk is per lane
+  const int px0 = tid >> 3, sl = tid & 7;
+  const int cchunk = sl ^ swz(px0 & 15);          // chunk inside the 64-channel block (px0 + 32 has the same column)
+  auto dma_tile = [&](int pt, unsigned buf, int k) {            // piece k of tile pt into buffer at LDS address buf
+    const int plane = k >> 1;
+    const long long p = (long long)pt * 64 + px0 + 32 * (k & 1);
+    const bool isx = plane < CIB;
+    const int blk = isx ? cit * CIB + plane : cot * COB + (plane - CIB);
+    const int chunk = blk * 8 + cchunk;
+    const bool ok = p < P && chunk < (isx ? nch_x : nch_d);
+    const unsigned voff = ok ? (unsigned)((p * (isx ? a.x_pitch : a.dy_pitch) + (isx ? a.x_coff : a.dy_coff) + chunk * CH) * ESZ) : 0x80000000u;
+    dma16_hidden(isx ? xrs : drs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(buf + plane * PLANE + (((k & 1) * 256 + wave * 64) << 4))));
+  };
+
+  f32x16 acc[CIB][COB];
+#pragma unroll
+  for (int i = 0; i < CIB; ++i)
+#pragma unroll
+    for (int o = 0; o < COB; ++o)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][o][e] = 0.f;
+  float bsum[COB][8];
+#pragma unroll
+  for (int o = 0; o < COB; ++o)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[o][e] = 0.f;
+  const bool do_bias = a.dbp != nullptr && cit == 0;
+  int aoff[2], boff[2];
+  aoff[0] = tr_lane_off(0, 0, rb, lane);  aoff[1] = tr_lane_off(0, 1, rb, lane);
+  boff[0] = tr_lane_off(0, 0, cbk, lane); boff[1] = tr_lane_off(0, 1, cbk, lane);
+
+  if (nt > 0) {
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) dma_tile(t0, lds0, k);
+  }
+#pragma unroll 1
+  for (int it = 0; it < nt; ++it) {
+    const char* const B0 = smem + (it & 1) * BUF_BYTES;
+    const unsigned nb = lds0 + ((it + 1) & 1) * BUF_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile `it` landed
+    __builtin_amdgcn_s_barrier();                         // ... for every wave; the other buffer is free
+    const bool more = it + 1 < nt;
+    if (do_bias) {
+      // lane owns LDS slot sl of pixels px0 and px0 + 32 of every dY plane
+#pragma unroll
+      for (int o = 0; o < COB; ++o)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const i32x4 raw = lds_read16(B0 + (CIB + o) * PLANE + ((tid + 256 * hf) << 4));
+          const uint32_t w4[4] = {(uint32_t)raw.x, (uint32_t)raw.y, (uint32_t)raw.z, (uint32_t)raw.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            bsum[o][2 * i] += Tr::to_f32((uint16_t)(w4[i] & 0xffff));
+            bsum[o][2 * i + 1] += Tr::to_f32((uint16_t)(w4[i] >> 16));
+          }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                 // K-step = one 16-pixel row of the planes
+      i32x4 af[CIB], bf[COB];
+#pragma unroll
+      for (int i = 0; i < CIB; ++i) af[i] = tr_read2(B0 + i * PLANE + r * 2048 + aoff[0], B0 + i * PLANE + r * 2048 + aoff[1]);
+#pragma unroll
+      for (int o = 0; o < COB; ++o) bf[o] = tr_read2(B0 + (CIB + o) * PLANE + r * 2048 + boff[0], B0 + (CIB + o) * PLANE + r * 2048 + boff[1]);
+      int k = r * (NPK / 4);
+#pragma unroll
+      for (int i = 0; i < CIB; ++i)
+#pragma unroll
+        for (int o = 0; o < COB; ++o) {
+          acc[i][o] = Tr::mma(af[i], bf[o], acc[i][o]);
+          if (more && k < (r + 1) * (NPK / 4) && ((i * COB + o) & 1) == 0) { dma_tile(t0 + it + 1, nb, k); ++k; }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- the workgroup's slab: [Cin][Cout] fp32, rows / columns beyond the real channel counts are dropped -------
+  {
+    const int hq = lane >> 5;
+    const size_t slab_elems = (size_t)a.Cin * a.Cout;
+    const __amdgpu_buffer_rsrc_t srs =
+        __builtin_amdgcn_make_buffer_rsrc(a.dwp + (size_t)slot * slab_elems, 0, (unsigned)(slab_elems * 4), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < CIB; ++i)
+#pragma unroll
+      for (int o = 0; o < COB; ++o) {
+        const int ci0 = (cit * CIB + i) * 64 + rb * 32 + 4 * hq;
+        const int co = (cot * COB + o) * 64 + cbk * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ci = ci0 + (e & 3) + 8 * (e >> 2);
+          const unsigned voff = (ci < a.Cin && co < a.Cout) ? (unsigned)((ci * a.Cout + co) * 4) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][o][e]), srs, voff, 0, 0);
+        }
+      }
+  }
+  if (do_bias) {
+    // fixed-order reduction of the per-lane chunk sums (same scheme as the 3x3 slab kernel), one dY plane at a time
+    float* const bred = reinterpret_cast<float*>(smem);      // [256][8]
+#pragma unroll
+    for (int o = 0; o < COB; ++o) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bred[tid * 8 + e] = bsum[o][e];
+      __syncthreads();
+      if (tid < 64) {
+        const int ch = tid >> 3, e = tid & 7;
+        float t = 0.f;
+        for (int p0 = 0; p0 < 32; ++p0) t += bred[((p0 << 3) + (ch ^ swz(p0 & 15))) * 8 + e];
+        const int c = (cot * COB + o) * 64 + tid;
+        if (c < a.Cout) a.dbp[(size_t)slot * a.Cout + c] = t;
+      }
+    }
+  }
+}
+
 // pixel slabs used by the slab-mode kernel for these arguments (0: atomic-mode kernel)
+// 1x1 slab kernel: tile shape (ci blocks x co blocks of 64) and slab count
+static void wgrad1x1_shape(const srk_wgrad_args& a, int& cib, int& cob) {
+  if (a.Cout >= a.Cin) { cib = 2; cob = 4; } else { cib = 4; cob = 2; }
+}
+static int wgrad1x1_slabs(const srk_wgrad_args& a) {
+  if (a.dtype == SRK_F32 || a.KH != 1 || a.KW != 1 || a.x_ps > 1 || a.dy_ps > 1) return 0;
+  if (getenv("SRK_NO_WS")) return 0;
+  const long long P = (long long)a.N * a.H * a.W;
+  if (P * a.x_pitch * 2 >= 0x7fff0000LL || P * a.dy_pitch * 2 >= 0x7fff0000LL) return 0;
+  int cib, cob;
+  wgrad1x1_shape(a, cib, cob);
+  const int cit = (a.Cin + 64 * cib - 1) / (64 * cib), cot = (a.Cout + 64 * cob - 1) / (64 * cob);
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  const long long ntiles = (P + 63) / 64;
+  long long slabs = cus / (cit * cot);
+  if (slabs < 1) slabs = 1;
+  if (slabs > ntiles) slabs = ntiles;
+  return (int)slabs;
+}
+
 static int wgrad_ws_slabs(const srk_wgrad_args& a) {
+  if (a.KH == 1 && a.KW == 1) return wgrad1x1_slabs(a);
   if (a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3 || a.x_ps > 1) return 0;
   if (getenv("SRK_NO_WS")) return 0;
   const int rd = a.dy_ps > 1 ? a.dy_ps : 1;
@@ -481,6 +656,28 @@ template <int DT> int launch_ws(const srk_wgrad_args& a, hipStream_t st, int sla
                      (int)(ntiles / slabs), (int)(ntiles % slabs));
   SRK_LAUNCH_CHECK();
   return 0;
+}
+
+template <int DT, int CIB, int COB> int launch_1x1(const srk_wgrad_args& a, hipStream_t st, int slabs) {
+  constexpr int LDS = 2 * (CIB + COB) * 64 * 128;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_ws_kernel<DT, CIB, COB>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr != hipSuccess) {
+    srk_set_error("srk_conv2d_wgrad(1x1): cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
+    return (int)attr;
+  }
+  const long long P = (long long)a.N * a.H * a.W;
+  const long long ntiles = (P + 63) / 64;
+  const int cit = (a.Cin + 64 * CIB - 1) / (64 * CIB), cot = (a.Cout + 64 * COB - 1) / (64 * COB);
+  hipLaunchKernelGGL((wgrad1x1_ws_kernel<DT, CIB, COB>), dim3(slabs, cit, cot), dim3(256), LDS, st, a, (int)ntiles,
+                     (unsigned)(P * a.x_pitch * 2), (unsigned)(P * a.dy_pitch * 2), (int)(ntiles / slabs), (int)(ntiles % slabs));
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+template <int DT> int launch_1x1_any(const srk_wgrad_args& a, hipStream_t st, int slabs) {
+  int cib, cob;
+  wgrad1x1_shape(a, cib, cob);
+  return cib == 2 ? launch_1x1<DT, 2, 4>(a, st, slabs) : launch_1x1<DT, 4, 2>(a, st, slabs);
 }
 
 template <int DT, int KS> int launch(const srk_wgrad_args& a, hipStream_t st) {
@@ -528,6 +725,7 @@ extern "C" int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int slabs = wgrad_ws_slabs(*a);
   SRK_CHECK_ARG(a->nslabs == slabs, "srk_conv2d_wgrad: nslabs=%d but srk_wgrad_slabs() is %d for these arguments", a->nslabs, slabs);
+  if (slabs > 0 && a->KH == 1) return a->dtype == SRK_BF16 ? launch_1x1_any<SRK_BF16>(*a, st, slabs) : launch_1x1_any<SRK_F16>(*a, st, slabs);
   if (slabs > 0) return a->dtype == SRK_BF16 ? launch_ws<SRK_BF16>(*a, st, slabs) : launch_ws<SRK_F16>(*a, st, slabs);
   switch (a->dtype) {
     case SRK_BF16: return dispatch<SRK_BF16>(*a, st);

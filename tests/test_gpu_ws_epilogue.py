@@ -55,3 +55,22 @@ def test_ws_epilogue_variants(A, dt, cin, n, h, w, variant):
     err = (got - ref).abs()
     tol = eps * ref.abs() * 1.5 + 4e-3 * eps * 256 / 256 + 1e-3 * float(ref.abs().max()) * (1 if dt == torch.bfloat16 else 0.1)
     assert bool((err <= tol).all()), f"max err {float(err.max()):.3e} (max |ref| {float(ref.abs().max()):.3f})"
+
+
+@pytest.mark.parametrize("dt", DT, ids=["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout", [(128, 768), (768, 112), (32, 64), (576, 64), (64, 64), (16, 16)])
+@pytest.mark.parametrize("n,h,w", [(2, 13, 7), (1, 48, 48), (1, 1, 1)])
+def test_wgrad_1x1_slab_kernel(A, dt, cin, cout, n, h, w):
+    """dW / db of a 1x1 conv through srk_conv2d_wgrad (the slab-mode GEMM kernel, both tile shapes, ragged 64-pixel
+    K tiles, channel counts that do not fill the 64-channel blocks) against float64 on the same rounded operands."""
+    g = torch.Generator().manual_seed(cin * 7 + cout + h)
+    x = ((torch.rand(n, h, w, cin, generator=g) - 0.5) * 2).to(dt).cuda()
+    dy = ((torch.rand(n, h, w, cout, generator=g) - 0.5) * 2).to(dt).cuda()
+    dw, db = A.ops.wgrad_raw(x, dy, N=n, H=h, W=w, Cin=cin, Cout=cout, k=1, w_shape=(cout, cin, 1, 1))
+    torch.cuda.synchronize()
+    xr, dr = x.double().cpu().reshape(-1, cin), dy.double().cpu().reshape(-1, cout)
+    ref_w = (dr.t() @ xr).reshape(cout, cin, 1, 1)
+    ref_b = dr.sum(0)
+    tol = 2e-5 * max(1.0, float(ref_w.abs().max()))          # fp32 accumulation of exact 16-bit products
+    assert float((dw.double().cpu() - ref_w).abs().max()) <= tol
+    assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-5 * max(1.0, float(ref_b.abs().max()))
