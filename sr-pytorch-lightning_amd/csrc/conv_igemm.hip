@@ -759,6 +759,21 @@ __global__ __launch_bounds__((ConvCfg<DT, TC, KS>::NT)) void conv_igemm_kernel(c
   if constexpr (TC >= 64) {
     if (fast) {
       const FastDst d = fast_dst(a, ctile * TC + wco0);
+      if constexpr (Tr::IS16 && C::CB_W == 2 && C::PB_W == 2 && KS == 1) {
+        // quad-transposed stores (see conv_epilogue_quad) for the 1x1 convs: WDSR's 128 -> 768 expansion writes 226 MB at
+        // batch 64 and was store-bound with 16-byte pieces (1.8 TB/s).  Not for 3x3: those are compute-bound and the
+        // transposes cost a wave of occupancy (128 -> 166 VGPRs; EDSR-large -9 %)
+        const int gxb = x0 + (px & ~3), qi = px & 3;
+        const int xm = min(max(a.W - gxb, 0), 4);
+        const int xmask = (1 << xm) - 1;
+        const int gy0 = y0 + pyb[0], gy1 = y0 + pyb[1];
+        const int pb0 = (n * a.H * d.rr + gy0 * d.rr + d.si) * (a.W * d.rr) + gxb * d.rr + d.sj;
+        const int pb1 = pb0 + 2 * d.rr * (a.W * d.rr);            // pyb[1] = pyb[0] + 2
+        const int cq = 32 * h + 8 * qi;
+        conv_epilogue_quad<DT>(a, acc, pb0, pb1, gy0 < a.H ? xmask : 0, gy1 < a.H ? xmask : 0, d.rr, d.cbase + cq,
+                               ctile * TC + wco0 + (cq & ~15) >= a.mask_from, qi);
+        return;
+      }
       int opix[C::PB_W];
 #pragma unroll
       for (int pb = 0; pb < C::PB_W; ++pb) opix[pb] = fast_opix(a, d, n, y0 + pyb[pb], x0 + px);
