@@ -246,6 +246,21 @@ typedef struct {
 } srk_sse_args;
 int srk_image_sse(const srk_sse_args* a, srk_stream_t stream);
 
+/* ---- SSIM with piq.ssim's defaults (reference srmodel.py:52-53,567-593 -> piq.ssim): images are average-pooled by
+ * `pool` = max(1, round(min(H, W) / 256)) (floor division of the extent, as F.avg_pool2d), filtered with the separable
+ * 11-tap Gaussian (sigma), and the SSIM map of the VALID region ((Hp-10) x (Wp-10)) is summed per (image, channel)
+ * plane.  The caller divides by the map size and averages over channels and images.  Inputs are used as given
+ * (the model clamps before its metrics).  fp32 NCHW planar. ------------------------------------------------------ */
+typedef struct srk_ssim_args {
+  const float* x;                         /* [N][C][H][W]                                                   */
+  const float* y;
+  int N, C, H, W;
+  int pool;                               /* >= 1                                                           */
+  float sigma, k1, k2;                    /* 1.5, 0.01, 0.03                                                */
+  double* sums;                           /* [N*C] sums of the SSIM map, caller-zeroed                      */
+} srk_ssim_args;
+int srk_image_ssim(const srk_ssim_args* a, srk_stream_t stream);
+
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* srk_last_error(void);
 int srk_version(void);

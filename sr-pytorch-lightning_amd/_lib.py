@@ -94,6 +94,11 @@ class SseArgs(C.Structure):
     _fields_ = [("sr", _p), ("hr", _p), ("N", _i), ("C", _i), ("H", _i), ("W", _i), ("luma", _i), ("shave", _i), ("sse", _p)]
 
 
+class SsimArgs(C.Structure):
+    _fields_ = [("x", _p), ("y", _p), ("N", _i), ("C", _i), ("H", _i), ("W", _i), ("pool", _i),
+                ("sigma", _f), ("k1", _f), ("k2", _f), ("sums", _p)]
+
+
 # every launcher declared in include/srk.h: name -> argument struct
 LAUNCHERS = {
     "srk_pack_conv_weights": PackArgs,
@@ -108,6 +113,7 @@ LAUNCHERS = {
     "srk_ca_bwd_apply": CaBwdArgs,
     "srk_sample_patches": PatchArgs,
     "srk_image_sse": SseArgs,
+    "srk_image_ssim": SsimArgs,
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group")

@@ -76,7 +76,96 @@ __global__ __launch_bounds__(256) void sse_kernel(const srk_sse_args a) {
   if (threadIdx.x == 0) atomicAdd(a.sse + n, red[0] + red[1] + red[2] + red[3]);
 }
 
+// SSIM map of one 16x16 tile per workgroup: (26 x 26) pooled pixels of both images in LDS, horizontal 11-tap pass for
+// the five moments (x, y, xx, yy, xy) on 26 rows x 16 columns, vertical pass + SSIM formula per output pixel, wave /
+// LDS reduction, one double atomic per workgroup.  HBM-bound (each input pixel is read ~1.6x), fp32 like piq.
+__global__ __launch_bounds__(256) void ssim_kernel(const srk_ssim_args a, int tilesX, int Hp, int Wp) {
+  __shared__ float X[26][27], Y[26][27];
+  __shared__ float Hm[5][26][16];
+  __shared__ float g[11];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int plane = blockIdx.y;
+  const int tX = blockIdx.x % tilesX, tY = blockIdx.x / tilesX;
+  const int y0 = tY * 16, x0 = tX * 16;
+  const float* xs = a.x + (size_t)plane * a.H * a.W;
+  const float* ys = a.y + (size_t)plane * a.H * a.W;
+  if (tid < 11) {
+    const float co = (float)tid - 5.0f;
+    g[tid] = expf(-(co * co) / (2.0f * a.sigma * a.sigma));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float sum = 0.f;
+    for (int i = 0; i < 11; ++i) sum += g[i];
+    for (int i = 0; i < 11; ++i) g[i] /= sum;
+  }
+  const int f = a.pool;
+  const float inv = 1.0f / (float)(f * f);
+  for (int i = tid; i < 26 * 26; i += 256) {
+    const int r = i / 26, c = i - r * 26;
+    const int py = y0 + r, px = x0 + c;
+    float vx = 0.f, vy = 0.f;
+    if (py < Hp && px < Wp) {
+      for (int dy = 0; dy < f; ++dy)
+        for (int dx = 0; dx < f; ++dx) {
+          const size_t o = (size_t)(py * f + dy) * a.W + (px * f + dx);
+          vx += xs[o];
+          vy += ys[o];
+        }
+      vx *= inv; vy *= inv;
+    }
+    X[r][c] = vx; Y[r][c] = vy;
+  }
+  __syncthreads();
+  for (int i = tid; i < 26 * 16; i += 256) {
+    const int r = i >> 4, c = i & 15;
+    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float xv = X[r][c + k], yv = Y[r][c + k], w = g[k];
+      m[0] += w * xv; m[1] += w * yv; m[2] += w * (xv * xv); m[3] += w * (yv * yv); m[4] += w * (xv * yv);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) Hm[q][r][c] = m[q];
+  }
+  __syncthreads();
+  const int r = tid >> 4, c = tid & 15;
+  double acc = 0.0;
+  if (y0 + r + 10 < Hp && x0 + c + 10 < Wp) {
+    float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = g[k];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) m[q] += w * Hm[q][r + k][c];
+    }
+    const float c1 = a.k1 * a.k1, c2 = a.k2 * a.k2;
+    const float sxx = m[2] - m[0] * m[0], syy = m[3] - m[1] * m[1], sxy = m[4] - m[0] * m[1];
+    const float cs = (2.f * sxy + c2) / (sxx + syy + c2);
+    const float ss = (2.f * m[0] * m[1] + c1) / (m[0] * m[0] + m[1] * m[1] + c1) * cs;
+    acc = (double)ss;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) atomicAdd(a.sums + plane, red[0] + red[1] + red[2] + red[3]);
+}
+
 }  // namespace
+
+extern "C" int srk_image_ssim(const srk_ssim_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->y && a->sums, "srk_image_ssim: null pointer");
+  SRK_CHECK_ARG(a->N > 0 && a->C > 0 && (long long)a->N * a->C <= 65535 && a->pool >= 1 && a->sigma > 0.f, "srk_image_ssim: bad sizes");
+  const int Hp = a->H / a->pool, Wp = a->W / a->pool;
+  SRK_CHECK_ARG(Hp >= 11 && Wp >= 11, "srk_image_ssim: image %dx%d (pooled %dx%d) is smaller than the 11x11 window", a->H, a->W, Hp, Wp);
+  const int tilesX = (Wp - 10 + 15) / 16, tilesY = (Hp - 10 + 15) / 16;
+  hipLaunchKernelGGL(ssim_kernel, dim3((unsigned)(tilesX * tilesY), (unsigned)(a->N * a->C)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), *a, tilesX, Hp, Wp);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int srk_sample_patches(const srk_patch_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a && a->table && a->lr_out && a->hr_out, "srk_sample_patches: null pointer");

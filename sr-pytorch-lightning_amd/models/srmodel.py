@@ -74,7 +74,11 @@ def _psnr(x, y):
 
 
 def _ssim(x, y, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
-    """SSIM with piq.ssim's defaults (11x11 Gaussian, sigma 1.5, avg-pool by round(min(H,W)/256))."""
+    """SSIM with piq.ssim's defaults (11x11 Gaussian, sigma 1.5, avg-pool by round(min(H,W)/256)).
+    On the GPU: the HIP reduction srk_image_ssim."""
+    if x.is_cuda and kernel_size == 11:
+        from .. import ops
+        return ops.ssim(x, y, sigma=sigma, k1=k1, k2=k2)
     x, y = x.float(), y.float()
     f = max(1, round(min(x.shape[-2:]) / 256))
     if f > 1:

@@ -703,3 +703,19 @@ def psnr(sr, hr, *, luma=False, shave=0, eps=1e-8):
     """10 log10(1 / (MSE + eps)) per image, batch mean (piq.psnr defaults: data_range 1, EPS 1e-8)."""
     sse, count = image_sse(sr, hr, luma=luma, shave=shave)
     return (10.0 * torch.log10(1.0 / (sse / count + eps))).mean().float()
+
+
+def ssim(x, y, *, sigma=1.5, k1=0.01, k2=0.03):
+    """SSIM with piq.ssim's defaults on the device (srk_image_ssim): average-pool by max(1, round(min(H, W) / 256)),
+    separable 11-tap Gaussian, mean of the valid SSIM map per (image, channel), then mean over channels and images.
+    No host synchronisation: the result is a 0-d device tensor."""
+    _need_gpu(x)
+    xs, ys = _f32c(x), _f32c(y)
+    n, c, h, w = xs.shape
+    f = max(1, round(min(h, w) / 256))
+    sums = torch.zeros(n * c, dtype=torch.float64, device=xs.device)
+    a = L.SsimArgs(x=xs.data_ptr(), y=ys.data_ptr(), N=n, C=c, H=h, W=w, pool=f, sigma=float(sigma), k1=float(k1), k2=float(k2),
+                   sums=sums.data_ptr())
+    L.call("srk_image_ssim", a, _stream())
+    count = (h // f - 10) * (w // f - 10)
+    return (sums / count).mean().float()

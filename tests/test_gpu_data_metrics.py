@@ -60,3 +60,23 @@ def test_psnr_reductions(n, h, w):
     m = A.EDSR(n_feats=16, n_resblocks=1, metrics=["PSNR", "SSIM", "PSNR-Y"])
     out = m._calculate_metrics(sr.clamp(0, 1).cuda(), hr.clamp(0, 1).cuda(), 1)
     assert abs(float(out["Set5/PSNR"]) - ref) < 1e-4 and abs(float(out["Set5/PSNR-Y"]) - refy) < 1e-3
+
+
+@pytest.mark.parametrize("n,c,h,w", [(1, 3, 37, 53), (2, 3, 192, 192), (1, 1, 11, 11), (2, 3, 600, 530), (1, 3, 1020, 768)])
+def test_ssim_device_reduction(n, c, h, w):
+    """srk_image_ssim against the float64 oracle (piq.ssim's published defaults): structured + noisy images, the pooled
+    path (min(H, W) >= 384 -> factor >= 2, extents not divisible by the factor), a single-window image."""
+    import sr_amd as A
+    g = torch.Generator().manual_seed(h * 7 + w)
+    yy, xx = torch.meshgrid(torch.linspace(0, 6.28, h), torch.linspace(0, 9.42, w), indexing="ij")
+    base = (0.5 + 0.25 * torch.sin(yy)[None, None] * torch.cos(xx)[None, None]).expand(n, c, h, w)
+    hr = (base + 0.1 * torch.rand(n, c, h, w, generator=g)).clamp(0, 1).contiguous()
+    sr = (hr + 0.05 * torch.randn(n, c, h, w, generator=g)).clamp(0, 1).contiguous()
+    ref = float(OM.ssim(sr, hr))
+    got = float(A.ops.ssim(sr.cuda(), hr.cuda()))
+    assert abs(got - ref) < 2e-5, (got, ref)
+    assert abs(float(A.ops.ssim(hr.cuda(), hr.cuda())) - 1.0) < 1e-6
+    if c == 3:
+        m = A.EDSR(n_feats=16, n_resblocks=1, metrics=["SSIM"])
+        out = m._calculate_metrics(sr.cuda(), hr.cuda(), 1)
+        assert abs(float(out["Set5/SSIM"]) - ref) < 2e-5
