@@ -820,6 +820,25 @@ SRK_DEV void dma16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
+// ---- barrier among the 4 waves of ONE wave group (the hardware barrier spans the workgroup) ----------------------------
+// A monotonic arrival counter per group in LDS: every wave adds 1 and polls until the count reaches 4 x generation.
+// All LDS accesses are inline asm (seen by the compiler they would be LDS reads that may alias the LDS-DMA).  The
+// caller makes its own prior accesses complete first (s_waitcnt vmcnt(..) for its DMA pieces; the wave's LDS reads are
+// ordered by the lgkmcnt(0) below).  Used by the FREE-running variant of conv_ws_kernel only.
+SRK_DEV unsigned grp_peek(unsigned addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+SRK_DEV void grp_barrier(unsigned addr, unsigned target, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    const unsigned one = 1;
+    asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(one) : "memory");
+  }
+  while (grp_peek(addr) < target) __builtin_amdgcn_s_sleep(1);
+}
+
 template <int DT, int CBW, int NKS, bool FAST, bool EARLY>
 __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
                                                           int nptiles, unsigned x_bytes, int tq, int trem, int /*unused*/,
@@ -975,6 +994,16 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     for (int e = 0; e < 4; ++e) pa4[e] = e < a.Cout ? a.post_add[e] : 0.f;
   }
 
+  // FREE (Cin = 16, i.e. 36 MFMAs per tile against a ~4k-cycle epilogue): the two groups do not alternate -- in lock
+  // step only one of them would be storing at any time -- but run free of each other, each with a 4-wave barrier on an
+  // LDS arrival counter after its phases.  (For the 64-channel layers free-running loses: the groups fall into step,
+  // and an enforced alternation costs what the workgroup barrier costs)
+  constexpr bool FREE = NKS == 1;
+  unsigned* const sync_ctr = reinterpret_cast<unsigned*>(smem + WPIECES * 16 + 2 * C::XS_BYTES + TCW * 4);
+  if (FREE && tid < 2) sync_ctr[tid] = 0;
+  const unsigned my_ctr = lds_addr_of(sync_ctr + grp);
+  unsigned gen = 0;
+
   f32x16 acc[CBW][2];
   // group 0 needs the weights and its halo tile now; group 1 idles through phase 0, so it only has to have landed its
   // share of the weights here (its 10-11 halo pieces are the youngest operations) and waits for its halo tile at the
@@ -1018,9 +1047,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     return g;
   };
   QuadRegs e0, e1;
+  if (FREE && grp == 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // its first halo tile
+    grp_barrier(my_ctr, 4 * ++gen, lane);
+  }
+  const int nloop = FREE ? 2 * nj : nph;
 #pragma unroll 1
-  for (int p = 0; p < nph; ++p) {
-    const int q = p - grp;            // this group's own phase counter
+  for (int p = 0; p < nloop; ++p) {
+    const int q = FREE ? p : p - grp;            // this group's own phase counter
     const int j = q >> 1;
     SRK_STAMP(2 * p);
     if (q >= 0 && j < nj) {
@@ -1180,9 +1214,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
         }
       }
     }
-    if (q < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 1, phase 0: its first halo tile
+    if (!FREE && q < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 1, phase 0: its first halo tile
     SRK_STAMP(2 * p + 1);
-    __builtin_amdgcn_s_barrier();
+    if constexpr (FREE) grp_barrier(my_ctr, 4 * ++gen, lane);
+    else __builtin_amdgcn_s_barrier();
   }
 #if SRK_WS_STAMPS
   if (stamp) {                       // [100] entry of the FIRST stamped launch, [101] entry / [102] exit of the last one
@@ -1216,7 +1251,7 @@ static int launch_ws_one(const srk_conv_args& b, hipStream_t st, unsigned grid, 
                          unsigned xb, int tq, int trem, int xs_img, int xs_row, int xs_col, int wtap) {
   typedef WsCfg C;
   constexpr int TCW = CBW * 32;
-  constexpr int LDS = 9 * 2 * NKS * TCW * 16 + 2 * C::XS_BYTES + (EARLY ? TCW * 4 : 0);      // weights, two halo buffers (, bias)
+  constexpr int LDS = 9 * 2 * NKS * TCW * 16 + 2 * C::XS_BYTES + TCW * 4 + 16;      // weights, two halo buffers, bias, group-barrier counters
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<DT, CBW, NKS, FAST, EARLY>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) {
