@@ -998,7 +998,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   // step only one of them would be storing at any time -- but run free of each other, each with a 4-wave barrier on an
   // LDS arrival counter after its phases.  (For the 64-channel layers free-running loses: the groups fall into step,
   // and an enforced alternation costs what the workgroup barrier costs)
-  constexpr bool FREE = NKS == 1;
+  constexpr bool FREE = NKS == 1 || EARLY;
   unsigned* const sync_ctr = reinterpret_cast<unsigned*>(smem + WPIECES * 16 + 2 * C::XS_BYTES + TCW * 4);
   if (FREE && tid < 2) sync_ctr[tid] = 0;
   const unsigned my_ctr = lds_addr_of(sync_ctr + grp);
@@ -1050,6 +1050,8 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   if (FREE && grp == 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // its first halo tile
     grp_barrier(my_ctr, 4 * ++gen, lane);
+    // start one MFMA phase late: with the epilogue the longer phase, groups that start out of phase stay out of phase
+    while (grp_peek(lds_addr_of(sync_ctr)) < 4) __builtin_amdgcn_s_sleep(1);
   }
   const int nloop = FREE ? 2 * nj : nph;
 #pragma unroll 1
