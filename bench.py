@@ -136,7 +136,7 @@ def dominant_kernel_roofline(A, batch, patch, feats, dtype, iters=100):
 # MI355X_MICROARCH.md "HBM"), measured with tools/pmc_conv.sh and committed under profiles/; None where not measured
 TRAFFIC_PMC = {
     (64, 48, 64, "bf16"): (10656.0 * 2 + 18432.0) * 1024,      # profiles/r1_pmc_n64_summary.txt
-    (64, 48, 256, "bf16"): (39556.3 * 2 + 73728.0) * 1024,     # profiles/r1_final_pmc_conv_n256.txt
+    (64, 48, 256, "bf16"): (39550.3 * 2 + 73728.0) * 1024,     # profiles/r1_final_pmc_conv_n256.txt
 }
 
 
