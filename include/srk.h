@@ -246,6 +246,24 @@ typedef struct {
 } srk_sse_args;
 int srk_image_sse(const srk_sse_args* a, srk_stream_t stream);
 
+/* ---- L1 loss of the training step (reference srmodel.py:160-171 -> F.l1_loss, 'mean' reduction), fused:
+ * forward reads sr and hr once, writes per-block partial sums of |sr - hr| (summed in a fixed order by the caller:
+ * reproducible) and the sign of (sr - hr) as int8; backward turns the sign map into the gradient
+ * sign * (*gout) * scale without touching sr / hr again.  gout is a DEVICE scalar (no host sync, graph-capturable). */
+typedef struct srk_l1_args {
+  const float* sr;                        /* forward: [n] ; backward: unused                                */
+  const float* hr;
+  long long n;
+  signed char* sign;                      /* [n] sign(sr - hr) in {-1, 0, 1}: written by forward, read by backward */
+  double* partial;                        /* forward: [srk_l1_blocks(n)] partial sums                       */
+  const float* gout;                      /* backward: device scalar                                        */
+  float scale;                            /* backward: weight / n                                           */
+  float* grad;                            /* backward: [n]                                                  */
+} srk_l1_args;
+int srk_l1_blocks(long long n);
+int srk_l1_loss_fwd(const srk_l1_args* a, srk_stream_t stream);
+int srk_l1_loss_bwd(const srk_l1_args* a, srk_stream_t stream);
+
 /* ---- SSIM with piq.ssim's defaults (reference srmodel.py:52-53,567-593 -> piq.ssim): images are average-pooled by
  * `pool` = max(1, round(min(H, W) / 256)) (floor division of the extent, as F.avg_pool2d), filtered with the separable
  * 11-tap Gaussian (sigma), and the SSIM map of the VALID region ((Hp-10) x (Wp-10)) is summed per (image, channel)

@@ -99,6 +99,11 @@ class SsimArgs(C.Structure):
                 ("sigma", _f), ("k1", _f), ("k2", _f), ("sums", _p)]
 
 
+class L1Args(C.Structure):
+    _fields_ = [("sr", _p), ("hr", _p), ("n", C.c_longlong), ("sign", _p), ("partial", _p), ("gout", _p),
+                ("scale", _f), ("grad", _p)]
+
+
 # every launcher declared in include/srk.h: name -> argument struct
 LAUNCHERS = {
     "srk_pack_conv_weights": PackArgs,
@@ -114,9 +119,11 @@ LAUNCHERS = {
     "srk_sample_patches": PatchArgs,
     "srk_image_sse": SseArgs,
     "srk_image_ssim": SsimArgs,
+    "srk_l1_loss_fwd": L1Args,
+    "srk_l1_loss_bwd": L1Args,
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
-                 "srk_pack_conv_weights_group")
+                 "srk_pack_conv_weights_group", "srk_l1_blocks")
 
 _lib = None
 
@@ -141,6 +148,8 @@ def load():
     lib.srk_wgrad_slabs.restype = C.c_int
     lib.srk_pack_conv_weights_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.srk_pack_conv_weights_group.restype = C.c_int
+    lib.srk_l1_blocks.argtypes = [C.c_longlong]
+    lib.srk_l1_blocks.restype = C.c_int
     lib.srk_last_error.restype = C.c_char_p
     lib.srk_version.restype = C.c_int
     lib.srk_device_cus.restype = C.c_int

@@ -153,7 +153,78 @@ __global__ __launch_bounds__(256) void ssim_kernel(const srk_ssim_args a, int ti
   if (tid == 0) atomicAdd(a.sums + plane, red[0] + red[1] + red[2] + red[3]);
 }
 
+// fused L1 loss.  Forward: grid-stride float4 loads of both tensors, |d| summed per thread in fp32 over at most
+// L1_PER_THREAD elements then in double, wave + LDS reduction, one partial per block (no atomics: the caller's sum over
+// the partials has a fixed order); sign(d) packed 4 per dword.  Backward: one int32 of signs -> one float4 of gradient.
+constexpr int L1_BLOCKS_MAX = 2048;
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const srk_l1_args a) {
+  __shared__ double red[4];
+  const long long n4 = a.n >> 2;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 s = reinterpret_cast<const float4*>(a.sr)[i], h = reinterpret_cast<const float4*>(a.hr)[i];
+    const float d[4] = {s.x - h.x, s.y - h.y, s.z - h.z, s.w - h.w};
+    unsigned pk = 0;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      t += fabsf(d[k]);
+      const int sg = (d[k] > 0.f) - (d[k] < 0.f);
+      pk |= (unsigned)(sg & 0xff) << (8 * k);
+    }
+    acc += (double)t;
+    reinterpret_cast<unsigned*>(a.sign)[i] = pk;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {            // tail (n not a multiple of 4)
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float d = a.sr[i] - a.hr[i];
+    acc += (double)fabsf(d);
+    a.sign[i] = (signed char)((d > 0.f) - (d < 0.f));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const srk_l1_args a) {
+  const float g = *a.gout * a.scale;
+  const long long n4 = a.n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const unsigned pk = reinterpret_cast<const unsigned*>(a.sign)[i];
+    float4 o;
+    o.x = g * (float)(signed char)(pk & 0xff);
+    o.y = g * (float)(signed char)((pk >> 8) & 0xff);
+    o.z = g * (float)(signed char)((pk >> 16) & 0xff);
+    o.w = g * (float)(signed char)(pk >> 24);
+    reinterpret_cast<float4*>(a.grad)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    a.grad[i] = g * (float)a.sign[i];
+  }
+}
+
 }  // namespace
+
+extern "C" int srk_l1_blocks(long long n) {
+  const long long b = (n / 4 + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > L1_BLOCKS_MAX ? L1_BLOCKS_MAX : b));
+}
+extern "C" int srk_l1_loss_fwd(const srk_l1_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->sr && a->hr && a->sign && a->partial && a->n > 0, "srk_l1_loss_fwd: null pointer / empty");
+  SRK_CHECK_ARG(((uintptr_t)a->sr | (uintptr_t)a->hr | (uintptr_t)a->sign) % 16 == 0, "srk_l1_loss_fwd: 16-byte alignment");
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(srk_l1_blocks(a->n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int srk_l1_loss_bwd(const srk_l1_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->sign && a->gout && a->grad && a->n > 0, "srk_l1_loss_bwd: null pointer / empty");
+  SRK_CHECK_ARG(((uintptr_t)a->grad | (uintptr_t)a->sign) % 16 == 0, "srk_l1_loss_bwd: 16-byte alignment");
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(srk_l1_blocks(a->n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int srk_image_ssim(const srk_ssim_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a && a->x && a->y && a->sums, "srk_image_ssim: null pointer");

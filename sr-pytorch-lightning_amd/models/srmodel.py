@@ -55,7 +55,15 @@ class _SubLoss:
 
 
 # models/srmodel.py:30-44 -- only the torch-native entries are on the path
-_supported_losses = {"l1": F.l1_loss, "l2": F.mse_loss, "mae": F.l1_loss, "mse": F.mse_loss}
+def _l1_loss(sr, hr):
+    """F.l1_loss; on the GPU the fused HIP forward/backward pair (ops.L1LossFn)."""
+    if sr.is_cuda and sr.dtype == torch.float32 and sr.shape == hr.shape:
+        from .. import ops
+        return ops.l1_loss(sr, hr)
+    return F.l1_loss(sr, hr)
+
+
+_supported_losses = {"l1": _l1_loss, "l2": F.mse_loss, "mae": _l1_loss, "mse": F.mse_loss}
 _out_of_scope_losses = {"adaptive", "dists", "edge_loss", "flip", "haarpsi", "lpips", "pencil_sketch", "pieapp"}
 
 # models/srmodel.py:57-64

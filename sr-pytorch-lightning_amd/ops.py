@@ -719,3 +719,40 @@ def ssim(x, y, *, sigma=1.5, k1=0.01, k2=0.03):
     L.call("srk_image_ssim", a, _stream())
     count = (h // f - 10) * (w // f - 10)
     return (sums / count).mean().float()
+
+
+class L1LossFn(torch.autograd.Function):
+    """mean |sr - hr| (F.l1_loss, reference srmodel.py:160-171) as two HIP launches per step instead of torch's
+    sub / abs / mean / sign / mul chain: forward reads both images once and keeps sign(sr - hr) as int8, backward
+    expands the signs into the gradient (no second read of the images, no host sync: gout stays on the device)."""
+
+    @staticmethod
+    def forward(ctx, sr, hr):
+        _need_gpu(sr)
+        s, h = _f32c(sr), _f32c(hr)
+        n = s.numel()
+        sign = torch.empty(n, dtype=torch.int8, device=s.device)
+        nb = L.load().srk_l1_blocks(n)
+        partial = torch.empty(nb, dtype=torch.float64, device=s.device)
+        a = L.L1Args(sr=s.data_ptr(), hr=h.data_ptr(), n=n, sign=sign.data_ptr(), partial=partial.data_ptr(), gout=0, scale=0.0, grad=0)
+        L.call("srk_l1_loss_fwd", a, _stream())
+        ctx.save_for_backward(sign)
+        ctx.shape = tuple(sr.shape)
+        return (partial.sum() / n).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        (sign,) = ctx.saved_tensors
+        n = sign.numel()
+        gout = g.detach().float().contiguous()
+        grad = torch.empty(ctx.shape, dtype=torch.float32, device=sign.device)
+        a = L.L1Args(sr=0, hr=0, n=n, sign=sign.data_ptr(), partial=0, gout=gout.data_ptr(), scale=1.0 / n, grad=grad.data_ptr())
+        L.call("srk_l1_loss_bwd", a, _stream())
+        return grad, None
+
+
+def l1_loss(sr, hr):
+    """F.l1_loss(sr, hr) for device tensors (hr needs no gradient)."""
+    if hr.requires_grad:
+        return torch.nn.functional.l1_loss(sr, hr)
+    return L1LossFn.apply(sr, hr)

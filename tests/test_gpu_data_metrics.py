@@ -80,3 +80,25 @@ def test_ssim_device_reduction(n, c, h, w):
         m = A.EDSR(n_feats=16, n_resblocks=1, metrics=["SSIM"])
         out = m._calculate_metrics(sr.cuda(), hr.cuda(), 1)
         assert abs(float(out["Set5/SSIM"]) - ref) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 48, 48), (1, 3, 37, 53), (3, 1, 5, 7), (4, 3, 192, 192)])
+def test_l1_loss_fused(shape):
+    """srk_l1_loss_fwd / _bwd against F.l1_loss: value (fixed-order double partials) and gradient, incl. exact zeros
+    (sr == hr somewhere: sign 0), sizes that are not a multiple of 4, an upstream gradient other than 1."""
+    import sr_amd as A
+    g = torch.Generator().manual_seed(sum(shape))
+    hr = torch.rand(shape, generator=g)
+    sr = (hr + 0.1 * torch.randn(shape, generator=g))
+    sr.view(-1)[::7] = hr.view(-1)[::7]
+    a = sr.clone().cuda().requires_grad_(True)
+    b = sr.clone().double().requires_grad_(True)
+    la = A.ops.l1_loss(a, hr.cuda())
+    lb = torch.nn.functional.l1_loss(b, hr.double())
+    (la * 0.37).backward()
+    (lb * 0.37).backward()
+    assert abs(float(la) - float(lb)) < 1e-6 * max(1.0, abs(float(lb)))
+    assert torch.equal(a.grad.cpu() == 0, b.grad == 0)
+    assert float((a.grad.cpu().double() - b.grad).abs().max()) < 1e-7 * float(b.grad.abs().max())
+    la2 = A.ops.l1_loss(a.detach(), hr.cuda())
+    assert float(la2) == float(la), "fixed-order reduction: bitwise reproducible"
