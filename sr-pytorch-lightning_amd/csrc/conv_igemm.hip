@@ -955,23 +955,63 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   // every workgroup needs the SAME weight bytes at the same moment: walking them in the same order would send all
   // CUs of an XCD to one L2 channel at a time, so each workgroup starts at its own 1-KB block (SRK_WS_ABLATE bit 16: off;
   // measured: no difference, the burst is bandwidth-bound)
+#if SRK_WS_STAMPS
+  const unsigned long long tA = __builtin_amdgcn_s_memtime();
+#endif
   static_assert(WPIECES % 64 == 0, "weight slab is a whole number of 1-KB blocks");
   constexpr int NBLK = WPIECES / 64;
-  const int rot = (dbg & 16) ? 0 : (int)((blockIdx.x * 11u) % (unsigned)NBLK);
-#pragma unroll 1
-  for (int k = 0; k < (NBLK + 7) / 8; ++k) {
-    const int blk = k * 8 + wave;
-    if (blk < NBLK) {
-      int rb = blk + rot;
-      if (rb >= NBLK) rb -= NBLK;
-      const int i = rb * 64 + lane;             // i = (tap*2*NKS + c)*TCW + co
-      const int co = i % TCW, c = (i / TCW) % (2 * NKS), tap = i / (TCW * 2 * NKS);
-      const size_t off = ((size_t)(tap * wtap + c) * a.CoutP + ctile * TCW + co) * CH;
-      if constexpr (EARLY) dma16(wg + off, Wl + (rb << 10));
-      else dma16_hidden(wrsrc, (unsigned)(off * sizeof(elem)), (unsigned)__builtin_amdgcn_readfirstlane((int)(wl_lds + (rb << 10))));
+  // STAGED prologue (the plain 64-channel variant).  Stamps: of the ~9k cycles between kernel entry and the first MFMA,
+  // 2k are per-lane set-up, 3.6k are spent ISSUING the 15 DMA pieces of a wave (all 8 waves at once: the CU accepts
+  // ~34 B/clk), 0.7k landing, 1.4k barrier skew.  So only the bytes the first K-steps need are issued before the first
+  // barrier -- group 0's halo tile, loaded by all 8 waves together, and taps 0-2 (66 of 115 KB) -- and group 1, idle
+  // through phase 0, fetches taps 3-8 behind it; group 0 meets it at a workgroup barrier just before the first
+  // fragment of tap 3 / tap 6 is read (K-steps 10 / 22), then group 1 loads its own first halo tile.
+  constexpr bool STAGED = !EARLY && FAST && CBW == 2 && NKS == 4;
+  const int rot = (STAGED || (dbg & 16)) ? 0 : (int)((blockIdx.x * 11u) % (unsigned)NBLK);
+  if constexpr (STAGED) {
+    const int pt0 = t0;                                   // group 0's first tile
+    const int tX = pt0 % tilesX, q0 = pt0 / tilesX, tY = q0 % tilesY, n0 = q0 / tilesY;
+    const int y0 = tY * 16, x0 = tX * 16;
+    const int tbase = (n0 * xs_img + y0 * xs_row + x0 * xs_col) * (int)sizeof(elem);
+    const unsigned x0_lds = lds_addr_of(smem + WPIECES * 16);
+#pragma unroll
+    for (int k = 0; k < (C::XPIECES + 511) / 512; ++k) {
+      const int i = tid + k * 512;
+      if (k * 512 + wave * 64 < C::XPIECES) {             // wave-uniform
+        const int sl = i & 7, p = i >> 3;
+        const int iy = p / C::TIN, ix = p - iy * C::TIN;
+        const int c = sl ^ swz(ix);
+        const int gy = y0 + iy - 1, gx = x0 + ix - 1;
+        const bool ok = i < C::XPIECES && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)(tbase + ((iy - 1) * xs_row + (ix - 1) * xs_col + a.x_coff + c * CH) * (int)sizeof(elem)) : 0x80000000u;
+        if (i < C::XPIECES)
+          dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(x0_lds + ((k * 512 + wave * 64) << 4))));
+      }
     }
   }
-  if (nj > 0) dma_x(0);
+  auto dma_wblock = [&](int blk) {                 // one 1-KB block (64 pieces) of the weight slab, by this wave
+    int rb = blk + rot;
+    if (rb >= NBLK) rb -= NBLK;
+    const int i = rb * 64 + lane;             // i = (tap*2*NKS + c)*TCW + co
+    const int co = i % TCW, c = (i / TCW) % (2 * NKS), tap = i / (TCW * 2 * NKS);
+    const size_t off = ((size_t)(tap * wtap + c) * a.CoutP + ctile * TCW + co) * CH;
+    if constexpr (EARLY) dma16(wg + off, Wl + (rb << 10));
+    else dma16_hidden(wrsrc, (unsigned)(off * sizeof(elem)), (unsigned)__builtin_amdgcn_readfirstlane((int)(wl_lds + (rb << 10))));
+  };
+  if constexpr (STAGED) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dma_wblock(k * 8 + wave);          // taps 0-2, all 8 waves; taps 3-8: group 1, below
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < (NBLK + 7) / 8; ++k) {
+      const int blk = k * 8 + wave;
+      if (blk < NBLK) dma_wblock(blk);
+    }
+  }
+  if (!STAGED && nj > 0) dma_x(0);
+#if SRK_WS_STAMPS
+  const unsigned long long tB = __builtin_amdgcn_s_memtime();
+#endif
 
   const int px = r & 15;
   int pyb[2];
@@ -1008,9 +1048,26 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   // group 0 needs the weights and its halo tile now; group 1 idles through phase 0, so it only has to have landed its
   // share of the weights here (its 10-11 halo pieces are the youngest operations) and waits for its halo tile at the
   // end of phase 0: 41.5 KB less in the all-CUs-at-once prologue burst (~12-14 B/clk/CU)
-  if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  if constexpr (STAGED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of group 0's halo tile and of taps 0-2
+  } else {
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  }
+#if SRK_WS_STAMPS
+  const unsigned long long tC = __builtin_amdgcn_s_memtime();
+#endif
   __builtin_amdgcn_s_barrier();
+#if SRK_WS_STAMPS
+  const unsigned long long tD = __builtin_amdgcn_s_memtime();
+#endif
+  if constexpr (STAGED) {
+    // group 1 (idle through phase 0) fetches taps 3-8: 12 blocks per wave, in tap order
+    if (grp == 1) {
+#pragma unroll
+      for (int kk = 0; kk < 12; ++kk) dma_wblock(24 + kk * 4 + w4);
+    }
+  }
   if constexpr (!EARLY) {
     // make the bias loads complete HERE: left pending into the tile loop, their first use (the first MFMA of a tile)
     // carries an `s_waitcnt vmcnt(0)` that would then run for every tile and wait for the epilogue's stores
@@ -1117,6 +1174,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
           const int c0 = s % 3, c2 = (s + 2) % 3;
           // ONE LDS read per MFMA gap (four waves x one ds_read_b128 = 16 of the gap's 32 LDS-array cycles); a burst of
           // 4 reads per wave in one gap oversubscribes the array while the waves run in step
+          if constexpr (STAGED) {
+            // first tile only: taps 3-5 / 6-8 are needed from K-steps 12 / 24 on, their fragments two steps earlier
+            if (p == 0 && (s == 10 || s == 22)) __builtin_amdgcn_s_barrier();      // group 1 has landed taps 3-5 / 6-8
+          }
           int q = 0;
           if constexpr (EARLY) {
             // one prefetch piece every 4th K-step (every step when the loop is short): a 16-byte-per-line load keeps the address path busy for ~64 cycles,
@@ -1216,6 +1277,15 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
         }
       }
     }
+    if constexpr (STAGED) {
+      if (q < 0) {                                        // group 1, phase 0: the two staged weight syncs of group 0
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // its 6 blocks of taps 3-5 (taps 6-8 are the 6 younger ones)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // taps 6-8
+        __builtin_amdgcn_s_barrier();
+        if (nj > 0) dma_x(0);                                 // its own first halo tile, behind everything group 0 waits for
+      }
+    }
     if (!FREE && q < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 1, phase 0: its first halo tile
     SRK_STAMP(2 * p + 1);
     if constexpr (FREE) grp_barrier(my_ctr, 4 * ++gen, lane);
@@ -1226,6 +1296,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     if (stamp[100] == 0) stamp[100] = t_entry;
     stamp[101] = t_entry;
     stamp[102] = __builtin_amdgcn_s_memtime();
+    stamp[104] = tA; stamp[105] = tB; stamp[106] = tC; stamp[107] = tD;
   }
 #endif
 }

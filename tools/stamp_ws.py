@@ -36,6 +36,8 @@ us = e0.elapsed_time(e1) * 1e3 / NL
 ticks = (st[102] - st[100]) / NL
 print(f"{us:.2f} us per launch (events), {ticks:.0f} s_memtime ticks per launch period -> {ticks/us:.1f} ticks/us")
 print(f"last launch: entry->first phase {st[0]-st[101]} ticks, entry->exit {st[102]-st[101]} ticks")
+if st[104]:
+    print(f"prologue of group 0 wave 0 (ticks from entry): setup done {st[104]-st[101]}, DMA issued {st[105]-st[101]}, own pieces landed {st[106]-st[101]}, barrier passed {st[107]-st[101]}")
 for g in (0, 1):
     t = st[g * 128:(g + 1) * 128]
     t0 = st[0]
