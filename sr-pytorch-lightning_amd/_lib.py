@@ -160,6 +160,8 @@ def load():
 def call(name, args, stream):
     """Invoke launcher `name`; raise RuntimeError with the library's message on failure."""
     lib = load()
+    if getattr(args, "N", 1) == 0:
+        return          # empty batch: nothing to launch (torch's convs accept it; outputs are empty, sums stay zero)
     rc = getattr(lib, name)(C.byref(args), C.c_void_p(stream))
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.srk_last_error().decode(errors='replace')}")

@@ -222,6 +222,9 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
     _need_gpu(x)
     dev = x.device
     cout, cin, kh, kw = w_shape
+    if N == 0:          # empty batch: zero gradients (the slab scratch would be uninitialised)
+        return (torch.zeros(w_shape, dtype=torch.float32, device=dev),
+                torch.zeros(cout, dtype=torch.float32, device=dev) if want_bias else None)
     a = L.WgradArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(x_ps),
                     dy=dy.data_ptr(), dy_pitch=_pitch(dy), dy_coff=0, dy_ps=int(dy_ps),
                     N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, dwp=0, dbp=0, nslabs=0, dtype=_DT[x.dtype])
@@ -753,6 +756,6 @@ class L1LossFn(torch.autograd.Function):
 
 def l1_loss(sr, hr):
     """F.l1_loss(sr, hr) for device tensors (hr needs no gradient)."""
-    if hr.requires_grad:
+    if hr.requires_grad or sr.numel() == 0:
         return torch.nn.functional.l1_loss(sr, hr)
     return L1LossFn.apply(sr, hr)

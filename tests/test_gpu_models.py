@@ -267,3 +267,18 @@ def test_full_image_inference_vs_oracle(A, dt, min_psnr):
     # uint8 rounding (torchvision.utils.save_image): identical except where the fp32 values straddle x.5/255
     d = (m.to_uint8(y).cpu().int() - m.to_uint8(y_ref).int()).abs()
     assert int(d.max()) <= 1 and float((d > 0).float().mean()) < (1e-3 if dt == torch.float32 else 0.08)
+
+
+@pytest.mark.parametrize("cls,kw", [("EDSR", dict(n_feats=64, n_resblocks=2)), ("RCAN", dict(n_feats=64, n_resgroups=1, n_resblocks=2)),
+                                    ("RDN", dict(rdn_config="A")), ("WDSR", dict(n_resblocks=2))])
+def test_empty_batch(cls, kw):
+    """A batch of zero patches (torch's convs accept it): empty output of the right shape, zero parameter gradients."""
+    import sr_amd as A
+    m = getattr(A, cls)(scale_factor=2, precision="bf16", **kw).cuda()
+    x = torch.rand(0, 3, 24, 24, device="cuda")
+    y = m(x)
+    assert tuple(y.shape) == (0, 3, 48, 48) and y.dtype == torch.float32
+    (y.sum() * 1.0).backward()
+    grads = [p.grad for p in m.parameters() if p.requires_grad]
+    assert any(g is not None for g in grads)
+    assert all(g is None or float(g.abs().sum()) == 0.0 for g in grads)
