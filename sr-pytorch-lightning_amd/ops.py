@@ -197,11 +197,34 @@ def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False):
 # --------------------------------------------------------------------------------------------
 # raw launch wrappers
 # --------------------------------------------------------------------------------------------
+_ADDR_LIMIT = 0x7fff0000      # bytes one launch of the 32-bit-offset (buffer instruction) kernels can address per tensor
+
+
+def _batch_chunks(n, *tensors):
+    """Number of batch chunks so that every tensor's chunk stays below _ADDR_LIMIT bytes (1 for ordinary sizes)."""
+    worst = 0
+    for t in tensors:
+        if t is not None and t.dim() > 0 and t.shape[0] > 0:
+            worst = max(worst, t.shape[0] * t.stride(0) * t.element_size())
+    if worst < _ADDR_LIMIT or n <= 1:
+        return 1
+    return min(n, -(-worst // (_ADDR_LIMIT // 2)))
+
+
 def conv_raw(x, pk, *, N, H, W, Cin, Cout, out, out_mode=L.OUT_NHWC, ps_r=0, relu=False, scale=1.0,
              res=None, mask=None, mask_from=0, post_add=None, x_ps=0, use_bias=True):
     """One srk_conv2d launch.  `x`, `out`, `res`, `mask` are NHWC tensors or channel-slice views
     (planar mode: `out`/`res` are NCHW fp32).  (N,H,W) are the conv-space dims."""
     _need_gpu(x)
+    nck = _batch_chunks(N, x, out, res, mask)
+    if nck > 1:         # a tensor of 2 GiB or more: the persistent kernels address 31 bits -> several launches over the batch
+        step = -(-N // nck)
+        for n0 in range(0, N, step):
+            n1 = min(N, n0 + step)
+            conv_raw(x[n0:n1], pk, N=n1 - n0, H=H, W=W, Cin=Cin, Cout=Cout, out=out[n0:n1], out_mode=out_mode, ps_r=ps_r,
+                     relu=relu, scale=scale, res=None if res is None else res[n0:n1], mask=None if mask is None else mask[n0:n1],
+                     mask_from=mask_from, post_add=post_add, x_ps=x_ps, use_bias=use_bias)
+        return out
     dt = x.dtype
     planar = out_mode == L.OUT_PLANAR
     a = L.ConvArgs(
@@ -225,6 +248,17 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
     if N == 0:          # empty batch: zero gradients (the slab scratch would be uninitialised)
         return (torch.zeros(w_shape, dtype=torch.float32, device=dev),
                 torch.zeros(cout, dtype=torch.float32, device=dev) if want_bias else None)
+    nck = _batch_chunks(N, x, dy)
+    if nck > 1:         # 2 GiB and more: sum the gradients of batch chunks (each chunk keeps the slab kernels)
+        step = -(-N // nck)
+        dw = db = None
+        for n0 in range(0, N, step):
+            n1 = min(N, n0 + step)
+            w_, b_ = wgrad_raw(x[n0:n1], dy[n0:n1], N=n1 - n0, H=H, W=W, Cin=Cin, Cout=Cout, k=k, w_shape=w_shape, ps_r=ps_r,
+                               scale=scale, x_ps=x_ps, dy_ps=dy_ps, want_bias=want_bias)
+            dw = w_ if dw is None else dw.add_(w_)
+            db = b_ if (db is None or b_ is None) else db.add_(b_)
+        return dw, db
     a = L.WgradArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(x_ps),
                     dy=dy.data_ptr(), dy_pitch=_pitch(dy), dy_coff=0, dy_ps=int(dy_ps),
                     N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, dwp=0, dbp=0, nslabs=0, dtype=_DT[x.dtype])

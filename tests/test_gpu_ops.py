@@ -322,3 +322,29 @@ def test_bad_args_raise(A):
     w = torch.nn.Parameter(torch.zeros(16, 16, 5, 5).cuda())
     with pytest.raises(RuntimeError, match="not supported"):
         A.ops.conv(torch.zeros(1, 4, 4, 16, device="cuda"), w, None)
+
+
+def test_tensors_beyond_2gib_are_chunked(A, monkeypatch):
+    """Tensors of 2 GiB and more are processed in batch chunks (the persistent kernels use 32-bit buffer offsets).
+    Exercised by lowering the limit instead of allocating gigabytes: results must equal the single-launch results."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    x = ((torch.rand(5, 20, 20, 64, generator=g) - 0.5)).to(dt).cuda()
+    res = ((torch.rand(5, 20, 20, 64, generator=g) - 0.5)).to(dt).cuda()
+    dy = ((torch.rand(5, 20, 20, 64, generator=g) - 0.5)).to(dt).cuda()
+    w = torch.nn.Parameter(((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.1).cuda())
+    b = torch.nn.Parameter(((torch.rand(64, generator=g) - 0.5) * 0.1).cuda())
+    pk = A.ops.pack_conv(w, b, dt)
+
+    def run():
+        out = torch.empty_like(x)
+        A.ops.conv_raw(x, pk, N=5, H=20, W=20, Cin=64, Cout=64, out=out, res=res, scale=0.5)
+        dw, db = A.ops.wgrad_raw(x, dy, N=5, H=20, W=20, Cin=64, Cout=64, k=3, w_shape=(64, 64, 3, 3))
+        torch.cuda.synchronize()
+        return out, dw, db
+    o1, w1, b1 = run()
+    monkeypatch.setattr(A.ops, "_ADDR_LIMIT", 2 * 20 * 20 * 64 * 2 + 1)      # two images per chunk
+    assert A.ops._batch_chunks(5, x) > 1
+    o2, w2, b2 = run()
+    assert torch.equal(o1, o2)
+    assert float((w1 - w2).abs().max()) <= 1e-5 * float(w1.abs().max()) and float((b1 - b2).abs().max()) <= 1e-5 * float(b1.abs().max())
