@@ -173,7 +173,13 @@ def main():
     if side is not None:
         side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-        net = T.wrap_ddp(model, dev, force=force_ddp)
+        # gradient averaging: trainer.GradSync (one flat all-reduce after backward) unless SRK_USE_TORCH_DDP=1
+        use_torch_ddp = os.environ.get("SRK_USE_TORCH_DDP") == "1"
+        net = T.wrap_ddp(model, dev, force=force_ddp) if use_torch_ddp else model
+        gsync = None
+        if ddp and not use_torch_ddp:
+            gsync = T.GradSync(model)
+            gsync.broadcast()
         # reference optimizer: Adam at torch defaults (srmodel.py:145-154,602-603).  Same update rule, torch's fused
         # multi-tensor implementation (one kernel for all 74 tensors instead of ~150 tiny per-tensor launches),
         # capturable so the step counter lives on the device for hipGraph replay
@@ -184,6 +190,8 @@ def main():
         sr = net(batch["lr"])
         loss = model._calculate_losses(img_sr=sr, img_hr=batch["hr"])["loss"]
         loss.backward()
+        if gsync is not None:
+            gsync.sync()
         opt.step()
         return loss
 
@@ -253,6 +261,7 @@ def main():
             "config": {"workload": f"{a.model} x{a.scale}, {a.patch}x{a.patch} LR patches, batch {a.batch}/GPU, "
                                    f"{'forward only' if a.inference else 'train step (L1 + Adam)'}",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": used_graph,
+                       "grad_sync": (None if not ddp else "torch_ddp" if use_torch_ddp else "flat_allreduce"),
                        "loss_after_warmup": loss_first, "loss_after_timed_steps": loss_last},
             "model_mfma_frac": round(value / world * flop_per_patch / 1e3 / PEAK_TFLOPS[a.dtype], 4),
         }

@@ -1,5 +1,6 @@
-"""world_size-2 data-parallel test on CPU (gloo): the N>1 path of trainer.py -- DDP wrap, one-bucket
-gradient all-reduce, identical replicas, and equality with a single process at 2x batch."""
+"""world_size-2 data-parallel test on CPU (gloo): the N>1 path of trainer.py -- the flat one-all-reduce gradient
+average (GradSync, default) and the torch DDP wrapper (SRK_USE_TORCH_DDP=1): identical replicas, and equality with a
+single process at 2x batch."""
 import os
 import socket
 import sys
@@ -19,8 +20,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, use_ddp):
     sys.path.insert(0, ROOT)
+    os.environ["SRK_USE_TORCH_DDP"] = "1" if use_ddp else "0"
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     import sr_amd
@@ -36,9 +38,10 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_ddp_equals_single_process(tmp_path):
+@pytest.mark.parametrize("use_ddp", [False, True], ids=["flat_allreduce", "torch_ddp"])
+def test_two_rank_ddp_equals_single_process(tmp_path, use_ddp):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), use_ddp), nprocs=2, join=True)
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     for k in a:
         assert torch.equal(a[k], b[k]), f"replicas diverged at {k}"
