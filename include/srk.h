@@ -142,6 +142,28 @@ typedef struct {
 } srk_wgrad_fin_args;
 int srk_wgrad_finalize(const srk_wgrad_fin_args* a, srk_stream_t stream);
 
+/* ---- grouped weight gradient: every 3x3 weight gradient of a training step in ONE dispatch ------------------------
+ * The weight gradients of a step are independent of each other; per layer they are 37 (EDSR-baseline) to 411 (RCAN)
+ * launches of only 144 tiles at the reference's batch of 16 (configs/train_default_sr.yml:3).  The host side defers
+ * them to the end of backward (torch.autograd's final callback) and issues two launches: this kernel, which walks a
+ * device table of jobs with equal tile counts per workgroup whatever the layer, and srk_wgrad_finalize_group.
+ *   srk_wgrad_group_ok   : 1 when `a` can be a job (16-bit, 3x3, slab mode: what srk_wgrad_slabs() > 0 means).
+ *   srk_wgrad_group_plan : in : jobs[i] with dbp != NULL where a bias gradient is wanted; `scratch` NULL = sizing pass.
+ *                          out: jobs[i].nslabs, *nblocks, *scratch_floats; with `scratch` (device, fp32, that many floats)
+ *                               also jobs[i].dwp / dbp (slab regions inside it) and, when given, the HOST images of the
+ *                               device tables: table_host [n * srk_wgrad_group_job_bytes()], block_job_host [nblocks].
+ *   srk_conv2d_wgrad_group: the launch; both tables in DEVICE memory (srk_upload_small gets them there).           */
+int srk_wgrad_group_ok(const srk_wgrad_args* a);
+int srk_wgrad_group_job_bytes(void);
+int srk_wgrad_group_plan(srk_wgrad_args* jobs, int n, float* scratch, void* table_host, int* block_job_host,
+                         int* nblocks, long long* scratch_floats);
+int srk_conv2d_wgrad_group(const void* table_dev, const int* block_job_dev, int nblocks, int dtype, srk_stream_t stream);
+/* `n` finalizations in one launch: `table_dev` is a DEVICE array of srk_wgrad_fin_args, `blocks_per_job` workgroups each */
+int srk_wgrad_finalize_group(const srk_wgrad_fin_args* table_dev, int n, int blocks_per_job, srk_stream_t stream);
+/* Copies a small HOST table (<= 4 MiB) to 16-byte-aligned DEVICE memory through kernel arguments: capturable into a
+ * hipGraph (a replay rewrites the same bytes), no pinned staging buffer.                                          */
+int srk_upload_small(void* dst_dev, const void* src_host, long long nbytes, srk_stream_t stream);
+
 /* ---- input unfold (model boundary) -----------------------------------------------------------------
  * Head convs 3->F (edsr.py:21-22, rcan.py:92-93, rdn.py:57-58, wdsr.py:69-71) and WDSR's 5x5 skip conv
  * (wdsr.py:90-94) have Cin <= 4: too thin for a 16-channel MFMA K-chunk.  The boundary kernel fuses the

@@ -123,7 +123,8 @@ LAUNCHERS = {
     "srk_l1_loss_bwd": L1Args,
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
-                 "srk_pack_conv_weights_group", "srk_l1_blocks")
+                 "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
+                 "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small")
 
 _lib = None
 
@@ -148,6 +149,18 @@ def load():
     lib.srk_wgrad_slabs.restype = C.c_int
     lib.srk_pack_conv_weights_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.srk_pack_conv_weights_group.restype = C.c_int
+    lib.srk_wgrad_group_ok.argtypes = [C.POINTER(WgradArgs)]
+    lib.srk_wgrad_group_ok.restype = C.c_int
+    lib.srk_wgrad_group_job_bytes.restype = C.c_int
+    lib.srk_wgrad_group_plan.argtypes = [C.POINTER(WgradArgs), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+    lib.srk_wgrad_group_plan.restype = C.c_int
+    lib.srk_conv2d_wgrad_group.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.srk_conv2d_wgrad_group.restype = C.c_int
+    lib.srk_wgrad_finalize_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.srk_wgrad_finalize_group.restype = C.c_int
+    lib.srk_upload_small.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+    lib.srk_upload_small.restype = C.c_int
     lib.srk_l1_blocks.argtypes = [C.c_longlong]
     lib.srk_l1_blocks.restype = C.c_int
     lib.srk_last_error.restype = C.c_char_p
@@ -165,6 +178,11 @@ def call(name, args, stream):
     rc = getattr(lib, name)(C.byref(args), C.c_void_p(stream))
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.srk_last_error().decode(errors='replace')}")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {load().srk_last_error().decode(errors='replace')}")
 
 
 def conv_tile(cout):

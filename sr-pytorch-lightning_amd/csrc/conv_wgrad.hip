@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const srk_wgrad_args
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int DT>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int ntiles,
-                                                                unsigned x_bytes, unsigned dy_bytes, int tq, int trem) {
+SRK_DEV void wgrad_ws_body(const srk_wgrad_args& a, const int slot, const int cib, const int cob, const int tilesX, const int tilesY,
+                           const unsigned x_bytes, const unsigned dy_bytes, const int tq, const int trem, char* const smem) {
   typedef WgCfg<DT, 3> C;
   typedef typename C::Tr Tr;
   typedef typename Tr::elem elem;
@@ -259,12 +259,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_a
   constexpr int NPK = (C::XPIECES + GT - 1) / GT;      // 11 halo pieces per lane
   constexpr int NDK = C::DYPIECES / GT;                // 8 dY pieces per lane
   constexpr int BUF_BYTES = C::XS_BYTES + C::DYS_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rb = wave >> 1, cbk = wave & 1;
-  const int slot = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
   const int H = a.H, W = a.W;
   const int nch_x = a.Cin / CH, nch_d = a.Cout / CH;
 
@@ -444,6 +442,41 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_a
       if (c < a.Cout) a.dbp[(size_t)slot * a.Cout + c] = t;
     }
   }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int ntiles,
+                                                                unsigned x_bytes, unsigned dy_bytes, int tq, int trem) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  wgrad_ws_body<DT>(a, blockIdx.x, blockIdx.y, blockIdx.z, tilesX, tilesY, x_bytes, dy_bytes, tq, trem, smem);
+}
+
+// ---- grouped launch: the weight gradients of MANY convolutions in one dispatch ---------------------------------------------
+// A training step's weight gradients do not depend on each other, only on (x_l, dy_l) pairs that all exist once the
+// data-gradient chain has run.  Launched per layer they are 37 (EDSR-baseline) to 411 (RCAN) dispatches of 144 tiles
+// at the reference's batch of 16 -- each one pays its own pipeline fill, slab store and a finalize launch for ~2.5 us
+// of matrix work per workgroup.  Here one dispatch walks a device table: block b belongs to job block_job[b], inside
+// that job it is (slot, ci block, co block) like the single launch, and `srk_wgrad_group_plan` sizes the slabs so
+// that every block gets the same number of tiles whatever its layer.  Same body, same slabs, same finalize.
+struct WgJob {
+  srk_wgrad_args a;
+  int tilesX, tilesY;
+  unsigned x_bytes, dy_bytes;
+  int tq, trem;
+  int ncib, ncob;
+  int block0, pad_;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_ws_group_kernel(const WgJob* __restrict__ jobs, const int* __restrict__ block_job) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int jid = block_job[blockIdx.x];
+  const WgJob j = jobs[jid];
+  const int local = (int)blockIdx.x - j.block0;
+  const int per = j.ncib * j.ncob;
+  const int slot = local / per, rem = local - slot * per;
+  const int cib = rem / j.ncob, cob = rem - cib * j.ncob;
+  wgrad_ws_body<DT>(j.a, slot, cib, cob, j.tilesX, j.tilesY, j.x_bytes, j.dy_bytes, j.tq, j.trem, smem);
 }
 
 // =================================================================================================
@@ -735,3 +768,104 @@ extern "C" int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream) {
 }
 
 extern "C" int srk_wgrad_slabs(const srk_wgrad_args* a) { return a ? wgrad_ws_slabs(*a) : 0; }
+
+// ---- grouped launch: planning (host) and dispatch --------------------------------------------------------------------------
+extern "C" int srk_wgrad_group_job_bytes(void) { return (int)sizeof(WgJob); }
+
+extern "C" int srk_wgrad_group_ok(const srk_wgrad_args* a) {
+  // jobs the grouped kernel takes: what the 3x3 slab kernel takes
+  return (a && a->KH == 3 && a->KW == 3 && a->N > 0 && wgrad_ws_slabs(*a) > 0) ? 1 : 0;
+}
+
+extern "C" int srk_wgrad_group_plan(srk_wgrad_args* jobs, int n, float* scratch, void* table_host, int* block_job_host,
+                                    int* nblocks_out, long long* scratch_floats_out) {
+  SRK_CHECK_ARG(jobs && n > 0 && nblocks_out && scratch_floats_out, "srk_wgrad_group_plan: null pointer / no jobs");
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  long long units = 0, maxnt = 0;
+  for (int i = 0; i < n; ++i) {
+    const srk_wgrad_args& a = jobs[i];
+    SRK_CHECK_ARG(srk_wgrad_group_ok(&a), "srk_wgrad_group_plan: job %d is not a 16-bit 3x3 slab-mode weight gradient", i);
+    SRK_CHECK_ARG(a.dtype == jobs[0].dtype, "srk_wgrad_group_plan: job %d has another dtype", i);
+    const long long nt = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+    units += nt * ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
+    if (nt > maxnt) maxnt = nt;
+  }
+  // tiles per workgroup T: every block gets <= T tiles of ONE job; blocks are dispatched as CUs free up, so the launch
+  // takes about ceil(blocks / CUs) rounds of (T + fill/store overhead) tile times.  Scan T upwards from the even split.
+  auto blocks_for = [&](long long T) {
+    long long nb = 0;
+    for (int i = 0; i < n; ++i) {
+      const srk_wgrad_args& a = jobs[i];
+      const long long nt = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+      nb += ((nt + T - 1) / T) * ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
+    }
+    return nb;
+  };
+  long long T = (units + cus - 1) / cus, bestT = 0;
+  if (T < 1) T = 1;
+  double best = 1e300;
+  for (long long t = T; t <= maxnt; t = t + 1 + t / 16) {
+    const long long nb = blocks_for(t);
+    const double cost = (double)((nb + cus - 1) / cus) * (double)(t + 3);
+    if (cost < best) { best = cost; bestT = t; }
+    if (nb <= cus && t > T) break;                 // one round already: larger T only lengthens it
+  }
+  if (bestT == 0) bestT = maxnt;
+  long long off = 0, nb = 0;
+  WgJob* tab = reinterpret_cast<WgJob*>(table_host);
+  for (int i = 0; i < n; ++i) {
+    srk_wgrad_args& a = jobs[i];
+    const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
+    const long long nt = (long long)a.N * tilesX * tilesY;
+    const int slabs = (int)((nt + bestT - 1) / bestT);
+    const int ncib = (a.Cin + 63) / 64, ncob = (a.Cout + 63) / 64;
+    const long long per = 9LL * a.Cin * a.Cout;
+    a.nslabs = slabs;
+    const bool want_b = a.dbp != nullptr;          // in: non-NULL = bias gradient wanted
+    if (scratch) {                                 // sizing pass (scratch == NULL): only nslabs and the totals
+      a.dwp = scratch + off;
+      a.dbp = want_b ? scratch + off + (long long)slabs * per : nullptr;
+    }
+    off += (long long)slabs * (per + a.Cout);
+    if (tab) {
+      SRK_CHECK_ARG(scratch, "srk_wgrad_group_plan: the table needs the scratch pointer");
+      WgJob& j = tab[i];
+      j.a = a;
+      const int rd = a.dy_ps > 1 ? a.dy_ps : 1;
+      j.tilesX = tilesX; j.tilesY = tilesY;
+      j.x_bytes = (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2);
+      j.dy_bytes = (unsigned)((long long)a.N * a.H * a.W * rd * rd * a.dy_pitch * 2);
+      j.tq = (int)(nt / slabs); j.trem = (int)(nt % slabs);
+      j.ncib = ncib; j.ncob = ncob; j.block0 = (int)nb; j.pad_ = 0;
+    }
+    const long long cnt = (long long)slabs * ncib * ncob;
+    if (block_job_host)
+      for (long long b = 0; b < cnt; ++b) block_job_host[nb + b] = i;
+    nb += cnt;
+  }
+  SRK_CHECK_ARG(nb < 0x7fffffffLL, "srk_wgrad_group_plan: %lld blocks", nb);
+  *nblocks_out = (int)nb;
+  *scratch_floats_out = off;
+  return 0;
+}
+
+extern "C" int srk_conv2d_wgrad_group(const void* table_dev, const int* block_job_dev, int nblocks, int dtype, srk_stream_t stream) {
+  SRK_CHECK_ARG(table_dev && block_job_dev && nblocks > 0, "srk_conv2d_wgrad_group: null pointer / no blocks");
+  SRK_CHECK_ARG(dtype == SRK_BF16 || dtype == SRK_F16, "srk_conv2d_wgrad_group: 16-bit dtypes only");
+  typedef WgCfg<SRK_BF16, 3> C;
+  constexpr int LDS = 2 * (C::XS_BYTES + C::DYS_BYTES);
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ws_group_kernel<SRK_BF16>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ws_group_kernel<SRK_F16>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr0 != hipSuccess || attr1 != hipSuccess) {
+    srk_set_error("srk_conv2d_wgrad_group: cannot reserve %d bytes of LDS", LDS);
+    return (int)(attr0 != hipSuccess ? attr0 : attr1);
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const WgJob* tab = reinterpret_cast<const WgJob*>(table_dev);
+  if (dtype == SRK_BF16) hipLaunchKernelGGL((conv_wgrad_ws_group_kernel<SRK_BF16>), dim3(nblocks), dim3(256), LDS, st, tab, block_job_dev);
+  else hipLaunchKernelGGL((conv_wgrad_ws_group_kernel<SRK_F16>), dim3(nblocks), dim3(256), LDS, st, tab, block_job_dev);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}

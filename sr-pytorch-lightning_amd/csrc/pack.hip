@@ -1,6 +1,7 @@
 // Weight packing (OIHW fp32 -> MFMA shadow layout), weight-gradient unpacking, NCHW<->NHWC conversion,
 // and the library's error/introspection entry points.
 #include <stdarg.h>
+#include <string.h>
 #include "srk_common.h"
 
 static thread_local char g_err[512] = "";
@@ -96,14 +97,13 @@ __global__ void pack_group_kernel(const srk_pack_args* __restrict__ table) {
 // Sums the per-workgroup slabs and converts [tap][ci][co'] -> OIHW.  Block = 128 consecutive slab elements x 8 waves;
 // wave w sums slabs w, w+8, ... with float2 loads (512 contiguous bytes per wave instruction, 8 loads in flight),
 // the 8 partial sums meet in LDS in a fixed order (bitwise reproducible).
-__global__ __launch_bounds__(512) void wgrad_finalize_kernel(const srk_wgrad_fin_args a) {
-  __shared__ float red[8][128];
+__device__ __forceinline__ void wgrad_finalize_body(const srk_wgrad_fin_args& a, float (&red)[8][128], const int bx, const int gx) {
   const int taps = a.KH * a.KW;
   const int ns = a.nslabs > 1 ? a.nslabs : 1;
   const size_t per = (size_t)taps * a.CinP * a.CoutP;       // multiple of 256 (CinP, CoutP multiples of 16)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long nchunks = ((long long)per + 127) / 128;
-  for (long long ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+  for (long long ch = bx; ch < nchunks; ch += gx) {
     const size_t e0 = (size_t)ch * 128 + 2 * lane;
     float s0 = 0.f, s1 = 0.f;
     if (e0 < per) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512) void wgrad_finalize_kernel(const srk_wgrad_fin
     }
     __syncthreads();
   }
-  if (a.db && a.dbp && blockIdx.x == 0) {
+  if (a.db && a.dbp && bx == 0) {
     // bias: 64 channels per pass, wave w sums slabs w, w+8, ... (loads in flight), fixed-order LDS reduce
     for (int c0 = 0; c0 < a.CoutP; c0 += 64) {
       const int cop = c0 + lane;
@@ -169,6 +169,17 @@ __global__ __launch_bounds__(512) void wgrad_finalize_kernel(const srk_wgrad_fin
       __syncthreads();
     }
   }
+}
+
+__global__ __launch_bounds__(512) void wgrad_finalize_kernel(const srk_wgrad_fin_args a) {
+  __shared__ float red[8][128];
+  wgrad_finalize_body(a, red, blockIdx.x, gridDim.x);
+}
+// one launch for every weight gradient of a step: blockIdx.y = table entry (the pack_group_kernel pattern)
+__global__ __launch_bounds__(512) void wgrad_finalize_group_kernel(const srk_wgrad_fin_args* __restrict__ table) {
+  __shared__ float red[8][128];
+  const srk_wgrad_fin_args a = table[blockIdx.y];
+  wgrad_finalize_body(a, red, blockIdx.x, gridDim.x);
 }
 
 // NCHW fp32 -> NHWC dtype; one thread per (pixel, 4-channel group)
@@ -334,6 +345,46 @@ extern "C" int srk_wgrad_finalize(const srk_wgrad_fin_args* a, srk_stream_t stre
   const long long rows = ((long long)a->KH * a->KW * a->CinP * a->CoutP + 127) / 128;
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)(rows > 2048 ? 2048 : (rows < 1 ? 1 : rows))), dim3(512), 0,
                      reinterpret_cast<hipStream_t>(stream), *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- small host table -> device memory through kernel arguments ------------------------------------------------------------
+// The grouped launches read per-job descriptors from a device table whose contents (tensor addresses) change every step
+// in eager mode.  A hipMemcpyAsync from pageable host memory cannot be captured into a hipGraph and a pinned staging
+// buffer would have to outlive every graph that references it; kernel arguments are copied at launch (or capture)
+// time, so the table travels as <= 3.5 KB by-value chunks and a replayed graph rewrites the same bytes.
+struct UploadChunk { unsigned char b[3584]; };
+__global__ void upload_kernel(unsigned char* __restrict__ dst, const UploadChunk c, int n) {
+  // 16 bytes per thread where possible (dst is 16-byte aligned per chunk: chunk size is a multiple of 16)
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i + 16 <= n) {
+    *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(c.b + i);
+  } else {
+    for (int k = i; k < n; ++k) dst[k] = c.b[k];
+  }
+}
+
+extern "C" int srk_upload_small(void* dst_dev, const void* src_host, long long nbytes, srk_stream_t stream) {
+  SRK_CHECK_ARG(dst_dev && src_host && nbytes >= 0, "srk_upload_small: null pointer");
+  SRK_CHECK_ARG(((uintptr_t)dst_dev & 15) == 0, "srk_upload_small: destination must be 16-byte aligned");
+  SRK_CHECK_ARG(nbytes <= (4 << 20), "srk_upload_small: %lld bytes is not a small table", nbytes);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (long long off = 0; off < nbytes; off += (long long)sizeof(UploadChunk)) {
+    UploadChunk c;
+    const int n = (int)((nbytes - off) < (long long)sizeof(UploadChunk) ? (nbytes - off) : (long long)sizeof(UploadChunk));
+    memcpy(c.b, reinterpret_cast<const unsigned char*>(src_host) + off, (size_t)n);
+    hipLaunchKernelGGL(upload_kernel, dim3((n + 16 * 256 - 1) / (16 * 256)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned char*>(dst_dev) + off, c, n);
+  }
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_wgrad_finalize_group(const srk_wgrad_fin_args* table_dev, int n, int blocks_per_job, srk_stream_t stream) {
+  SRK_CHECK_ARG(table_dev && n > 0 && n <= 65535, "srk_wgrad_finalize_group: bad table (%d entries)", n);
+  const int bx = blocks_per_job < 1 ? 1 : (blocks_per_job > 2048 ? 2048 : blocks_per_job);
+  hipLaunchKernelGGL(wgrad_finalize_group_kernel, dim3(bx, n), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), table_dev);
   SRK_LAUNCH_CHECK();
   return 0;
 }

@@ -282,6 +282,145 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
     return dw, db
 
 
+# --------------------------------------------------------------------------------------------
+# deferred, grouped weight gradients
+# --------------------------------------------------------------------------------------------
+class _WgradQueue:
+    """Weight-gradient jobs of the backward pass in flight (one process per GPU: autograd's device thread appends,
+    the thread that called backward() flushes from the engine's final callback)."""
+
+    def __init__(self):
+        self.jobs = []          # [WgradArgs, fin dict, keepalive tensors, dw, db, round]
+        self.armed = False
+        self.enabled = True
+        self.targets = {}       # data_ptr of a dw buffer -> number of jobs queued on it (weight sharing -> rounds)
+        self.gen = 0            # backward-pass generation (bumped by every flush)
+
+
+_WQ = _WgradQueue()
+_WG_BLOCKS_PER_JOB = 24
+
+
+def set_defer_wgrad(enabled):
+    """Deferral switch (default on).  Off = every weight gradient is its own launch inside backward, which is what
+    code that reads gradients from inside backward needs (torch's DistributedDataParallel reducer, tensor hooks)."""
+    prev = _WQ.enabled
+    _WQ.enabled = bool(enabled)
+    return prev
+
+
+def _grad_slot(p, shape):
+    """How a deferred job delivers the gradient of leaf `p`:  ('new', None)  -> a fresh tensor handed to autograd;
+    ('acc', tensor) -> accumulate into the existing fp32 gradient, autograd gets None;  None -> cannot defer."""
+    if p is None:
+        return ("new", None)
+    if not (isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad):
+        return None
+    if getattr(p, "_backward_hooks", None):
+        return None
+    hooks = getattr(p, "_post_accumulate_grad_hooks", None)
+    if hooks and not p.__dict__.get("_srk_flush_aware", False):
+        return None
+    g = p.grad
+    if g is None:
+        return ("new", None)
+    if g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == tuple(shape) and g.is_cuda:
+        return ("acc", g)
+    return None
+
+
+def flush_wgrads():
+    """Launch every queued weight gradient: ONE grouped slab kernel per dtype and ONE grouped finalize per round."""
+    import ctypes as C
+    jobs, _WQ.jobs, _WQ.armed, _WQ.targets = _WQ.jobs, [], False, {}
+    _WQ.gen += 1
+    if not jobs:
+        return
+    lib = L.load()
+    st = _stream()
+    for dt in sorted({j[0].dtype for j in jobs}):
+        grp = [j for j in jobs if j[0].dtype == dt]
+        n = len(grp)
+        arr = (L.WgradArgs * n)(*[j[0] for j in grp])
+        nblocks, sfl = C.c_int(0), C.c_longlong(0)
+        L.check(lib.srk_wgrad_group_plan(arr, n, None, None, None, C.byref(nblocks), C.byref(sfl)), "srk_wgrad_group_plan")
+        dev = grp[0][2][0].device
+        scratch = torch.empty(sfl.value, dtype=torch.float32, device=dev)
+        jb = lib.srk_wgrad_group_job_bytes()
+        off_bj = _roundup(n * jb, 16)
+        off_fin = _roundup(off_bj + 4 * nblocks.value, 16)
+        fin_sz = C.sizeof(L.WgradFinArgs)
+        total = _roundup(off_fin + n * fin_sz, 16)
+        host = (C.c_ubyte * total)()
+        base = C.addressof(host)
+        L.check(lib.srk_wgrad_group_plan(arr, n, scratch.data_ptr(), base, base + off_bj, C.byref(nblocks), C.byref(sfl)),
+                "srk_wgrad_group_plan")
+        # finalize table, ordered by round (jobs that accumulate into a buffer another job of this pass writes come later)
+        order = sorted(range(n), key=lambda i: grp[i][5])
+        rounds = {}
+        for pos, i in enumerate(order):
+            a, f = arr[i], grp[i][1]
+            fa = L.WgradFinArgs(dwp=a.dwp, dbp=a.dbp or 0, nslabs=a.nslabs, dw=f["dw"], db=f["db"], Cout=f["Cout"], Cin=f["Cin"],
+                                KH=3, KW=3, CinP=a.Cin, CoutP=a.Cout, ps_r=f["ps_r"], scale=f["scale"], accumulate=f["acc"])
+            C.memmove(base + off_fin + pos * fin_sz, C.addressof(fa), fin_sz)
+            rounds.setdefault(grp[i][5], [pos, 0])[1] += 1
+        table = torch.empty(total, dtype=torch.uint8, device=dev)
+        L.check(lib.srk_upload_small(table.data_ptr(), base, total, st), "srk_upload_small")
+        L.check(lib.srk_conv2d_wgrad_group(table.data_ptr(), table.data_ptr() + off_bj, nblocks.value, dt, st), "srk_conv2d_wgrad_group")
+        for r in sorted(rounds):
+            pos, cnt = rounds[r]
+            L.check(lib.srk_wgrad_finalize_group(table.data_ptr() + off_fin + pos * fin_sz, cnt, _WG_BLOCKS_PER_JOB, st),
+                    "srk_wgrad_finalize_group")
+        # `table`, `scratch` and the operands are referenced by enqueued work only: the caching allocator keeps a freed
+        # block on this stream, so later allocations are ordered behind these launches
+
+
+def wgrad(x, dy, *, wparam=None, bparam=None, **kw):
+    """Weight (+ bias) gradient of one conv.  3x3 16-bit convs whose parameters are leaves are QUEUED and computed by
+    one grouped launch when the backward pass ends (`flush_wgrads`, the autograd engine's final callback); everything
+    else runs now (`wgrad_raw`).  Returns what backward() hands to autograd for (weight, bias)."""
+    want_bias = kw.get("want_bias", True)
+    k, w_shape = kw["k"], kw["w_shape"]
+    if not (_WQ.enabled and k == 3 and x.dtype in (torch.bfloat16, torch.float16) and kw["N"] > 0 and kw.get("x_ps", 0) <= 1):
+        return wgrad_raw(x, dy, **kw)
+    sw = _grad_slot(wparam, w_shape)
+    sb = _grad_slot(bparam, (w_shape[0],)) if want_bias else ("new", None)
+    if sw is None or sb is None or wparam is None or (want_bias and sb[0] != sw[0]) or _batch_chunks(kw["N"], x, dy) > 1:
+        return wgrad_raw(x, dy, **kw)
+    a = L.WgradArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(kw.get("x_ps", 0)),
+                    dy=dy.data_ptr(), dy_pitch=_pitch(dy), dy_coff=0, dy_ps=int(kw.get("dy_ps", 0)),
+                    N=kw["N"], H=kw["H"], W=kw["W"], Cin=kw["Cin"], Cout=kw["Cout"], KH=3, KW=3, dwp=0, dbp=1 if want_bias else 0,
+                    nslabs=0, dtype=_DT[x.dtype])
+    if not L.load().srk_wgrad_group_ok(a):
+        return wgrad_raw(x, dy, **kw)
+    cout, cin, kh, kwid = w_shape
+    dev = x.device
+    ret_w = ret_b = None
+    if sw[0] == "new":
+        seen = wparam.__dict__.get("_srk_pending")          # second use of a shared weight in this pass -> accumulate round
+        if seen is not None and seen[0] == _WQ.gen:
+            dw, db, acc = seen[1], seen[2], 1
+        else:
+            dw = torch.empty(w_shape, dtype=torch.float32, device=dev)
+            db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+            acc = 0
+            ret_w, ret_b = dw, db
+            wparam.__dict__["_srk_pending"] = (_WQ.gen, dw, db)
+    else:
+        dw, db, acc = sw[1], (sb[1] if want_bias else None), 1
+    rnd = _WQ.targets.get(dw.data_ptr(), 0)                 # jobs on one buffer finalize in successive rounds
+    _WQ.targets[dw.data_ptr()] = rnd + 1
+    fin = dict(dw=dw.data_ptr(), db=_ptr(db), Cout=cout, Cin=cin, ps_r=int(kw.get("ps_r", 0)), scale=float(kw.get("scale", 1.0)), acc=acc)
+    _WQ.jobs.append([a, fin, (x, dy, dw, db), dw, db, rnd])
+    if not _WQ.armed:
+        _WQ.armed = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+        except RuntimeError:            # not inside a backward pass (a Function's backward called by hand)
+            flush_wgrads()
+    return ret_w, ret_b
+
+
 def unfold_raw(x, sub, k, dtype):
     """NCHW fp32 -> NHWC im2col [N,H,W,pad16(C*k*k)] (- sub[c]), the head-conv input."""
     _need_gpu(x)
@@ -360,6 +499,7 @@ class ConvFn(torch.autograd.Function):
             conv_raw(x, pk, N=n, H=h, W=wd, Cin=cinp, Cout=out.shape[3], out=out, scale=scale, res=res)
         ctx.save_for_backward(x, w)
         ctx.cfg = (scale, ps_r, b is not None, res is not None)
+        ctx.wb = (w, b)
         return out
 
     @staticmethod
@@ -376,8 +516,8 @@ class ConvFn(torch.autograd.Function):
             gx = torch.empty_like(x)
             conv_raw(g, pkd, N=n, H=h, W=wd, Cin=coutp, Cout=cinp, out=gx, scale=scale, x_ps=ps_r, use_bias=False)
         if ctx.needs_input_grad[1]:
-            gw, gb = wgrad_raw(x, g, N=n, H=h, W=wd, Cin=cinp, Cout=coutp, k=k, w_shape=tuple(w.shape),
-                               ps_r=ps_r, scale=scale, dy_ps=ps_r, want_bias=has_b)
+            gw, gb = wgrad(x, g, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cinp, Cout=coutp, k=k,
+                           w_shape=tuple(w.shape), ps_r=ps_r, scale=scale, dy_ps=ps_r, want_bias=has_b)
         return gx, gw, gb, (g if has_res else None), None, None
 
 
@@ -445,6 +585,7 @@ class TailConvFn(torch.autograd.Function):
                  res=resc, post_add=post_add)
         ctx.save_for_backward(x, w)
         ctx.cfg = (ps_r, b is not None, res is not None)
+        ctx.wb = (w, b)
         return out
 
     @staticmethod
@@ -460,8 +601,8 @@ class TailConvFn(torch.autograd.Function):
             gx = torch.empty_like(x)
             conv_raw(dy, pkd, N=n, H=h, W=wd, Cin=dy.shape[3], Cout=cinp, out=gx, use_bias=False)
         if ctx.needs_input_grad[1]:
-            gw, gb = wgrad_raw(x, dy, N=n, H=h, W=wd, Cin=cinp, Cout=dy.shape[3], k=k, w_shape=tuple(w.shape),
-                               want_bias=has_b)
+            gw, gb = wgrad(x, dy, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cinp, Cout=dy.shape[3], k=k,
+                           w_shape=tuple(w.shape), want_bias=has_b)
         return gx, gw, gb, (g if has_res else None), None, None
 
 
@@ -533,6 +674,7 @@ class ConvChainFn(torch.autograd.Function):
                 acts.append(a)
         ctx.save_for_backward(*acts, *ws)
         ctx.cfg = (scale, tuple(relus), tuple(b is not None for b in bs))
+        ctx.wb = (tuple(ws), tuple(bs))
         return a
 
     @staticmethod
@@ -550,8 +692,8 @@ class ConvChainFn(torch.autograd.Function):
             k = w.shape[2]
             sc = scale if i == L_ - 1 else 1.0
             if ctx.needs_input_grad[3 + 2 * i]:
-                gw, gb = wgrad_raw(a_in, dy, N=n, H=h, W=wd, Cin=a_in.shape[3], Cout=dy.shape[3], k=k,
-                                   w_shape=tuple(w.shape), scale=sc, want_bias=has_b[i])
+                gw, gb = wgrad(a_in, dy, wparam=ctx.wb[0][i], bparam=ctx.wb[1][i], N=n, H=h, W=wd, Cin=a_in.shape[3],
+                               Cout=dy.shape[3], k=k, w_shape=tuple(w.shape), scale=sc, want_bias=has_b[i])
                 grads[2 * i], grads[2 * i + 1] = gw, gb
             pkd = pack_conv(w, None, g.dtype, dgrad=True)
             gin = torch.empty_like(a_in)
@@ -600,6 +742,7 @@ class RCABFn(torch.autograd.Function):
             s_out=s.data_ptr(), z_out=z.data_ptr(), out=out.data_ptr(), out_pitch=cp, out_coff=0,
             N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt]), _stream())
         ctx.save_for_backward(x, y1, t, sums, s, z, w1, w2, cw1, cw2)
+        ctx.wb = (w1, b1, w2, b2)
         return out
 
     @staticmethod
@@ -623,10 +766,12 @@ class RCABFn(torch.autograd.Function):
             z=z.data_ptr(), w1=w1f.data_ptr(), w2=w2f.data_ptr(), dw1=dw1.data_ptr(), db1=db1.data_ptr(),
             dw2=dw2.data_ptr(), db2=db2.data_ptr(), gt=gt.data_ptr(), gt_pitch=cp, gt_coff=0,
             N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt]), _stream())
-        gw2, gb2 = wgrad_raw(y1, gt, N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w2.shape[2], w_shape=tuple(w2.shape))
+        gw2, gb2 = wgrad(y1, gt, wparam=ctx.wb[2], bparam=ctx.wb[3], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w2.shape[2],
+                         w_shape=tuple(w2.shape), want_bias=ctx.wb[3] is not None)
         g1 = torch.empty_like(x)
         conv_raw(gt, pack_conv(w2, None, dt, dgrad=True), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1, use_bias=False)
-        gw1, gb1 = wgrad_raw(x, g1, N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w1.shape[2], w_shape=tuple(w1.shape))
+        gw1, gb1 = wgrad(x, g1, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w1.shape[2],
+                         w_shape=tuple(w1.shape), want_bias=ctx.wb[1] is not None)
         gx = torch.empty_like(x)
         conv_raw(g1, pack_conv(w1, None, dt, dgrad=True), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=gx, res=g, use_bias=False)
         # un-pad the CA parameter gradients (rows/cols beyond the real C are zero)
@@ -683,6 +828,7 @@ class RDBFn(torch.autograd.Function):
         conv_raw(feat, pack_conv(wl, bl, x.dtype), N=n, H=h, W=wd, Cin=ctot, Cout=g0, out=out, res=x)
         ctx.save_for_backward(feat, *ws, wl)
         ctx.cfg = (nconv, g0, g)
+        ctx.wb = (tuple(ws), tuple(bs))
         return out
 
     @staticmethod
@@ -703,8 +849,9 @@ class RDBFn(torch.autograd.Function):
         for c in range(nconv - 1, -1, -1):
             cin = g0 + c * g
             dy = gfeat[..., cin:cin + g]
-            gw, gb = wgrad_raw(feat[..., :cin], dy, N=n, H=h, W=wd, Cin=cin, Cout=g, k=ws[c].shape[2],
-                               w_shape=tuple(ws[c].shape))
+            # (slice c of gfeat is final here: the remaining dgrads only touch the channels below it, so the job can wait)
+            gw, gb = wgrad(feat[..., :cin], dy, wparam=ctx.wb[0][c], bparam=ctx.wb[1][c], N=n, H=h, W=wd, Cin=cin, Cout=g,
+                           k=ws[c].shape[2], w_shape=tuple(ws[c].shape), want_bias=ctx.wb[1][c] is not None)
             grads[2 * c], grads[2 * c + 1] = gw, gb
             pref = gfeat[..., :cin]
             conv_raw(dy, pack_conv(ws[c], None, dt, dgrad=True), N=n, H=h, W=wd, Cin=g, Cout=cin, out=pref, res=pref,

@@ -3,8 +3,8 @@
 The reference has no distributed code of its own: Lightning's Trainer picks DDP when `devices > 1`
 (configs/all.yml:83,125-127) and torch DDP all-reduces the fp32 gradients over NCCL (SURVEY.md section 5,
 8(e)).  Here: one process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm) or
-"gloo" on CPU, and ONE all-reduce of a flat gradient buffer per step (`GradSync`; xGMI is point-to-point: fewer,
-larger messages).  `wrap_ddp` (DistributedDataParallel, one bucket sized to the model, bucket views) is kept as the
+"gloo" on CPU, and a flat gradient buffer averaged in a few large buckets whose all-reduces overlap backward
+(`GradSync`; xGMI is point-to-point: fewer, larger messages).  `wrap_ddp` (DistributedDataParallel, one bucket sized to the model, bucket views) is kept as the
 `SRK_USE_TORCH_DDP=1` alternative.  The gradient mean is the only collective on the path.
 """
 import os
@@ -37,10 +37,19 @@ def init_distributed(device_type, force=False):
     return rank, world, local
 
 
+def _flush_deferred():
+    from . import ops
+    ops.flush_wgrads()
+
+
 def wrap_ddp(model, device, force=False):
-    """DDP wrapper tuned for this path: one bucket (all grads), bucket views, no unused-parameter scan."""
+    """DDP wrapper tuned for this path: one bucket (all grads), bucket views, no unused-parameter scan.
+    torch's reducer copies each gradient into its bucket from inside backward, so the HIP path's deferred (grouped)
+    weight gradients are switched off under it: every weight gradient is computed where autograd asks for it."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return model
+    from . import ops
+    ops.set_defer_wgrad(False)
     nbytes = sum(p.numel() * 4 for p in model.parameters() if p.requires_grad)
     cap_mb = max(1, int(nbytes / 2 ** 20) + 1)
     kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=cap_mb, broadcast_buffers=False, find_unused_parameters=False)
@@ -50,20 +59,58 @@ def wrap_ddp(model, device, force=False):
 
 
 class GradSync:
-    """The path's only collective, without the DDP wrapper: after backward the fp32 gradients are gathered into ONE flat
-    buffer (one multi-tensor copy), averaged with ONE all-reduce (RCCL over xGMI on the GPUs, gloo on CPU) and handed
-    back to the parameters as views of that buffer.  Same arithmetic as DistributedDataParallel with a single bucket
-    (mean over ranks); what it drops is the per-parameter autograd hooks and the reducer's bookkeeping, which cost
-    0.65 ms of a 9 ms EDSR-baseline step on one rank.  Nothing overlaps with backward, by design: the largest model
-    here (EDSR-large, 172 MB of gradients) is a ~1 ms all-reduce against a 44 ms step.
+    """The path's only collective, without the DDP wrapper: the fp32 gradients live in ONE flat buffer cut into a few
+    large buckets (reverse parameter order = the order backward produces them); a bucket's all-reduce (RCCL over xGMI
+    on the GPUs, gloo on CPU) is launched asynchronously from a post-accumulate-grad hook as soon as its last gradient
+    exists, so it OVERLAPS the rest of backward (what Lightning's DDP does for the reference, configs/all.yml:83,
+    125-127), and `sync()` only waits.  Buckets are launched strictly in index order, so every rank issues the same
+    sequence of collectives.  Same arithmetic as DistributedDataParallel (mean over ranks); what it drops is the
+    reducer's per-step bookkeeping (0.65 ms of a 9 ms EDSR-baseline step on one rank).
+
+    `overlap=False` registers no hooks: `sync()` then packs all gradients and issues the bucket all-reduces after
+    backward -- the form a hipGraph-captured step uses (bench.py captures forward + backward + `pack()` in one graph,
+    calls `reduce()` eagerly, and replays the optimizer step as a second graph: no collective inside a capture).
     Replicas start identical: `broadcast()` sends rank 0's parameters and buffers."""
 
-    def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module, overlap=True, bucket_bytes=32 << 20):
         self.module = module
-        self.flat = None
-        self.views = None
+        self.params = [p for p in module.parameters() if p.requires_grad]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.overlap = bool(overlap)
+        order = list(reversed(self.params))              # backward reaches the last layers' parameters first
+        self.flat = None
+        self.views = {}
+        self.buckets = []                                # [start, end, [params]]
+        total = sum(p.numel() for p in order)
+        if order:
+            self.flat = torch.zeros(total, dtype=torch.float32, device=order[0].device)
+            off, cur = 0, None
+            for p in order:
+                n = p.numel()
+                if cur is None or (cur[1] - cur[0]) * 4 + n * 4 > bucket_bytes:
+                    cur = [off, off, []]
+                    self.buckets.append(cur)
+                self.views[p] = self.flat[off:off + n].view_as(p)
+                cur[1] = off + n
+                cur[2].append(p)
+                off += n
+        self._bucket_of = {p: i for i, b in enumerate(self.buckets) for p in b[2]}
+        self._ready = [0] * len(self.buckets)
+        self._next = 0                                   # first bucket not launched yet
+        self._works = []
+        self._avg = dist.is_initialized() and dist.get_backend() == "nccl"
+        self._hooks = []
+        if self.overlap and dist.is_initialized():
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                p.__dict__["_srk_flush_aware"] = True     # this hook flushes ops' deferred weight gradients before it reads them
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            p.__dict__.pop("_srk_flush_aware", None)
 
     def broadcast(self):
         if self.world > 1:
@@ -71,26 +118,67 @@ class GradSync:
                 for t in list(self.module.parameters()) + list(self.module.buffers()):
                     dist.broadcast(t, src=0)
 
-    def sync(self):
-        """Average the gradients over the ranks (call between backward and the optimizer step)."""
+    # -- bucket plumbing ------------------------------------------------------------------------------------
+    def _pack_bucket(self, i):
+        """Gradients of bucket i -> their slices of the flat buffer (one multi-tensor copy); parameters without a
+        gradient this step contribute zeros.  Afterwards p.grad IS the slice."""
+        ps = self.buckets[i][2]
+        src = [p.grad for p in ps if p.grad is not None and p.grad.data_ptr() != self.views[p].data_ptr()]
+        dst = [self.views[p] for p in ps if p.grad is not None and p.grad.data_ptr() != self.views[p].data_ptr()]
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p in ps:
+            if p.grad is None:
+                self.views[p].zero_()
+            else:
+                p.grad = self.views[p]
+
+    def _reduce_bucket(self, i, async_op):
+        b = self.buckets[i]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        return dist.all_reduce(self.flat[b[0]:b[1]], op=op, async_op=async_op)
+
+    def _on_grad(self, p):
+        i = self._bucket_of[p]
+        self._ready[i] += 1
+        while self._next < len(self.buckets) and self._ready[self._next] >= len(self.buckets[self._next][2]):
+            _flush_deferred()            # the HIP path queues its weight gradients: compute them before they are read
+            with torch.no_grad():
+                self._pack_bucket(self._next)
+                self._works.append(self._reduce_bucket(self._next, True))
+            self._next += 1
+
+    def pack(self):
+        """All gradients -> the flat buffer (graph-capturable: no collective)."""
+        with torch.no_grad():
+            for i in range(len(self.buckets)):
+                self._pack_bucket(i)
+
+    def reduce(self):
+        """Average the flat buffer over the ranks, bucket by bucket (after `pack()`)."""
         if not dist.is_initialized():
             return
-        live = [(p, p.grad) for p in self.params if p.grad is not None]
-        if not live:
-            return
-        total = sum(g.numel() for _, g in live)
-        if self.flat is None or self.flat.numel() != total or self.flat.device != live[0][1].device:
-            self.flat = torch.empty(total, dtype=torch.float32, device=live[0][1].device)
-        views, off = [], 0
-        for _, g in live:
-            views.append(self.flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
-        torch._foreach_copy_(views, [g for _, g in live])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        if self.world > 1:
+        for i in range(len(self.buckets)):
+            self._reduce_bucket(i, False)
+        if not self._avg and self.world > 1:
             self.flat.mul_(1.0 / self.world)
-        for (p, _), v in zip(live, views):
-            p.grad = v
+
+    def sync(self):
+        """Average the gradients over the ranks (call between backward and the optimizer step)."""
+        if not dist.is_initialized() or self.flat is None:
+            return
+        _flush_deferred()
+        with torch.no_grad():
+            for i in range(self._next, len(self.buckets)):       # buckets the hooks did not complete (or no hooks)
+                self._pack_bucket(i)
+                self._works.append(self._reduce_bucket(i, True))
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._next = 0
+        self._ready = [0] * len(self.buckets)
+        if not self._avg and self.world > 1:
+            self.flat.mul_(1.0 / self.world)
 
 
 def synthetic_batch(n, channels, lr_size, scale, seed, device):
@@ -123,7 +211,7 @@ class Trainer:
         net = wrap_ddp(model, self.device) if use_ddp else model
         gsync = None
         if not use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            gsync = GradSync(model)
+            gsync = GradSync(model, bucket_bytes=int(os.environ.get("SRK_BUCKET_BYTES", 32 << 20)))
             gsync.broadcast()
         optimizer = model.configure_optimizers()[0]
         scaler = None

@@ -1,6 +1,7 @@
-"""world_size-2 data-parallel test on CPU (gloo): the N>1 path of trainer.py -- the flat one-all-reduce gradient
-average (GradSync, default) and the torch DDP wrapper (SRK_USE_TORCH_DDP=1): identical replicas, and equality with a
-single process at 2x batch."""
+"""world_size-2 data-parallel test on CPU (gloo): the N>1 path of trainer.py -- the bucketed gradient average whose
+all-reduces are launched from post-accumulate-grad hooks during backward (GradSync, default; one bucket and several) and
+the torch DDP wrapper (SRK_USE_TORCH_DDP=1): identical replicas, and equality with a single process at 2x batch.
+Also the hook-less form bench.py's hipGraph step uses (pack / reduce)."""
 import os
 import socket
 import sys
@@ -22,7 +23,9 @@ def _free_port():
 
 def _worker(rank, world, port, out, use_ddp):
     sys.path.insert(0, ROOT)
-    os.environ["SRK_USE_TORCH_DDP"] = "1" if use_ddp else "0"
+    os.environ["SRK_USE_TORCH_DDP"] = "1" if use_ddp == "torch_ddp" else "0"
+    if use_ddp == "buckets":
+        os.environ["SRK_BUCKET_BYTES"] = "4096"         # SRCNN: several buckets, all-reduces launched from the grad hooks
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     import sr_amd
@@ -38,7 +41,7 @@ def _worker(rank, world, port, out, use_ddp):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("use_ddp", [False, True], ids=["flat_allreduce", "torch_ddp"])
+@pytest.mark.parametrize("use_ddp", ["flat", "buckets", "torch_ddp"], ids=["one_bucket", "overlapped_buckets", "torch_ddp"])
 def test_two_rank_ddp_equals_single_process(tmp_path, use_ddp):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), use_ddp), nprocs=2, join=True)
@@ -56,3 +59,38 @@ def test_two_rank_ddp_equals_single_process(tmp_path, use_ddp):
     tr.fit(m, [T.synthetic_batch(4, 3, 16, 2, 100 + s, "cpu") for s in range(3)])
     for k, v in m.state_dict().items():
         assert torch.allclose(v, a[k], rtol=1e-5, atol=1e-7), k
+
+
+def _worker_pack_reduce(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import sr_amd
+    from sr_amd import trainer as T
+    T.init_distributed("cpu")
+    torch.manual_seed(0)
+    m = sr_amd.SRCNN(scale_factor=2, optimizer="SGD")
+    gs = T.GradSync(m, overlap=False, bucket_bytes=4096)
+    gs.broadcast()
+    b = T.synthetic_batch(4, 3, 16, 2, 7, "cpu")
+    sh = {"lr": b["lr"][rank * 2:(rank + 1) * 2], "hr": b["hr"][rank * 2:(rank + 1) * 2]}
+    m._calculate_losses(img_sr=m(sh["lr"]), img_hr=sh["hr"])["loss"].backward()
+    gs.pack()
+    gs.reduce()
+    assert all(p.grad.data_ptr() == gs.views[p].data_ptr() for p in gs.params)
+    torch.save([p.grad.clone() for p in m.parameters()], os.path.join(out, f"g{rank}.pt"))
+    if rank == 0:
+        torch.manual_seed(0)
+        ref = sr_amd.SRCNN(scale_factor=2, optimizer="SGD")
+        ref._calculate_losses(img_sr=ref(b["lr"]), img_hr=b["hr"])["loss"].backward()
+        torch.save([p.grad.clone() for p in ref.parameters()], os.path.join(out, "ref.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_pack_reduce_form_matches_full_batch_gradient(tmp_path):
+    mp.spawn(_worker_pack_reduce, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g0, g1, ref = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt"), torch.load(tmp_path / "ref.pt")
+    for a, b, r in zip(g0, g1, ref):
+        assert torch.equal(a, b)
+        assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-12
