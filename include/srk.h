@@ -201,14 +201,17 @@ int srk_nhwc_to_nchw(const srk_to_nchw_args* a, srk_stream_t stream);
 
 /* ---- RCAN channel attention -----------------------------------------------------------------------
  * CALayer.forward (models/rcan.py:10-29) fused with RCAB's `res += x` (rcan.py:52-54):
- *   sums[n][c] = sum_{hw} t          (srk_ca_pool, wave reductions + fp32 atomics, caller zeroes sums)
+ *   sums[n][s][c] = sum over the pixels of block s of t (or t*u)   (srk_ca_pool: wave/LDS reductions, ONE plain store
+ *                   per block and channel -- S = srk_ca_splits(N, HW) blocks per sample, no atomics, nothing to zero,
+ *                   bitwise reproducible; the consumers add the S partials in block order)
  *   z = relu(W1 mean + b1); s = sigmoid(W2 z + b2); out = t * s + res    (srk_ca_apply)
- * and its backward (srk_ca_bwd_reduce / srk_ca_bwd_apply).  W1:[Cr][C], W2:[C][Cr] are the raw
+ * and its backward (srk_ca_pool with u = g, srk_ca_bwd_apply).  W1:[Cr][C], W2:[C][Cr] are the raw
  * fp32 parameters conv_du.0.weight / conv_du.2.weight.                                         */
+int srk_ca_splits(int N, int HW);
 typedef struct {
   const void* t; int t_pitch, t_coff;
   const void* u; int u_pitch, u_coff;   /* NULL: plain sum of t; else sum of t*u (backward)      */
-  float* sums;                          /* [N][C] fp32, caller-zeroed                            */
+  float* sums;                          /* [N][S][C] fp32 partial sums, S = srk_ca_splits(N, HW) */
   int N, HW, C; int dtype;
 } srk_ca_pool_args;
 int srk_ca_pool(const srk_ca_pool_args* a, srk_stream_t stream);
@@ -216,7 +219,7 @@ int srk_ca_pool(const srk_ca_pool_args* a, srk_stream_t stream);
 typedef struct {
   const void* t; int t_pitch, t_coff;
   const void* res; int res_pitch, res_coff;     /* nullable */
-  const float* sums;                    /* [N][C] from srk_ca_pool                               */
+  const float* sums;                    /* [N][S][C] from srk_ca_pool                            */
   const float* w1; const float* b1; const float* w2; const float* b2;
   float* s_out; float* z_out;           /* [N][C], [N][Cr] saved for backward (nullable)         */
   void* out; int out_pitch, out_coff;
@@ -226,10 +229,12 @@ int srk_ca_apply(const srk_ca_apply_args* a, srk_stream_t stream);
 
 typedef struct {
   const void* g; int g_pitch, g_coff;   /* gradient w.r.t. the CA output (t*s)                   */
-  const float* gsum;                    /* [N][C] = sum_hw g*t from srk_ca_pool(t,u=g)           */
+  const float* gsum;                    /* [N][S][C] = partial sums of g*t from srk_ca_pool(t,u=g) */
   const float* sums; const float* s; const float* z;   /* saved by forward                      */
   const float* w1; const float* w2;
-  float* dw1; float* db1; float* dw2; float* db2;      /* fp32, caller-zeroed, atomically added  */
+  float* dw1; float* db1; float* dw2; float* db2;      /* out: PER-SAMPLE contributions; each pointer is the   */
+                                        /* sample-0 slot, sample n is 2*C*Cr + Cr + C floats further; the  */
+                                        /* caller sums over n (fixed order: reproducible)                  */
   void* gt; int gt_pitch, gt_coff;      /* out: gradient w.r.t. t = g*s + dmean/HW               */
   int N, HW, C, Cr; int dtype;
 } srk_ca_bwd_args;

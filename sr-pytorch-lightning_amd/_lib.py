@@ -124,7 +124,7 @@ LAUNCHERS = {
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
-                 "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small")
+                 "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits")
 
 _lib = None
 
@@ -161,6 +161,8 @@ def load():
     lib.srk_wgrad_finalize_group.restype = C.c_int
     lib.srk_upload_small.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
     lib.srk_upload_small.restype = C.c_int
+    lib.srk_ca_splits.argtypes = [C.c_int, C.c_int]
+    lib.srk_ca_splits.restype = C.c_int
     lib.srk_l1_blocks.argtypes = [C.c_longlong]
     lib.srk_l1_blocks.restype = C.c_int
     lib.srk_last_error.restype = C.c_char_p

@@ -82,19 +82,41 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_pool_kernel(const 
     const int c_cc = tid / CH, c_e = tid % CH;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[(r * nch + c_cc) * CH + c_e];
-    atomicAdd(a.sums + (size_t)n * a.C + tid, s);
+    a.sums[((size_t)n * gridDim.y + split) * a.C + tid] = s;       // this block's partial: no atomics, nothing to zero
   }
+}
+
+// out[c] = scale * sum of the per-block partials of sample n, channel c (c < C), computed by the whole workgroup:
+// thread (q, c), q = tid / C, adds blocks q, q + Q, ... (loads independent: all in flight together), the Q strided sums
+// meet in LDS in a fixed order (bitwise reproducible).  Ends with a barrier; `red` holds CA_NT floats.
+SRK_DEV void ca_sum_partials(const float* __restrict__ sums, int n, int nsplit, int C, float scale, float* red, float* out) {
+  const int tid = threadIdx.x;
+  const int Q = CA_NT / C;                       // C <= CA_MAXC = CA_NT
+  const int q = tid / C, c = tid - q * C;
+  float t = 0.f;
+  if (q < Q) {
+    const float* p = sums + (size_t)n * nsplit * C + c;
+#pragma unroll 4
+    for (int sp = q; sp < nsplit; sp += Q) t += p[(size_t)sp * C];
+  }
+  red[tid] = t;
+  __syncthreads();
+  if (tid < C) {
+    float u = 0.f;
+    for (int k = 0; k < Q; ++k) u += red[k * C + tid];
+    out[tid] = u * scale;
+  }
+  __syncthreads();
 }
 
 template <int DT> __global__ __launch_bounds__(CA_NT) void ca_apply_kernel(const srk_ca_apply_args a, int pix_per_block) {
   typedef DTraits<DT> Tr;
   typedef typename Tr::elem elem;
   constexpr int CH = Tr::CH;
-  __shared__ float mean[CA_MAXC], sv[CA_MAXC], zv[CA_MAXCR];
+  __shared__ float mean[CA_MAXC], sv[CA_MAXC], zv[CA_MAXCR], red[CA_NT];
   const int n = blockIdx.x, split = blockIdx.y, tid = threadIdx.x;
   const int C = a.C, Cr = a.Cr;
-  if (tid < C) mean[tid] = a.sums[(size_t)n * C + tid] / (float)a.HW;
-  __syncthreads();
+  ca_sum_partials(a.sums, n, gridDim.y, C, 1.f / (float)a.HW, red, mean);
   if (tid < Cr) {
     float z = a.b1[tid];
     for (int c = 0; c < C; ++c) z += a.w1[tid * C + c] * mean[c];
@@ -140,13 +162,15 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_bwd_kernel(const s
   typedef DTraits<DT> Tr;
   typedef typename Tr::elem elem;
   constexpr int CH = Tr::CH;
-  __shared__ float dpre2[CA_MAXC], dmean[CA_MAXC], sv[CA_MAXC], dpre1[CA_MAXCR], zv[CA_MAXCR];
+  __shared__ float dpre2[CA_MAXC], dmean[CA_MAXC], sv[CA_MAXC], mean[CA_MAXC], dpre1[CA_MAXCR], zv[CA_MAXCR], red[CA_NT];
   const int n = blockIdx.x, split = blockIdx.y, tid = threadIdx.x;
   const int C = a.C, Cr = a.Cr;
+  ca_sum_partials(a.gsum, n, gridDim.y, C, 1.f, red, dpre2);
+  if (split == 0) ca_sum_partials(a.sums, n, gridDim.y, C, 1.f / (float)a.HW, red, mean);        // block-uniform branch
   if (tid < C) {
     const float s = a.s[(size_t)n * C + tid];
     sv[tid] = s;
-    dpre2[tid] = a.gsum[(size_t)n * C + tid] * s * (1.f - s);
+    dpre2[tid] *= s * (1.f - s);
   }
   if (tid < Cr) zv[tid] = a.z[(size_t)n * Cr + tid];
   __syncthreads();
@@ -163,16 +187,17 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_bwd_kernel(const s
   }
   __syncthreads();
   if (split == 0) {
-    // parameter gradients of the two 1x1 convs, summed over samples with fp32 atomics
-    const float invHW = 1.f / (float)a.HW;
+    // this SAMPLE's contribution to the parameter gradients of the two 1x1 convs, stored to the sample's own slot
+    // (stride 2*C*Cr + Cr + C floats); the caller sums the slots over n: no atomics, nothing to zero, reproducible
+    const size_t so = (size_t)n * (2 * C * Cr + Cr + C);
     for (int i = tid; i < C * Cr; i += CA_NT) {
       const int c = i / Cr, j = i % Cr;
-      atomicAdd(a.dw2 + i, dpre2[c] * zv[j]);                                        // dW2[c][j]
+      a.dw2[so + i] = dpre2[c] * zv[j];                                              // dW2[c][j]
       const int j1 = i / C, c1 = i % C;
-      atomicAdd(a.dw1 + i, dpre1[j1] * (a.sums[(size_t)n * C + c1] * invHW));        // dW1[j][c]
+      a.dw1[so + i] = dpre1[j1] * mean[c1];                                          // dW1[j][c]
     }
-    if (tid < C) atomicAdd(a.db2 + tid, dpre2[tid]);
-    if (tid < Cr) atomicAdd(a.db1 + tid, dpre1[tid]);
+    if (tid < C) a.db2[so + tid] = dpre2[tid];
+    if (tid < Cr) a.db1[so + tid] = dpre1[tid];
   }
   const int nch = C / CH, rows = CA_NT / nch;
   const int cc = tid % nch, prow = tid / nch;
@@ -224,6 +249,13 @@ int check_c(int C, int Cr, int dtype, const char* who) {
     case SRK_F32: hipLaunchKernelGGL(KERNEL<SRK_F32>, GRID, dim3(CA_NT), 0, ST, ARGS, PPB); break;        \
     default: srk_set_error("channel attention: dtype %d", (ARGS).dtype); return SRK_E_BADARG;             \
   }
+
+extern "C" int srk_ca_splits(int N, int HW) {
+  if (N <= 0 || HW <= 0) return 1;
+  int splits, ppb;
+  split_for(N, HW, &splits, &ppb);
+  return splits;
+}
 
 extern "C" int srk_ca_pool(const srk_ca_pool_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a && a->t && a->sums, "srk_ca_pool: null pointer");

@@ -801,15 +801,20 @@ extern "C" int srk_wgrad_group_plan(srk_wgrad_args* jobs, int n, float* scratch,
     }
     return nb;
   };
-  long long T = (units + cus - 1) / cus, bestT = 0;
-  if (T < 1) T = 1;
+  // candidates from 8 tiles per block up to the largest job (geometric steps) plus the even split; more blocks than CUs
+  // is fine -- RCAN has 411 jobs -- as long as the rounds fill: cost = rounds x (T + 3 tiles of fill / slab-store overhead)
+  long long bestT = 0;
   double best = 1e300;
-  for (long long t = T; t <= maxnt; t = t + 1 + t / 16) {
+  auto consider = [&](long long t) {
+    if (t < 1) t = 1;
+    if (t > maxnt) t = maxnt;
     const long long nb = blocks_for(t);
     const double cost = (double)((nb + cus - 1) / cus) * (double)(t + 3);
-    if (cost < best) { best = cost; bestT = t; }
-    if (nb <= cus && t > T) break;                 // one round already: larger T only lengthens it
-  }
+    if (cost < best || (cost == best && t > bestT)) { best = cost; bestT = t; }
+  };
+  consider((units + cus - 1) / cus);
+  for (long long t = 8; t <= maxnt; t = t + 1 + t / 12) consider(t);
+  consider(maxnt);
   if (bestT == 0) bestT = maxnt;
   long long off = 0, nb = 0;
   WgJob* tab = reinterpret_cast<WgJob*>(table_host);

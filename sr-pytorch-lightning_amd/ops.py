@@ -287,23 +287,38 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
 # --------------------------------------------------------------------------------------------
 class _WgradQueue:
     """Weight-gradient jobs of the backward pass in flight (one process per GPU: autograd's device thread appends,
-    the thread that called backward() flushes from the engine's final callback)."""
+    the engine's final callback -- or a gradient-bucket hook -- flushes)."""
 
     def __init__(self):
-        self.jobs = []          # [WgradArgs, fin dict, keepalive tensors, dw, db, round]
-        self.armed = False
+        self.jobs = []          # dicts, see wgrad()
+        self.armed = False      # somebody will flush (final callback queued, or inside hold_wgrads)
         self.enabled = True
-        self.targets = {}       # data_ptr of a dw buffer -> number of jobs queued on it (weight sharing -> rounds)
+        self.targets = {}       # address of a dw buffer -> number of jobs queued on it (weight sharing -> rounds)
         self.gen = 0            # backward-pass generation (bumped by every flush)
+        self.stream = None      # stream of the backward pass (the flush launches there, whatever thread runs it)
 
 
 _WQ = _WgradQueue()
 _WG_BLOCKS_PER_JOB = 24
 
 
+class hold_wgrads:
+    """Context manager for code that calls `wgrad` OUTSIDE an autograd backward pass (tests, micro-benchmarks): jobs are
+    queued inside the block and flushed as one grouped launch when it exits."""
+
+    def __enter__(self):
+        self.prev, _WQ.armed = _WQ.armed, True
+        return self
+
+    def __exit__(self, *exc):
+        _WQ.armed = self.prev
+        if not self.prev and exc[0] is None:
+            flush_wgrads()
+
+
 def set_defer_wgrad(enabled):
     """Deferral switch (default on).  Off = every weight gradient is its own launch inside backward, which is what
-    code that reads gradients from inside backward needs (torch's DistributedDataParallel reducer, tensor hooks)."""
+    code that reads gradients from inside backward needs (torch's DistributedDataParallel reducer)."""
     prev = _WQ.enabled
     _WQ.enabled = bool(enabled)
     return prev
@@ -317,7 +332,7 @@ def _grad_slot(p, shape):
     if not (isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad):
         return None
     if getattr(p, "_backward_hooks", None):
-        return None
+        return None                     # a tensor hook reads the gradient inside backward
     hooks = getattr(p, "_post_accumulate_grad_hooks", None)
     if hooks and not p.__dict__.get("_srk_flush_aware", False):
         return None
@@ -329,6 +344,10 @@ def _grad_slot(p, shape):
     return None
 
 
+def _view_of(storage, shape, device):
+    return torch.empty(0, dtype=torch.float32, device=device).set_(storage, 0, tuple(shape))
+
+
 def flush_wgrads():
     """Launch every queued weight gradient: ONE grouped slab kernel per dtype and ONE grouped finalize per round."""
     import ctypes as C
@@ -337,48 +356,61 @@ def flush_wgrads():
     if not jobs:
         return
     lib = L.load()
-    st = _stream()
-    for dt in sorted({j[0].dtype for j in jobs}):
-        grp = [j for j in jobs if j[0].dtype == dt]
-        n = len(grp)
-        arr = (L.WgradArgs * n)(*[j[0] for j in grp])
-        nblocks, sfl = C.c_int(0), C.c_longlong(0)
-        L.check(lib.srk_wgrad_group_plan(arr, n, None, None, None, C.byref(nblocks), C.byref(sfl)), "srk_wgrad_group_plan")
-        dev = grp[0][2][0].device
-        scratch = torch.empty(sfl.value, dtype=torch.float32, device=dev)
-        jb = lib.srk_wgrad_group_job_bytes()
-        off_bj = _roundup(n * jb, 16)
-        off_fin = _roundup(off_bj + 4 * nblocks.value, 16)
-        fin_sz = C.sizeof(L.WgradFinArgs)
-        total = _roundup(off_fin + n * fin_sz, 16)
-        host = (C.c_ubyte * total)()
-        base = C.addressof(host)
-        L.check(lib.srk_wgrad_group_plan(arr, n, scratch.data_ptr(), base, base + off_bj, C.byref(nblocks), C.byref(sfl)),
-                "srk_wgrad_group_plan")
-        # finalize table, ordered by round (jobs that accumulate into a buffer another job of this pass writes come later)
-        order = sorted(range(n), key=lambda i: grp[i][5])
-        rounds = {}
-        for pos, i in enumerate(order):
-            a, f = arr[i], grp[i][1]
-            fa = L.WgradFinArgs(dwp=a.dwp, dbp=a.dbp or 0, nslabs=a.nslabs, dw=f["dw"], db=f["db"], Cout=f["Cout"], Cin=f["Cin"],
-                                KH=3, KW=3, CinP=a.Cin, CoutP=a.Cout, ps_r=f["ps_r"], scale=f["scale"], accumulate=f["acc"])
-            C.memmove(base + off_fin + pos * fin_sz, C.addressof(fa), fin_sz)
-            rounds.setdefault(grp[i][5], [pos, 0])[1] += 1
-        table = torch.empty(total, dtype=torch.uint8, device=dev)
-        L.check(lib.srk_upload_small(table.data_ptr(), base, total, st), "srk_upload_small")
-        L.check(lib.srk_conv2d_wgrad_group(table.data_ptr(), table.data_ptr() + off_bj, nblocks.value, dt, st), "srk_conv2d_wgrad_group")
-        for r in sorted(rounds):
-            pos, cnt = rounds[r]
-            L.check(lib.srk_wgrad_finalize_group(table.data_ptr() + off_fin + pos * fin_sz, cnt, _WG_BLOCKS_PER_JOB, st),
-                    "srk_wgrad_finalize_group")
-        # `table`, `scratch` and the operands are referenced by enqueued work only: the caching allocator keeps a freed
-        # block on this stream, so later allocations are ordered behind these launches
+    stream = _WQ.stream if _WQ.stream is not None else torch.cuda.current_stream()
+    with torch.cuda.stream(stream):         # the flush may run on another thread than the backward nodes: same stream
+        st = stream.cuda_stream
+        for dt in sorted({j["a"].dtype for j in jobs}):
+            grp = [j for j in jobs if j["a"].dtype == dt]
+            n = len(grp)
+            arr = (L.WgradArgs * n)(*[j["a"] for j in grp])
+            nblocks, sfl = C.c_int(0), C.c_longlong(0)
+            L.check(lib.srk_wgrad_group_plan(arr, n, None, None, None, C.byref(nblocks), C.byref(sfl)), "srk_wgrad_group_plan")
+            dev = grp[0]["keep"][0].device
+            scratch = torch.empty(sfl.value, dtype=torch.float32, device=dev)
+            jb = lib.srk_wgrad_group_job_bytes()
+            off_bj = _roundup(n * jb, 16)
+            off_fin = _roundup(off_bj + 4 * nblocks.value, 16)
+            fin_sz = C.sizeof(L.WgradFinArgs)
+            total = _roundup(off_fin + n * fin_sz, 16)
+            host = (C.c_ubyte * total)()
+            base = C.addressof(host)
+            L.check(lib.srk_wgrad_group_plan(arr, n, scratch.data_ptr(), base, base + off_bj, C.byref(nblocks), C.byref(sfl)),
+                    "srk_wgrad_group_plan")
+            # finalize table ordered by round (a job that accumulates into a buffer another job of this pass writes comes later)
+            order = sorted(range(n), key=lambda i: grp[i]["round"])
+            rounds = {}
+            for pos, i in enumerate(order):
+                a, f = arr[i], grp[i]
+                fa = L.WgradFinArgs(dwp=a.dwp, dbp=a.dbp or 0, nslabs=a.nslabs, dw=f["dw"], db=f["db"], Cout=f["Cout"], Cin=f["Cin"],
+                                    KH=3, KW=3, CinP=a.Cin, CoutP=a.Cout, ps_r=f["ps_r"], scale=f["scale"], accumulate=f["acc"])
+                C.memmove(base + off_fin + pos * fin_sz, C.addressof(fa), fin_sz)
+                rounds.setdefault(f["round"], [pos, 0])[1] += 1
+            table = torch.empty(total, dtype=torch.uint8, device=dev)
+            L.check(lib.srk_upload_small(table.data_ptr(), base, total, st), "srk_upload_small")
+            L.check(lib.srk_conv2d_wgrad_group(table.data_ptr(), table.data_ptr() + off_bj, nblocks.value, dt, st), "srk_conv2d_wgrad_group")
+            for r in sorted(rounds):
+                pos, cnt = rounds[r]
+                L.check(lib.srk_wgrad_finalize_group(table.data_ptr() + off_fin + pos * fin_sz, cnt, _WG_BLOCKS_PER_JOB, st),
+                        "srk_wgrad_finalize_group")
+        # a gradient autograd COPIED instead of adopting (create_graph, layout contract) holds the bytes of the then
+        # unfilled buffer: refresh it from the filled one.  ('new' jobs only: .grad was None, so the copy is all it holds)
+        with torch.no_grad():
+            for j in jobs:
+                for p, ptr, stg, shape in j["new"]:
+                    g = p.grad if p is not None else None
+                    if g is not None and g.data_ptr() != ptr and tuple(g.shape) == tuple(shape):
+                        g.copy_(_view_of(stg, shape, g.device))
+    # `table`, `scratch`, operands and result storages are referenced by enqueued work only from here on: the caching
+    # allocator re-issues a freed block on this stream behind these launches
 
 
 def wgrad(x, dy, *, wparam=None, bparam=None, **kw):
     """Weight (+ bias) gradient of one conv.  3x3 16-bit convs whose parameters are leaves are QUEUED and computed by
     one grouped launch when the backward pass ends (`flush_wgrads`, the autograd engine's final callback); everything
-    else runs now (`wgrad_raw`).  Returns what backward() hands to autograd for (weight, bias)."""
+    else runs now (`wgrad_raw`).  Returns what backward() hands to autograd for (weight, bias).
+
+    A queued job returns EMPTY tensors that autograd adopts as `.grad` (AccumulateGrad takes over a gradient nobody else
+    references); the queue keeps their storages -- not the tensors -- alive and the flush fills them by address."""
     want_bias = kw.get("want_bias", True)
     k, w_shape = kw["k"], kw["w_shape"]
     if not (_WQ.enabled and k == 3 and x.dtype in (torch.bfloat16, torch.float16) and kw["N"] > 0 and kw.get("x_ps", 0) <= 1):
@@ -393,25 +425,35 @@ def wgrad(x, dy, *, wparam=None, bparam=None, **kw):
                     nslabs=0, dtype=_DT[x.dtype])
     if not L.load().srk_wgrad_group_ok(a):
         return wgrad_raw(x, dy, **kw)
-    cout, cin, kh, kwid = w_shape
+    cout, cin = w_shape[0], w_shape[1]
     dev = x.device
     ret_w = ret_b = None
+    keep = [x, dy]
+    new = []
     if sw[0] == "new":
         seen = wparam.__dict__.get("_srk_pending")          # second use of a shared weight in this pass -> accumulate round
         if seen is not None and seen[0] == _WQ.gen:
-            dw, db, acc = seen[1], seen[2], 1
+            dw_ptr, db_ptr, acc = seen[1], seen[2], 1
         else:
-            dw = torch.empty(w_shape, dtype=torch.float32, device=dev)
-            db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
-            acc = 0
-            ret_w, ret_b = dw, db
-            wparam.__dict__["_srk_pending"] = (_WQ.gen, dw, db)
+            ret_w = torch.empty(w_shape, dtype=torch.float32, device=dev)
+            ret_b = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+            dw_ptr, db_ptr, acc = ret_w.data_ptr(), _ptr(ret_b), 0
+            sw_stg = ret_w.untyped_storage()
+            keep.append(sw_stg)
+            new.append((wparam, dw_ptr, sw_stg, w_shape))
+            if ret_b is not None:
+                sb_stg = ret_b.untyped_storage()
+                keep.append(sb_stg)
+                new.append((bparam, db_ptr, sb_stg, (cout,)))
+            wparam.__dict__["_srk_pending"] = (_WQ.gen, dw_ptr, db_ptr)
     else:
-        dw, db, acc = sw[1], (sb[1] if want_bias else None), 1
-    rnd = _WQ.targets.get(dw.data_ptr(), 0)                 # jobs on one buffer finalize in successive rounds
-    _WQ.targets[dw.data_ptr()] = rnd + 1
-    fin = dict(dw=dw.data_ptr(), db=_ptr(db), Cout=cout, Cin=cin, ps_r=int(kw.get("ps_r", 0)), scale=float(kw.get("scale", 1.0)), acc=acc)
-    _WQ.jobs.append([a, fin, (x, dy, dw, db), dw, db, rnd])
+        dw_ptr, db_ptr, acc = sw[1].data_ptr(), (sb[1].data_ptr() if want_bias else 0), 1
+        keep += [sw[1], sb[1]]
+    rnd = _WQ.targets.get(dw_ptr, 0)                        # jobs on one buffer finalize in successive rounds
+    _WQ.targets[dw_ptr] = rnd + 1
+    _WQ.jobs.append(dict(a=a, dw=dw_ptr, db=db_ptr, Cout=cout, Cin=cin, ps_r=int(kw.get("ps_r", 0)), scale=float(kw.get("scale", 1.0)),
+                         acc=acc, round=rnd, keep=keep, new=new))
+    _WQ.stream = torch.cuda.current_stream()
     if not _WQ.armed:
         _WQ.armed = True
         try:
@@ -729,7 +771,8 @@ class RCABFn(torch.autograd.Function):
         conv_raw(x, pack_conv(w1, b1, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=y1, relu=True)
         t = torch.empty_like(x)
         conv_raw(y1, pack_conv(w2, b2, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=t)
-        sums = torch.zeros((n, cp), dtype=torch.float32, device=x.device)
+        ns = L.load().srk_ca_splits(n, h * wd)
+        sums = torch.empty((n, ns, cp), dtype=torch.float32, device=x.device)      # per-block partials: nothing to zero
         L.call("srk_ca_pool", L.CaPoolArgs(t=t.data_ptr(), t_pitch=cp, t_coff=0, u=0, u_pitch=0, u_coff=0,
                                            sums=sums.data_ptr(), N=n, HW=h * wd, C=cp, dtype=_DT[dt]), _stream())
         s = torch.empty((n, cp), dtype=torch.float32, device=x.device)
@@ -753,13 +796,17 @@ class RCABFn(torch.autograd.Function):
         dt = x.dtype
         c, cr = w2.shape[0], cw1.shape[0]
         dev = x.device
-        gsum = torch.zeros((n, cp), dtype=torch.float32, device=dev)
+        gsum = torch.empty_like(sums)
         L.call("srk_ca_pool", L.CaPoolArgs(t=t.data_ptr(), t_pitch=cp, t_coff=0, u=g.data_ptr(), u_pitch=_pitch(g), u_coff=0,
                                            sums=gsum.data_ptr(), N=n, HW=h * wd, C=cp, dtype=_DT[dt]), _stream())
         w1f, _, w2f, _ = _ca_params(cw1, None, cw2, None, cp)
-        scratch = torch.zeros(2 * cr * cp + cr + cp, dtype=torch.float32, device=dev)
-        dw1, db1 = scratch[:cr * cp], scratch[cr * cp:cr * cp + cr]
-        dw2, db2 = scratch[cr * cp + cr:2 * cr * cp + cr], scratch[2 * cr * cp + cr:]
+        # per-sample parameter-gradient contributions [N][dW1 | db1 | dW2 | db2], summed over n below (one reduction
+        # instead of a zero-fill + float atomics + per-tensor copies)
+        per = torch.empty((max(n, 1), 2 * cr * cp + cr + cp), dtype=torch.float32, device=dev)
+        if n == 0:
+            per.zero_()
+        dw1, db1 = per[0, :cr * cp], per[0, cr * cp:cr * cp + cr]
+        dw2, db2 = per[0, cr * cp + cr:2 * cr * cp + cr], per[0, 2 * cr * cp + cr:]
         gt = torch.empty_like(x)
         L.call("srk_ca_bwd_apply", L.CaBwdArgs(
             g=g.data_ptr(), g_pitch=_pitch(g), g_coff=0, gsum=gsum.data_ptr(), sums=sums.data_ptr(), s=s.data_ptr(),
@@ -774,10 +821,13 @@ class RCABFn(torch.autograd.Function):
                          w_shape=tuple(w1.shape), want_bias=ctx.wb[1] is not None)
         gx = torch.empty_like(x)
         conv_raw(g1, pack_conv(w1, None, dt, dgrad=True), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=gx, res=g, use_bias=False)
-        # un-pad the CA parameter gradients (rows/cols beyond the real C are zero)
-        gcw1 = dw1.view(cr, cp)[:, :c].reshape(cr, c, 1, 1).contiguous()
-        gcw2 = dw2.view(cp, cr)[:c].reshape(c, cr, 1, 1).contiguous()
-        return gx, gw1, gb1, gw2, gb2, gcw1, db1.clone(), gcw2, db2[:c].clone()
+        tot = per.sum(0)
+        dw1, db1 = tot[:cr * cp], tot[cr * cp:cr * cp + cr]
+        dw2, db2 = tot[cr * cp + cr:2 * cr * cp + cr], tot[2 * cr * cp + cr:]
+        # un-pad the CA parameter gradients (rows/cols beyond the real C are zero); views of `tot`, no copies when C == Cp
+        gcw1 = dw1.view(cr, cp)[:, :c].reshape(cr, c, 1, 1)
+        gcw2 = dw2.view(cp, cr)[:c].reshape(c, cr, 1, 1)
+        return gx, gw1, gb1, gw2, gb2, gcw1, db1, gcw2, db2[:c]
 
 
 def _ca_params(cw1, cb1, cw2, cb2, cp):
