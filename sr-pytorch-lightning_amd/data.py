@@ -10,11 +10,68 @@ for angle / hflip / vflip), with the origin drawn as (row, column) from (height,
 tensor branch (srdata.py:151-154); its PIL branch swaps the two (`lr_h, lr_w = lr_image.size`, :149-150).
 """
 import ctypes as C
+import math
+import os
 import random
 
 import torch
 
 from . import _lib as L
+
+
+def shard_indices(n, rank=0, world=1, *, shuffle=True, seed=0, epoch=0, drop_last=False):
+    """The sample indices rank `rank` of `world` processes visits in one epoch: the index split of
+    torch.utils.data.DistributedSampler, which Lightning installs for the reference when `devices > 1`
+    (configs/all.yml:127 `use_distributed_sampler: true`) -- same permutation (generator seeded with seed + epoch), same
+    padding by wrap-around to a multiple of `world` (or truncation with drop_last), rank r takes positions r, r+world, ...
+    Every rank sees the same number of samples, the union covers the data set."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g).tolist()
+    else:
+        idx = list(range(n))
+    if drop_last and n % world != 0:
+        per = math.ceil((n - world) / world)
+    else:
+        per = math.ceil(n / world)
+    total = per * world
+    if not drop_last:
+        pad = total - len(idx)
+        if pad > 0:
+            idx += (idx * math.ceil(pad / max(len(idx), 1)))[:pad]
+    else:
+        idx = idx[:total]
+    return idx[rank:total:world]
+
+
+def load_image_pairs(directory, scale_factor, lr_directory=None):
+    """PNG/JPEG files of `directory` as (lr, hr) uint8 HWC arrays.  HR is cropped to a multiple of the scale; LR comes
+    from `lr_directory` (same file names) or is synthesised like the reference's on-the-fly path: PIL bicubic resize
+    (srdata.py:222-231, TF.resize(..., BICUBIC) on a PIL image)."""
+    import numpy as np
+    from PIL import Image
+    names = sorted(f for f in os.listdir(directory) if f.lower().endswith((".png", ".jpg", ".jpeg", ".bmp")))
+    pairs, stems = [], []
+    for f in names:
+        hr = Image.open(os.path.join(directory, f)).convert("RGB")
+        w, h = hr.size
+        w, h = w - w % scale_factor, h - h % scale_factor
+        hr = hr.crop((0, 0, w, h))
+        if lr_directory is not None:
+            lr = Image.open(os.path.join(lr_directory, f)).convert("RGB")
+            assert lr.size == (w // scale_factor, h // scale_factor), f"Wrong sizes: LR {lr.size}, HR {hr.size}"
+        else:
+            lr = hr.resize((w // scale_factor, h // scale_factor), Image.BICUBIC)
+        pairs.append((np.asarray(lr).copy(), np.asarray(hr).copy()))
+        stems.append(os.path.splitext(f)[0])
+    return pairs, stems
+
+
+def image_to_tensor(arr):
+    """uint8 HWC -> float CHW in [0,1] (torchvision's to_tensor, srdata.py:99-100)."""
+    import numpy as np
+    return torch.from_numpy(np.array(arr, copy=True)).permute(2, 0, 1).float() / 255.0
 
 
 class PatchSampler:

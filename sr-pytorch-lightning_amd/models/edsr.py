@@ -26,14 +26,14 @@ class EDSR(SRModel):
 
     def forward(self, x):
         """NCHW float in [0,1] -> NCHW fp32, x scale_factor (edsr.py:40-54)."""
-        ops.begin_forward(self._pack_group())
-        rgb = self._channels == 3
-        f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, -self.sub_mean.shift() if rgb else None,
-                          self.compute_dtype)
-        r = f
-        for blk in list(self.body)[:-1]:
-            r = blk(r)
-        r = self.body[-1](r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
-        r = self.tail[0](r)                              # upsampler, PixelShuffle fused into the conv store
-        t = self.tail[1]
-        return ops.tail_conv(r, t.weight, t.bias, post_add=self.add_mean.shift() if rgb else None)
+        with ops.forward_scope(self._pack_group()):
+            rgb = self._channels == 3
+            f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, -self.sub_mean.shift() if rgb else None,
+                              self.compute_dtype)
+            r = f
+            for blk in list(self.body)[:-1]:
+                r = blk(r)
+            r = self.body[-1](r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
+            r = self.tail[0](r)                              # upsampler, PixelShuffle fused into the conv store
+            t = self.tail[1]
+            return ops.tail_conv(r, t.weight, t.bias, post_add=self.add_mean.shift() if rgb else None)

@@ -81,14 +81,14 @@ class RCAN(SRModel):
 
     def forward(self, x):
         """rcan.py:115-129"""
-        ops.begin_forward(self._pack_group())
-        rgb = self._channels == 3
-        f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, -self.sub_mean.shift() if rgb else None,
-                          self.compute_dtype)
-        r = f
-        for grp in list(self.body)[:-1]:
-            r = grp(r)
-        r = self.body[-1](r, res=f)
-        r = self.tail[0](r)
-        t = self.tail[1]
-        return ops.tail_conv(r, t.weight, t.bias, post_add=self.add_mean.shift() if rgb else None)
+        with ops.forward_scope(self._pack_group()):
+            rgb = self._channels == 3
+            f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, -self.sub_mean.shift() if rgb else None,
+                              self.compute_dtype)
+            r = f
+            for grp in list(self.body)[:-1]:
+                r = grp(r)
+            r = self.body[-1](r, res=f)
+            r = self.tail[0](r)
+            t = self.tail[1]
+            return ops.tail_conv(r, t.weight, t.bias, post_add=self.add_mean.shift() if rgb else None)

@@ -58,17 +58,17 @@ class RDN(SRModel):
 
     def forward(self, x):
         """rdn.py:99-111.  No MeanShift in this model."""
-        ops.begin_forward(self._pack_group())
-        f1 = ops.head_conv(x, self.SFENet1.weight, self.SFENet1.bias, None, self.compute_dtype)
-        x = ops.conv(f1, self.SFENet2.weight, self.SFENet2.bias)
-        outs = []
-        for blk in self._RDBs:
-            x = blk(x)
-            outs.append(x)
-        x = ops.conv(torch.cat(outs, dim=3), self.GFF[0].weight, self.GFF[0].bias)    # 1x1 over D*G0 channels
-        x = ops.conv(x, self.GFF[1].weight, self.GFF[1].bias, res=f1)                  # `x += f__1`
-        mods = list(self.UPNet)
-        for conv, ps in zip(mods[0:-1:2], mods[1:-1:2]):
-            x = ops.conv(x, conv.weight, conv.bias, ps_r=ps.upscale_factor)
-        last = mods[-1]
-        return ops.tail_conv(x, last.weight, last.bias)
+        with ops.forward_scope(self._pack_group()):
+            f1 = ops.head_conv(x, self.SFENet1.weight, self.SFENet1.bias, None, self.compute_dtype)
+            x = ops.conv(f1, self.SFENet2.weight, self.SFENet2.bias)
+            outs = []
+            for blk in self._RDBs:
+                x = blk(x)
+                outs.append(x)
+            x = ops.conv(torch.cat(outs, dim=3), self.GFF[0].weight, self.GFF[0].bias)    # 1x1 over D*G0 channels
+            x = ops.conv(x, self.GFF[1].weight, self.GFF[1].bias, res=f1)                  # `x += f__1`
+            mods = list(self.UPNet)
+            for conv, ps in zip(mods[0:-1:2], mods[1:-1:2]):
+                x = ops.conv(x, conv.weight, conv.bias, ps_r=ps.upscale_factor)
+            last = mods[-1]
+            return ops.tail_conv(x, last.weight, last.bias)

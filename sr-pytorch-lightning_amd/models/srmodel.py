@@ -228,14 +228,70 @@ class SRModel(_Base):
         self._validation_step_outputs.append(result)
         return result
 
-    # -- srmodel.py:375-433 (forward + clamp; PNG writing is out of scope) ----------------------------
+    # -- srmodel.py:345-373 ---------------------------------------------------------------------------
+    def on_validation_epoch_end(self):
+        """Plain mean of the per-image metrics, per key (`<dataset>/<metric>`): what the reference logs at the end of a
+        validation epoch.  The result is also kept in `last_validation_metrics` (no Lightning logger needed) and the
+        step outputs are cleared (they hold device tensors)."""
+        trainer = getattr(self, "_trainer", None)
+        if not self._validation_step_outputs or (trainer is not None and getattr(trainer, "sanity_checking", False)):
+            self._validation_step_outputs.clear()
+            return {}
+
+        def _mean(keys, metrics):
+            out = {}
+            for k in keys:
+                vals = [m[k] for m in metrics if k in m]
+                out[k] = torch.stack([torch.as_tensor(v).squeeze().float() for v in vals]).mean().cpu().detach()
+            return out
+
+        outs = self._validation_step_outputs
+        metrics_dict = {}
+        if isinstance(outs[0], dict):                       # one list of per-batch dicts (keys carry the dataset name)
+            keys = []
+            for m in outs:
+                keys += [k for k in m if k not in keys]
+            metrics_dict.update(_mean(keys, outs))
+        else:                                               # list (per dataset) of lists of dicts
+            for dataset_result in outs:
+                metrics_dict.update(_mean(dataset_result[0].keys(), dataset_result))
+        self.log_dict(metrics_dict, prog_bar=False, logger=True, add_dataloader_idx=False)
+        self.last_validation_metrics = metrics_dict
+        self._validation_step_outputs.clear()
+        return metrics_dict
+
+    # -- srmodel.py:375-433: forward + clamp + PNG on disk (the logger image dumps are out of scope) -------------
     def predict_step(self, batch, batch_idx, dataloader_idx=0):
-        return self.forward(batch['lr']).clamp(0, 1)
+        img_sr = self.forward(batch['lr']).clamp(0, 1)
+        if self._predict_datasets and 'path' in batch and dataloader_idx < len(self._predict_datasets):
+            from pathlib import Path
+            local = Path(f'{self._default_root_dir}') / self._predict_datasets[dataloader_idx]
+            local.mkdir(parents=True, exist_ok=True)
+            name = batch['path'][0]
+            self.save_png(img_sr[0], local / f'{name}.png')
+            h, w = img_sr.shape[-2:]
+            if h >= 96 and w >= 96:                          # K.CenterCrop(96) of the reference (srmodel.py:382-392)
+                t, l = (h - 96) // 2, (w - 96) // 2
+                self.save_png(img_sr[0, :, t:t + 96, l:l + 96], local / f'{name}_center.png')
+        return img_sr
 
     @staticmethod
     def to_uint8(img):
         """torchvision.utils.save_image rounding (srmodel.py:311-315): floor(clamp(x,0,1)*255 + 0.5)."""
         return torch.floor(img.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8)
+
+    @classmethod
+    def save_png(cls, img, path):
+        """One CHW float image -> PNG with torchvision.utils.save_image's rounding (srmodel.py:409-412), through PIL."""
+        from PIL import Image
+        u8 = cls.to_uint8(img.detach().float()).permute(1, 2, 0).cpu().numpy()
+        Image.fromarray(u8[..., 0] if u8.shape[2] == 1 else u8).save(str(path))
+
+    # the packed-weight group holds ctypes tables with device pointers: never copied / pickled with the module
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_srk_packs", None)
+        return state
 
     # -- srmodel.py:435-501 ------------------------------------------------------------------------------
     def _create_losses(self, losses_str: str, patch_size: int, precision=32) -> list[_SubLoss]:

@@ -70,14 +70,14 @@ class WDSR(SRModel):
 
     def forward(self, x):
         """wdsr.py:102-117: x - mean; s = PS(skip(x)); x = PS(tail(body(head(x)))); x += s; x + mean."""
-        ops.begin_forward(None)      # weight-norm weights are fresh tensors every step: packed per use
-        mean = None
-        if self._channels == 3:
-            self.rgb_mean = self.rgb_mean.to(x.device)
-            mean = self.rgb_mean.view(3).contiguous()
-        r = self._scale_factor
-        s = ops.skip_conv(x, _wn_weight(self.skip[0]), self.skip[0].bias, mean, r, self.compute_dtype)
-        f = ops.head_conv(x, _wn_weight(self.head[0]), self.head[0].bias, mean, self.compute_dtype)
-        for blk in self.body:
-            f = blk(f)
-        return ops.tail_conv(f, _wn_weight(self.tail[0]), self.tail[0].bias, res=s, post_add=mean, ps_r=r)
+        with ops.forward_scope(None):      # weight-norm weights are fresh tensors every step: packed per use
+            mean = None
+            if self._channels == 3:
+                self.rgb_mean = self.rgb_mean.to(x.device)
+                mean = self.rgb_mean.view(3).contiguous()
+            r = self._scale_factor
+            s = ops.skip_conv(x, _wn_weight(self.skip[0]), self.skip[0].bias, mean, r, self.compute_dtype)
+            f = ops.head_conv(x, _wn_weight(self.head[0]), self.head[0].bias, mean, self.compute_dtype)
+            for blk in self.body:
+                f = blk(f)
+            return ops.tail_conv(f, _wn_weight(self.tail[0]), self.tail[0].bias, res=s, post_add=mean, ps_r=r)

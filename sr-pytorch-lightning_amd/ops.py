@@ -85,28 +85,35 @@ class pack_cache:
 class PackGroup:
     """The packed shadow weights of ONE model, re-packed by a single kernel launch per step.
 
-    `begin_forward(group)` (called at the top of a model's forward) launches `srk_pack_conv_weights_group` over a
+    `forward_scope(group)` (entered at the top of a model's forward) launches `srk_pack_conv_weights_group` over a
     device-side table of every (parameter, layout) pair the model has used so far -- forward and dgrad layouts --
     so the ~2 pack launches per conv per training step collapse into one.  Entries are discovered on the first
-    step (packed individually then).  Buffers are persistent, so the launch is hipGraph-capturable."""
+    step (packed individually then).  Buffers are persistent, so the launch is hipGraph-capturable.
+
+    Validity: packed buffers are served ONLY (a) inside the forward window that refreshed them and (b) to the
+    backward of a graph built in that window (the Functions carry the (group, epoch) token they were built under and
+    a newer refresh invalidates it).  Anything else -- a block called on its own after the model's forward, a sub-module
+    called directly, another model's parameters -- packs per call from the current parameter values: an optimizer step
+    between two forwards can never be served stale weights (torch's fused Adam does not bump `_version`)."""
 
     def __init__(self):
         self.entries = {}       # key -> [PackArgs, Packed, w, b]
         self.table = None
         self.dirty = False
-        self.fresh = False      # packed buffers correspond to the current parameter values
+        self.epoch = 0          # number of refreshes so far
+        self.open = False       # inside the forward window of the latest refresh
 
     def lookup(self, key):
         e = self.entries.get(key)
-        return e[1] if (e is not None and self.fresh) else None
+        return e[1] if e is not None else None
 
     def add(self, key, args, packed, w, b):
         self.entries[key] = [args, packed, w, b]
         self.dirty = True
 
     def refresh(self):
+        self.epoch += 1
         if not self.entries:
-            self.fresh = True
             return
         for e in self.entries.values():          # parameters moved / re-allocated since the table was built?
             a, _, w, b = e
@@ -115,7 +122,6 @@ class PackGroup:
                 a.w, a.bias = w.data_ptr(), bp
                 self.dirty = True
         if self.dirty:
-            import ctypes as C
             arr = (L.PackArgs * len(self.entries))(*[e[0] for e in self.entries.values()])
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             dev = next(iter(self.entries.values()))[2].device
@@ -124,34 +130,61 @@ class PackGroup:
         rc = L.load().srk_pack_conv_weights_group(self.table.data_ptr(), len(self.entries), _stream())
         if rc != 0:
             raise RuntimeError(f"srk_pack_conv_weights_group failed (rc={rc}): {L.load().srk_last_error().decode()}")
-        self.fresh = True
 
 
 import threading
+import weakref
 _TLS = threading.local()
 
 
-def begin_forward(group):
-    """Refresh `group` (one launch) and make it the group that new (parameter, layout) pairs register with."""
-    _TLS.group = group
-    if group is not None:
-        group.refresh()
+class forward_scope:
+    """`with forward_scope(group):` around a model's forward: refreshes `group` (one launch) and makes it the group that
+    serves / registers packed weights until the block exits.  `group=None`: no grouping (every conv packs per use)."""
+
+    def __init__(self, group):
+        self.group = group
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "group", None)
+        _TLS.group = self.group
+        if self.group is not None:
+            self.group.refresh()
+            self.group.open = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.group is not None:
+            self.group.open = False
+        _TLS.group = self.prev
 
 
-def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False):
+def _tok():
+    """(group, epoch) token of the forward window a Function is being built in, or None."""
+    g = getattr(_TLS, "group", None)
+    return (weakref.ref(g), g.epoch) if (g is not None and g.open) else None
+
+
+def _group_for(token):
+    """The PackGroup allowed to serve this call: the open forward window's, or the one named by a still-current token."""
+    if token is not None:
+        g = token[0]()
+        return g if (g is not None and g.epoch == token[1]) else None
+    g = getattr(_TLS, "group", None)
+    return g if (g is not None and g.open) else None
+
+
+def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False, token=None):
     """OIHW fp32 `w` (+ bias) -> packed shadow layout for srk_conv2d (forward or dgrad).
-    as_1x1: present the OIHW weight as the 1x1 conv over Cin*KH*KW unfolded channels (head / skip convs)."""
+    as_1x1: present the OIHW weight as the 1x1 conv over Cin*KH*KW unfolded channels (head / skip convs).
+    token: the (group, epoch) a Function's forward was built under (backward calls pass it: see PackGroup)."""
     _need_gpu(w)
     is_param = isinstance(w, torch.nn.Parameter)
     key = (id(w), dtype, bool(dgrad), int(ps_r), bool(as_1x1))
-    group = None
-    if is_param:
-        gref = w.__dict__.get("_srk_group")
-        group = gref() if gref is not None else getattr(_TLS, "group", None)
-        if group is not None:
-            hit = group.lookup(key)
-            if hit is not None:
-                return hit
+    group = _group_for(token) if is_param else None
+    if group is not None:
+        hit = group.lookup(key)
+        if hit is not None:
+            return hit
     ver = (w._version, -1 if b is None else b._version, w.data_ptr())
     store = None
     if cache and _PACK_CACHE_ENABLED and is_param:
@@ -188,9 +221,7 @@ def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False):
     if store is not None:
         store[key] = (ver, p)
     if group is not None and wf.data_ptr() == w.data_ptr() and (bf is None or bf.data_ptr() == b.data_ptr()):
-        import weakref
         group.add(key, a, p, w, b if not dgrad else None)
-        w.__dict__["_srk_group"] = weakref.ref(group)
     return p
 
 
@@ -542,6 +573,7 @@ class ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.cfg = (scale, ps_r, b is not None, res is not None)
         ctx.wb = (w, b)
+        ctx.pg = _tok()
         return out
 
     @staticmethod
@@ -554,7 +586,7 @@ class ConvFn(torch.autograd.Function):
         coutp = pad16(cout)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            pkd = pack_conv(w, None, x.dtype, dgrad=True, ps_r=ps_r)
+            pkd = pack_conv(w, None, x.dtype, dgrad=True, ps_r=ps_r, token=ctx.pg)
             gx = torch.empty_like(x)
             conv_raw(g, pkd, N=n, H=h, W=wd, Cin=coutp, Cout=cinp, out=gx, scale=scale, x_ps=ps_r, use_bias=False)
         if ctx.needs_input_grad[1]:
@@ -628,6 +660,7 @@ class TailConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.cfg = (ps_r, b is not None, res is not None)
         ctx.wb = (w, b)
+        ctx.pg = _tok()
         return out
 
     @staticmethod
@@ -639,7 +672,7 @@ class TailConvFn(torch.autograd.Function):
         dy = to_nhwc(g, x.dtype, ps_r=ps_r)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            pkd = pack_conv(w, None, x.dtype, dgrad=True)
+            pkd = pack_conv(w, None, x.dtype, dgrad=True, token=ctx.pg)
             gx = torch.empty_like(x)
             conv_raw(dy, pkd, N=n, H=h, W=wd, Cin=dy.shape[3], Cout=cinp, out=gx, use_bias=False)
         if ctx.needs_input_grad[1]:
@@ -717,6 +750,7 @@ class ConvChainFn(torch.autograd.Function):
         ctx.save_for_backward(*acts, *ws)
         ctx.cfg = (scale, tuple(relus), tuple(b is not None for b in bs))
         ctx.wb = (tuple(ws), tuple(bs))
+        ctx.pg = _tok()
         return a
 
     @staticmethod
@@ -737,7 +771,7 @@ class ConvChainFn(torch.autograd.Function):
                 gw, gb = wgrad(a_in, dy, wparam=ctx.wb[0][i], bparam=ctx.wb[1][i], N=n, H=h, W=wd, Cin=a_in.shape[3],
                                Cout=dy.shape[3], k=k, w_shape=tuple(w.shape), scale=sc, want_bias=has_b[i])
                 grads[2 * i], grads[2 * i + 1] = gw, gb
-            pkd = pack_conv(w, None, g.dtype, dgrad=True)
+            pkd = pack_conv(w, None, g.dtype, dgrad=True, token=ctx.pg)
             gin = torch.empty_like(a_in)
             conv_raw(dy, pkd, N=n, H=h, W=wd, Cin=dy.shape[3], Cout=a_in.shape[3], out=gin, scale=sc,
                      res=g if i == 0 else None,
@@ -786,6 +820,7 @@ class RCABFn(torch.autograd.Function):
             N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt]), _stream())
         ctx.save_for_backward(x, y1, t, sums, s, z, w1, w2, cw1, cw2)
         ctx.wb = (w1, b1, w2, b2)
+        ctx.pg = _tok()
         return out
 
     @staticmethod
@@ -816,11 +851,11 @@ class RCABFn(torch.autograd.Function):
         gw2, gb2 = wgrad(y1, gt, wparam=ctx.wb[2], bparam=ctx.wb[3], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w2.shape[2],
                          w_shape=tuple(w2.shape), want_bias=ctx.wb[3] is not None)
         g1 = torch.empty_like(x)
-        conv_raw(gt, pack_conv(w2, None, dt, dgrad=True), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1, use_bias=False)
+        conv_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1, use_bias=False)
         gw1, gb1 = wgrad(x, g1, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w1.shape[2],
                          w_shape=tuple(w1.shape), want_bias=ctx.wb[1] is not None)
         gx = torch.empty_like(x)
-        conv_raw(g1, pack_conv(w1, None, dt, dgrad=True), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=gx, res=g, use_bias=False)
+        conv_raw(g1, pack_conv(w1, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=gx, res=g, use_bias=False)
         tot = per.sum(0)
         dw1, db1 = tot[:cr * cp], tot[cr * cp:cr * cp + cr]
         dw2, db2 = tot[cr * cp + cr:2 * cr * cp + cr], tot[2 * cr * cp + cr:]
@@ -879,6 +914,7 @@ class RDBFn(torch.autograd.Function):
         ctx.save_for_backward(feat, *ws, wl)
         ctx.cfg = (nconv, g0, g)
         ctx.wb = (tuple(ws), tuple(bs))
+        ctx.pg = _tok()
         return out
 
     @staticmethod
@@ -894,7 +930,7 @@ class RDBFn(torch.autograd.Function):
         grads[-2], grads[-1] = gwl, gbl
         gfeat = torch.empty_like(feat)
         # LFF dgrad fills the whole gradient buffer; the top slice (output of the last dense conv) gets its ReLU mask
-        conv_raw(gout, pack_conv(wl, None, dt, dgrad=True), N=n, H=h, W=wd, Cin=g0, Cout=ctot, out=gfeat,
+        conv_raw(gout, pack_conv(wl, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=g0, Cout=ctot, out=gfeat,
                  mask=feat, mask_from=ctot - g, use_bias=False)
         for c in range(nconv - 1, -1, -1):
             cin = g0 + c * g
@@ -904,7 +940,7 @@ class RDBFn(torch.autograd.Function):
                            k=ws[c].shape[2], w_shape=tuple(ws[c].shape), want_bias=ctx.wb[1][c] is not None)
             grads[2 * c], grads[2 * c + 1] = gw, gb
             pref = gfeat[..., :cin]
-            conv_raw(dy, pack_conv(ws[c], None, dt, dgrad=True), N=n, H=h, W=wd, Cin=g, Cout=cin, out=pref, res=pref,
+            conv_raw(dy, pack_conv(ws[c], None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=g, Cout=cin, out=pref, res=pref,
                      mask=feat[..., :cin] if c > 0 else None, mask_from=cin - g if c > 0 else 0, use_bias=False)
         gx = gfeat[..., :g0] + gout
         return (gx, *grads)
