@@ -29,11 +29,16 @@ def main(argv=None):
     p.add_argument("--accelerator", default="auto", choices=("auto", "gpu", "cpu"))
     p.add_argument("--default_root_dir", default="results")
     p.add_argument("--predict_datasets", nargs="+", required=True, help="directories of LR images")
+    p.add_argument("--n_feats", type=int, default=None)
+    p.add_argument("--n_resblocks", type=int, default=None)
+    p.add_argument("--n_resgroups", type=int, default=None)
+    p.add_argument("--res_scale", type=float, default=None)
     a = p.parse_args(argv)
+    kw = {k: getattr(a, k) for k in ("n_feats", "n_resblocks", "n_resgroups", "res_scale") if getattr(a, k) is not None}
     names = {m.lower(): m for m in sr_amd.models.__all__ if m != "SRModel"}
     cls = getattr(sr_amd, names[a.model.lower()])
     ds_names = [os.path.basename(os.path.normpath(d)) for d in a.predict_datasets]
-    model = cls(scale_factor=a.scale_factor, precision=a.precision, default_root_dir=a.default_root_dir, predict_datasets=ds_names)
+    model = cls(scale_factor=a.scale_factor, precision=a.precision, default_root_dir=a.default_root_dir, predict_datasets=ds_names, **kw)
     if a.checkpoint:
         sd = torch.load(a.checkpoint, map_location="cpu")
         model.load_state_dict(sd.get("state_dict", sd), strict=True)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Build gate: static check of the hand-ordered prefetch in conv_ws_kernel<..., EARLY = true> on the generated ISA.
+
+The residual / mask pieces of the prefetch variant are loaded from inline asm, which the compiler treats as an ordinary
+register definition: nothing tells it that the registers only become valid at the explicit `s_waitcnt vmcnt(0)` that
+closes the MFMA phase.  The kernel is correct only if, in the code hipcc actually generated, (1) no instruction reads
+or writes a prefetch destination between that load and the wait, (2) the path between them is straight-line (no
+label: a branch target there could be entered with other registers in flight) and (3) the compiler placed no vmcnt
+wait of its own behind the first prefetch.  A toolchain upgrade that breaks any of these fails the BUILD (the Makefile
+runs this on every change of conv_igemm.hip); `SRK_NO_EARLY=1` at run time routes those launches to the plain variant.
+
+usage: check_isa.py conv_igemm.s   (exit code 0 = all instantiations pass)"""
+import re
+import sys
+
+
+def _regs(line):
+    out = set()
+    for m in re.finditer(r"v\[(\d+):(\d+)\]", line):
+        out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", line):
+        out.add(int(m.group(1)))
+    return out
+
+
+def check_kernel(asm, dt, nks):
+    """Raises AssertionError with the offending line; returns the number of instructions inspected."""
+    name = f"_ZN12_GLOBAL__N_114conv_ws_kernelILi{dt}ELi2ELi{nks}ELb1ELb1EEEv13srk_conv_args"
+    start = asm.index(name + "iiiijiiiiiii:")
+    body = asm[start:asm.index(".Lfunc_end", start)].split("\n")
+    loads = [k for k, l in enumerate(body)
+             if "buffer_load_dwordx4" in l and " lds" not in l and "ASMSTART" in body[k - 1]]
+    assert len(loads) == 8, f"expected 4 pieces x 2 pixel blocks, found {len(loads)}"
+    mfma = [k for k, l in enumerate(body) if "v_mfma" in l]
+    assert len(mfma) == 36 * nks, f"{len(mfma)} MFMAs"
+    waits = [k for k, l in enumerate(body) if "s_waitcnt vmcnt(0)" in l and "ASMSTART" in body[k - 1] and k > mfma[-1]]
+    assert waits, "the closing wait of the MFMA phase is missing"
+    wait = waits[0]
+    assert mfma[0] < loads[0] and loads[-1] < mfma[-1] < wait, "loads must sit inside the MFMA phase, the wait right behind it"
+    assert not [k for k in range(loads[0], wait) if body[k].startswith(".LBB")], "branch target between a prefetch and its wait"
+    seen = 0
+    for k in loads:
+        dst = _regs(re.search(r"v\[\d+:\d+\]", body[k]).group(0))
+        assert len(dst) == 4
+        for x in range(k + 1, wait):
+            line = body[x].strip()
+            if not line or line.startswith((";", ".")):
+                continue
+            seen += 1
+            assert not (_regs(line) & dst), f"line {x} touches an in-flight prefetch register: {line}"
+    own = [l.strip() for k, l in enumerate(body) if "s_waitcnt vmcnt" in l and "ASMSTART" not in body[k - 1] and k > loads[0]]
+    assert not own, f"compiler-placed vmcnt wait behind the prefetch: {own}"
+    return seen
+
+
+def main(path):
+    asm = open(path).read()
+    ok = True
+    for dt in (0, 1):
+        for nks in (4, 1):
+            try:
+                n = check_kernel(asm, dt, nks)
+                print(f"check_isa: conv_ws_kernel<dtype {dt}, NKS {nks}, EARLY>: ok ({n} instructions between prefetch and wait)")
+            except (AssertionError, ValueError) as e:
+                ok = False
+                print(f"check_isa: conv_ws_kernel<dtype {dt}, NKS {nks}, EARLY>: FAILED: {e}", file=sys.stderr)
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

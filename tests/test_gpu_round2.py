@@ -1,0 +1,349 @@
+"""GPU tests added in round 2 (VERDICT r1 "what's weak" 1, 3, 10d and "missing" 4):
+
+* north_star's "PSNR within 0.01 dB of reference": a TRAINED EDSR-baseline on smooth images, HIP bf16 / fp16 forward vs
+  the fp32 CPU oracle with the same weights, PSNR of both against the common HR target;
+* full-size backward (EDSR-baseline / -large, RCAN 10x20, RDN-A/B, WDSR-A/B) against the reference's own gradient
+  summaries in tests/golden (fp32 path);
+* two models alternating in one process (BASELINE configs[4]: WDSR-B + RDN, fp16);
+* the RCCL path in the GPU suite: a HIP model under trainer.GradSync on a 1-rank `nccl` group (and 2 ranks when the
+  box has 2 GPUs);
+* predict.py on a saved checkpoint: PNG out with save_image's rounding.
+"""
+import json
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fill, functional as OF
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+LARGE = sorted(k for k, v in MANIFEST.items() if v["class"] != "SRCNN" and v["n_params_trainable"] >= 1_000_000)
+
+
+@pytest.fixture(scope="module")
+def A():
+    import sr_amd
+    assert torch.cuda.is_available()
+    return sr_amd
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full-size backward vs the reference's gradient summaries
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", LARGE)
+def test_fullsize_backward_vs_reference_grad_sums(A, name):
+    """dL/dparams for L = sum(y * t) of the full-size nets (fp32 path) against [sum, abs-sum, square-sum] of every
+    parameter gradient as the REFERENCE computed them (generate_golden.py: grad_summary).  The composed 400-conv
+    backward chain of RCAN 10x20 is in here."""
+    ent = MANIFEST[name]
+    m = getattr(A, ent["class"])(precision=32, **ent["kwargs"])
+    fill.formula_fill_module(m)
+    m = m.cuda()
+    g = np.load(os.path.join(GOLDEN, f"model_{name}.npz"))
+    y = m(torch.from_numpy(g["x"]).cuda())
+    t = fill.formula_tensor(tuple(y.shape), 77, 1.0).cuda()
+    (y * t).sum().backward()
+    torch.cuda.synchronize()
+    yr = g["y"]
+    assert float(np.abs(y.detach().cpu().numpy() - yr).max()) <= 1e-3 * max(1.0, float(np.abs(yr).max()))
+    params = dict(m.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    assert len(names) == sum(1 for p in m.parameters() if p.requires_grad)
+    # scale on which tiny gradients are judged: the largest abs-sum per element in the net
+    worst = 0.0
+    for n, s in zip(names, g["grad_sums"]):
+        gr = params[n].grad.double().flatten().cpu()
+        got = np.array([float(gr.sum()), float(gr.abs().sum()), float((gr * gr).sum())])
+        # abs-sum and square-sum are well conditioned; the plain sum can cancel (cf. tests/test_oracle_golden.py)
+        e1 = abs(got[1] - s[1]) / max(s[1], 1e-30)
+        e2 = abs(got[2] - s[2]) / max(s[2], 1e-30)
+        e0 = abs(got[0] - s[0]) / max(s[1], 1e-30)
+        worst = max(worst, e0, e1, e2)
+        assert e1 < 4e-2 and e2 < 8e-2 and e0 < 4e-2, f"{name} grad {n}: sum {e0:.2e} abs-sum {e1:.2e} square-sum {e2:.2e}"
+    print(f"{name}: worst relative deviation of a gradient summary {worst:.2e} over {len(names)} tensors")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PSNR within 0.01 dB of the reference path
+# ---------------------------------------------------------------------------------------------------------------
+def smooth_images(n, size, seed):
+    """Smooth synthetic 'photographs': sums of low-frequency sin*cos products per channel plus a little noise, in [0,1]."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, size), torch.linspace(0, 1, size), indexing="ij")
+    out = torch.zeros(n, 3, size, size)
+    for i in range(n):
+        for c in range(3):
+            img = torch.zeros(size, size)
+            for _ in range(6):
+                fx, fy = (torch.rand(2, generator=g) * 9 + 0.5).tolist()
+                px, py = (torch.rand(2, generator=g) * 6.28).tolist()
+                amp = float(torch.rand(1, generator=g)) * 0.25
+                img += amp * torch.sin(6.28 * fx * xx + px) * torch.cos(6.28 * fy * yy + py)
+            out[i, c] = 0.5 + img
+    out += 0.01 * torch.randn(out.shape, generator=g)
+    return out.clamp(0, 1)
+
+
+def psnr(a, b):
+    mse = ((a.double().clamp(0, 1) - b.double().clamp(0, 1)) ** 2).flatten(1).mean(1)
+    return float((10.0 * torch.log10(1.0 / (mse + 1e-12))).mean())
+
+
+@pytest.fixture(scope="module")
+def trained_edsr(A):
+    """EDSR-baseline x4 trained for 300 Adam steps (bf16 HIP path) on smooth 192x192 images, bicubic LR."""
+    kw = dict(n_feats=64, n_resblocks=16, res_scale=0.1, scale_factor=4)
+    torch.manual_seed(0)
+    m = A.EDSR(precision="bf16", **kw).cuda()
+    hr = smooth_images(48, 192, 11)
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+    hr_d, lr_d = hr.cuda(), lr.cuda()
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)      # the reference's effective optimizer
+    g = torch.Generator().manual_seed(1)
+    first = last = None
+    for step in range(300):
+        idx = torch.randint(0, 48, (16,), generator=g).cuda()
+        opt.zero_grad(set_to_none=True)
+        loss = m.training_step({"lr": lr_d[idx], "hr": hr_d[idx]}, step)["loss"]
+        loss.backward()
+        opt.step()
+        first = float(loss) if first is None else first
+        last = float(loss)
+    assert math.isfinite(last) and last < 0.5 * first, (first, last)
+    sd = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+    hr_t = smooth_images(6, 192, 99)
+    lr_t = F.interpolate(hr_t, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+    with torch.no_grad():
+        y_ref = OF.forward("EDSR", sd, lr_t, **kw)
+    return kw, sd, lr_t, hr_t, y_ref
+
+
+@pytest.mark.parametrize("prec", ["bf16", 16, 32])
+def test_psnr_within_0p01_db_of_reference_path(A, trained_edsr, prec):
+    kw, sd, lr_t, hr_t, y_ref = trained_edsr
+    m = A.EDSR(precision=prec, **kw)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        y = m(lr_t.cuda()).float().cpu()
+    p_ref, p_build = psnr(y_ref, hr_t), psnr(y, hr_t)
+    p_cross = psnr(y, y_ref)
+    print(f"precision {prec}: PSNR(oracle, hr) {p_ref:.3f} dB, PSNR(build, hr) {p_build:.3f} dB, delta {p_build - p_ref:+.4f} dB, "
+          f"PSNR(build, oracle) {p_cross:.1f} dB, max|err| {float((y - y_ref).abs().max()):.2e}")
+    assert p_ref > 20.0, "the trained net should actually super-resolve the smooth images"
+    assert abs(p_build - p_ref) < 0.01, f"PSNR(build, hr) - PSNR(oracle, hr) = {p_build - p_ref:+.4f} dB"
+    # and image by image
+    for i in range(hr_t.shape[0]):
+        assert abs(psnr(y[i:i + 1], hr_t[i:i + 1]) - psnr(y_ref[i:i + 1], hr_t[i:i + 1])) < 0.01, i
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# two models alternating in one process (BASELINE configs[4])
+# ---------------------------------------------------------------------------------------------------------------
+def _steps(A, cls, kw, batches, other=None):
+    torch.manual_seed(0)
+    m = getattr(A, cls)(precision=16, **kw).cuda()
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4, fused=True)
+    losses = []
+    for b in batches:
+        opt.zero_grad(set_to_none=True)
+        loss = m.training_step(b, 0)["loss"]
+        (loss * 128.0).backward()
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad.mul_(1.0 / 128.0)
+        opt.step()
+        losses.append(float(loss))
+        if other is not None:
+            other()
+    return losses, {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+
+
+def test_two_models_alternating_match_each_alone(A):
+    """WDSR-B and RDN (fp16) take training steps alternately in one process: each must follow exactly the trajectory it
+    follows alone (packed-weight groups, deferred weight-gradient queue and thread-local state are per model / per
+    pass; nothing leaks between the two)."""
+    g = torch.Generator().manual_seed(8)
+    bw = [{"lr": torch.rand(2, 3, 24, 24, generator=g).cuda(), "hr": torch.rand(2, 3, 96, 96, generator=g).cuda()} for _ in range(3)]
+    br = [{"lr": torch.rand(2, 3, 20, 28, generator=g).cuda(), "hr": torch.rand(2, 3, 80, 112, generator=g).cuda()} for _ in range(3)]
+    kw_w, kw_r = dict(type="B", scale_factor=4, n_resblocks=4), dict(rdn_config="A", scale_factor=4)
+    lw, sw = _steps(A, "WDSR", kw_w, bw)
+    lr_, sr = _steps(A, "RDN", kw_r, br)
+    # interleaved: an RDN step runs between every two WDSR steps (and vice versa)
+    torch.manual_seed(0)
+    rdn = A.RDN(precision=16, **kw_r).cuda()
+    ropt = torch.optim.Adam([p for p in rdn.parameters() if p.requires_grad], lr=1e-4, fused=True)
+    it = iter(br)
+    rl = []
+
+    def rdn_step():
+        b = next(it)
+        ropt.zero_grad(set_to_none=True)
+        loss = rdn.training_step(b, 0)["loss"]
+        (loss * 128.0).backward()
+        for p in rdn.parameters():
+            if p.grad is not None:
+                p.grad.mul_(1.0 / 128.0)
+        ropt.step()
+        rl.append(float(loss))
+    lw2, sw2 = _steps(A, "WDSR", kw_w, bw, other=rdn_step)
+    sr2 = {k: v.detach().float().cpu() for k, v in rdn.state_dict().items()}
+    assert lw2 == lw and rl == lr_, (lw, lw2, lr_, rl)
+    for k in sw:
+        assert torch.equal(sw[k], sw2[k]), k
+    for k in sr:
+        assert torch.equal(sr[k], sr2[k]), k
+
+
+def test_standalone_block_after_model_forward_packs_fresh_weights(A):
+    """a block called on its own after a model's forward must not be served the model's packed weights
+    (stale after an optimizer step): the packed group only serves inside its forward window."""
+    torch.manual_seed(0)
+    m = A.EDSR(n_feats=64, n_resblocks=2, scale_factor=2, precision="bf16").cuda()
+    x = torch.rand(1, 3, 16, 16, device="cuda")
+    m(x)
+    blk = m.body[0]
+    f = (torch.rand(1, 16, 16, 64, device="cuda") - 0.5).to(torch.bfloat16)
+    with torch.no_grad():
+        y0 = blk(f).float()
+        for p in blk.parameters():
+            p.mul_(0.0)                      # an "optimizer step" that does not bump what the group keys on
+        y1 = blk(f).float()
+    assert float((y1 - f.float()).abs().max()) == 0.0, "zeroed weights: the block must return its input"
+    assert float((y0 - f.float()).abs().max()) > 0.0
+
+
+def test_nan_input_reaches_the_loss(A):
+    """Documented deviation: the fused ReLU is max(x, 0) with IEEE maxNum semantics, so a NaN
+    pre-activation becomes 0 where torch.relu would keep it.  A non-finite activation still reaches the output (and the
+    loss, and GradScaler's inf check) through the skip connections."""
+    torch.manual_seed(0)
+    m = A.EDSR(n_feats=64, n_resblocks=2, scale_factor=2, precision=16).cuda()
+    x = torch.rand(1, 3, 16, 16, device="cuda")
+    x[0, 1, 5, 7] = float("nan")
+    with torch.no_grad():
+        y = m(x)
+    assert not bool(torch.isfinite(y).all())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# RCCL path: GradSync on a 1-rank nccl group (2 ranks when there are 2 GPUs)
+# ---------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+DDP_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+import sr_amd
+from sr_amd import trainer as T
+rank, world, local = T.init_distributed("cuda", force=True)
+dev = torch.device("cuda", local)
+torch.manual_seed(0)
+m = sr_amd.EDSR(n_feats=64, n_resblocks=2, res_scale=0.1, scale_factor=2, precision="bf16").to(dev)
+g = torch.Generator().manual_seed(5)
+full = [{{"lr": torch.rand(4, 3, 24, 24, generator=g), "hr": torch.rand(4, 3, 48, 48, generator=g)}} for _ in range(3)]
+per = 4 // world
+mode = {mode!r}
+gs = T.GradSync(m, overlap=(mode == "hooks"), bucket_bytes=64 << 10)
+gs.broadcast()
+opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, fused=True)
+for b in full:
+    sh = {{k: v[rank * per:(rank + 1) * per].to(dev) for k, v in b.items()}}
+    opt.zero_grad(set_to_none=True)
+    m._calculate_losses(img_sr=m(sh["lr"]), img_hr=sh["hr"])["loss"].backward()
+    if mode == "hooks":
+        gs.sync()
+    else:
+        gs.pack(); gs.reduce()
+    assert all(p.grad.data_ptr() == gs.views[p].data_ptr() for p in gs.params)
+    opt.step()
+torch.cuda.synchronize()
+torch.save({{k: v.float().cpu() for k, v in m.state_dict().items()}}, os.path.join({out!r}, f"{{mode}}_r{{rank}}.pt"))
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["hooks", "pack_reduce"])
+def test_gradsync_over_rccl(A, tmp_path, mode):
+    """A HIP EDSR trains 3 steps under trainer.GradSync on an `nccl` (= RCCL) process group: 1 rank always (the
+    collective path itself), 2 ranks when the box has 2 GPUs (replica equality).  The result must equal the same
+    steps without any process group (global batch)."""
+    ngpu = torch.cuda.device_count()
+    world = 2 if ngpu >= 2 else 1
+    script = tmp_path / "worker.py"
+    script.write_text(DDP_WORKER.format(root=ROOT, mode=mode, out=str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    sds = [torch.load(tmp_path / f"{mode}_r{r}.pt") for r in range(world)]
+    for k in sds[0]:
+        for s in sds[1:]:
+            assert torch.equal(sds[0][k], s[k]), f"replicas diverged at {k}"
+    # the same three steps in this process, no process group
+    torch.manual_seed(0)
+    m = A.EDSR(n_feats=64, n_resblocks=2, res_scale=0.1, scale_factor=2, precision="bf16").cuda()
+    g = torch.Generator().manual_seed(5)
+    full = [{"lr": torch.rand(4, 3, 24, 24, generator=g), "hr": torch.rand(4, 3, 48, 48, generator=g)} for _ in range(3)]
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, fused=True)
+    for b in full:
+        opt.zero_grad(set_to_none=True)
+        m._calculate_losses(img_sr=m(b["lr"].cuda()), img_hr=b["hr"].cuda())["loss"].backward()
+        opt.step()
+    for k, v in m.state_dict().items():
+        d = float((v.float().cpu() - sds[0][k]).abs().max())
+        assert d <= (2e-6 if world == 1 else 2e-4) * max(1.0, float(v.abs().max())), (k, d)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# predict.py on a saved checkpoint
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+def test_predict_script_writes_pngs(A, tmp_path):
+    from PIL import Image
+    torch.manual_seed(0)
+    kw = dict(n_feats=64, n_resblocks=2, res_scale=0.1, scale_factor=4)
+    m = A.EDSR(precision="bf16", **kw)
+    ck = tmp_path / "edsr.ckpt"
+    torch.save({"state_dict": m.state_dict()}, ck)
+    d = tmp_path / "Set5"
+    d.mkdir()
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 255, (37, 45, 3), dtype=np.uint8)
+    Image.fromarray(img).save(d / "bird.png")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "predict.py"), "-m", "edsr", "--checkpoint", str(ck), "--n_feats", "64", "--n_resblocks", "2", "--res_scale", "0.1",
+                          "--predict_datasets", str(d), "--default_root_dir", str(tmp_path / "res")],
+                         capture_output=True, text=True, timeout=800)
+    if out.returncode != 0 and "unrecognized arguments" in out.stderr:
+        pytest.fail(out.stderr[-1500:])
+    assert out.returncode == 0, out.stderr[-3000:]
+    got = np.asarray(Image.open(tmp_path / "res" / "Set5" / "bird.png"))
+    assert got.shape == (148, 180, 3)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        sr = m.predict_step({"lr": torch.from_numpy(img.copy()).permute(2, 0, 1).float()[None].cuda() / 255.0}, 0)
+    want = m.to_uint8(sr[0]).permute(1, 2, 0).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert (tmp_path / "res" / "Set5" / "bird_center.png").exists()

@@ -18,13 +18,11 @@ CSRC = os.path.join(os.path.dirname(HERE), "sr-pytorch-lightning_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def _regs(line):
-    out = set()
-    for m in re.finditer(r"v\[(\d+):(\d+)\]", line):
-        out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
-    for m in re.finditer(r"\bv(\d+)\b", line):
-        out.add(int(m.group(1)))
-    return out
+import importlib.util
+
+_spec = importlib.util.spec_from_file_location("check_isa", os.path.join(CSRC, "check_isa.py"))
+check_isa = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(check_isa)
 
 
 @pytest.fixture(scope="module")
@@ -41,27 +39,18 @@ def asm(tmp_path_factory):
 @pytest.mark.parametrize("nks", [4, 1])
 @pytest.mark.parametrize("dt", [0, 1])
 def test_prefetch_registers_untouched_until_wait(asm, dt, nks):
-    name = f"_ZN12_GLOBAL__N_114conv_ws_kernelILi{dt}ELi2ELi{nks}ELb1ELb1EEEv13srk_conv_args"
+    """The same check the Makefile runs as a build gate (csrc/check_isa.py)."""
+    assert check_isa.check_kernel(asm, dt, nks) > 100
+
+
+def test_gate_rejects_a_touched_register(asm):
+    """Plant a read of a prefetch destination between a load and the wait: the gate must fail."""
+    name = "_ZN12_GLOBAL__N_114conv_ws_kernelILi0ELi2ELi4ELb1ELb1EEEv13srk_conv_args"
     start = asm.index(name + "iiiijiiiiiii:")
     body = asm[start:asm.index(".Lfunc_end", start)].split("\n")
-    loads = [k for k, l in enumerate(body)
-             if "buffer_load_dwordx4" in l and " lds" not in l and "ASMSTART" in body[k - 1]]
-    assert len(loads) == 8, "4 pieces x 2 pixel blocks"
-    mfma = [k for k, l in enumerate(body) if "v_mfma" in l]
-    assert len(mfma) == 36 * nks
-    waits = [k for k, l in enumerate(body) if "s_waitcnt vmcnt(0)" in l and "ASMSTART" in body[k - 1] and k > mfma[-1]]
-    assert waits, "the closing wait of the MFMA phase"
-    wait = waits[0]
-    assert mfma[0] < loads[0] and loads[-1] < mfma[-1] < wait, "loads sit inside the MFMA phase, the wait right behind it"
-    assert not [k for k in range(loads[0], wait) if body[k].startswith(".LBB")], "straight-line code up to the wait"
-    for k in loads:
-        dst = _regs(re.search(r"v\[\d+:\d+\]", body[k]).group(0))
-        assert len(dst) == 4
-        for x in range(k + 1, wait):
-            line = body[x].strip()
-            if not line or line.startswith((";", ".")):
-                continue
-            assert not (_regs(line) & dst), f"line {x} touches an in-flight prefetch register: {line}"
-    # and the compiler put no wait of its own on the vector-memory counter anywhere in the kernel's loops
-    own = [l.strip() for k, l in enumerate(body) if "s_waitcnt vmcnt" in l and "ASMSTART" not in body[k - 1] and k > loads[0]]
-    assert not own, own
+    k = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l and " lds" not in l and "ASMSTART" in body[i - 1]][0]
+    reg = re.search(r"v\[(\d+):\d+\]", body[k]).group(1)
+    body.insert(k + 3, f"\tv_mov_b32_e32 v1, v{reg}")
+    bad = asm[:start] + "\n".join(body) + asm[asm.index(".Lfunc_end", start):]
+    with pytest.raises(AssertionError):
+        check_isa.check_kernel(bad, 0, 4)
