@@ -158,7 +158,8 @@ int srk_wgrad_group_job_bytes(void);
 int srk_wgrad_group_plan(srk_wgrad_args* jobs, int n, float* scratch, void* table_host, int* block_job_host,
                          int* nblocks, long long* scratch_floats);
 int srk_conv2d_wgrad_group(const void* table_dev, const int* block_job_dev, int nblocks, int dtype, srk_stream_t stream);
-/* `n` finalizations in one launch: `table_dev` is a DEVICE array of srk_wgrad_fin_args, `blocks_per_job` workgroups each */
+/* `n` finalizations of 3x3 gradients (KH = KW = 3) in one launch: `table_dev` is a DEVICE array of srk_wgrad_fin_args,
+ * `blocks_per_job` workgroups each; slabs are summed in slab order (bitwise reproducible) */
 int srk_wgrad_finalize_group(const srk_wgrad_fin_args* table_dev, int n, int blocks_per_job, srk_stream_t stream);
 /* Copies a small HOST table (<= 4 MiB) to 16-byte-aligned DEVICE memory through kernel arguments: capturable into a
  * hipGraph (a replay rewrites the same bytes), no pinned staging buffer.                                          */

@@ -175,11 +175,79 @@ __global__ __launch_bounds__(512) void wgrad_finalize_kernel(const srk_wgrad_fin
   __shared__ float red[8][128];
   wgrad_finalize_body(a, red, blockIdx.x, gridDim.x);
 }
+
+// ---- 3x3 finalize through an LDS transpose (the grouped launch) ----------------------------------------------------------------
+// The slab layout is [tap][ci][co'] (co' fastest), OIHW wants [co][ci][tap]: element by element (wgrad_finalize_body)
+// every 4-byte store lands in its own 64-byte segment (stride 9*Cin floats).  Here a workgroup owns 2 input channels x
+// 64 output channels of one job: it reads the 18 slab rows (tap, ci) as float4 (16 lanes = one 256-byte row; the slab
+// loop unrolled 8 deep, slabs added in order: bitwise reproducible) into an LDS tile and writes, per output channel, the
+// 18 CONTIGUOUS floats [ci0, ci0+1][9 taps] (two lanes x 36 bytes).
+__device__ __forceinline__ void wgrad_finalize3x3_tile(const srk_wgrad_fin_args& a, float (&tile)[18][68], const int ci0, const int co0) {
+  const int ns = a.nslabs > 1 ? a.nslabs : 1;
+  const size_t per = (size_t)9 * a.CinP * a.CoutP;
+  const int tid = threadIdx.x;          // 256 threads: 16 row slots x 16 float4 columns
+  const int c4 = tid & 15, rr = tid >> 4;
+  for (int r = rr; r < 18; r += 16) {   // row r = tap * 2 + (ci - ci0)
+    const int tap = r >> 1, ci = ci0 + (r & 1);
+    float4 t = {0.f, 0.f, 0.f, 0.f};
+    if (ci < a.CinP && co0 + 4 * c4 < a.CoutP) {
+      const float* p = a.dwp + ((size_t)tap * a.CinP + ci) * a.CoutP + co0 + 4 * c4;
+#pragma unroll 8
+      for (int sl = 0; sl < ns; ++sl) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)sl * per);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+    }
+    tile[r][4 * c4 + 0] = t.x; tile[r][4 * c4 + 1] = t.y; tile[r][4 * c4 + 2] = t.z; tile[r][4 * c4 + 3] = t.w;
+  }
+  __syncthreads();
+  if (tid < 128) {                      // thread (co, cil): the 9 taps of one (co, ci)
+    const int col = tid >> 1, cil = tid & 1;
+    const int cop = co0 + col, ci = ci0 + cil;
+    if (cop < a.Cout && ci < a.Cin) {
+      int co = cop;
+      if (a.ps_r > 1) {          // packed co' = ij*Cc + c  ->  torch co = c*r*r + ij
+        const int r2p = a.ps_r * a.ps_r, Cc = a.Cout / r2p;
+        const int ij = cop / Cc, c = cop - ij * Cc;
+        co = c * r2p + ij;
+      }
+      float* o = a.dw + ((size_t)co * a.Cin + ci) * 9;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float v = a.scale * tile[tap * 2 + cil][col];
+        if (a.accumulate) o[tap] += v; else o[tap] = v;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // one launch for every weight gradient of a step: blockIdx.y = table entry (the pack_group_kernel pattern)
-__global__ __launch_bounds__(512) void wgrad_finalize_group_kernel(const srk_wgrad_fin_args* __restrict__ table) {
-  __shared__ float red[8][128];
+__global__ __launch_bounds__(256) void wgrad_finalize_group_kernel(const srk_wgrad_fin_args* __restrict__ table) {
+  __shared__ float tile[18][68];
   const srk_wgrad_fin_args a = table[blockIdx.y];
-  wgrad_finalize_body(a, red, blockIdx.x, gridDim.x);
+  const int ncob = (a.CoutP + 63) / 64, ncib = (a.CinP + 1) / 2;
+  for (int t = blockIdx.x; t < ncob * ncib; t += gridDim.x) {
+    const int cob = t % ncob, cib = t / ncob;
+    wgrad_finalize3x3_tile(a, tile, cib * 2, cob * 64);
+  }
+  if (a.db && a.dbp && blockIdx.x == 0) {
+    // bias: slabs summed in order per channel (a few hundred floats)
+    const int ns = a.nslabs > 1 ? a.nslabs : 1;
+    for (int cop = threadIdx.x; cop < a.Cout; cop += blockDim.x) {
+      float u = 0.f;
+#pragma unroll 8
+      for (int sl = 0; sl < ns; ++sl) u += a.dbp[(size_t)sl * a.CoutP + cop];
+      int co = cop;
+      if (a.ps_r > 1) {
+        const int r2p = a.ps_r * a.ps_r, Cc = a.Cout / r2p;
+        const int ij = cop / Cc, c = cop - ij * Cc;
+        co = c * r2p + ij;
+      }
+      const float v = a.scale * u;
+      if (a.accumulate) a.db[co] += v; else a.db[co] = v;
+    }
+  }
 }
 
 // NCHW fp32 -> NHWC dtype; one thread per (pixel, 4-channel group)
@@ -384,7 +452,7 @@ extern "C" int srk_upload_small(void* dst_dev, const void* src_host, long long n
 extern "C" int srk_wgrad_finalize_group(const srk_wgrad_fin_args* table_dev, int n, int blocks_per_job, srk_stream_t stream) {
   SRK_CHECK_ARG(table_dev && n > 0 && n <= 65535, "srk_wgrad_finalize_group: bad table (%d entries)", n);
   const int bx = blocks_per_job < 1 ? 1 : (blocks_per_job > 2048 ? 2048 : blocks_per_job);
-  hipLaunchKernelGGL(wgrad_finalize_group_kernel, dim3(bx, n), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), table_dev);
+  hipLaunchKernelGGL(wgrad_finalize_group_kernel, dim3(bx, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table_dev);
   SRK_LAUNCH_CHECK();
   return 0;
 }

@@ -330,7 +330,7 @@ class _WgradQueue:
 
 
 _WQ = _WgradQueue()
-_WG_BLOCKS_PER_JOB = 24
+_WG_BLOCKS_PER_JOB = 32
 
 
 class hold_wgrads:
