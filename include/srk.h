@@ -307,6 +307,67 @@ typedef struct srk_ssim_args {
 } srk_ssim_args;
 int srk_image_ssim(const srk_ssim_args* a, srk_stream_t stream);
 
+/* ---- remaining conv models: SRResNet and DDBPN ---------------------------------------------------
+ * im2col / col2im on NHWC tensors for any kernel size K, stride and zero padding:
+ *   cols[n][oy][ox][(kh*K + kw)*C + c] = x[n][oy*stride + kh - pad][ox*stride + kw - pad][c]          (srk_unfold_nhwc)
+ *   out[n][y][x][c] = bias[c] + sum of cols[n][iy][ix][(kh*K + kw)*C + c] over y = iy*stride - pad + kh, x = ...  (srk_fold_nhwc)
+ * nn.Conv2d(k, stride, padding) (models/ddbpn.py:10-24 `projection_conv(up=False)`, the 9x9 tail conv of
+ * models/srresnet.py:24-29) = srk_unfold_nhwc -> 1x1 srk_conv2d with the weight as a [Cout][K*K*Cin] matrix;
+ * nn.ConvTranspose2d (ddbpn.py `projection_conv(up=True)`) = 1x1 srk_conv2d to K*K*Cout channels -> srk_fold_nhwc.
+ * Each kernel is the other's adjoint, so the data gradients use the same pair.                                   */
+typedef struct {
+  const void* x; int x_pitch, x_coff;     /* NHWC input, C channels from x_coff                                   */
+  void* cols; int cols_pitch;             /* out [N][Ho][Wo][>= K*K*C]                                             */
+  int N, H, W, C;                         /* C: multiple of 16 bytes / sizeof(dtype)                               */
+  int K, stride, pad;
+  int Ho, Wo;                             /* (H + 2 pad - K) / stride + 1                                           */
+  int dtype;
+} srk_unfold_nhwc_args;
+int srk_unfold_nhwc(const srk_unfold_nhwc_args* a, srk_stream_t stream);
+
+typedef struct {
+  const void* cols; int cols_pitch;       /* [N][Hi][Wi][>= K*K*C]                                                  */
+  const float* bias;                      /* [C] added once per output element, or NULL                             */
+  void* out; int out_pitch, out_coff;     /* NHWC [N][Ho][Wo][C]                                                    */
+  int N, Hi, Wi, C;
+  int K, stride, pad;
+  int Ho, Wo;                             /* ConvTranspose2d: (Hi - 1)*stride - 2 pad + K                           */
+  int dtype;
+} srk_fold_nhwc_args;
+int srk_fold_nhwc(const srk_fold_nhwc_args* a, srk_stream_t stream);
+
+/* Per-channel partial sums over P pixels of an NHWC tensor (fp32 accumulate), one plain store per block and channel:
+ * partial[b][0][c], partial[b][1][c] for b < srk_chan_stats_blocks(P); the caller adds the blocks in order.
+ *   mode 0: sum x, sum x^2          nn.BatchNorm2d batch statistics (srresnet.py:16-21 via common.py:97-98)
+ *   mode 1: sum y, sum x*y          BatchNorm backward (y = upstream gradient)
+ *   mode 2: sum over x <= 0 of x*y  nn.PReLU slope gradient (partial[b][1] = 0)                                   */
+typedef struct {
+  const void* x; int x_pitch, x_coff;
+  const void* y; int y_pitch, y_coff;     /* modes 1, 2                                                             */
+  long long P; int C;                     /* C <= 256                                                               */
+  int mode;
+  float* partial;                         /* [blocks][2][C]                                                         */
+  int dtype;
+} srk_chan_stats_args;
+int srk_chan_stats_blocks(long long P);
+int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream);
+
+/* out[p][c] = post( (a[c]*x + b[c]*y + d[c]) * gate ),  gate = (z > 0 ? 1 : slope[c*slope_stride]) when z is given,
+ * post = PReLU with the same slope when post_prelu.  a / b / d NULL = 1 / 1 / 0; y NULL = no second input.
+ * BatchNorm apply (+ residual in y), BatchNorm backward (x = dy, y = saved input), nn.PReLU forward and backward.  */
+typedef struct {
+  const void* x; int x_pitch, x_coff;
+  const void* y; int y_pitch, y_coff;
+  const void* z; int z_pitch, z_coff;
+  const float* a; const float* b; const float* d;   /* [C] fp32                                                     */
+  const float* slope; int slope_stride;    /* nn.PReLU weight: stride 1 = per channel, 0 = one shared value           */
+  int post_prelu;
+  void* out; int out_pitch, out_coff;
+  long long P; int C;
+  int dtype;
+} srk_chan_apply_args;
+int srk_chan_apply(const srk_chan_apply_args* a, srk_stream_t stream);
+
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* srk_last_error(void);
 int srk_version(void);

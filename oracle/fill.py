@@ -34,6 +34,22 @@ def formula_fill_state_dict(sd, trainable):
     on the path equals the state_dict order (no buffers on the hot path,
     SURVEY.md 8(a) a14).
     """
+    order = getattr(sd, "param_order", None)
+    if order is not None and (len(order) != len(sd) or any(a != b for a, b in zip(order, sd))):
+        # BatchNorm buffers / modules registered twice (SRResNet): k is the index among named_parameters(), which counts
+        # the frozen MeanShift tensors too -- they are not in `trainable`, so splice them in where the keys put them
+        names = [n for n in sd if n in set(order) or (n.startswith(("sub_mean", "add_mean")))]
+        seen, plist = set(), []
+        for n in names:
+            if id(sd[n]) in seen:
+                continue
+            seen.add(id(sd[n]))
+            plist.append(n)
+        for k, name in enumerate(plist):
+            if name in trainable:
+                with torch.no_grad():
+                    sd[name].copy_(fill_value(name, tuple(sd[name].shape), k))
+        return sd
     for k, (name, t) in enumerate(sd.items()):
         if name not in trainable:
             continue

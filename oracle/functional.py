@@ -202,6 +202,88 @@ def srcnn_forward(sd, x, *, scale):
     return conv_same(sd, "_net.4", x)
 
 
+def batch_norm(sd, prefix, x, training=True, momentum=0.1, eps=1e-5):
+    """`nn.BatchNorm2d` (models/srresnet.py:17,20 via common.py:97-98): batch statistics + running-buffer update in
+    training mode (the state dict's `running_mean` / `running_var` / `num_batches_tracked` are updated in place, like
+    the module's buffers), running statistics in eval mode."""
+    if training:
+        sd[prefix + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"], sd[prefix + ".bias"],
+                        training, momentum, eps)
+
+
+def prelu(sd, prefix, x):
+    """`nn.PReLU` with one shared slope (srresnet.py:14,20,27) or one per channel (ddbpn.py:33,42-53,82-86)."""
+    return F.prelu(x, sd[prefix + ".weight"])
+
+
+def res_block_bn(sd, prefix, x, res_scale, training=True):
+    """`ResBlock.forward` with norm = BatchNorm2d and act = PReLU (models/common.py:74-109 as built by srresnet.py:16-19):
+    body = [conv, bn, prelu, conv, bn] where indices 1 and 4 are ONE BatchNorm2d instance (same tensors, both keys)."""
+    r = conv_same(sd, prefix + ".body.0", x)
+    r = batch_norm(sd, prefix + ".body.1", r, training)
+    r = prelu(sd, prefix + ".body.2", r)
+    r = conv_same(sd, prefix + ".body.3", r)
+    r = batch_norm(sd, prefix + ".body.4", r, training)
+    return r * res_scale + x
+
+
+def srresnet_forward(sd, x, *, n_resblocks, scale, training=True):
+    """`SRResNet.forward` (models/srresnet.py:32-36; ctor :10-30): head = BasicBlock(9x9 conv, PReLU); body =
+    n x ResBlock(BN, PReLU) + BasicBlock(3x3 conv, BN), `+ x`; tail = UpscaleBlock(act = one shared PReLU) + 9x9 conv."""
+    x = prelu(sd, "head.1", conv_same(sd, "head.0", x))
+    r = x
+    for i in range(n_resblocks):
+        r = res_block_bn(sd, f"body.{i}", r, 1.0, training)
+    r = batch_norm(sd, f"body.{n_resblocks}.1", conv_same(sd, f"body.{n_resblocks}.0", r), training)
+    x = r + x
+    rr = 2 if scale % 2 == 0 else 3
+    for i in range(int(log2(scale))):                        # UpscaleBlock with act: [conv, PixelShuffle, act] per stage
+        x = F.pixel_shuffle(conv_same(sd, f"tail.0.{3 * i}", x), rr)
+        x = prelu(sd, f"tail.0.{3 * i + 2}", x)
+    return conv_same(sd, "tail.1", x)
+
+
+DDBPN_PROJ = {2: (6, 2, 2), 4: (8, 4, 2), 8: (12, 8, 2)}     # models/ddbpn.py:11-15 (kernel, stride, padding)
+
+
+def projection(sd, prefix, x, scale, up):
+    """`projection_conv` + PReLU (models/ddbpn.py:10-24,40-53): ConvTranspose2d when `up`, else Conv2d."""
+    _, stride, pad = DDBPN_PROJ[scale]
+    w, b = sd[prefix + ".0.weight"], sd[prefix + ".0.bias"]
+    y = F.conv_transpose2d(x, w, b, stride=stride, padding=pad) if up else F.conv2d(x, w, b, stride=stride, padding=pad)
+    return prelu(sd, prefix + ".1", y)
+
+
+def dense_projection(sd, prefix, x, scale, up, bottleneck):
+    """`DenseProjection.forward` (models/ddbpn.py:55-64)."""
+    if bottleneck:
+        x = prelu(sd, prefix + ".bottleneck.1", F.conv2d(x, sd[prefix + ".bottleneck.0.weight"], sd[prefix + ".bottleneck.0.bias"]))
+    a_0 = projection(sd, prefix + ".conv_1", x, scale, up)
+    b_0 = projection(sd, prefix + ".conv_2", a_0, scale, not up)
+    e = b_0.sub(x)
+    a_1 = projection(sd, prefix + ".conv_3", e, scale, up)
+    return a_0.add(a_1)
+
+
+def ddbpn_forward(sd, x, *, scale, channels=3, depth=6):
+    """`DDBPN.forward` (models/ddbpn.py:112-137; ctor :71-110)."""
+    if channels == 3:
+        x = mean_shift(sd, "sub_mean", x)
+    x = prelu(sd, "initial.1", conv_same(sd, "initial.0", x))
+    x = prelu(sd, "initial.3", conv_same(sd, "initial.2", x))
+    h_list, l_list = [], []
+    for i in range(depth - 1):
+        l = x if i == 0 else torch.cat(l_list, dim=1)
+        h_list.append(dense_projection(sd, f"upmodules.{i}", l, scale, True, i > 1))
+        l_list.append(dense_projection(sd, f"downmodules.{i}", torch.cat(h_list, dim=1), scale, False, i != 0))
+    h_list.append(dense_projection(sd, f"upmodules.{depth - 1}", torch.cat(l_list, dim=1), scale, True, depth - 1 > 1))
+    out = conv_same(sd, "reconstruction.0", torch.cat(h_list, dim=1))
+    if channels == 3:
+        out = mean_shift(sd, "add_mean", out)
+    return out
+
+
 def forward(cls, sd, x, **kw):
     """Dispatch on the reference class name with the reference's ctor kwargs."""
     scale = kw.get("scale_factor", 4)
@@ -219,4 +301,8 @@ def forward(cls, sd, x, **kw):
                             res_scale=kw.get("res_scale", 1), scale=scale, channels=channels)
     if cls == "SRCNN":
         return srcnn_forward(sd, x, scale=scale)
+    if cls == "SRResNet":
+        return srresnet_forward(sd, x, n_resblocks=kw.get("n_resblocks", 16), scale=scale, training=kw.get("training", True))
+    if cls == "DDBPN":
+        return ddbpn_forward(sd, x, scale=scale, channels=channels)
     raise KeyError(cls)

@@ -17,10 +17,46 @@ import torch.nn as nn
 from .functional import RDN_CONFIGS, RGB_MEAN
 
 
+class StateDict(OrderedDict):
+    """OrderedDict + `param_order`: the names `module.named_parameters()` yields, in order (first name of a shared
+    parameter only, no buffers).  Equals the key order for every model without BatchNorm / shared modules."""
+    param_order = None
+
+
 class _Builder:
     def __init__(self):
-        self.sd = OrderedDict()
+        self.sd = StateDict()
         self.trainable = set()
+        self.order = []
+
+    def batch_norm(self, name, c, alias=None):
+        """nn.BatchNorm2d: weight 1, bias 0, running_mean 0, running_var 1, num_batches_tracked 0 (no RNG draws).
+        `alias`: a second name under which the reference registers the SAME module (common.py:97-98)."""
+        w, b = torch.ones(c), torch.zeros(c)
+        rm, rv, nb = torch.zeros(c), torch.ones(c), torch.tensor(0, dtype=torch.long)
+        for nm in (name,):
+            self._add(nm + ".weight", w)
+            self._add(nm + ".bias", b)
+            self.sd[nm + ".running_mean"], self.sd[nm + ".running_var"], self.sd[nm + ".num_batches_tracked"] = rm, rv, nb
+        return (w, b, rm, rv, nb)
+
+    def alias_batch_norm(self, name, tensors):
+        w, b, rm, rv, nb = tensors                      # same tensor objects: shared parameters and buffers
+        self.sd[name + ".weight"], self.sd[name + ".bias"] = w, b
+        self.sd[name + ".running_mean"], self.sd[name + ".running_var"], self.sd[name + ".num_batches_tracked"] = rm, rv, nb
+
+    def prelu(self, name, n=1):
+        t = torch.full((n,), 0.25)                      # nn.PReLU(num_parameters=n, init=0.25)
+        self._add(name + ".weight", t)
+        return t
+
+    def alias(self, name, t):
+        self.sd[name] = t
+
+    def conv_t(self, name, cin, cout, k, stride, pad):
+        m = nn.ConvTranspose2d(cin, cout, k, stride=stride, padding=pad)      # consumes the RNG as the reference does
+        self._add(name + ".weight", m.weight.detach().clone())
+        self._add(name + ".bias", m.bias.detach().clone())
 
     def conv(self, name, cin, cout, k, weight_norm=False):
         m = nn.Conv2d(cin, cout, k)            # consumes the RNG as the reference does
@@ -44,6 +80,7 @@ class _Builder:
     def _add(self, key, t):
         self.sd[key] = t
         self.trainable.add(key)
+        self.order.append(key)
 
 
 def _upscale(b, prefix, scale, n_feats):
@@ -90,7 +127,7 @@ def build_state_dict(cls, **kw):
         order = [k for k in b.sd if k.startswith("sub_mean")] + \
                 [k for k in b.sd if k.startswith("head")] + [k for k in b.sd if k.startswith("body")] + \
                 [k for k in b.sd if k.startswith("tail")] + [k for k in b.sd if k.startswith("add_mean")]
-        b.sd = OrderedDict((k, b.sd[k]) for k in order)
+        b.sd = StateDict((k, b.sd[k]) for k in order)
     elif cls == "RDN":                              # models/rdn.py:47-97
         D, C, G = RDN_CONFIGS[kw.get("rdn_config", "B")]
         G0, k = kw.get("G0", 64), kw.get("kernel_size", 3)
@@ -129,6 +166,68 @@ def build_state_dict(cls, **kw):
         b.conv("_net.0", ch, 64, 9)
         b.conv("_net.2", 64, 32, 1)
         b.conv("_net.4", 32, ch, 5)
+    elif cls == "SRResNet":                         # models/srresnet.py:10-30
+        F_, B = kw.get("n_feats", 64), kw.get("n_resblocks", 16)
+        b.conv("head.0", ch, F_, 9)
+        b.prelu("head.1")
+        for i in range(B):
+            p = f"body.{i}.body"
+            # ctor argument order: norm = BatchNorm2d and act = PReLU are built BEFORE the block's convs (no RNG in either);
+            # registration order inside the Sequential: conv, norm, act, conv, norm (the same instance again)
+            b.conv(p + ".0", F_, F_, 3)
+            bn = b.batch_norm(p + ".1", F_)
+            b.prelu(p + ".2")
+            b.conv(p + ".3", F_, F_, 3)
+            b.alias_batch_norm(p + ".4", bn)
+        b.conv(f"body.{B}.0", F_, F_, 3)
+        b.batch_norm(f"body.{B}.1", F_)
+        r = 2 if scale % 2 == 0 else 3
+        act = None
+        for i in range(int(log2(scale))):           # UpscaleBlock(act=PReLU): [conv, PixelShuffle, act] with ONE act instance
+            b.conv(f"tail.0.{3 * i}", F_, F_ * r * r, 3)
+            if act is None:
+                act = b.prelu(f"tail.0.{3 * i + 2}")
+            else:
+                b.alias(f"tail.0.{3 * i + 2}.weight", act)
+        b.conv("tail.1", F_, ch, 9)
+    elif cls == "DDBPN":                            # models/ddbpn.py:71-110
+        n0, nr, depth = 128, 32, 6
+        k, st, pd = {2: (6, 2, 2), 4: (8, 4, 2), 8: (12, 8, 2)}[scale]
+
+        def dense(prefix, cin, up, bottleneck):     # ddbpn.py:27-53
+            if bottleneck:
+                b.conv(prefix + ".bottleneck.0", cin, nr, 1)
+                b.prelu(prefix + ".bottleneck.1", nr)
+                inter = nr
+            else:
+                inter = cin
+            for j, (ci, co, u) in enumerate(((inter, nr, up), (nr, inter, not up), (inter, nr, up)), start=1):
+                if u:
+                    b.conv_t(f"{prefix}.conv_{j}.0", ci, co, k, st, pd)
+                else:
+                    m = nn.Conv2d(ci, co, k, stride=st, padding=pd)
+                    b._add(f"{prefix}.conv_{j}.0.weight", m.weight.detach().clone())
+                    b._add(f"{prefix}.conv_{j}.0.bias", m.bias.detach().clone())
+                b.prelu(f"{prefix}.conv_{j}.1", co)
+        if ch == 3:
+            b.mean_shift("sub_mean", -1)
+        b.conv("initial.0", ch, n0, 3)
+        b.prelu("initial.1", n0)
+        b.conv("initial.2", n0, nr, 1)
+        b.prelu("initial.3", nr)
+        channels = nr
+        for i in range(depth):
+            dense(f"upmodules.{i}", channels, True, i > 1)
+            if i != 0:
+                channels += nr
+        channels = nr
+        for i in range(depth - 1):
+            dense(f"downmodules.{i}", channels, False, i != 0)
+            channels += nr
+        b.conv("reconstruction.0", depth * nr, ch, 3)
+        if ch == 3:
+            b.mean_shift("add_mean", +1)
     else:
         raise KeyError(cls)
+    b.sd.param_order = [k for k in b.order]
     return b.sd, b.trainable

@@ -104,6 +104,28 @@ class L1Args(C.Structure):
                 ("scale", _f), ("grad", _p)]
 
 
+class UnfoldNhwcArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("cols", _p), ("cols_pitch", _i),
+                ("N", _i), ("H", _i), ("W", _i), ("C", _i), ("K", _i), ("stride", _i), ("pad", _i), ("Ho", _i), ("Wo", _i), ("dtype", _i)]
+
+
+class FoldNhwcArgs(C.Structure):
+    _fields_ = [("cols", _p), ("cols_pitch", _i), ("bias", _p), ("out", _p), ("out_pitch", _i), ("out_coff", _i),
+                ("N", _i), ("Hi", _i), ("Wi", _i), ("C", _i), ("K", _i), ("stride", _i), ("pad", _i), ("Ho", _i), ("Wo", _i), ("dtype", _i)]
+
+
+class ChanStatsArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("y", _p), ("y_pitch", _i), ("y_coff", _i),
+                ("P", C.c_longlong), ("C", _i), ("mode", _i), ("partial", _p), ("dtype", _i)]
+
+
+class ChanApplyArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("y", _p), ("y_pitch", _i), ("y_coff", _i),
+                ("z", _p), ("z_pitch", _i), ("z_coff", _i), ("a", _p), ("b", _p), ("d", _p),
+                ("slope", _p), ("slope_stride", _i), ("post_prelu", _i), ("out", _p), ("out_pitch", _i), ("out_coff", _i),
+                ("P", C.c_longlong), ("C", _i), ("dtype", _i)]
+
+
 # every launcher declared in include/srk.h: name -> argument struct
 LAUNCHERS = {
     "srk_pack_conv_weights": PackArgs,
@@ -121,10 +143,14 @@ LAUNCHERS = {
     "srk_image_ssim": SsimArgs,
     "srk_l1_loss_fwd": L1Args,
     "srk_l1_loss_bwd": L1Args,
+    "srk_unfold_nhwc": UnfoldNhwcArgs,
+    "srk_fold_nhwc": FoldNhwcArgs,
+    "srk_chan_stats": ChanStatsArgs,
+    "srk_chan_apply": ChanApplyArgs,
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
-                 "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits")
+                 "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks")
 
 _lib = None
 
@@ -161,6 +187,8 @@ def load():
     lib.srk_wgrad_finalize_group.restype = C.c_int
     lib.srk_upload_small.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
     lib.srk_upload_small.restype = C.c_int
+    lib.srk_chan_stats_blocks.argtypes = [C.c_longlong]
+    lib.srk_chan_stats_blocks.restype = C.c_int
     lib.srk_ca_splits.argtypes = [C.c_int, C.c_int]
     lib.srk_ca_splits.restype = C.c_int
     lib.srk_l1_blocks.argtypes = [C.c_longlong]

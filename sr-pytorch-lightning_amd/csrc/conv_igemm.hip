@@ -1411,7 +1411,8 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
     // 3x3 with ONE 128-byte input block: weights stay in LDS, persistent workgroups (conv_ws_kernel)
     const int rin = a.x_ps > 1 ? a.x_ps : 1;
     const long long xbytes = ((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2;
-    if (a.KH == 3 && xbytes < 0x7fffffffLL && getenv("SRK_NO_WS") == nullptr) {
+    static const bool no_ws = getenv("SRK_NO_WS") != nullptr;      // diagnostics knob, read once
+    if (a.KH == 3 && xbytes < 0x7fffffffLL && !no_ws) {
       if (a.CoutP % 64 == 0 && conv_fast_ok(a, 2)) {
         if (rin == 1 && a.Cin == 64) return launch_ws<DT, 2, 4, true>(a, st);
         if (rin == 1 && a.Cin == 16) return launch_ws<DT, 2, 1, true>(a, st);          // e.g. dgrad of the 3-channel tail conv

@@ -1,0 +1,280 @@
+// Kernels for the remaining conv models of the zoo: SRResNet (models/srresnet.py:9-36 --
+// 9x9 convs, BatchNorm2d and PReLU inside `ResBlock` / `BasicBlock`, models/common.py:33-56,74-109) and DDBPN
+// (models/ddbpn.py:10-137 -- Conv2d / ConvTranspose2d projections of 6x6 / 8x8 / 12x12 with stride 2 / 4 / 8, PReLU).
+//
+//   srk_unfold_nhwc / srk_fold_nhwc   im2col / col2im on NHWC tensors, any kernel size, stride and padding.  A strided
+//       or large-kernel convolution is  unfold -> 1x1 conv on MFMA (srk_conv2d);  a transposed convolution is
+//       1x1 conv -> fold.  Each is the other's adjoint, so the data gradients use the same two kernels, and every FLOP
+//       of these layers runs in the 1x1 implicit-GEMM / slab weight-gradient kernels the other models already use.
+//       16-byte accesses; the fold GATHERS its <= ceil(K/s)^2 contributions per output pixel in fp32 (no atomics).
+//   srk_chan_stats   per-channel partial sums over pixels: {sum x, sum x^2} (BatchNorm statistics), {sum y, sum x*y}
+//       (BatchNorm backward), {sum over x<=0 of x*y} (PReLU slope gradient).  One plain store per block and channel,
+//       partials added by the caller in block order: no atomics, bitwise reproducible.
+//   srk_chan_apply   out = post( (a[c]*x + b[c]*y + d[c]) * gate(z) ): BatchNorm apply (+ residual), BatchNorm backward
+//       (two inputs), PReLU forward (post) and backward (gate).  HBM-bound streaming, 16-byte accesses.
+#include "srk_common.h"
+
+namespace {
+
+constexpr int GEN_NT = 256;
+
+template <int DT> SRK_DEV void chunk_to_f32(i32x4 raw, float* v) {
+  typedef DTraits<DT> Tr;
+  if constexpr (Tr::IS16) {
+    unpack2<DT>((uint32_t)raw.x, v[0], v[1]); unpack2<DT>((uint32_t)raw.y, v[2], v[3]);
+    unpack2<DT>((uint32_t)raw.z, v[4], v[5]); unpack2<DT>((uint32_t)raw.w, v[6], v[7]);
+  } else {
+    v[0] = __int_as_float(raw.x); v[1] = __int_as_float(raw.y); v[2] = __int_as_float(raw.z); v[3] = __int_as_float(raw.w);
+  }
+}
+template <int DT> SRK_DEV i32x4 f32_to_chunk(const float* v) {
+  typedef DTraits<DT> Tr;
+  if constexpr (Tr::IS16) {
+    return i32x4{(int)pack2<DT>(v[0], v[1]), (int)pack2<DT>(v[2], v[3]), (int)pack2<DT>(v[4], v[5]), (int)pack2<DT>(v[6], v[7])};
+  } else {
+    return i32x4{__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
+  }
+}
+
+// cols[n][oy][ox][(kh*K + kw)*C + c] = x[n][oy*s + kh - p][ox*s + kw - p][c]   (0 outside the image)
+template <int DT> __global__ __launch_bounds__(GEN_NT) void unfold_nhwc_kernel(const srk_unfold_nhwc_args a) {
+  typedef DTraits<DT> Tr;
+  typedef typename Tr::elem elem;
+  constexpr int CH = Tr::CH;
+  const int nch = a.C / CH, KK = a.K * a.K;
+  const long long total = (long long)a.N * a.Ho * a.Wo * KK * nch;
+  const elem* x = reinterpret_cast<const elem*>(a.x);
+  elem* cols = reinterpret_cast<elem*>(a.cols);
+  for (long long i = (long long)blockIdx.x * GEN_NT + threadIdx.x; i < total; i += (long long)gridDim.x * GEN_NT) {
+    const int cc = (int)(i % nch);
+    long long q = i / nch;
+    const int tap = (int)(q % KK);
+    q /= KK;
+    const int ox = (int)(q % a.Wo);
+    q /= a.Wo;
+    const int oy = (int)(q % a.Ho);
+    const int n = (int)(q / a.Ho);
+    const int kh = tap / a.K, kw = tap - kh * a.K;
+    const int iy = oy * a.stride + kh - a.pad, ix = ox * a.stride + kw - a.pad;
+    i32x4 v = {0, 0, 0, 0};
+    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+      v = gload16(x + ((size_t)(n * a.H + iy) * a.W + ix) * a.x_pitch + a.x_coff + cc * CH);
+    *reinterpret_cast<i32x4*>(cols + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.cols_pitch + (size_t)tap * a.C + cc * CH) = v;
+  }
+}
+
+// out[n][y][x][c] = bias[c] + sum over taps (kh, kw) with (y + p - kh) % s == 0, (x + p - kw) % s == 0 and the source
+// pixel ((y + p - kh) / s, (x + p - kw) / s) inside the Hi x Wi grid of cols[..][(kh*K + kw)*C + c]
+template <int DT> __global__ __launch_bounds__(GEN_NT) void fold_nhwc_kernel(const srk_fold_nhwc_args a) {
+  typedef DTraits<DT> Tr;
+  typedef typename Tr::elem elem;
+  constexpr int CH = Tr::CH;
+  const int nch = a.C / CH;
+  const long long total = (long long)a.N * a.Ho * a.Wo * nch;
+  const elem* cols = reinterpret_cast<const elem*>(a.cols);
+  elem* out = reinterpret_cast<elem*>(a.out);
+  for (long long i = (long long)blockIdx.x * GEN_NT + threadIdx.x; i < total; i += (long long)gridDim.x * GEN_NT) {
+    const int cc = (int)(i % nch);
+    long long q = i / nch;
+    const int x = (int)(q % a.Wo);
+    q /= a.Wo;
+    const int y = (int)(q % a.Ho);
+    const int n = (int)(q / a.Ho);
+    float acc[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] = a.bias ? a.bias[cc * CH + e] : 0.f;
+    // kh = (y + p) - s*iy  for iy in [ceil((y + p - K + 1)/s), floor((y + p)/s)]
+    const int ty = y + a.pad, tx = x + a.pad;
+    int iy0 = ty - a.K + 1;
+    iy0 = iy0 > 0 ? (iy0 + a.stride - 1) / a.stride : 0;
+    int ix0 = tx - a.K + 1;
+    ix0 = ix0 > 0 ? (ix0 + a.stride - 1) / a.stride : 0;
+    const int iy1 = min(ty / a.stride, a.Hi - 1), ix1 = min(tx / a.stride, a.Wi - 1);
+    for (int iy = iy0; iy <= iy1; ++iy) {
+      const int kh = ty - iy * a.stride;
+      for (int ix = ix0; ix <= ix1; ++ix) {
+        const int kw = tx - ix * a.stride;
+        float v[CH];
+        chunk_to_f32<DT>(gload16(cols + ((size_t)(n * a.Hi + iy) * a.Wi + ix) * a.cols_pitch + (size_t)(kh * a.K + kw) * a.C + cc * CH), v);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[e] += v[e];
+      }
+    }
+    *reinterpret_cast<i32x4*>(out + ((size_t)(n * a.Ho + y) * a.Wo + x) * a.out_pitch + a.out_coff + cc * CH) = f32_to_chunk<DT>(acc);
+  }
+}
+
+// ---- per-channel partial sums ---------------------------------------------------------------------------------------
+// grid = blocks over pixels; thread = (16-byte channel chunk, pixel row); partial[block][2][C]
+template <int DT> __global__ __launch_bounds__(GEN_NT) void chan_stats_kernel(const srk_chan_stats_args a, long long pix_per_block) {
+  typedef DTraits<DT> Tr;
+  typedef typename Tr::elem elem;
+  constexpr int CH = Tr::CH;
+  __shared__ float red[2][GEN_NT * 8];
+  const int tid = threadIdx.x;
+  const int nch = a.C / CH, rows = GEN_NT / nch;
+  const int cc = tid % nch, prow = tid / nch;
+  const long long p0 = (long long)blockIdx.x * pix_per_block, p1 = min(a.P, p0 + pix_per_block);
+  float s0[CH], s1[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) s0[e] = s1[e] = 0.f;
+  if (prow < rows) {
+    const elem* x = reinterpret_cast<const elem*>(a.x) + a.x_coff + cc * CH;
+    const elem* y = a.y ? reinterpret_cast<const elem*>(a.y) + a.y_coff + cc * CH : nullptr;
+    for (long long p = p0 + prow; p < p1; p += rows) {
+      float xv[CH];
+      chunk_to_f32<DT>(gload16(x + (size_t)p * a.x_pitch), xv);
+      if (a.mode == 0) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }
+      } else {
+        float yv[CH];
+        chunk_to_f32<DT>(gload16(y + (size_t)p * a.y_pitch), yv);
+        if (a.mode == 1) {
+#pragma unroll
+          for (int e = 0; e < CH; ++e) { s0[e] += yv[e]; s1[e] += xv[e] * yv[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < CH; ++e) s0[e] += xv[e] <= 0.f ? xv[e] * yv[e] : 0.f;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    red[0][tid * CH + e] = (prow < rows) ? s0[e] : 0.f;
+    red[1][tid * CH + e] = (prow < rows) ? s1[e] : 0.f;
+  }
+  __syncthreads();
+  if (tid < a.C) {
+    const int c_cc = tid / CH, c_e = tid % CH;
+    float t0 = 0.f, t1 = 0.f;
+    for (int r = 0; r < rows; ++r) {
+      t0 += red[0][(r * nch + c_cc) * CH + c_e];
+      t1 += red[1][(r * nch + c_cc) * CH + c_e];
+    }
+    a.partial[((size_t)blockIdx.x * 2 + 0) * a.C + tid] = t0;
+    a.partial[((size_t)blockIdx.x * 2 + 1) * a.C + tid] = t1;
+  }
+}
+
+// ---- per-channel affine of one or two inputs, optional PReLU gate / PReLU output ----------------------------------------
+template <int DT> __global__ __launch_bounds__(GEN_NT) void chan_apply_kernel(const srk_chan_apply_args a) {
+  typedef DTraits<DT> Tr;
+  typedef typename Tr::elem elem;
+  constexpr int CH = Tr::CH;
+  const int nch = a.C / CH;
+  const long long total = a.P * nch;
+  const elem* x = reinterpret_cast<const elem*>(a.x);
+  const elem* y = reinterpret_cast<const elem*>(a.y);
+  const elem* z = reinterpret_cast<const elem*>(a.z);
+  elem* out = reinterpret_cast<elem*>(a.out);
+  for (long long i = (long long)blockIdx.x * GEN_NT + threadIdx.x; i < total; i += (long long)gridDim.x * GEN_NT) {
+    const int cc = (int)(i % nch);
+    const long long p = i / nch;
+    float xv[CH], v[CH];
+    chunk_to_f32<DT>(gload16(x + (size_t)p * a.x_pitch + a.x_coff + cc * CH), xv);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      const int c = cc * CH + e;
+      v[e] = (a.a ? a.a[c] : 1.f) * xv[e] + (a.d ? a.d[c] : 0.f);
+    }
+    if (y) {
+      float yv[CH];
+      chunk_to_f32<DT>(gload16(y + (size_t)p * a.y_pitch + a.y_coff + cc * CH), yv);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] += (a.b ? a.b[cc * CH + e] : 1.f) * yv[e];
+    }
+    if (z) {          // gate: PReLU backward, d/dz prelu(z) = z > 0 ? 1 : slope
+      float zv[CH];
+      chunk_to_f32<DT>(gload16(z + (size_t)p * a.z_pitch + a.z_coff + cc * CH), zv);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] *= zv[e] > 0.f ? 1.f : a.slope[(cc * CH + e) * a.slope_stride];
+    }
+    if (a.post_prelu) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope[(cc * CH + e) * a.slope_stride];
+    }
+    *reinterpret_cast<i32x4*>(out + (size_t)p * a.out_pitch + a.out_coff + cc * CH) = f32_to_chunk<DT>(v);
+  }
+}
+
+inline unsigned grid_for(long long total) {
+  long long b = (total + GEN_NT - 1) / GEN_NT;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+inline int stats_blocks(long long P) {
+  // >= 64 pixels per block, at most 1024 blocks
+  long long b = (P + 63) / 64;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define GEN_DISPATCH(KERNEL, DTYPE, GRID, ST, ...)                                                          \
+  switch (DTYPE) {                                                                                          \
+    case SRK_BF16: hipLaunchKernelGGL(KERNEL<SRK_BF16>, dim3(GRID), dim3(GEN_NT), 0, ST, __VA_ARGS__); break; \
+    case SRK_F16: hipLaunchKernelGGL(KERNEL<SRK_F16>, dim3(GRID), dim3(GEN_NT), 0, ST, __VA_ARGS__); break;   \
+    case SRK_F32: hipLaunchKernelGGL(KERNEL<SRK_F32>, dim3(GRID), dim3(GEN_NT), 0, ST, __VA_ARGS__); break;   \
+    default: srk_set_error("dtype %d", (int)(DTYPE)); return SRK_E_BADARG;                                  \
+  }
+
+extern "C" int srk_unfold_nhwc(const srk_unfold_nhwc_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->cols, "srk_unfold_nhwc: null pointer");
+  const int ch = a->dtype == SRK_F32 ? 4 : 8;
+  SRK_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0 && a->K > 0 && a->stride > 0 && a->pad >= 0, "srk_unfold_nhwc: bad dims");
+  SRK_CHECK_ARG(a->C > 0 && a->C % ch == 0 && a->x_pitch % ch == 0 && a->x_coff % ch == 0 && a->cols_pitch % ch == 0 &&
+                    a->cols_pitch >= a->K * a->K * a->C, "srk_unfold_nhwc: channels / pitches must be 16-byte multiples");
+  SRK_CHECK_ARG(a->Ho == (a->H + 2 * a->pad - a->K) / a->stride + 1 && a->Wo == (a->W + 2 * a->pad - a->K) / a->stride + 1,
+                "srk_unfold_nhwc: Ho x Wo = %d x %d does not match the conv geometry", a->Ho, a->Wo);
+  const long long total = (long long)a->N * a->Ho * a->Wo * a->K * a->K * (a->C / ch);
+  GEN_DISPATCH(unfold_nhwc_kernel, a->dtype, grid_for(total), reinterpret_cast<hipStream_t>(stream), *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_fold_nhwc(const srk_fold_nhwc_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->cols && a->out, "srk_fold_nhwc: null pointer");
+  const int ch = a->dtype == SRK_F32 ? 4 : 8;
+  SRK_CHECK_ARG(a->N > 0 && a->Hi > 0 && a->Wi > 0 && a->K > 0 && a->stride > 0 && a->pad >= 0 && a->Ho > 0 && a->Wo > 0, "srk_fold_nhwc: bad dims");
+  SRK_CHECK_ARG(a->C > 0 && a->C % ch == 0 && a->out_pitch % ch == 0 && a->out_coff % ch == 0 && a->cols_pitch % ch == 0 &&
+                    a->cols_pitch >= a->K * a->K * a->C, "srk_fold_nhwc: channels / pitches must be 16-byte multiples");
+  const long long total = (long long)a->N * a->Ho * a->Wo * (a->C / ch);
+  GEN_DISPATCH(fold_nhwc_kernel, a->dtype, grid_for(total), reinterpret_cast<hipStream_t>(stream), *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_chan_stats_blocks(long long P) { return stats_blocks(P); }
+
+extern "C" int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->partial && (a->mode == 0 || a->y), "srk_chan_stats: null pointer");
+  const int ch = a->dtype == SRK_F32 ? 4 : 8;
+  SRK_CHECK_ARG(a->mode >= 0 && a->mode <= 2, "srk_chan_stats: mode %d", a->mode);
+  SRK_CHECK_ARG(a->C > 0 && a->C <= GEN_NT && a->C % ch == 0 && a->x_pitch % ch == 0 && a->x_coff % ch == 0 &&
+                    (!a->y || (a->y_pitch % ch == 0 && a->y_coff % ch == 0)), "srk_chan_stats: C=%d (multiple of %d, <= %d) / alignment", a->C, ch, GEN_NT);
+  if (a->P <= 0) return 0;
+  const int nb = stats_blocks(a->P);
+  const long long ppb = (a->P + nb - 1) / nb;
+  GEN_DISPATCH(chan_stats_kernel, a->dtype, nb, reinterpret_cast<hipStream_t>(stream), *a, ppb);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_chan_apply(const srk_chan_apply_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->out, "srk_chan_apply: null pointer");
+  const int ch = a->dtype == SRK_F32 ? 4 : 8;
+  SRK_CHECK_ARG(a->C > 0 && a->C % ch == 0 && a->x_pitch % ch == 0 && a->x_coff % ch == 0 && a->out_pitch % ch == 0 && a->out_coff % ch == 0 &&
+                    (!a->y || (a->y_pitch % ch == 0 && a->y_coff % ch == 0)) && (!a->z || (a->z_pitch % ch == 0 && a->z_coff % ch == 0)),
+                "srk_chan_apply: channels / pitches must be 16-byte multiples");
+  SRK_CHECK_ARG((!a->z && !a->post_prelu) || a->slope, "srk_chan_apply: gate / PReLU needs the slope");
+  if (a->P <= 0) return 0;
+  GEN_DISPATCH(chan_apply_kernel, a->dtype, grid_for(a->P * (a->C / ch)), reinterpret_cast<hipStream_t>(stream), *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}

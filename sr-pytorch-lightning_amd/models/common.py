@@ -1,9 +1,11 @@
 """Building blocks with the reference's names, constructor arguments and state_dict layout
 (models/common.py:1-139), computing on the MI355X HIP path.
 
-Inside a model, tensors are NHWC `[N,H,W,C]` in the model's compute dtype (see ops.py); these
-modules therefore take/return NHWC tensors, NOT the reference's NCHW.  The NCHW contract lives
-at `SRModel.forward()`, which converts at the head and tail convs.  Parameter creation order and
+Inside a model, tensors are NHWC `[N,H,W,C]` in the model's compute dtype (see ops.py): the models call the
+blocks' `.nhwc(...)` methods.  `forward(x)` keeps the REFERENCE's contract -- NCHW float in, NCHW float out -- so a user
+subclass of `SRModel` that composes these blocks on NCHW tensors (README.md:97-101 of the reference) works unchanged:
+it converts at the block boundary (two layout kernels) and computes in `self.compute_dtype` (fp32 unless the attribute
+is set on the block).  Parameter creation order and
 initialisation are exactly torch's `nn.Conv2d` (the classes derive from it), so
 `torch.manual_seed(s); Model(...)` reproduces the reference's weights bit for bit.
 """
@@ -15,7 +17,16 @@ from torch import nn
 from .. import ops
 
 
-class DefaultConv2d(nn.Conv2d):
+class _NCHWContract:
+    """forward(x NCHW float) -> NCHW fp32 around the block's NHWC implementation (`nhwc`); `_cout()` = real output channels."""
+
+    def forward(self, x, *args, **kwargs):
+        dt = getattr(self, "compute_dtype", torch.float32)
+        y = self.nhwc(ops.nchw_to_nhwc(x, dt), *args, **kwargs)
+        return ops.nhwc_to_nchw(y, self._cout())
+
+
+class DefaultConv2d(_NCHWContract, nn.Conv2d):
     """Conv2d that keeps H and W ('same' zero padding, stride 1).  Reference: common.py:7-30."""
 
     def __init__(self, kernel_size, padding='same', **kwargs):
@@ -34,8 +45,48 @@ class DefaultConv2d(nn.Conv2d):
                 or self.dilation != (1, 1) or self.groups != 1:
             raise NotImplementedError("the HIP path implements square, stride-1, 'same' convolutions (all the hot path uses)")
 
-    def forward(self, x, res=None, scale=1.0, ps_r=0):
+    def _cout(self):
+        return self.out_channels
+
+    def nhwc(self, x, res=None, scale=1.0, ps_r=0):
         return ops.conv(x, self.weight, self.bias, res=res, scale=scale, ps_r=ps_r)
+
+
+class BasicBlock(_NCHWContract, nn.Sequential):
+    """Conv2d [+ norm] [+ activation].  Reference: common.py:33-56 (SRResNet's head and body tail, srresnet.py:13-21)."""
+
+    def __init__(self, in_channels=64, out_channels=64, kernel_size=3, bias=True, conv=DefaultConv2d, norm=None, act=nn.ReLU(True)):
+        m = [conv(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size, bias=bias)]
+        if norm is not None:
+            m.append(norm)
+        if act is not None:
+            m.append(act)
+        super().__init__(*m)
+
+    def _cout(self):
+        return self[0].out_channels
+
+    def nhwc(self, x, res=None):
+        """x: NHWC features.  `res` is added after the norm (fused into the BatchNorm apply kernel when there is one)."""
+        mods = list(self)
+        conv = mods[0]
+        norm = next((m for m in mods[1:] if isinstance(m, nn.BatchNorm2d)), None)
+        act = next((m for m in mods[1:] if isinstance(m, (nn.PReLU, nn.ReLU))), None)
+        if conv.kernel_size[0] in (1, 3):
+            r = conv.nhwc(x, res=res if (norm is None and act is None) else None)
+        else:
+            r = ops.conv_general(x, conv.weight, conv.bias, stride=1, pad=conv.kernel_size[0] // 2)
+        done_res = norm is None and act is None and conv.kernel_size[0] in (1, 3)
+        if norm is not None:
+            r = ops.batch_norm(r, norm, res=res if act is None else None)
+            done_res = done_res or act is None
+        if isinstance(act, nn.PReLU):
+            r = ops.prelu(r, act.weight)
+        elif act is not None:
+            r = torch.relu(r)
+        if res is not None and not done_res:
+            r = r + res
+        return r
 
 
 class MeanShift(nn.Conv2d):
@@ -62,50 +113,93 @@ class MeanShift(nn.Conv2d):
         return self.bias
 
     def forward(self, x):
-        raise RuntimeError("MeanShift is fused into the head/tail HIP kernels; call shift()")
+        """The reference's op on an NCHW image (3 multiply-adds per pixel; inside the models the shift is fused into the
+        head / tail kernels instead)."""
+        return x + self.shift().view(1, 3, 1, 1).to(x.dtype)
 
 
-class ResBlock(nn.Module):
-    """conv -> ReLU -> conv, * res_scale, += x.  Reference: common.py:74-109 (n_conv_layers convs,
-    activation between them, no norm on the hot path)."""
+class ResBlock(_NCHWContract, nn.Module):
+    """conv [-> norm] -> act -> conv [-> norm], * res_scale, += x.  Reference: common.py:74-109.  The SAME `norm` / `act`
+    module instance is appended after every conv, exactly like the reference (shared BatchNorm parameters and running
+    statistics inside a block: srresnet.py:16-19 passes one nn.BatchNorm2d and one nn.PReLU per block)."""
 
     def __init__(self, conv=DefaultConv2d, n_feats=64, kernel_size=3, n_conv_layers=2, bias=True, norm=None,
                  act=nn.ReLU(True), res_scale=1.):
         super().__init__()
-        if norm is not None or not (act is None or isinstance(act, nn.ReLU)):
-            raise NotImplementedError("the HIP path implements ReLU / no norm (what EDSR uses)")
+        if not (norm is None or isinstance(norm, nn.BatchNorm2d)) or not (act is None or isinstance(act, (nn.ReLU, nn.PReLU))):
+            raise NotImplementedError("the HIP path implements BatchNorm2d / no norm and ReLU / PReLU / no activation")
         m = []
         for i in range(n_conv_layers):
             m.append(conv(in_channels=n_feats, out_channels=n_feats, kernel_size=kernel_size, bias=bias))
+            if norm is not None:
+                m.append(norm)
             if act is not None and i < n_conv_layers - 1:
                 m.append(act)
         self.body = nn.Sequential(*m)
         self.res_scale = res_scale
         self._has_act = act is not None
 
-    def forward(self, x):
-        convs = [m for m in self.body if isinstance(m, nn.Conv2d)]
-        relus = [self._has_act and i < len(convs) - 1 for i in range(len(convs))]
-        return ops.conv_chain(x, [(c.weight, c.bias) for c in convs], relus, scale=self.res_scale)
+    def _cout(self):
+        return self.body[0].out_channels
+
+    def nhwc(self, x):
+        mods = list(self.body)
+        convs = [m for m in mods if isinstance(m, nn.Conv2d)]
+        plain = all(isinstance(m, (nn.Conv2d, nn.ReLU)) for m in mods)
+        if plain:              # EDSR: the fused conv chain (ReLU, * res_scale and += x are conv epilogues)
+            relus = [self._has_act and i < len(convs) - 1 for i in range(len(convs))]
+            return ops.conv_chain(x, [(c.weight, c.bias) for c in convs], relus, scale=self.res_scale)
+        # SRResNet: conv -> BatchNorm -> PReLU -> conv -> BatchNorm (+ x fused into the last BatchNorm apply)
+        r = x
+        fused_res = False
+        for i, m in enumerate(mods):
+            last = i == len(mods) - 1
+            if isinstance(m, nn.Conv2d):
+                r = m.nhwc(r)
+            elif isinstance(m, nn.BatchNorm2d):
+                if last and self.res_scale == 1:
+                    r = ops.batch_norm(r, m, res=x)
+                    fused_res = True
+                else:
+                    r = ops.batch_norm(r, m)
+            elif isinstance(m, nn.PReLU):
+                r = ops.prelu(r, m.weight)
+            else:
+                r = torch.relu(r)
+        if not fused_res:
+            r = r * self.res_scale + x
+        return r
 
 
-class UpscaleBlock(nn.Sequential):
-    """[conv3x3(F -> F r^2), PixelShuffle(r)] x int(log2(s)).  Reference: common.py:112-139.
-    The PixelShuffle modules are kept (index/layout compatibility) but the shuffle is the conv's store."""
+class UpscaleBlock(_NCHWContract, nn.Sequential):
+    """[conv3x3(F -> F r^2), PixelShuffle(r) [, act]] x int(log2(s)).  Reference: common.py:112-139.
+    The PixelShuffle modules are kept (index/layout compatibility) but the shuffle is the conv's store; `act` (SRResNet:
+    one shared nn.PReLU, srresnet.py:26-27) runs as its own HIP kernel behind it."""
 
     def __init__(self, scale_factor=4, n_feats=64, kernel_size=3, act=None):
         assert scale_factor in {2, 3, 4, 8}
-        if act is not None:
-            raise NotImplementedError("UpscaleBlock activation is not used on the hot path")
+        if not (act is None or isinstance(act, (nn.PReLU, nn.ReLU))):
+            raise NotImplementedError("UpscaleBlock activation: PReLU / ReLU / none")
         layers = []
         for _ in range(int(log2(scale_factor))):
             r = 2 if scale_factor % 2 == 0 else 3
             layers += [DefaultConv2d(in_channels=n_feats, out_channels=n_feats * r * r, kernel_size=kernel_size),
                        nn.PixelShuffle(r)]
+            if act is not None:
+                layers.append(act)
         super().__init__(*layers)
 
-    def forward(self, x):
+    def _cout(self):
+        return self[0].in_channels
+
+    def nhwc(self, x):
         mods = list(self)
-        for conv, ps in zip(mods[0::2], mods[1::2]):
-            x = conv(x, ps_r=ps.upscale_factor)
+        i = 0
+        while i < len(mods):
+            conv, ps = mods[i], mods[i + 1]
+            x = conv.nhwc(x, ps_r=ps.upscale_factor)
+            i += 2
+            if i < len(mods) and isinstance(mods[i], (nn.PReLU, nn.ReLU)):
+                x = ops.prelu(x, mods[i].weight) if isinstance(mods[i], nn.PReLU) else torch.relu(x)
+                i += 1
         return x

@@ -1,0 +1,101 @@
+"""D-DBPN on the HIP path.  Reference: models/ddbpn.py:10-137 (same ctor, same state_dict keys).
+
+The up / down projection units use nn.ConvTranspose2d / nn.Conv2d with kernel 6/8/12, stride 2/4/8, padding 2
+(ddbpn.py:10-24).  Here: strided conv = NHWC im2col + 1x1 MFMA conv, transposed conv = 1x1 MFMA conv + col2im gather
+(ops.conv_general / ops.conv_transpose_general), PReLU = srk_chan_apply.  The dense concatenations and the two
+elementwise ops of a projection unit (`b_0.sub(x)`, `a_0.add(a_1)`, ddbpn.py:57-62) stay torch ops on NHWC tensors."""
+from typing import Any
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .common import MeanShift
+from .srmodel import SRModel
+
+
+def projection_conv(in_channels, out_channels, scale, up=True):
+    kernel_size, stride, padding = {2: (6, 2, 2), 4: (8, 4, 2), 8: (12, 8, 2)}[scale]
+    conv_f = nn.ConvTranspose2d if up else nn.Conv2d
+    return conv_f(in_channels, out_channels, kernel_size, stride=stride, padding=padding)
+
+
+def _proj(seq, x):
+    """[projection conv, PReLU] on NHWC x."""
+    c, act = seq[0], seq[1]
+    if isinstance(c, nn.ConvTranspose2d):
+        y = ops.conv_transpose_general(x, c.weight, c.bias, stride=c.stride[0], pad=c.padding[0])
+    else:
+        y = ops.conv_general(x, c.weight, c.bias, stride=c.stride[0], pad=c.padding[0])
+    return ops.prelu(y, act.weight)
+
+
+class DenseProjection(nn.Module):
+    """ddbpn.py:27-64"""
+
+    def __init__(self, in_channels, nr, scale, up=True, bottleneck=True):
+        super().__init__()
+        if bottleneck:
+            self.bottleneck = nn.Sequential(*[nn.Conv2d(in_channels, nr, 1), nn.PReLU(nr)])
+            inter_channels = nr
+        else:
+            self.bottleneck = None
+            inter_channels = in_channels
+        self.conv_1 = nn.Sequential(*[projection_conv(inter_channels, nr, scale, up), nn.PReLU(nr)])
+        self.conv_2 = nn.Sequential(*[projection_conv(nr, inter_channels, scale, not up), nn.PReLU(inter_channels)])
+        self.conv_3 = nn.Sequential(*[projection_conv(inter_channels, nr, scale, up), nn.PReLU(nr)])
+
+    def nhwc(self, x):
+        if self.bottleneck is not None:
+            x = ops.prelu(ops.conv(x, self.bottleneck[0].weight, self.bottleneck[0].bias), self.bottleneck[1].weight)
+        a_0 = _proj(self.conv_1, x)
+        b_0 = _proj(self.conv_2, a_0)
+        e = b_0.sub(x)
+        a_1 = _proj(self.conv_3, e)
+        return a_0.add(a_1)
+
+    def forward(self, x):
+        """NCHW float in / out, like the reference module."""
+        dt = getattr(self, "compute_dtype", torch.float32)
+        return ops.nhwc_to_nchw(self.nhwc(ops.nchw_to_nhwc(x, dt)), self.conv_1[0].out_channels)
+
+
+class DDBPN(SRModel):
+    def __init__(self, **kwargs: dict[str, Any]):
+        super().__init__(**kwargs)
+        n0, nr = 128, 32
+        self.depth = 6
+        if self._channels == 3:
+            self.sub_mean = MeanShift()
+        initial = [nn.Conv2d(self._channels, n0, 3, padding=1), nn.PReLU(n0), nn.Conv2d(n0, nr, 1), nn.PReLU(nr)]
+        self.initial = nn.Sequential(*initial)
+        self.upmodules = nn.ModuleList()
+        self.downmodules = nn.ModuleList()
+        channels = nr
+        for i in range(self.depth):
+            self.upmodules.append(DenseProjection(channels, nr, self._scale_factor, True, i > 1))
+            if i != 0:
+                channels += nr
+        channels = nr
+        for i in range(self.depth - 1):
+            self.downmodules.append(DenseProjection(channels, nr, self._scale_factor, False, i != 0))
+            channels += nr
+        self.reconstruction = nn.Sequential(*[nn.Conv2d(self.depth * nr, self._channels, 3, padding=1)])
+        if self._channels == 3:
+            self.add_mean = MeanShift(sign=1)
+
+    def forward(self, x):
+        """ddbpn.py:112-137.  NCHW float in [0,1] -> NCHW fp32."""
+        with ops.forward_scope(self._pack_group()):
+            rgb = self._channels == 3
+            i0, a0, i2, a2 = self.initial
+            x = ops.prelu(ops.head_conv(x, i0.weight, i0.bias, -self.sub_mean.shift() if rgb else None, self.compute_dtype), a0.weight)
+            x = ops.prelu(ops.conv(x, i2.weight, i2.bias), a2.weight)
+            h_list, l_list = [], []
+            for i in range(self.depth - 1):
+                l = x if i == 0 else torch.cat(l_list, dim=3)
+                h_list.append(self.upmodules[i].nhwc(l))
+                l_list.append(self.downmodules[i].nhwc(torch.cat(h_list, dim=3)))
+            h_list.append(self.upmodules[-1].nhwc(torch.cat(l_list, dim=3)))
+            rec = self.reconstruction[0]
+            return ops.tail_conv(torch.cat(h_list, dim=3), rec.weight, rec.bias, post_add=self.add_mean.shift() if rgb else None)

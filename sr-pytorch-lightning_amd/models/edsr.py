@@ -32,8 +32,8 @@ class EDSR(SRModel):
                               self.compute_dtype)
             r = f
             for blk in list(self.body)[:-1]:
-                r = blk(r)
-            r = self.body[-1](r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
-            r = self.tail[0](r)                              # upsampler, PixelShuffle fused into the conv store
+                r = blk.nhwc(r)
+            r = self.body[-1].nhwc(r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
+            r = self.tail[0].nhwc(r)                              # upsampler, PixelShuffle fused into the conv store
             t = self.tail[1]
             return ops.tail_conv(r, t.weight, t.bias, post_add=self.add_mean.shift() if rgb else None)

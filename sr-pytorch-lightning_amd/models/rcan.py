@@ -4,7 +4,7 @@ from typing import Any
 import torch.nn as nn
 
 from .. import ops
-from .common import DefaultConv2d, MeanShift, UpscaleBlock
+from .common import DefaultConv2d, MeanShift, UpscaleBlock, _NCHWContract
 from .srmodel import SRModel
 
 
@@ -21,7 +21,7 @@ class CALayer(nn.Module):
             nn.Sigmoid())
 
 
-class RCAB(nn.Module):
+class RCAB(_NCHWContract, nn.Module):
     """conv -> ReLU -> conv -> CA, += x; `res_scale` is stored but NOT applied (rcan.py:33-55)."""
 
     def __init__(self, conv, n_feat, kernel_size, reduction, bias=True, bn=False, act=nn.ReLU(True), res_scale=1):
@@ -37,13 +37,16 @@ class RCAB(nn.Module):
         self.body = nn.Sequential(*modules_body)
         self.res_scale = res_scale
 
-    def forward(self, x):
+    def _cout(self):
+        return self.body[0].out_channels
+
+    def nhwc(self, x):
         c1, c2, ca = self.body[0], self.body[2], self.body[3]
         return ops.rcab(x, c1.weight, c1.bias, c2.weight, c2.bias,
                         ca.conv_du[0].weight, ca.conv_du[0].bias, ca.conv_du[2].weight, ca.conv_du[2].bias)
 
 
-class ResidualGroup(nn.Module):
+class ResidualGroup(_NCHWContract, nn.Module):
     """n x RCAB, conv, += x (rcan.py:59-74)."""
 
     def __init__(self, conv, n_feat, kernel_size, reduction, act, res_scale, n_resblocks):
@@ -53,11 +56,14 @@ class ResidualGroup(nn.Module):
         modules_body.append(conv(in_channels=n_feat, out_channels=n_feat, kernel_size=kernel_size))
         self.body = nn.Sequential(*modules_body)
 
-    def forward(self, x):
+    def _cout(self):
+        return self.body[-1].out_channels
+
+    def nhwc(self, x):
         r = x
         for blk in list(self.body)[:-1]:
-            r = blk(r)
-        return self.body[-1](r, res=x)
+            r = blk.nhwc(r)
+        return self.body[-1].nhwc(r, res=x)
 
 
 class RCAN(SRModel):
@@ -87,8 +93,8 @@ class RCAN(SRModel):
                               self.compute_dtype)
             r = f
             for grp in list(self.body)[:-1]:
-                r = grp(r)
-            r = self.body[-1](r, res=f)
-            r = self.tail[0](r)
+                r = grp.nhwc(r)
+            r = self.body[-1].nhwc(r, res=f)
+            r = self.tail[0].nhwc(r)
             t = self.tail[1]
             return ops.tail_conv(r, t.weight, t.bias, post_add=self.add_mean.shift() if rgb else None)

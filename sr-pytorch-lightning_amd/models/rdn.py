@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .common import _NCHWContract
 from .srmodel import SRModel
 
 
@@ -17,7 +18,7 @@ class _RDB_Conv(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(inChannels, growRate, kSize, padding=(kSize - 1) // 2, stride=1), nn.ReLU())
 
 
-class _RDB(nn.Module):
+class _RDB(_NCHWContract, nn.Module):
     """rdn.py:24-40"""
 
     def __init__(self, growRate0, growRate, nConvLayers, kSize=3):
@@ -26,7 +27,10 @@ class _RDB(nn.Module):
         self.convs = nn.Sequential(*[_RDB_Conv(G0 + c * G, G) for c in range(C)])
         self.LFF = nn.Conv2d(G0 + C * G, G0, 1, padding=0, stride=1)
 
-    def forward(self, x):
+    def _cout(self):
+        return self.LFF.out_channels
+
+    def nhwc(self, x):
         return ops.rdb(x, [(m.conv[0].weight, m.conv[0].bias) for m in self.convs], (self.LFF.weight, self.LFF.bias))
 
 
@@ -63,7 +67,7 @@ class RDN(SRModel):
             x = ops.conv(f1, self.SFENet2.weight, self.SFENet2.bias)
             outs = []
             for blk in self._RDBs:
-                x = blk(x)
+                x = blk.nhwc(x)
                 outs.append(x)
             x = ops.conv(torch.cat(outs, dim=3), self.GFF[0].weight, self.GFF[0].bias)    # 1x1 over D*G0 channels
             x = ops.conv(x, self.GFF[1].weight, self.GFF[1].bias, res=f1)                  # `x += f__1`

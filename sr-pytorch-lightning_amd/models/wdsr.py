@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .common import _NCHWContract
 from .srmodel import SRModel
 
 
@@ -14,7 +15,7 @@ def _wn_weight(m):
     return torch._weight_norm(m.weight_v, m.weight_g, 0)
 
 
-class _Block_A(nn.Module):
+class _Block_A(_NCHWContract, nn.Module):
     """3x3 (F -> 4F) -> ReLU -> 3x3 (4F -> F), * res_scale, += x (wdsr.py:9-27)."""
 
     def __init__(self, n_feats, kernel_size, wn, act=nn.ReLU(True), res_scale=1):
@@ -24,12 +25,15 @@ class _Block_A(nn.Module):
         self.body = nn.Sequential(wn(nn.Conv2d(n_feats, block_feats, kernel_size, padding=kernel_size // 2)), act,
                                   wn(nn.Conv2d(block_feats, n_feats, kernel_size, padding=kernel_size // 2)))
 
-    def forward(self, x):
+    def _cout(self):
+        return self.body[0].in_channels
+
+    def nhwc(self, x):
         c1, c2 = self.body[0], self.body[2]
         return ops.conv_chain(x, [(_wn_weight(c1), c1.bias), (_wn_weight(c2), c2.bias)], [True, False], scale=self.res_scale)
 
 
-class _Block_B(nn.Module):
+class _Block_B(_NCHWContract, nn.Module):
     """1x1 (F -> 6F) -> ReLU -> 1x1 (6F -> int(.8F)) -> 3x3 (-> F), * res_scale, += x (wdsr.py:30-51)."""
 
     def __init__(self, n_feats, kernel_size, wn, act=nn.ReLU(True), res_scale=1):
@@ -40,7 +44,10 @@ class _Block_B(nn.Module):
                                   wn(nn.Conv2d(n_feats * expand, int(n_feats * linear), 1, padding=1 // 2)),
                                   wn(nn.Conv2d(int(n_feats * linear), n_feats, kernel_size, padding=kernel_size // 2)))
 
-    def forward(self, x):
+    def _cout(self):
+        return self.body[0].in_channels
+
+    def nhwc(self, x):
         c1, c2, c3 = self.body[0], self.body[2], self.body[3]
         return ops.conv_chain(x, [(_wn_weight(c1), c1.bias), (_wn_weight(c2), c2.bias), (_wn_weight(c3), c3.bias)],
                               [True, False, False], scale=self.res_scale)
@@ -79,5 +86,5 @@ class WDSR(SRModel):
             s = ops.skip_conv(x, _wn_weight(self.skip[0]), self.skip[0].bias, mean, r, self.compute_dtype)
             f = ops.head_conv(x, _wn_weight(self.head[0]), self.head[0].bias, mean, self.compute_dtype)
             for blk in self.body:
-                f = blk(f)
+                f = blk.nhwc(f)
             return ops.tail_conv(f, _wn_weight(self.tail[0]), self.tail[0].bias, res=s, post_add=mean, ps_r=r)

@@ -538,6 +538,40 @@ def to_nchw(src, C=None):
     return dst
 
 
+class ToNhwcFn(torch.autograd.Function):
+    """NCHW float -> NHWC `dtype`, channels padded to 16 (the inverse of ToNchwFn; backward is the other kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.c = x.shape[1]
+        return to_nhwc(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_nchw(g.contiguous(), ctx.c), None
+
+
+class ToNchwFn(torch.autograd.Function):
+    """NHWC (padded channels) -> NCHW fp32, first C channels."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        ctx.dt = x.dtype
+        return to_nchw(x, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_nhwc(g, ctx.dt), None
+
+
+def nchw_to_nhwc(x, dtype):
+    return ToNhwcFn.apply(x, dtype)
+
+
+def nhwc_to_nchw(x, C):
+    return ToNchwFn.apply(x, int(C))
+
+
 def _f32c(t):
     t = t.detach()
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
@@ -951,6 +985,228 @@ def rdb(x, convs, lff):
     for w, b in convs:
         flat += [w, b]
     return RDBFn.apply(x, *flat, lff[0], lff[1])
+
+
+# --------------------------------------------------------------------------------------------
+# remaining conv models: strided / transposed / large-kernel convs, BatchNorm, PReLU
+# --------------------------------------------------------------------------------------------
+def _unfold_raw(x, k, stride, pad):
+    n, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    cols = torch.empty((n, ho, wo, k * k * c), dtype=x.dtype, device=x.device)
+    L.call("srk_unfold_nhwc", L.UnfoldNhwcArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, cols=cols.data_ptr(), cols_pitch=k * k * c,
+                                               N=n, H=h, W=w, C=c, K=k, stride=stride, pad=pad, Ho=ho, Wo=wo, dtype=_DT[x.dtype]), _stream())
+    return cols
+
+
+def _fold_raw(cols, c, k, stride, pad, ho, wo, bias=None):
+    n, hi, wi, kkc = cols.shape
+    assert kkc == k * k * c
+    out = torch.empty((n, ho, wo, c), dtype=cols.dtype, device=cols.device)
+    L.call("srk_fold_nhwc", L.FoldNhwcArgs(cols=cols.data_ptr(), cols_pitch=_pitch(cols), bias=_ptr(bias), out=out.data_ptr(), out_pitch=c, out_coff=0,
+                                           N=n, Hi=hi, Wi=wi, C=c, K=k, stride=stride, pad=pad, Ho=ho, Wo=wo, dtype=_DT[cols.dtype]), _stream())
+    return out
+
+
+class UnfoldFn(torch.autograd.Function):
+    """im2col on an NHWC tensor (srk_unfold_nhwc); backward = col2im (srk_fold_nhwc), its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        _need_gpu(x)
+        ctx.cfg = (tuple(x.shape), k, stride, pad)
+        return _unfold_raw(x.contiguous(), k, stride, pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        (n, h, w, c), k, stride, pad = ctx.cfg
+        return _fold_raw(g.contiguous(), c, k, stride, pad, h, w), None, None, None
+
+
+class FoldFn(torch.autograd.Function):
+    """col2im (srk_fold_nhwc) + per-channel bias; backward = im2col of the gradient, bias gradient = its pixel sum."""
+
+    @staticmethod
+    def forward(ctx, cols, bias, c, k, stride, pad, ho, wo):
+        _need_gpu(cols)
+        b32 = None
+        if bias is not None:
+            b32 = _f32c(bias)
+            if b32.numel() != c:
+                b32 = torch.nn.functional.pad(b32, (0, c - b32.numel()))
+        ctx.cfg = (k, stride, pad, None if bias is None else bias.numel())
+        return _fold_raw(cols.contiguous(), c, k, stride, pad, ho, wo, b32)
+
+    @staticmethod
+    def backward(ctx, g):
+        k, stride, pad, nb = ctx.cfg
+        g = g.contiguous()
+        gb = None
+        if nb is not None and ctx.needs_input_grad[1]:
+            gb = chan_sums(g)[0][:nb]
+        return _unfold_raw(g, k, stride, pad), gb, None, None, None, None, None, None
+
+
+def chan_sums(x, y=None, mode=None):
+    """Per-channel sums over all pixels of NHWC `x`: (sum x, sum x^2); with y: mode 1 (sum y, sum x*y) or 2 (sum over x <= 0
+    of x*y, 0).  srk_chan_stats partials added in block order (fp32, reproducible)."""
+    _need_gpu(x)
+    c = x.shape[-1]
+    P = x.numel() // c
+    mode = (0 if y is None else 1) if mode is None else mode
+    if P == 0:
+        z = torch.zeros(c, dtype=torch.float32, device=x.device)
+        return z, z.clone()
+    nb = L.load().srk_chan_stats_blocks(P)
+    part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
+    L.call("srk_chan_stats", L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
+                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype]), _stream())
+    tot = part.sum(0)
+    return tot[0], tot[1]
+
+
+def _pitch4(t):
+    return _pitch(t) if t.dim() == 4 else t.shape[-1]
+
+
+def chan_apply(x, *, y=None, z=None, a=None, b=None, d=None, slope=None, post_prelu=False):
+    """out = post((a*x + b*y + d) * gate(z)) per channel (srk_chan_apply).  a/b/d/slope: fp32 [C] (slope may have 1 element)."""
+    _need_gpu(x)
+    c = x.shape[-1]
+    P = x.numel() // c
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if P == 0:
+        return out
+    sl = None if slope is None else _f32c(slope)
+
+    def vec(v):
+        if v is None:
+            return None
+        v = _f32c(v)
+        return v if v.numel() == c else torch.nn.functional.pad(v, (0, c - v.numel()))
+    a, b, d = vec(a), vec(b), vec(d)
+    if sl is not None and sl.numel() not in (1, c):
+        sl = torch.nn.functional.pad(sl, (0, c - sl.numel()))
+    L.call("srk_chan_apply", L.ChanApplyArgs(
+        x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
+        z=_ptr(z), z_pitch=0 if z is None else _pitch4(z), z_coff=0, a=_ptr(a), b=_ptr(b), d=_ptr(d),
+        slope=_ptr(sl), slope_stride=0 if (sl is None or sl.numel() == 1) else 1, post_prelu=int(post_prelu),
+        out=out.data_ptr(), out_pitch=c, out_coff=0, P=P, C=c, dtype=_DT[x.dtype]), _stream())
+    return out
+
+
+class PReLUFn(torch.autograd.Function):
+    """nn.PReLU (one shared slope or one per channel) on an NHWC tensor: srk_chan_apply forward, gate + slope-gradient
+    reduction backward (models/srresnet.py:14,20,27; models/ddbpn.py:33,42-53,82-86)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        return chan_apply(x, slope=weight, post_prelu=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = chan_apply(g, z=x, slope=weight) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            s = chan_sums(x, g, mode=2)[0]
+            gw = s.sum().view(1) if weight.numel() == 1 else s[:weight.numel()]
+        return gx, gw
+
+
+def prelu(x, weight):
+    return PReLUFn.apply(x, weight)
+
+
+class BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm2d on an NHWC tensor, training (batch statistics, running buffers updated like torch) or eval mode,
+    optionally fused with a residual add: out = gamma*(x - mean)*invstd + beta (+ res).
+    Reference: the `norm` of `ResBlock` / `BasicBlock` (models/common.py:33-56,97-98) in SRResNet (srresnet.py:16-21).
+    Statistics: srk_chan_stats (fp32 sums); apply and backward: srk_chan_apply; [C]-sized vector math stays in torch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, res):
+        x = x.contiguous()
+        c = weight.numel()
+        cp = x.shape[-1]
+        M = x.numel() // cp
+        if training:
+            s1, s2 = chan_sums(x)
+            mean = s1 / M
+            var = (s2 / M - mean * mean).clamp_min(0.0)
+            if running_mean is not None:
+                with torch.no_grad():
+                    running_mean.mul_(1 - momentum).add_(mean[:c], alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(var[:c] * (M / max(M - 1, 1)), alpha=momentum)
+        else:
+            mean = torch.nn.functional.pad(running_mean.float(), (0, cp - c))
+            var = torch.nn.functional.pad(running_var.float(), (0, cp - c), value=1.0)
+        invstd = torch.rsqrt(var + eps)
+        gamma = torch.nn.functional.pad(weight.detach().float(), (0, cp - c))
+        beta = torch.nn.functional.pad(bias.detach().float(), (0, cp - c))
+        a = gamma * invstd
+        out = chan_apply(x, y=res, a=a, d=beta - mean * a)
+        ctx.save_for_backward(x, mean, invstd, gamma)
+        ctx.cfg = (training, c, M, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, invstd, gamma = ctx.saved_tensors
+        training, c, M, has_res = ctx.cfg
+        g = g.contiguous()
+        sg, sxg = chan_sums(x, g)                       # sum dy, sum x*dy
+        dbeta = sg
+        dgamma = invstd * (sxg - mean * sg)             # sum dy * xhat
+        if training:
+            # dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M),  xhat = (x - mean)*invstd
+            k = gamma * invstd
+            bx = -k * invstd * dgamma / M
+            gx = chan_apply(g, y=x, a=k, b=bx, d=-k * dbeta / M - bx * mean)
+        else:
+            gx = chan_apply(g, a=gamma * invstd)
+        return gx, dgamma[:c], dbeta[:c], None, None, None, None, None, (g if has_res else None)
+
+
+def batch_norm(x, bn, res=None):
+    """`bn`: an nn.BatchNorm2d (parameters, running buffers, training flag, momentum, eps) applied to NHWC `x`."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    use_batch = bn.training or bn.running_mean is None
+    return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, res)
+
+
+def conv_general(x, w, b, *, stride=1, pad=0):
+    """nn.Conv2d with any square kernel / stride / zero padding on NHWC `x`: im2col (srk_unfold_nhwc) + the 1x1 MFMA conv
+    with the OIHW weight presented as a [Cout][K*K*Cin] matrix in (kh, kw, ci) order.  The permute / reshape of the
+    parameter is a view-level torch op, so its gradient flows back to the OIHW parameter through autograd."""
+    cout, cin, k, _ = w.shape
+    cp = x.shape[-1]
+    if cp != cin:                                   # zero-padded storage channels: pad the weight's input channels too
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cp - cin))
+    wm = w.permute(0, 2, 3, 1).reshape(cout, k * k * cp, 1, 1)
+    cols = UnfoldFn.apply(x, k, stride, pad)
+    return conv(cols, wm, b)
+
+
+def conv_transpose_general(x, w, b, *, stride=1, pad=0):
+    """nn.ConvTranspose2d (weight [Cin][Cout][K][K]) on NHWC `x`: 1x1 MFMA conv to K*K*Cout channels + col2im gather
+    (srk_fold_nhwc) with the bias added once per output element."""
+    cin, cout, k, _ = w.shape
+    n, h, wd, cp = x.shape
+    coutp = pad16(cout)
+    if cp != cin:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cp - cin))
+    if coutp != cout:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, coutp - cout))
+    wm = w.permute(2, 3, 1, 0).reshape(k * k * coutp, cp, 1, 1)
+    cols = conv(x, wm, None)
+    ho, wo = (h - 1) * stride - 2 * pad + k, (wd - 1) * stride - 2 * pad + k
+    return FoldFn.apply(cols, b, coutp, k, stride, pad, ho, wo)
 
 
 # --------------------------------------------------------------------------------------------

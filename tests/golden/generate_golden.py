@@ -132,8 +132,9 @@ def grad_summary(t):
     return [float(t.sum()), float(t.abs().sum()), float((t * t).sum())]
 
 
-def run_case(model, x, with_grads=True, full_grads=False):
-    """y = model(x); L = sum(y * t) with a formula target t -> grads."""
+def run_case(model, x, with_grads=True, full_grads=False, with_eval=False):
+    """y = model(x); L = sum(y * t) with a formula target t -> grads.  with_eval (models with BatchNorm): also the
+    eval-mode output AFTER this one training-mode forward (running statistics updated once) and the buffers."""
     model.zero_grad()
     x = x.clone().requires_grad_(True)
     y = model(x)
@@ -152,6 +153,14 @@ def run_case(model, x, with_grads=True, full_grads=False):
                 out["g:" + name] = p.grad.numpy()
         out["grad_names"] = np.array(names)
         out["grad_sums"] = np.array(sums, dtype=np.float64)
+    if with_eval:
+        model.eval()
+        with torch.no_grad():
+            out["y_eval"] = model(x.detach()).numpy()
+        model.train()
+        bnames = [n for n, _ in model.named_buffers()]
+        out["buffer_names"] = np.array(bnames)
+        out["buffer_sums"] = np.array([grad_summary(b.double()) for _, b in model.named_buffers()], dtype=np.float64)
     return out
 
 
@@ -167,6 +176,12 @@ def main():
     from models import common, rcan, rdn, wdsr  # reference modules
 
     manifest = {}
+    # GOLDEN_ONLY=<substring>[,<substring>...]: regenerate only the model cases whose name contains one of them and merge
+    # their entries into the existing manifest (blocks / trajectories are left alone)
+    only = [t for t in os.environ.get("GOLDEN_ONLY", "").split(",") if t]
+    if only:
+        with open(os.path.join(OUT, "manifest.json")) as f:
+            manifest = json.load(f)
 
     # ---- (1) blocks at true width, small spatial extent -------------------
     print("blocks:")
@@ -185,7 +200,7 @@ def main():
         "block_wdsr_a128": (wdsr._Block_A(128, 3, wn=nn.utils.weight_norm, res_scale=1), (1, 128, 8, 8)),
         "block_wdsr_b128": (wdsr._Block_B(128, 3, wn=nn.utils.weight_norm, res_scale=1), (1, 128, 8, 8)),
     }
-    for name, (mod, shp) in blocks.items():
+    for name, (mod, shp) in ([] if only else blocks.items()):
         formula_fill(mod)
         # feature maps: centred values, like post-conv activations
         x = formula_tensor(shp, 1000, 1.0)
@@ -193,9 +208,10 @@ def main():
     ms = common.MeanShift()
     ma = common.MeanShift(sign=1)
     x = formula_input((2, 3, 6, 6))
-    save("block_meanshift", x=x.numpy(), y_sub=ms(x).detach().numpy(), y_add=ma(x).detach().numpy(),
-         sub_weight=ms.weight.detach().numpy(), sub_bias=ms.bias.detach().numpy(),
-         add_weight=ma.weight.detach().numpy(), add_bias=ma.bias.detach().numpy())
+    if not only:
+        save("block_meanshift", x=x.numpy(), y_sub=ms(x).detach().numpy(), y_add=ma(x).detach().numpy(),
+           sub_weight=ms.weight.detach().numpy(), sub_bias=ms.bias.detach().numpy(),
+           add_weight=ma.weight.detach().numpy(), add_bias=ma.bias.detach().numpy())
 
     # ---- (2) full models: reduced and full-size, formula-filled -----------
     print("models:")
@@ -225,8 +241,19 @@ def main():
         "wdsr_a_full_x4": ("WDSR", dict(type="A", scale_factor=4), (1, 3, 8, 8)),
         "rdn_b_full_x4": ("RDN", dict(rdn_config="B", scale_factor=4), (1, 3, 8, 8)),
         "rdn_a_full_x4": ("RDN", dict(rdn_config="A", scale_factor=4), (1, 3, 8, 8)),
+        # SRResNet (BatchNorm + PReLU, 9x9 convs; training-mode forward/backward + eval-mode output)
+        # and D-DBPN (strided / transposed projection convs).  DDBPN has no width/depth ctor arguments.
+        "srresnet_f16_b2_x4": ("SRResNet", dict(n_feats=16, n_resblocks=2, scale_factor=4), (2, 3, 8, 8)),
+        "srresnet_f16_b2_x2": ("SRResNet", dict(n_feats=16, n_resblocks=2, scale_factor=2), (1, 3, 9, 7)),
+        "srresnet_f16_b2_x3": ("SRResNet", dict(n_feats=16, n_resblocks=2, scale_factor=3), (2, 3, 6, 6)),
+        "srresnet_full_x4": ("SRResNet", dict(scale_factor=4), (2, 3, 12, 12)),
+        "ddbpn_x2": ("DDBPN", dict(scale_factor=2), (1, 3, 6, 7)),
+        "ddbpn_x4": ("DDBPN", dict(scale_factor=4), (1, 3, 6, 6)),
+        "ddbpn_x8": ("DDBPN", dict(scale_factor=8), (1, 3, 4, 4)),
     }
     for name, (cls, kw, shp) in cases.items():
+        if only and not any(t in name for t in only):
+            continue
         torch.manual_seed(0)
         m = getattr(models, cls)(**kw)
         # init checksums BEFORE the formula fill: pins torch-default init under seed 0
@@ -242,11 +269,11 @@ def main():
         formula_fill(m)
         x = formula_input(shp)
         small = manifest[name]["n_params_trainable"] < 60000
-        save("model_" + name, **run_case(m, x, with_grads=True, full_grads=small))
+        save("model_" + name, **run_case(m, x, with_grads=True, full_grads=small, with_eval=bool(list(m.named_buffers()))))
 
     # ---- (3) three-step training trajectories via the reference's own hooks
     print("trajectories:")
-    for tag, losses, opt in (("l1_adam", "l1", "ADAM"), ("l2_sgd", "0.5*l2 + 0.5*l1", "SGD")):
+    for tag, losses, opt in ([] if only else (("l1_adam", "l1", "ADAM"), ("l2_sgd", "0.5*l2 + 0.5*l1", "SGD"))):
         m = models.EDSR(n_feats=16, n_resblocks=2, res_scale=0.1, scale_factor=4, losses=losses,
                         optimizer=opt, optimizer_params=["lr=1e-2"] if opt == "SGD" else ["lr=1e-4"])
         formula_fill(m)

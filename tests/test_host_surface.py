@@ -35,16 +35,17 @@ def test_library_exports_every_declared_symbol():
 
 
 def _header_struct_fields(name):
-    body = re.search(r"typedef struct \{([^{}]*)\}\s*" + name + r"\s*;", HEADER).group(1)
-    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    header = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)          # comments first: some contain braces
+    body = re.search(r"typedef struct(?:\s+\w+)?\s*\{([^{}]*)\}\s*" + name + r"\s*;", header).group(1)
     fields = []
     for stmt in body.split(";"):
         stmt = stmt.strip()
         if not stmt:
             continue
         # "const void* x" / "int x_pitch, x_coff" / "float scale"
-        m = re.match(r"(const\s+)?(void|float|int)\s*(\*?)\s*(.*)", stmt)
+        m = re.match(r"(const\s+)?(void|float|int|double|long long|signed char|uint8_t|srk_patch_desc)\s*(\*?)\s*(.*)", stmt)
         base, ptr, rest = m.group(2), m.group(3), m.group(4)
+        base = {"long long": "q"}.get(base, base)
         for nm in rest.split(","):
             nm = nm.strip()
             is_ptr = bool(ptr) or nm.startswith("*")
@@ -56,11 +57,14 @@ def _header_struct_fields(name):
                                         ("srk_wgrad_fin_args", "WgradFinArgs"), ("srk_unfold_args", "UnfoldArgs"),
                                         ("srk_to_nhwc_args", "ToNhwcArgs"), ("srk_to_nchw_args", "ToNchwArgs"),
                                         ("srk_ca_pool_args", "CaPoolArgs"), ("srk_ca_apply_args", "CaApplyArgs"),
-                                        ("srk_ca_bwd_args", "CaBwdArgs")])
+                                        ("srk_ca_bwd_args", "CaBwdArgs"), ("srk_patch_desc", "PatchDesc"), ("srk_patch_args", "PatchArgs"),
+                                        ("srk_sse_args", "SseArgs"), ("srk_ssim_args", "SsimArgs"), ("srk_l1_args", "L1Args"),
+                                        ("srk_unfold_nhwc_args", "UnfoldNhwcArgs"), ("srk_fold_nhwc_args", "FoldNhwcArgs"),
+                                        ("srk_chan_stats_args", "ChanStatsArgs"), ("srk_chan_apply_args", "ChanApplyArgs")])
 def test_ctypes_structs_mirror_header(cname, cls):
     want = _header_struct_fields(cname)
     st = getattr(sr_amd._lib, cls)
-    kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_float: "f"}
+    kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_float: "f", ctypes.c_longlong: "q"}
     got = [(n, kind[t]) for n, t in st._fields_]
     assert got == want
 
@@ -79,11 +83,12 @@ def test_state_dict_layout_and_init_match_reference(name):
         t = sd[k].double()
         got = [float(t.sum()), float(t.abs().sum())] + [float(v) for v in sd[k].flatten()[:3]]
         np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7, err_msg=k)
-    assert not list(m.named_buffers())          # like the reference
+    if ent["class"] != "SRResNet":              # BatchNorm running statistics are the only buffers in the zoo
+        assert not list(m.named_buffers())      # like the reference
 
 
 def test_ctor_defaults_and_registry():
-    assert sr_amd.models.__all__ == ['EDSR', 'RCAN', 'RDN', 'SRCNN', 'SRModel', 'WDSR']
+    assert sr_amd.models.__all__ == ['DDBPN', 'EDSR', 'RCAN', 'RDN', 'SRCNN', 'SRModel', 'SRResNet', 'WDSR']
     m = sr_amd.EDSR()
     assert (m._batch_size, m._channels, m._scale_factor) == (16, 3, 4)
     assert tuple(m.example_input_array.shape) == (16, 3, 32, 32)     # patch_size 128 // scale 4

@@ -77,6 +77,13 @@ def test_model_forward_backward(name):
         assert abs(got[0] - s[0]) <= rt * max(s[1], 1e-12), n
         if "g:" + n in g:
             _close(sd[n].grad.numpy(), g["g:" + n], 1e-4)
+    if "y_eval" in g:          # BatchNorm models: eval-mode output after the ONE training-mode forward above, and the buffers
+        with torch.no_grad():
+            ye = OF.forward(ent["class"], sd, torch.from_numpy(g["x"]), training=False, **ent["kwargs"])
+        _close(ye.numpy(), g["y_eval"])
+        for n, s3 in zip([str(v) for v in g["buffer_names"]], g["buffer_sums"]):
+            b = sd[n].double().flatten()
+            np.testing.assert_allclose([float(b.sum()), float(b.abs().sum()), float((b * b).sum())], s3, rtol=1e-5, atol=1e-9, err_msg=n)
 
 
 BLOCKS = {
