@@ -338,7 +338,8 @@ int srk_fold_nhwc(const srk_fold_nhwc_args* a, srk_stream_t stream);
 
 /* Per-channel partial sums over P pixels of an NHWC tensor (fp32 accumulate), one plain store per block and channel:
  * partial[b][0][c], partial[b][1][c] for b < srk_chan_stats_blocks(P); the caller adds the blocks in order.
- *   mode 0: sum x, sum x^2          nn.BatchNorm2d batch statistics (srresnet.py:16-21 via common.py:97-98)
+ *   mode 0: sum x, sum x^2          nn.BatchNorm2d batch statistics (srresnet.py:16-21 via common.py:97-98): one pass for
+ *                                   the mean, a second pass with shift = mean for the variance
  *   mode 1: sum y, sum x*y          BatchNorm backward (y = upstream gradient)
  *   mode 2: sum over x <= 0 of x*y  nn.PReLU slope gradient (partial[b][1] = 0)                                   */
 typedef struct {
@@ -348,6 +349,8 @@ typedef struct {
   int mode;
   float* partial;                         /* [blocks][2][C]                                                         */
   int dtype;
+  const float* shift;                     /* [C] or NULL: x is replaced by x - shift[c] in every sum (second pass of a  */
+                                          /* two-pass variance, centred BatchNorm backward: no cancellation in fp32)   */
 } srk_chan_stats_args;
 int srk_chan_stats_blocks(long long P);
 int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream);

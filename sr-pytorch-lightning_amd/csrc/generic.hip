@@ -115,15 +115,20 @@ template <int DT> __global__ __launch_bounds__(GEN_NT) void chan_stats_kernel(co
   const int nch = a.C / CH, rows = GEN_NT / nch;
   const int cc = tid % nch, prow = tid / nch;
   const long long p0 = (long long)blockIdx.x * pix_per_block, p1 = min(a.P, p0 + pix_per_block);
-  float s0[CH], s1[CH];
+  float s0[CH], s1[CH], sh[CH];
 #pragma unroll
-  for (int e = 0; e < CH; ++e) s0[e] = s1[e] = 0.f;
+  for (int e = 0; e < CH; ++e) {
+    s0[e] = s1[e] = 0.f;
+    sh[e] = (a.shift && prow < rows) ? a.shift[cc * CH + e] : 0.f;      // x is centred first: sums of (x - shift[c])
+  }
   if (prow < rows) {
     const elem* x = reinterpret_cast<const elem*>(a.x) + a.x_coff + cc * CH;
     const elem* y = a.y ? reinterpret_cast<const elem*>(a.y) + a.y_coff + cc * CH : nullptr;
     for (long long p = p0 + prow; p < p1; p += rows) {
       float xv[CH];
       chunk_to_f32<DT>(gload16(x + (size_t)p * a.x_pitch), xv);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) xv[e] -= sh[e];
       if (a.mode == 0) {
 #pragma unroll
         for (int e = 0; e < CH; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }

@@ -1047,9 +1047,10 @@ class FoldFn(torch.autograd.Function):
         return _unfold_raw(g, k, stride, pad), gb, None, None, None, None, None, None
 
 
-def chan_sums(x, y=None, mode=None):
+def chan_sums(x, y=None, mode=None, shift=None):
     """Per-channel sums over all pixels of NHWC `x`: (sum x, sum x^2); with y: mode 1 (sum y, sum x*y) or 2 (sum over x <= 0
-    of x*y, 0).  srk_chan_stats partials added in block order (fp32, reproducible)."""
+    of x*y, 0).  `shift` [C] fp32: x is centred (x - shift[c]) first.  srk_chan_stats partials added in block order
+    (fp32, reproducible)."""
     _need_gpu(x)
     c = x.shape[-1]
     P = x.numel() // c
@@ -1060,7 +1061,7 @@ def chan_sums(x, y=None, mode=None):
     nb = L.load().srk_chan_stats_blocks(P)
     part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
     L.call("srk_chan_stats", L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype]), _stream())
+                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift)), _stream())
     tot = part.sum(0)
     return tot[0], tot[1]
 
@@ -1134,9 +1135,11 @@ class BatchNormFn(torch.autograd.Function):
         cp = x.shape[-1]
         M = x.numel() // cp
         if training:
-            s1, s2 = chan_sums(x)
-            mean = s1 / M
-            var = (s2 / M - mean * mean).clamp_min(0.0)
+            # two-pass statistics: the mean, then the sums of the CENTRED values (E[x^2] - mean^2 cancels in fp32 when
+            # |mean| >> std, which formula-filled / badly scaled nets do have)
+            mean = (chan_sums(x)[0] / M).contiguous()
+            c1, c2 = chan_sums(x, shift=mean)
+            var = (c2 / M - (c1 / M) ** 2).clamp_min(0.0)
             if running_mean is not None:
                 with torch.no_grad():
                     running_mean.mul_(1 - momentum).add_(mean[:c], alpha=momentum)
@@ -1158,9 +1161,9 @@ class BatchNormFn(torch.autograd.Function):
         x, mean, invstd, gamma = ctx.saved_tensors
         training, c, M, has_res = ctx.cfg
         g = g.contiguous()
-        sg, sxg = chan_sums(x, g)                       # sum dy, sum x*dy
+        sg, sxg = chan_sums(x, g, shift=mean.contiguous())   # sum dy, sum (x - mean)*dy
         dbeta = sg
-        dgamma = invstd * (sxg - mean * sg)             # sum dy * xhat
+        dgamma = invstd * sxg                           # sum dy * xhat
         if training:
             # dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M),  xhat = (x - mean)*invstd
             k = gamma * invstd
