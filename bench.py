@@ -38,6 +38,9 @@ MODELS = {
     "rcan": ("RCAN", dict(n_feats=64, reduction=16, n_resgroups=10, n_resblocks=20), 73.350, 64),
     "wdsr_b": ("WDSR", dict(type="B"), 21.974, 128),
     "rdn_b": ("RDN", dict(rdn_config="B"), 104.737, 64),
+    # SURVEY.md 8(f) rank 4 (conv FLOPs counted on the reference's module graph, ConvTranspose2d included)
+    "srresnet": ("SRResNet", dict(), 10.221, 64),
+    "ddbpn": ("DDBPN", dict(), 11.506, 64),
 }
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # dense MFMA, MI355X_MICROARCH.md
 PREC = {"bf16": "bf16", "f16": 16, "f32": 32}

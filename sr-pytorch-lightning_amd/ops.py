@@ -419,10 +419,12 @@ def flush_wgrads():
             table = torch.empty(total, dtype=torch.uint8, device=dev)
             L.check(lib.srk_upload_small(table.data_ptr(), base, total, st), "srk_upload_small")
             L.check(lib.srk_conv2d_wgrad_group(table.data_ptr(), table.data_ptr() + off_bj, nblocks.value, dt, st), "srk_conv2d_wgrad_group")
+            # workgroups per job: one per (2 input channels x 64 output channels) tile of the largest job, 32..256
+            tiles = max(((a_.Cin + 1) // 2) * ((a_.Cout + 63) // 64) for a_ in arr)
+            bpj = max(_WG_BLOCKS_PER_JOB, min(256, tiles))
             for r in sorted(rounds):
                 pos, cnt = rounds[r]
-                L.check(lib.srk_wgrad_finalize_group(table.data_ptr() + off_fin + pos * fin_sz, cnt, _WG_BLOCKS_PER_JOB, st),
-                        "srk_wgrad_finalize_group")
+                L.check(lib.srk_wgrad_finalize_group(table.data_ptr() + off_fin + pos * fin_sz, cnt, bpj, st), "srk_wgrad_finalize_group")
         # a gradient autograd COPIED instead of adopting (create_graph, layout contract) holds the bytes of the then
         # unfilled buffer: refresh it from the filled one.  ('new' jobs only: .grad was None, so the copy is all it holds)
         with torch.no_grad():
