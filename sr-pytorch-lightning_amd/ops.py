@@ -331,6 +331,9 @@ class _WgradQueue:
 
 _WQ = _WgradQueue()
 _WG_BLOCKS_PER_JOB = 32
+import os as _os
+if _os.environ.get("SRK_NO_DEFER_WGRAD") == "1":      # A/B knob (tools/): every weight gradient as its own launch, like round 1
+    _WQ.enabled = False
 
 
 class hold_wgrads:
