@@ -107,6 +107,35 @@ int srk_conv2d(const srk_conv_args* a, srk_stream_t stream);
 /* channel tile (32/64/128) the launcher uses for a given number of output channels */
 int srk_conv_tile(int Cout);
 
+/* ---- two chained 3x3 64->64 convolutions in one launch (small batches) ---------------------------
+ * Replaces, at the reference's batch of 16 where a layer is one tile per CU and launches dominate, the conv pair of
+ * ResBlock (models/common.py:74-109: conv, ReLU, conv, `* res_scale`, `res += x`) and of RCAB (models/rcan.py:33-55),
+ * and -- given data-gradient packs -- the backward chain of either:
+ *     mid = conv3x3(x, w1) + b1;  if relu_mid: mid = max(mid,0);  mid *= scale_mid;
+ *     if mask: mid = (mask > 0) ? mid : 0;            (mid is rounded to the storage dtype, as the two-launch form does)
+ *     out = (conv3x3(mid, w2) + b2) * scale_out + res
+ * Zero padding of both convs refers to the image, exactly as two srk_conv2d calls.  All tensors NHWC with 64 channels at
+ * (pitch, coff); w1 / w2 are srk_pack_conv_weights outputs for Cin = Cout = 64, b1 / b2 the packed (MFMA-row order)
+ * biases or NULL.  `mid` (nullable) receives the intermediate (training keeps it for the backward pass).
+ * res_from_x = 1 says res IS x (same pointer, pitch, offset): the residual is then taken from the input tile in LDS.
+ * Results are bit-identical to the two-launch form.  bf16 / fp16 only.                                              */
+typedef struct {
+  const void* x; int x_pitch, x_coff;
+  int N, H, W;
+  const void* w1; const float* b1;
+  const void* w2; const float* b2;
+  int relu_mid; float scale_mid;
+  const void* mask; int mask_pitch, mask_coff;
+  void* mid; int mid_pitch, mid_coff;
+  float scale_out;
+  const void* res; int res_pitch, res_coff; int res_from_x;
+  void* out; int out_pitch, out_coff;
+  int dtype;
+} srk_conv_pair_args;
+int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream);
+/* workgroups (14x14 output tiles) such a launch has: the host uses the pair while this is about two per CU or less */
+int srk_conv_pair_tiles(int N, int H, int W);
+
 /* ---- weight / bias gradient -------------------------------------------------------------------
  * Replaces autograd's conv weight-gradient for the convs above:
  *     dwp[tap][ci][co] += sum_{n,y,x} x[n][y+kh-ph][x+kw-pw][ci] * dy[n][y][x][co]   (fp32 atomics)

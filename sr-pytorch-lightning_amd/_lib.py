@@ -34,6 +34,17 @@ class ConvArgs(C.Structure):
                 ("post_add", _p), ("dtype", _i)]
 
 
+class ConvPairArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("N", _i), ("H", _i), ("W", _i),
+                ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p),
+                ("relu_mid", _i), ("scale_mid", _f),
+                ("mask", _p), ("mask_pitch", _i), ("mask_coff", _i),
+                ("mid", _p), ("mid_pitch", _i), ("mid_coff", _i),
+                ("scale_out", _f),
+                ("res", _p), ("res_pitch", _i), ("res_coff", _i), ("res_from_x", _i),
+                ("out", _p), ("out_pitch", _i), ("out_coff", _i), ("dtype", _i)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("x_ps", _i),
                 ("dy", _p), ("dy_pitch", _i), ("dy_coff", _i), ("dy_ps", _i),
@@ -130,6 +141,7 @@ class ChanApplyArgs(C.Structure):
 LAUNCHERS = {
     "srk_pack_conv_weights": PackArgs,
     "srk_conv2d": ConvArgs,
+    "srk_conv_pair": ConvPairArgs,
     "srk_conv2d_wgrad": WgradArgs,
     "srk_wgrad_finalize": WgradFinArgs,
     "srk_unfold_nchw": UnfoldArgs,
@@ -150,7 +162,8 @@ LAUNCHERS = {
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
-                 "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks")
+                 "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
+                 "srk_conv_pair_tiles")
 
 _lib = None
 
@@ -171,6 +184,8 @@ def load():
         fn.restype = C.c_int
     lib.srk_conv_tile.argtypes = [C.c_int]
     lib.srk_conv_tile.restype = C.c_int
+    lib.srk_conv_pair_tiles.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.srk_conv_pair_tiles.restype = C.c_int
     lib.srk_wgrad_slabs.argtypes = [C.POINTER(WgradArgs)]
     lib.srk_wgrad_slabs.restype = C.c_int
     lib.srk_pack_conv_weights_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

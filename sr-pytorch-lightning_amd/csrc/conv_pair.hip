@@ -1,0 +1,453 @@
+// Two chained 3x3 64->64 convolutions in ONE launch, for the small-batch regime (the reference's batch of 16).
+//
+//     mid = epi_mid( conv3x3(x, W1) + b1 )          epi_mid: ReLU | ReLU-backward mask, * scale_mid
+//     out = conv3x3(mid, W2) + b2, * scale_out, + res
+//
+// i.e. a whole ResBlock (models/common.py:74-109: conv -> ReLU -> conv, * res_scale, += x), the conv pair of an RCAB
+// (models/rcan.py:33-55) and, with data-gradient weights, the backward chain of either (dgrad of conv 2 with the ReLU
+// mask, dgrad of conv 1, + upstream gradient).
+//
+// Why: at 16 patches of 48x48 a 64->64 layer is 144 tiles of 16x16 -- one per workgroup of the weight-stationary kernel,
+// on 144 of 256 CUs -- and a launch spends 7.2k cycles before its first MFMA (per-lane set-up, 115 KB of LDS-DMA issue), 5.5k
+// in MFMAs, 2.4k in the epilogue, 1.2k leaving and 3.8k between launches: 8.1 us in the kernel for 2.6 us of matrix work
+// (DESIGN.md section 7).  The chain of 70 such launches is 54 % of an EDSR-baseline training step at that batch.
+// Here one workgroup owns a 14x14 OUTPUT tile and recomputes the intermediate on the 16x16 pixels around it (= exactly 8
+// MFMA pixel blocks; 31 % more conv-1 work) from an 18x18 input tile, so nothing is exchanged between workgroups: one
+// launch, one prologue and one drain per PAIR of layers, the second layer's weights arrive while the first computes, the
+// intermediate never leaves LDS on its way to conv 2 and the residual comes from the input tile already in LDS.
+// 48x48 x 16 images = 256 tiles = every CU.
+//
+// LDS (152,064 B): input tile 18x18x128 B (swizzled image format of srk_common.h), intermediate 16 rows x pitch 18,
+// and a 3-slot ring of weight slabs of 3 taps each (24 KB: six slabs a0 a1 a2 b0 b1 b2 stream through it by LDS-DMA, two
+// slabs ahead of the MFMAs).  8 waves: wave w owns pixel block w (2 tile rows x 16 columns = 32 pixels) x all 64
+// channels (2 accumulator tiles): per K-step 2 weight fragments + 1 pixel fragment -> 2 MFMAs.
+#include "srk_common.h"
+
+// diagnostics build only (make stamp, tools/stamp_pair.py): s_memtime stamps of workgroup 0 through `b2` (conv 2 then runs
+// without bias)
+#ifndef SRK_PAIR_STAMPS
+#define SRK_PAIR_STAMPS 0
+#endif
+
+namespace {
+
+struct PairCfg {
+  static constexpr int NT = 512;
+  static constexpr int TO = 14;                        // output tile edge
+  static constexpr int XT = 18, XP = 18;               // input tile edge / row pitch (pixels)
+  static constexpr int MT = 16, MP = 18;               // intermediate tile edge / row pitch
+  static constexpr int XS_BYTES = XT * XP * 128;       // 41,472
+  static constexpr int MS_BYTES = MT * MP * 128;       // 36,864
+  static constexpr int WG_BYTES = 3 * 8 * 64 * 16;     // one slab = 3 taps: 24,576
+  static constexpr int LDS_BYTES = XS_BYTES + MS_BYTES + 3 * WG_BYTES;
+  static constexpr int XPIECES = XT * XT * 8;          // 2,592
+  static constexpr int XK = (XPIECES + NT - 1) / NT;   // 6 pieces per lane
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+SRK_DEV __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int DT>
+__global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args a, int tilesX, int tilesY, unsigned x_bytes) {
+  typedef DTraits<DT> Tr;
+  typedef typename Tr::elem elem;
+  typedef PairCfg C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;
+  char* const Ms = smem + C::XS_BYTES;
+  char* const Wr = smem + C::XS_BYTES + C::MS_BYTES;      // ring of 3 slabs
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W;
+#if SRK_PAIR_STAMPS
+  unsigned long long* const stamp = (blockIdx.x == 0 && (tid & 255) == 0) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.b2)) + (wave >> 2) * 16 : nullptr;
+#define SRK_PSTAMP(i) do { if (stamp) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  const float* const bias2 = nullptr;
+#else
+#define SRK_PSTAMP(i) do { } while (0)
+  const float* const bias2 = a.b2;
+#endif
+  SRK_PSTAMP(0);
+
+  int pt = blockIdx.x;
+  const int tX = pt % tilesX;
+  pt /= tilesX;
+  const int tY = pt % tilesY;
+  const int n = pt / tilesY;
+  const int y0 = tY * C::TO, x0 = tX * C::TO;            // output tile origin; intermediate origin (y0-1, x0-1); input (y0-2, x0-2)
+
+  const elem* const xg = reinterpret_cast<const elem*>(a.x);
+  const i32x4 xrsrc = make_rsrc4(xg, x_bytes);
+  const i32x4 w1rsrc = make_rsrc4(a.w1, 9 * 8 * 64 * 16), w2rsrc = make_rsrc4(a.w2, 9 * 8 * 64 * 16);
+  const unsigned xs_lds = lds_addr_of(Xs), wr_lds = lds_addr_of(Wr);
+
+  // ---- prologue: input tile + slabs a0 a1 a2 ---------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < C::XK; ++k) {
+    const int i = tid + k * C::NT;
+    if (k * C::NT + wave * 64 < C::XPIECES) {             // wave-uniform
+      const int sl = i & 7, p = i >> 3;
+      const int iy = p / C::XT, ix = p - iy * C::XT;
+      const int c = sl ^ swz(ix);
+      const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * Tr::CH) * (int)sizeof(elem)) : 0x80000000u;
+      // the last 1 KB piece is half tile: its upper lanes are switched off (EXEC), they would land on the intermediate tile
+      if (i < C::XPIECES)
+        dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + ((k * C::NT + wave * 64) << 4))));
+    }
+  }
+  // slab g (0..5): taps 3*(g%3)..+2 of conv (g/3); 24 pieces of 1 KB, 3 per wave; a straight copy of the packed layout
+  auto dma_slab = [&](int g) {
+    const i32x4 rs = g < 3 ? w1rsrc : w2rsrc;
+    const int gg = g < 3 ? g : g - 3;
+    const unsigned dst = wr_lds + (unsigned)((g % 3) * C::WG_BYTES);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int piece = wave * 3 + k;
+      dma16_hidden(rs, (unsigned)(gg * C::WG_BYTES + piece * 1024 + lane * 16),
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));
+    }
+  };
+  SRK_PSTAMP(1);
+  dma_slab(0);
+  dma_slab(1);
+  dma_slab(2);
+  SRK_PSTAMP(2);
+
+  // ---- per-lane constants -----------------------------------------------------------------------------------------------
+  // Waves 0..3 compute (one per SIMD), each a 64-channel x 64-pixel tile = pixel blocks 2w, 2w+1 (tile rows 4w .. 4w+3):
+  // 2 weight + 2 pixel fragments per K-step feed 4 MFMAs, the 1:1 read:MFMA ratio at which the CU's 128 B/clk of LDS
+  // keeps up (32-pixel wave tiles on all 8 waves need 1.5 reads per MFMA and ran LDS-bound).  Waves 4..7 only issue DMA.
+  const bool cw = wave < 4;
+  const int px = r & 15;
+  int gsw[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) gsw[kw] = swz(px + kw);
+  const char* const wlane = Wr + ((h * 64 + r) << 4);
+  int prow[2];
+  const char* xl[2];
+  const char* ml[2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    prow[pb] = 4 * (wave & 3) + 2 * pb + (r >> 4);
+    xl[pb] = Xs + ((prow[pb] * C::XP + px) << 7);
+    ml[pb] = Ms + ((prow[pb] * C::MP + px) << 7);
+  }
+
+  f32x16 acc[2][2];                                       // [channel block][pixel block]
+  auto init_acc = [&](const float* bias) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          acc[cb][pb][4 * i + 0] = b.x; acc[cb][pb][4 * i + 1] = b.y; acc[cb][pb][4 * i + 2] = b.z; acc[cb][pb][4 * i + 3] = b.w;
+        }
+      }
+  };
+  // One conv = 36 K-steps (slab = kernel row kh = s / 12, tap column kw, K-step ks), 4 MFMAs each; the fragments of
+  // step s+2 are read during step s, one ds_read_b128 per MFMA gap (a burst of four per gap oversubscribes the LDS
+  // array while the four waves run in step).  `at_step(s)` runs the slab hand-over (barriers, waits, DMA) between steps.
+  auto conv_loop = [&](int g0, const char* const (&pix)[2], int pitch, auto&& at_step) {
+    i32x4 fa[3][2], fb[3][2];
+    auto frag1 = [&](int s, int q, i32x4 (&af)[2], i32x4 (&bf)[2]) {
+      const int kh = s / 12, kw = (s % 12) / 4, ks = s % 4;
+      if (q < 2) af[q] = lds_read16(wlane + ((g0 + kh) % 3) * C::WG_BYTES + (((kw * 8 + 2 * ks) * 64 + q * 32) << 4));
+      else bf[q - 2] = lds_read16(pix[q - 2] + ((kh * pitch + kw) << 7) + (((2 * ks + h) ^ gsw[kw]) << 4));
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) frag1(0, q, fa[0], fb[0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) frag1(1, q, fa[1], fb[1]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+      at_step(s);
+      const int c0 = s % 3, c2 = (s + 2) % 3;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (s + 2 < 36) frag1(s + 2, m, fa[c2], fb[c2]);
+        const int cb = m >> 1, pb = m & 1;
+        acc[cb][pb] = Tr::mma(fa[c0][cb], fb[c0][pb], acc[cb][pb]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // every LDS read of this wave has returned, then the workgroup barrier: the ring slot / tile behind it may be rewritten
+  auto drain_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  init_acc(a.b1);
+  int mpix[2];
+  bool m_in[2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const int my = y0 - 1 + prow[pb], mx = x0 - 1 + px;   // this lane's intermediate pixels in the image
+    m_in[pb] = (unsigned)my < (unsigned)H && (unsigned)mx < (unsigned)W;
+    mpix[pb] = (n * H + my) * W + mx;
+  }
+  // ReLU-backward mask: its 16x16 tile goes by LDS-DMA to WHERE THE INTERMEDIATE WILL BE WRITTEN -- each lane reads its own
+  // mask chunks right before it overwrites them.  (Per-lane 16-byte loads of one pixel each occupy the address path for
+  // ~64 cycles apiece: eight of them cost more than the tile transfer.)  32 pieces of 8 pixels, 4 per wave.
+  const unsigned ms_lds = lds_addr_of(Ms);
+  auto dma_mask = [&]() {
+    if (a.mask) {
+      const i32x4 mrsrc = make_rsrc4(a.mask, 0x7fffffffu);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int blk = wave + 8 * k;
+        const int iy = blk >> 1, ix = (blk & 1) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz(ix);
+        const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.mask_pitch + a.mask_coff + c * Tr::CH) * 2) : 0x80000000u;
+        dma16_hidden(mrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(ms_lds + ((iy * C::MP + (blk & 1) * 8) << 7))));
+      }
+    }
+  };
+  // Only the input tile and kernel row 0 of conv 1 (66 of the 115 KB) are waited for here; rows 1 and 2 (slabs a1, a2: the
+  // 6 youngest transfers of every wave) land under the first MFMAs.
+  SRK_PSTAMP(3);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  SRK_PSTAMP(4);
+  __builtin_amdgcn_s_barrier();
+  SRK_PSTAMP(5);
+
+  // ---- conv 1 on the 16x16 intermediate pixels ------------------------------------------------------------------------------
+  // Hand-over at K-step 10 / 22 (fragments are read two steps ahead, so the reads of kernel row 0 / 1 have all been issued
+  // and, after the drain, returned): kernel row 1 / 2 has landed (own pieces by the counted wait, the others' by the
+  // barrier) and ring slot 0 / 1 is free for conv 2's slab b0 / b1.  The mask tile is requested at the first hand-over,
+  // ahead of b0, so that the second one's count covers it.
+  auto hand1 = [&]() { asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); dma_mask(); dma_slab(3); };
+  auto hand2 = [&]() { asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); dma_slab(4); };
+  if (cw) {
+    conv_loop(0, xl, C::XP, [&](int s) {
+      if (s == 10) hand1();
+      if (s == 22) hand2();
+    });
+  } else {
+    hand1();
+    hand2();
+  }
+
+  SRK_PSTAMP(6);
+  // intermediate epilogue: [ReLU | mask], * scale_mid, zero outside the image (conv 2 pads the IMAGE with zeros), into the
+  // LDS tile in the image format (this lane: 32 contiguous channels 32h .. 32h+31 of its pixel = chunks 4h .. 4h+3)
+  if (cw) {
+    const float sm = a.scale_mid;
+    const f32x2 sm2 = {sm, sm};
+    const int g = swz(px);
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      char* const mp = const_cast<char*>(ml[pb]);
+      uint32_t P[16];
+      if (a.relu_mid && sm == 1.f) {                       // forward: ReLU on the packed pairs (the form srk_conv2d uses)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int d = 0; d < 8; ++d) P[8 * cb + d] = relu_pk16(pack2<DT>(acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]));
+      } else {
+        f32x2 v[16];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int d = 0; d < 8; ++d) v[8 * cb + d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]};
+        if (a.relu_mid) {
+#pragma unroll
+          for (int d = 0; d < 16; ++d) v[d] = f32x2{fmaxf(v[d].x, 0.f), fmaxf(v[d].y, 0.f)};
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) v[d] = v[d] * sm2;
+        if (a.mask) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const i32x4 m = lds_read16(mp + (((4 * h + j) ^ g) << 4));
+            const int mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float q0, q1;
+              unpack2<DT>((uint32_t)mw[e], q0, q1);
+              v[4 * j + e] = f32x2{q0 > 0.f ? v[4 * j + e].x : 0.f, q1 > 0.f ? v[4 * j + e].y : 0.f};
+            }
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) P[d] = pack2<DT>(v[d].x, v[d].y);
+      }
+      if (!m_in[pb]) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) P[d] = 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        lds_write16(mp + (((4 * h + j) ^ g) << 4), i32x4{(int)P[4 * j], (int)P[4 * j + 1], (int)P[4 * j + 2], (int)P[4 * j + 3]});
+    }
+  }
+  SRK_PSTAMP(7);
+  drain_barrier();                                        // intermediate tile written; input tile and ring slot 2 are free
+  SRK_PSTAMP(8);
+  dma_slab(5);
+  // a residual that is not the input: its tile replaces the input tile (28 pieces of 8 pixels: rows 2..15, columns 2..17)
+  const unsigned xs_res = a.res && !a.res_from_x;
+  if (xs_res) {
+    const i32x4 rrsrc = make_rsrc4(a.res, 0x7fffffffu);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int blk = wave + 8 * k;                        // 28..31: rows 16, 17 of the tile, never read
+      const int iy = 2 + (blk >> 1), ix = 2 + (blk & 1) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz(ix);
+      const int gy = y0 + iy - 2, gx = x0 + ix - 2;
+      const bool ok = blk < 28 && gy < H && gx < W;
+      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.res_pitch + a.res_coff + c * Tr::CH) * 2) : 0x80000000u;
+      dma16_hidden(rrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + ((iy * C::XP + 2 + (blk & 1) * 8) << 7))));
+    }
+  }
+  // slab b0 (ring slot 0) was requested two slabs ago: at most slab b2's three pieces (and nothing older than slab b1's) may
+  // still be in flight.  The counts below assume no residual transfer; with it they are merely stricter.
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- conv 2 on the 14x14 output tile: rows 0..13 x 16 column slots (14 used).  Wave 3's second pixel block is rows
+  // 14, 15: computed (it reads past the intermediate tile into the weight ring, inside the allocation) and dropped. ----------
+  SRK_PSTAMP(9);
+  init_acc(bias2);
+  // slab b1 is needed from step 10 on (fragments are read two steps ahead), b2 from step 22: this wave's pieces by the
+  // counted wait, every other wave's by the barrier
+  if (cw) {
+    conv_loop(3, ml, C::MP, [&](int s) {
+      if (s == 10) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+      if (s == 22) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    });
+  } else {
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+    // the idle waves copy this workgroup's 14x14 of the intermediate to HBM while conv 2 runs: whole 128-byte pixels,
+    // 8 lanes each, neighbouring pixels of a row contiguous
+    if (a.mid) {
+      const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.mid);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int i = (tid - 256) + 256 * k;
+        const int p = i >> 3, c = i & 7;
+        const int row = p / C::TO, col = p - row * C::TO;
+        const int gy = y0 + row, gx = x0 + col;
+        const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
+        const i32x4 q = lds_read16(Ms + (((row + 1) * C::MP + col + 1) << 7) + ((c ^ swz(col + 1)) << 4));
+        const unsigned vo = ok ? (unsigned)((((n * H + gy) * W + gx) * a.mid_pitch + a.mid_coff + c * Tr::CH) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
+      }
+    }
+  }
+
+  SRK_PSTAMP(10);
+  // ---- output epilogue: * scale_out, + residual (in the input tile's place either way), the result written back over the
+  // residual it used; then all eight waves copy the 14x14 tile to HBM in whole pixels -------------------------------------
+  if (cw) {
+    const float so = a.scale_out;
+    const f32x2 so2 = {so, so};
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      f32x2 v[16];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) v[8 * cb + d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]} * so2;
+      char* const xr = Xs + (((prow[pb] + 2) * C::XP + px + 2) << 7);
+      const int g = swz(px + 2);
+      if (a.res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const i32x4 q = lds_read16(xr + (((4 * h + j) ^ g) << 4));
+          const int qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float f0, f1;
+            unpack2<DT>((uint32_t)qw[e], f0, f1);
+            v[4 * j + e] = v[4 * j + e] + f32x2{f0, f1};
+          }
+        }
+      }
+      if (prow[pb] < C::TO && px < C::TO) {                // rows 14, 15 / columns 14, 15 are not part of the tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          lds_write16(xr + (((4 * h + j) ^ g) << 4),
+                      i32x4{(int)pack2<DT>(v[4 * j].x, v[4 * j].y), (int)pack2<DT>(v[4 * j + 1].x, v[4 * j + 1].y),
+                            (int)pack2<DT>(v[4 * j + 2].x, v[4 * j + 2].y), (int)pack2<DT>(v[4 * j + 3].x, v[4 * j + 3].y)});
+      }
+    }
+  }
+  drain_barrier();
+  {
+    const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.out);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + C::NT * k;
+      const int p = i >> 3, c = i & 7;
+      const int row = p / C::TO, col = p - row * C::TO;
+      const int gy = y0 + row, gx = x0 + col;
+      const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
+      const i32x4 q = lds_read16(Xs + (((row + 2) * C::XP + col + 2) << 7) + ((c ^ swz(col + 2)) << 4));
+      const unsigned vo = ok ? (unsigned)((((n * H + gy) * W + gx) * a.out_pitch + a.out_coff + c * Tr::CH) * 2) : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
+    }
+  }
+#if SRK_PAIR_STAMPS
+  SRK_PSTAMP(11);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SRK_PSTAMP(12);
+#endif
+}
+
+}  // namespace
+
+extern "C" int srk_conv_pair_tiles(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  const long long t = (long long)N * ((H + PairCfg::TO - 1) / PairCfg::TO) * ((W + PairCfg::TO - 1) / PairCfg::TO);
+  return t > 0x7fffffffLL ? 0x7fffffff : (int)t;
+}
+
+extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->w1 && a->w2 && a->out, "srk_conv_pair: null pointer");
+  SRK_CHECK_ARG(a->dtype == SRK_BF16 || a->dtype == SRK_F16, "srk_conv_pair: 16-bit dtypes only");
+  SRK_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0, "srk_conv_pair: bad dims N=%d H=%d W=%d", a->N, a->H, a->W);
+  SRK_CHECK_ARG(a->x_pitch % 8 == 0 && a->x_coff % 8 == 0 && a->out_pitch % 8 == 0 && a->out_coff % 8 == 0, "srk_conv_pair: 16-byte alignment of x / out");
+  SRK_CHECK_ARG(!a->mid || (a->mid_pitch % 8 == 0 && a->mid_coff % 8 == 0), "srk_conv_pair: alignment of mid");
+  SRK_CHECK_ARG(!a->mask || (a->mask_pitch % 8 == 0 && a->mask_coff % 8 == 0), "srk_conv_pair: alignment of mask");
+  SRK_CHECK_ARG(!a->res || (a->res_pitch % 8 == 0 && a->res_coff % 8 == 0), "srk_conv_pair: alignment of res");
+  SRK_CHECK_ARG(!(a->relu_mid && a->mask), "srk_conv_pair: relu_mid and mask are exclusive");
+  SRK_CHECK_ARG(!a->res_from_x || (a->res == a->x && a->res_pitch == a->x_pitch && a->res_coff == a->x_coff),
+                "srk_conv_pair: res_from_x needs res to BE x");
+  const long long px = (long long)a->N * a->H * a->W;
+  long long mx = px * a->x_pitch;
+  if (px * a->out_pitch > mx) mx = px * a->out_pitch;
+  if (a->mid && px * a->mid_pitch > mx) mx = px * a->mid_pitch;
+  if (a->mask && px * a->mask_pitch > mx) mx = px * a->mask_pitch;
+  if (a->res && px * a->res_pitch > mx) mx = px * a->res_pitch;
+  SRK_CHECK_ARG(mx * 2 < 0x7fff0000LL, "srk_conv_pair: tensors of 2 GiB and more are not supported (small-batch kernel)");
+  typedef PairCfg C;
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<SRK_BF16>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<SRK_F16>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  if (attr0 != hipSuccess || attr1 != hipSuccess) {
+    srk_set_error("srk_conv_pair: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+    return (int)(attr0 != hipSuccess ? attr0 : attr1);
+  }
+  const int tilesX = (a->W + C::TO - 1) / C::TO, tilesY = (a->H + C::TO - 1) / C::TO;
+  const long long nb = (long long)a->N * tilesX * tilesY;
+  SRK_CHECK_ARG(nb <= 0x7fffffffLL, "srk_conv_pair: %lld tiles", nb);
+  const unsigned xb = (unsigned)(px * a->x_pitch * 2);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == SRK_BF16) hipLaunchKernelGGL((conv_pair_kernel<SRK_BF16>), dim3((unsigned)nb), dim3(C::NT), C::LDS_BYTES, st, *a, tilesX, tilesY, xb);
+  else hipLaunchKernelGGL((conv_pair_kernel<SRK_F16>), dim3((unsigned)nb), dim3(C::NT), C::LDS_BYTES, st, *a, tilesX, tilesY, xb);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}

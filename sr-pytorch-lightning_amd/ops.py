@@ -11,6 +11,8 @@ cached per parameter version.
 Nothing here falls back to PyTorch arithmetic: every op raises if the tensors are
 not on a GPU or the HIP library is missing.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -267,6 +269,44 @@ def conv_raw(x, pk, *, N, H, W, Cin, Cout, out, out_mode=L.OUT_NHWC, ps_r=0, rel
         out=out.data_ptr(), out_pitch=0 if planar else _pitch(out), out_coff=0, out_mode=out_mode, ps_r=int(ps_r),
         post_add=_ptr(post_add), dtype=_DT[dt])
     L.call("srk_conv2d", a, _stream())
+    return out
+
+
+_PAIR_OFF = os.environ.get("SRK_NO_PAIR", "0") == "1"
+_PAIR_MAX_TILES = int(os.environ.get("SRK_PAIR_MAX_TILES", "0"))
+
+
+def pair_ok(x, w1, w2):
+    """Whether two chained 3x3 64->64 convs on `x` (NHWC) run as ONE srk_conv_pair launch: 16-bit storage, 64 channels and
+    so few tiles (about two 14x14 output tiles per CU or less: the reference's 16 patches of 48x48 are 256) that launches,
+    not MFMAs, set the time.  Larger batches keep the weight-stationary kernel, whose prologue amortises over many tiles."""
+    if _PAIR_OFF or x.dtype not in (torch.bfloat16, torch.float16) or x.shape[3] != 64:
+        return False
+    if tuple(w1.shape) != (64, 64, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3):
+        return False
+    n, h, wd, _ = x.shape
+    if n == 0 or x.numel() * 2 >= _ADDR_LIMIT:
+        return False
+    lim = _PAIR_MAX_TILES or 2 * L.load().srk_device_cus()
+    return L.load().srk_conv_pair_tiles(n, h, wd) <= lim
+
+
+def conv_pair_raw(x, pk1, pk2, *, out, relu_mid=False, scale_mid=1.0, mask=None, mid=None, scale_out=1.0, res=None,
+                  use_bias=True):
+    """One srk_conv_pair launch: out = (conv(epi(conv(x, pk1)), pk2)) * scale_out + res (include/srk.h)."""
+    _need_gpu(x)
+    n, h, wd, _ = x.shape
+    from_x = res is not None and res.data_ptr() == x.data_ptr() and _pitch(res) == _pitch(x)
+    a = L.ConvPairArgs(
+        x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, N=n, H=h, W=wd,
+        w1=pk1.wpk.data_ptr(), b1=_ptr(pk1.bias) if use_bias else 0, w2=pk2.wpk.data_ptr(), b2=_ptr(pk2.bias) if use_bias else 0,
+        relu_mid=int(relu_mid), scale_mid=float(scale_mid),
+        mask=_ptr(mask), mask_pitch=0 if mask is None else _pitch(mask), mask_coff=0,
+        mid=_ptr(mid), mid_pitch=0 if mid is None else _pitch(mid), mid_coff=0,
+        scale_out=float(scale_out),
+        res=_ptr(res), res_pitch=0 if res is None else _pitch(res), res_coff=0, res_from_x=int(from_x),
+        out=out.data_ptr(), out_pitch=_pitch(out), out_coff=0, dtype=_DT[x.dtype])
+    L.call("srk_conv_pair", a, _stream())
     return out
 
 
@@ -775,7 +815,13 @@ class ConvChainFn(torch.autograd.Function):
         n, h, wd, _ = x.shape
         acts = [x]
         a = x
-        for i in range(L_):
+        paired = L_ == 2 and tuple(relus) == (True, False) and pair_ok(x, ws[0], ws[1])
+        if paired:      # small batch: the whole block is one launch, the intermediate goes to HBM only for the backward pass
+            y1 = torch.empty_like(x)
+            a = conv_pair_raw(x, pack_conv(ws[0], bs[0], x.dtype), pack_conv(ws[1], bs[1], x.dtype), out=torch.empty_like(x),
+                              relu_mid=True, mid=y1, scale_out=scale, res=x)
+            acts.append(y1)
+        for i in range(0 if paired else L_):
             w = ws[i]
             cout, cin, k, _ = w.shape
             pk = pack_conv(w, bs[i], x.dtype)
@@ -801,6 +847,19 @@ class ConvChainFn(torch.autograd.Function):
         n, h, wd, _ = g.shape
         grads = [None] * (2 * L_)
         dy = g
+        paired = L_ == 2 and relus == (True, False) and pair_ok(g, ws[0], ws[1])
+        if paired:      # dgrad 2 (ReLU mask, * scale) and dgrad 1 (+ g) in one launch; the two weight gradients as usual
+            x, y1 = acts
+            g1 = torch.empty_like(g)
+            gx = conv_pair_raw(g, pack_conv(ws[1], None, g.dtype, dgrad=True, token=ctx.pg),
+                               pack_conv(ws[0], None, g.dtype, dgrad=True, token=ctx.pg), out=torch.empty_like(g),
+                               scale_mid=scale, mask=y1, mid=g1, res=g, use_bias=False)
+            for i, (a_in, d, sc) in enumerate(((x, g1, 1.0), (y1, g, scale))):
+                if ctx.needs_input_grad[3 + 2 * i]:
+                    grads[2 * i], grads[2 * i + 1] = wgrad(
+                        a_in, d, wparam=ctx.wb[0][i], bparam=ctx.wb[1][i], N=n, H=h, W=wd, Cin=64, Cout=64, k=3,
+                        w_shape=tuple(ws[i].shape), scale=sc, want_bias=has_b[i])
+            return (gx, None, None, *grads)
         for i in range(L_ - 1, -1, -1):
             w = ws[i]
             a_in = acts[i]
@@ -841,9 +900,12 @@ class RCABFn(torch.autograd.Function):
         c = w2.shape[0]
         cr = cw1.shape[0]
         y1 = torch.empty_like(x)
-        conv_raw(x, pack_conv(w1, b1, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=y1, relu=True)
         t = torch.empty_like(x)
-        conv_raw(y1, pack_conv(w2, b2, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=t)
+        if pair_ok(x, w1, w2):
+            conv_pair_raw(x, pack_conv(w1, b1, dt), pack_conv(w2, b2, dt), out=t, relu_mid=True, mid=y1)
+        else:
+            conv_raw(x, pack_conv(w1, b1, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=y1, relu=True)
+            conv_raw(y1, pack_conv(w2, b2, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=t)
         ns = L.load().srk_ca_splits(n, h * wd)
         sums = torch.empty((n, ns, cp), dtype=torch.float32, device=x.device)      # per-block partials: nothing to zero
         L.call("srk_ca_pool", L.CaPoolArgs(t=t.data_ptr(), t_pitch=cp, t_coff=0, u=0, u_pitch=0, u_coff=0,
@@ -890,11 +952,17 @@ class RCABFn(torch.autograd.Function):
         gw2, gb2 = wgrad(y1, gt, wparam=ctx.wb[2], bparam=ctx.wb[3], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w2.shape[2],
                          w_shape=tuple(w2.shape), want_bias=ctx.wb[3] is not None)
         g1 = torch.empty_like(x)
-        conv_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1, use_bias=False)
+        gx = torch.empty_like(x)
+        paired = pair_ok(gt, w1, w2)
+        if paired:
+            conv_pair_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), pack_conv(w1, None, dt, dgrad=True, token=ctx.pg),
+                          out=gx, mask=y1, mid=g1, res=g, use_bias=False)
+        else:
+            conv_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1, use_bias=False)
         gw1, gb1 = wgrad(x, g1, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w1.shape[2],
                          w_shape=tuple(w1.shape), want_bias=ctx.wb[1] is not None)
-        gx = torch.empty_like(x)
-        conv_raw(g1, pack_conv(w1, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=gx, res=g, use_bias=False)
+        if not paired:
+            conv_raw(g1, pack_conv(w1, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=gx, res=g, use_bias=False)
         tot = per.sum(0)
         dw1, db1 = tot[:cr * cp], tot[cr * cp:cr * cp + cr]
         dw2, db2 = tot[cr * cp + cr:2 * cr * cp + cr], tot[2 * cr * cp + cr:]

@@ -1,0 +1,168 @@
+"""GPU tests of srk_conv_pair (two chained 3x3 64->64 convolutions in one launch, the small-batch form of ResBlock
+models/common.py:74-109 and of RCAB's conv pair models/rcan.py:33-55, forward and backward).
+
+The pair must give BIT-IDENTICAL results to the two srk_conv2d launches it replaces (same MFMA order, same epilogue
+arithmetic, the intermediate rounded to the storage dtype in both), for every epilogue form the models use, on tile-aligned
+and ragged images, and the block-level Functions must take it at the reference's batch and agree with the two-launch path
+in outputs and every gradient."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import sr_amd
+    assert torch.cuda.is_available()
+    sr_amd._lib.load()
+    return sr_amd
+
+
+def _rand(g, *shape, dt, dev, lo=-0.5):
+    return (torch.rand(*shape, generator=g) + lo).to(dt).to(dev)
+
+
+def _two_launch(A, x, pk1, pk2, *, relu_mid, scale_mid, mask, scale_out, res, use_bias):
+    n, h, w, _ = x.shape
+    mid = torch.empty_like(x)
+    A.ops.conv_raw(x, pk1, N=n, H=h, W=w, Cin=64, Cout=64, out=mid, relu=relu_mid, scale=scale_mid, mask=mask, use_bias=use_bias)
+    out = torch.empty_like(x)
+    A.ops.conv_raw(mid, pk2, N=n, H=h, W=w, Cin=64, Cout=64, out=out, scale=scale_out, res=res, use_bias=use_bias)
+    return mid, out
+
+
+SHAPES = [(16, 48, 48), (1, 14, 14), (2, 28, 42), (3, 20, 33), (2, 5, 7), (1, 1, 1), (1, 15, 29), (5, 48, 48)]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("form", ["resblock", "resblock_bwd", "rcab", "rcab_bwd", "plain"])
+def test_pair_is_bit_identical_to_two_launches(A, dt, form):
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    for (n, h, w) in SHAPES:
+        x = _rand(g, n, h, w, 64, dt=dt, dev=dev)
+        w1 = torch.nn.Parameter((torch.rand(64, 64, 3, 3, generator=g) - 0.5).mul(0.1).to(dev))
+        w2 = torch.nn.Parameter((torch.rand(64, 64, 3, 3, generator=g) - 0.5).mul(0.1).to(dev))
+        b1 = torch.nn.Parameter((torch.rand(64, generator=g) - 0.5).to(dev))
+        b2 = torch.nn.Parameter((torch.rand(64, generator=g) - 0.5).to(dev))
+        other = _rand(g, n, h, w, 64, dt=dt, dev=dev)
+        maskt = _rand(g, n, h, w, 64, dt=dt, dev=dev)          # about half the entries <= 0
+        maskt = torch.where(maskt > 0, maskt, torch.zeros_like(maskt))
+        bwd = form.endswith("_bwd")
+        pk1 = A.ops.pack_conv(w1, None if bwd else b1, dt, dgrad=bwd)
+        pk2 = A.ops.pack_conv(w2, None if bwd else b2, dt, dgrad=bwd)
+        kw = dict(relu_mid=False, scale_mid=1.0, mask=None, scale_out=1.0, res=None, use_bias=not bwd)
+        if form == "resblock":
+            kw.update(relu_mid=True, scale_out=0.1, res=x)
+        elif form == "resblock_bwd":
+            kw.update(scale_mid=0.1, mask=maskt, res=x)
+        elif form == "rcab":
+            kw.update(relu_mid=True)
+        elif form == "rcab_bwd":
+            kw.update(mask=maskt, res=other)
+        mid_ref, out_ref = _two_launch(A, x, pk1, pk2, **kw)
+        mid = torch.full_like(x, float("nan"))
+        out = torch.full_like(x, float("nan"))
+        A.ops.conv_pair_raw(x, pk1, pk2, out=out, mid=mid, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(mid.view(torch.int16), mid_ref.view(torch.int16)), (form, n, h, w, "mid")
+        assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)), (form, n, h, w, "out")
+        # without the intermediate store the output is the same
+        out2 = torch.full_like(x, float("nan"))
+        A.ops.conv_pair_raw(x, pk1, pk2, out=out2, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out2.view(torch.int16), out_ref.view(torch.int16)), (form, n, h, w, "out, no mid")
+
+
+def test_pair_on_channel_slices_of_wider_tensors(A):
+    """pitch != 64: x, mid, out and res may be 64-channel slices of wider NHWC buffers."""
+    dev = torch.device("cuda")
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 2, 19, 30
+    big = _rand(g, n, h, w, 192, dt=dt, dev=dev)
+    x = big[..., 64:128]
+    w1 = torch.nn.Parameter((torch.rand(64, 64, 3, 3, generator=g) - 0.5).mul(0.1).to(dev))
+    w2 = torch.nn.Parameter((torch.rand(64, 64, 3, 3, generator=g) - 0.5).mul(0.1).to(dev))
+    pk1, pk2 = A.ops.pack_conv(w1, None, dt), A.ops.pack_conv(w2, None, dt)
+    obig = torch.zeros(n, h, w, 128, dtype=dt, device=dev)
+    mbig = torch.zeros(n, h, w, 128, dtype=dt, device=dev)
+    A.ops.conv_pair_raw(x, pk1, pk2, out=obig[..., 64:], mid=mbig[..., :64], relu_mid=True, scale_out=0.5, res=x)
+    mid_ref, out_ref = _two_launch(A, x.contiguous(), pk1, pk2, relu_mid=True, scale_mid=1.0, mask=None, scale_out=0.5,
+                                   res=x.contiguous(), use_bias=True)
+    torch.cuda.synchronize()
+    assert torch.equal(obig[..., 64:], out_ref) and torch.equal(mbig[..., :64], mid_ref)
+    assert float(obig[..., :64].abs().max()) == 0.0 and float(mbig[..., 64:].abs().max()) == 0.0, "neighbouring channels untouched"
+
+
+def test_pair_argument_errors(A):
+    dev = torch.device("cuda")
+    x = torch.zeros(1, 8, 8, 64, dtype=torch.float32, device=dev)
+    w = torch.nn.Parameter(torch.zeros(64, 64, 3, 3, device=dev))
+    pk = A.ops.pack_conv(w, None, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="16-bit"):
+        A.ops.conv_pair_raw(x, pk, pk, out=torch.empty_like(x))
+    xb = x.to(torch.bfloat16)
+    with pytest.raises(RuntimeError, match="exclusive"):
+        A.ops.conv_pair_raw(xb, pk, pk, out=torch.empty_like(xb), relu_mid=True, mask=xb)
+    assert A._lib.load().srk_conv_pair_tiles(16, 48, 48) == 256
+    assert A._lib.load().srk_conv_pair_tiles(1, 15, 14) == 2
+
+
+def _block_grads(A, make, x0, paired):
+    prev = A.ops._PAIR_OFF
+    A.ops._PAIR_OFF = not paired
+    try:
+        torch.manual_seed(0)
+        m = make()
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        (y.float() * torch.linspace(-1, 1, y.numel(), device=y.device).view_as(y)).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach(), x.grad.detach(), [p.grad.detach().clone() for p in m.parameters()]
+    finally:
+        A.ops._PAIR_OFF = prev
+
+
+@pytest.mark.parametrize("kind", ["resblock", "rcab"])
+def test_blocks_take_the_pair_at_batch_16_and_agree_with_two_launches(A, kind, monkeypatch):
+    """ResBlock / RCAB modules at the reference's 16 x 48 x 48: the Functions choose the pair; outputs and input gradient
+    are bit-identical to the two-launch path, weight gradients agree to fp32 summation order."""
+    dev = torch.device("cuda")
+    dt = torch.bfloat16
+    from sr_amd.models import common, rcan
+
+    def make():
+        if kind == "resblock":
+            m = common.ResBlock(n_feats=64, kernel_size=3, res_scale=0.1)
+        else:
+            m = rcan.RCAB(common.DefaultConv2d, 64, 3, 16)
+        m = m.to(dev)
+        m.compute_dtype = dt          # fp32 parameters, bf16 activations (models/common._NCHWContract)
+        return m
+
+    calls = []
+    real = A.ops.conv_pair_raw
+    monkeypatch.setattr(A.ops, "conv_pair_raw", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    g = torch.Generator().manual_seed(2)
+    x0 = _rand(g, 16, 64, 48, 48, dt=torch.float32, dev=dev)
+    yp, gxp, gp = _block_grads(A, make, x0, True)
+    assert len(calls) == 2, "one pair launch forward, one backward"
+    yt, gxt, gt = _block_grads(A, make, x0, False)
+    assert len(calls) == 2
+    assert torch.equal(yp, yt) and torch.equal(gxp, gxt)
+    for a, b in zip(gp, gt):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-5 * float(b.float().abs().max()) + 1e-7
+
+
+def test_pair_threshold_follows_tile_count(A):
+    dev = torch.device("cuda")
+    w = torch.zeros(64, 64, 3, 3, device=dev)
+    cus = A._lib.load().srk_device_cus()
+    small = torch.zeros(16, 48, 48, 64, dtype=torch.bfloat16, device=dev)
+    assert A.ops.pair_ok(small, w, w)
+    big = torch.zeros(256, 48, 48, 64, dtype=torch.bfloat16, device=dev)
+    assert A._lib.load().srk_conv_pair_tiles(256, 48, 48) > 2 * cus and not A.ops.pair_ok(big, w, w)
+    assert not A.ops.pair_ok(small.float(), w, w)
+    assert not A.ops.pair_ok(small, torch.zeros(64, 64, 1, 1, device=dev), w)
