@@ -283,10 +283,13 @@ def main():
         if ddp and not use_torch_ddp:
             gsync = T.GradSync(model, overlap=(mode == "eager"))
             gsync.broadcast()
-        # reference optimizer: Adam at torch defaults (srmodel.py:145-154,602-603).  Same update rule, torch's fused
-        # multi-tensor implementation (one kernel for all 74 tensors instead of ~150 tiny per-tensor launches),
-        # capturable so the step counter lives on the device for hipGraph replay
-        opt = torch.optim.Adam(params, fused=True, capturable=(mode != "eager"))
+        # reference optimizer: Adam at torch defaults (srmodel.py:145-154,602-603) = what configure_optimizers() returns:
+        # torch.optim.Adam's update rule as ONE launch over all parameter tensors (optim.py / csrc/optim.hip), the step
+        # counter on the device for hipGraph replay.  SRK_TORCH_ADAM=1: torch's own fused multi-tensor kernels (A/B).
+        if os.environ.get("SRK_TORCH_ADAM") == "1":
+            opt = torch.optim.Adam(params, fused=True, capturable=(mode != "eager"))
+        else:
+            opt = A.optim.Adam(params)
 
     def fwd_bwd():
         opt.zero_grad(set_to_none=True)

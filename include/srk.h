@@ -400,6 +400,28 @@ typedef struct {
 } srk_chan_apply_args;
 int srk_chan_apply(const srk_chan_apply_args* a, srk_stream_t stream);
 
+/* ---- optimizer: Adam over every parameter tensor in one launch -----------------------------------
+ * Replaces torch.optim.Adam(...).step() as models/srmodel.py:145-154 configures it (torch defaults; :602-603 drops every
+ * user-supplied hyper-parameter).  fp32 parameters, gradients and moments.  The tensors are described by a DEVICE table
+ * (srk_adam_slot), the work by a device list of blocks (srk_adam_block: `count` elements of tensor `slot` from `start`);
+ * the first and second moments of all tensors live in two flat buffers `m` / `v`, tensor i at `state_off` floats.
+ *     t = steps[step_idx] + 1;  g' = maximize ? -g : g;  g' += weight_decay * p;
+ *     m += (g' - m) * (1 - beta1);  v = beta2 * v + (1 - beta2) * g' * g';
+ *     p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * `steps` (device floats: the number of updates each tensor has had -- torch counts per parameter, a tensor without a
+ * gradient skips the step) are advanced by the call itself (a second tiny launch) for the tensors in the table, so a
+ * captured hipGraph can replay it; `ticket` is reserved (may be NULL).                                                   */
+typedef struct { float* p; const float* g; long long state_off; long long n; long long step_idx; } srk_adam_slot;
+typedef struct { int slot; int count; long long start; } srk_adam_block;
+typedef struct {
+  const srk_adam_slot* slots; const srk_adam_block* blocks; int nslots, nblocks;
+  float* m; float* v;
+  float* steps; unsigned int* ticket;
+  float lr, beta1, beta2, eps, weight_decay; int maximize;
+  float one_minus_beta1, one_minus_beta2;   /* 1 - beta rounded from double, as torch forms them */
+} srk_adam_args;
+int srk_adam_step(const srk_adam_args* a, srk_stream_t stream);
+
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* srk_last_error(void);
 int srk_version(void);

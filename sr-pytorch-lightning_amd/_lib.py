@@ -45,6 +45,20 @@ class ConvPairArgs(C.Structure):
                 ("out", _p), ("out_pitch", _i), ("out_coff", _i), ("dtype", _i)]
 
 
+class AdamSlot(C.Structure):
+    _fields_ = [("p", _p), ("g", _p), ("state_off", C.c_longlong), ("n", C.c_longlong), ("step_idx", C.c_longlong)]
+
+
+class AdamBlock(C.Structure):
+    _fields_ = [("slot", _i), ("count", _i), ("start", C.c_longlong)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("slots", _p), ("blocks", _p), ("nslots", _i), ("nblocks", _i), ("m", _p), ("v", _p), ("steps", _p), ("ticket", _p),
+                ("lr", _f), ("beta1", _f), ("beta2", _f), ("eps", _f), ("weight_decay", _f), ("maximize", _i),
+                ("one_minus_beta1", _f), ("one_minus_beta2", _f)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("x_ps", _i),
                 ("dy", _p), ("dy_pitch", _i), ("dy_coff", _i), ("dy_ps", _i),
@@ -142,6 +156,7 @@ LAUNCHERS = {
     "srk_pack_conv_weights": PackArgs,
     "srk_conv2d": ConvArgs,
     "srk_conv_pair": ConvPairArgs,
+    "srk_adam_step": AdamArgs,
     "srk_conv2d_wgrad": WgradArgs,
     "srk_wgrad_finalize": WgradFinArgs,
     "srk_unfold_nchw": UnfoldArgs,

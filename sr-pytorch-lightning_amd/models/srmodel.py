@@ -20,6 +20,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.optim as optim
 
+from .. import optim as _hip_optim
+
 try:  # pragma: no cover - lightning is not installed in the build image
     import lightning.pytorch as pl
     _Base = pl.LightningModule
@@ -67,7 +69,8 @@ _supported_losses = {"l1": _l1_loss, "l2": F.mse_loss, "mae": _l1_loss, "mse": F
 _out_of_scope_losses = {"adaptive", "dists", "edge_loss", "flip", "haarpsi", "lpips", "pencil_sketch", "pieapp"}
 
 # models/srmodel.py:57-64
-_supported_optimizers = {"ADAM": optim.Adam, "RMSprop": optim.RMSprop, "SGD": optim.SGD}
+# 'ADAM' is torch.optim.Adam with the update of GPU parameters as one HIP launch (sr-pytorch-lightning_amd/optim.py)
+_supported_optimizers = {"ADAM": _hip_optim.Adam, "RMSprop": optim.RMSprop, "SGD": optim.SGD}
 _out_of_scope_optimizers = {"Ranger", "RangerVA", "RangerQH"}
 
 

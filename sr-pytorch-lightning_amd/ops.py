@@ -963,6 +963,8 @@ class RCABFn(torch.autograd.Function):
                          w_shape=tuple(w1.shape), want_bias=ctx.wb[1] is not None)
         if not paired:
             conv_raw(g1, pack_conv(w1, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=gx, res=g, use_bias=False)
+        # (summing the slots inside the launch -- last block by ticket -- was measured: the device-scope release it needs
+        # writes back the L2 of every XCD and costs what this reduction launch costs)
         tot = per.sum(0)
         dw1, db1 = tot[:cr * cp], tot[cr * cp:cr * cp + cr]
         dw2, db2 = tot[cr * cp + cr:2 * cr * cp + cr], tot[2 * cr * cp + cr:]

@@ -1,0 +1,182 @@
+"""Optimizers of the training hot path on the HIP kernels.
+
+`Adam` is torch.optim.Adam -- the optimizer the reference builds (models/srmodel.py:57-64 `_supported_optimizers['ADAM']`,
+:145-154 `configure_optimizers`, always at torch's defaults because :602-603 drops the user's parameters) -- with the whole
+update as ONE launch of `srk_adam_step` (csrc/optim.hip) instead of one launch per few dozen tensors.  Same constructor,
+same `state_dict()` layout (`step`, `exp_avg`, `exp_avg_sq` per parameter), same arithmetic in fp32.  The step count lives
+on the device, so `step()` can be captured into a hipGraph and replayed.
+
+Nothing here falls back to PyTorch arithmetic: parameters must be fp32 tensors on a GPU and the HIP library must load.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_CHUNK = 4096           # elements per workgroup (256 threads x 4 x float4)
+
+
+class _Plan:
+    """Per parameter group: flat moment buffers, the device step counter and the device table of (parameter, gradient)."""
+
+    def __init__(self):
+        self.offsets = {}       # param -> offset (floats) into the flat moment buffers
+        self.index = {}         # param -> index into `steps`
+        self.m = self.v = None
+        self.steps = self.ticket = None  # per-parameter update counts (torch counts per parameter)
+        self.table = None       # device bytes: slots | blocks
+        self.host = None        # page-locked staging copy of the table
+        self.copied = None      # event behind the last eager upload from `host`
+        self.key = None
+        self.grads = None       # the gradient tensors the table was built for (kept alive: their addresses are in it)
+        self.live = []          # the parameters in the table
+        self.nslots = self.nblocks = self.blocks_off = 0
+
+
+class Adam(torch.optim.Adam):
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay, amsgrad) with a single-launch step for GPU parameters.
+
+    `amsgrad=True` is not implemented (the reference never sets it); `maximize` and L2 `weight_decay` are.  A model whose
+    parameters live on the CPU (SRCNN, the reference's CPU-runnable case, runs on torch ops there) steps through
+    torch.optim.Adam itself; GPU parameters always take the HIP kernel and raise if the library is missing."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *, maximize=False):
+        if not 0.0 <= lr:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        if not 0.0 <= eps:
+            raise ValueError(f"Invalid epsilon value: {eps}")
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError(f"Invalid beta parameter at index 0: {betas[0]}")
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError(f"Invalid beta parameter at index 1: {betas[1]}")
+        if not 0.0 <= weight_decay:
+            raise ValueError(f"Invalid weight_decay value: {weight_decay}")
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not implemented by the HIP Adam (the reference never enables it)")
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=maximize)
+        self._plans = {}
+
+    # -- state ------------------------------------------------------------------------------------
+    def _plan(self, gi, group):
+        plan = self._plans.get(gi)
+        params = [p for p in group["params"] if p.requires_grad]
+        if plan is not None and all(p in plan.offsets for p in params):
+            return plan
+        if not params:
+            return None
+        dev = params[0].device
+        for p in params:
+            if not p.is_cuda:
+                raise RuntimeError("sr-pytorch-lightning_amd.optim.Adam runs on the GPU only (parameters are on %s); there is no CPU path" % p.device)
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                raise RuntimeError("HIP Adam needs contiguous fp32 parameters on one device")
+        plan = _Plan()
+        off = 0
+        for k, p in enumerate(params):
+            plan.offsets[p], plan.index[p] = off, k
+            off += (p.numel() + 3) // 4 * 4                 # every tensor starts 16-byte aligned
+        plan.m = torch.zeros(max(off, 4), dtype=torch.float32, device=dev)
+        plan.v = torch.zeros(max(off, 4), dtype=torch.float32, device=dev)
+        plan.steps = torch.zeros(len(params), dtype=torch.float32, device=dev)
+        plan.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        # table of the largest case (every parameter has a gradient): tensors | 16-byte gap | blocks
+        cap = C.sizeof(L.AdamSlot) * len(params) + 16 + C.sizeof(L.AdamBlock) * sum((p.numel() + _CHUNK - 1) // _CHUNK for p in params)
+        plan.table = torch.empty(cap, dtype=torch.uint8, device=dev)
+        plan.host = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        host_steps = [0.0] * len(params)
+        for k, p in enumerate(params):
+            st = self.state[p]
+            o, n = plan.offsets[p], p.numel()
+            mv, vv = plan.m[o:o + n].view_as(p), plan.v[o:o + n].view_as(p)
+            if "exp_avg" in st:                              # loaded (load_state_dict) or carried-over (add_param_group) state
+                mv.copy_(st["exp_avg"])
+                vv.copy_(st["exp_avg_sq"])
+                host_steps[k] = float(st.get("step", 0))
+            st["exp_avg"], st["exp_avg_sq"], st["step"] = mv, vv, plan.steps[k]
+        if any(host_steps):
+            plan.steps.copy_(torch.tensor(host_steps, dtype=torch.float32))
+        self._plans[gi] = plan
+        return plan
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans = {}                                     # re-adopt the loaded moments into flat buffers at the next step
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_plans"):
+            self._plans.pop(len(self.param_groups) - 1, None)
+
+    # -- device table --------------------------------------------------------------------------------
+    def _table(self, plan, group):
+        live = [(p, p.grad) for p in group["params"] if p.requires_grad and p.grad is not None]
+        key = tuple((p.data_ptr(), g.data_ptr(), g.numel()) for p, g in live)
+        if key == plan.key:
+            return
+        slots = (L.AdamSlot * max(len(live), 1))()
+        blocks = []
+        for i, (p, g) in enumerate(live):
+            if g.is_sparse:
+                raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device or g.numel() != p.numel():
+                raise RuntimeError("HIP Adam needs contiguous fp32 gradients on the parameter's device")
+            n = p.numel()
+            slots[i].p, slots[i].g, slots[i].state_off, slots[i].n, slots[i].step_idx = p.data_ptr(), g.data_ptr(), plan.offsets[p], n, plan.index[p]
+            for s0 in range(0, n, _CHUNK):
+                blocks.append((i, min(_CHUNK, n - s0), s0))
+        barr = (L.AdamBlock * max(len(blocks), 1))()
+        for j, (i, cnt, s0) in enumerate(blocks):
+            barr[j].slot, barr[j].count, barr[j].start = i, cnt, s0
+        ssz = C.sizeof(L.AdamSlot) * len(live)
+        boff = (ssz + 15) // 16 * 16
+        total = boff + C.sizeof(L.AdamBlock) * len(blocks)
+        if total:
+            # one host-to-device copy from a page-locked staging buffer sized when the plan was made (so nothing is
+            # allocated here): captured into a hipGraph it is ONE memcpy node that replays the same bytes
+            assert total <= plan.host.numel()
+            capturing = torch.cuda.is_current_stream_capturing()
+            if plan.copied is not None and not capturing:
+                plan.copied.synchronize()                   # the previous table may still be on its way out of `host`
+            C.memmove(plan.host.data_ptr(), C.addressof(slots), ssz)
+            C.memmove(plan.host.data_ptr() + boff, C.addressof(barr), total - boff)
+            plan.table[:total].copy_(plan.host[:total], non_blocking=True)
+            if not capturing:
+                plan.copied = torch.cuda.Event()
+                plan.copied.record()
+        plan.key, plan.grads, plan.live = key, [g for _, g in live], [p for p, _ in live]
+        plan.nslots, plan.nblocks, plan.blocks_off = len(live), len(blocks), boff
+
+    # -- step -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        on_gpu = {p.is_cuda for group in self.param_groups for p in group["params"]}
+        if on_gpu == {False}:
+            return super().step(closure)
+        if on_gpu != {True}:
+            raise RuntimeError("Adam: parameters on both CPU and GPU")
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            plan = self._plan(gi, group)
+            if plan is None:
+                continue
+            with torch.cuda.device(plan.m.device):
+                stream = torch.cuda.current_stream().cuda_stream
+                self._table(plan, group)
+                if plan.nblocks == 0:
+                    continue
+                b1, b2 = group["betas"]
+                a = L.AdamArgs(slots=plan.table.data_ptr(), blocks=plan.table.data_ptr() + plan.blocks_off,
+                               nslots=plan.nslots, nblocks=plan.nblocks,
+                               m=plan.m.data_ptr(), v=plan.v.data_ptr(), steps=plan.steps.data_ptr(), ticket=plan.ticket.data_ptr(),
+                               lr=float(group["lr"]), beta1=float(b1), beta2=float(b2), eps=float(group["eps"]),
+                               weight_decay=float(group["weight_decay"]), maximize=int(bool(group["maximize"])),
+                               one_minus_beta1=1.0 - float(b1), one_minus_beta2=1.0 - float(b2))
+                L.call("srk_adam_step", a, stream)
+                # the kernel wrote through raw pointers: tell autograd (and the packed-weight cache, which keys on it) that
+                # the parameters changed, as an in-place torch op would
+                torch.autograd.graph.increment_version(plan.live)
+        return loss

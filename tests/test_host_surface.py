@@ -148,3 +148,23 @@ def test_srcnn_cpu_plumbing_matches_reference(name):
     assert set(res) == {"loss", "loss/l1"}
     opt = m.configure_optimizers()[0]
     assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 1e-3
+
+
+def test_adam_on_cpu_parameters_is_torch_adam():
+    """sr_amd.optim.Adam subclasses torch.optim.Adam: CPU-resident models (SRCNN, the reference's CPU-runnable case) step
+    through torch's implementation; the HIP launch is for GPU parameters only."""
+    import sr_amd
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.nn.Parameter(torch.rand(5, 3, generator=g)), torch.nn.Parameter(torch.rand(7, generator=g))]
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, ropt = sr_amd.optim.Adam(ps, lr=1e-2), torch.optim.Adam(rs, lr=1e-2)
+    for _ in range(3):
+        for p, r in zip(ps, rs):
+            p.grad = torch.rand(p.shape, generator=g)
+            r.grad = p.grad.clone()
+        opt.step()
+        ropt.step()
+    for p, r in zip(ps, rs):
+        assert torch.equal(p, r)
+    with pytest.raises(NotImplementedError):
+        sr_amd.optim.Adam(ps, amsgrad=True)
