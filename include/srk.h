@@ -131,6 +131,11 @@ typedef struct {
   const void* res; int res_pitch, res_coff; int res_from_x;
   void* out; int out_pitch, out_coff;
   int dtype;
+  /* optional channel-attention pooling of the output while it leaves (models/rcan.py:10-29 AdaptiveAvgPool2d numerator and
+   * its backward): pool[(n*T + tile)*64 + c] = sum over the tile's pixels of out[.][c] * (pool_aux ? pool_aux[.][c] : 1),
+   * T = srk_conv_pair_tiles(1, H, W) partial rows per sample (srk_ca_apply / srk_ca_bwd_apply take them via sums_rows /
+   * gsum_rows), summed in a fixed order over the stored (rounded) values                                              */
+  float* pool; const void* pool_aux; int pool_aux_pitch, pool_aux_coff;
 } srk_conv_pair_args;
 int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream);
 /* workgroups (14x14 output tiles) such a launch has: the host uses the pair while this is about two per CU or less */
@@ -254,6 +259,7 @@ typedef struct {
   float* s_out; float* z_out;           /* [N][C], [N][Cr] saved for backward (nullable)         */
   void* out; int out_pitch, out_coff;
   int N, HW, C, Cr; int dtype;
+  int sums_rows;                        /* partial rows per sample in `sums`; 0 = srk_ca_splits(N, HW) (srk_ca_pool's)   */
 } srk_ca_apply_args;
 int srk_ca_apply(const srk_ca_apply_args* a, srk_stream_t stream);
 
@@ -267,6 +273,7 @@ typedef struct {
                                         /* caller sums over n (fixed order: reproducible)                  */
   void* gt; int gt_pitch, gt_coff;      /* out: gradient w.r.t. t = g*s + dmean/HW               */
   int N, HW, C, Cr; int dtype;
+  int sums_rows, gsum_rows;             /* partial rows per sample in `sums` / `gsum`; 0 = srk_ca_splits(N, HW)          */
 } srk_ca_bwd_args;
 int srk_ca_bwd_apply(const srk_ca_bwd_args* a, srk_stream_t stream);
 

@@ -42,7 +42,8 @@ class ConvPairArgs(C.Structure):
                 ("mid", _p), ("mid_pitch", _i), ("mid_coff", _i),
                 ("scale_out", _f),
                 ("res", _p), ("res_pitch", _i), ("res_coff", _i), ("res_from_x", _i),
-                ("out", _p), ("out_pitch", _i), ("out_coff", _i), ("dtype", _i)]
+                ("out", _p), ("out_pitch", _i), ("out_coff", _i), ("dtype", _i),
+                ("pool", _p), ("pool_aux", _p), ("pool_aux_pitch", _i), ("pool_aux_coff", _i)]
 
 
 class AdamSlot(C.Structure):
@@ -96,14 +97,14 @@ class CaApplyArgs(C.Structure):
     _fields_ = [("t", _p), ("t_pitch", _i), ("t_coff", _i), ("res", _p), ("res_pitch", _i), ("res_coff", _i),
                 ("sums", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p), ("s_out", _p), ("z_out", _p),
                 ("out", _p), ("out_pitch", _i), ("out_coff", _i),
-                ("N", _i), ("HW", _i), ("C", _i), ("Cr", _i), ("dtype", _i)]
+                ("N", _i), ("HW", _i), ("C", _i), ("Cr", _i), ("dtype", _i), ("sums_rows", _i)]
 
 
 class CaBwdArgs(C.Structure):
     _fields_ = [("g", _p), ("g_pitch", _i), ("g_coff", _i), ("gsum", _p), ("sums", _p), ("s", _p), ("z", _p),
                 ("w1", _p), ("w2", _p), ("dw1", _p), ("db1", _p), ("dw2", _p), ("db2", _p),
                 ("gt", _p), ("gt_pitch", _i), ("gt_coff", _i),
-                ("N", _i), ("HW", _i), ("C", _i), ("Cr", _i), ("dtype", _i)]
+                ("N", _i), ("HW", _i), ("C", _i), ("Cr", _i), ("dtype", _i), ("sums_rows", _i), ("gsum_rows", _i)]
 
 
 class PatchDesc(C.Structure):

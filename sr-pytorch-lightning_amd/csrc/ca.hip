@@ -116,7 +116,7 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_apply_kernel(const
   __shared__ float mean[CA_MAXC], sv[CA_MAXC], zv[CA_MAXCR], red[CA_NT];
   const int n = blockIdx.x, split = blockIdx.y, tid = threadIdx.x;
   const int C = a.C, Cr = a.Cr;
-  ca_sum_partials(a.sums, n, gridDim.y, C, 1.f / (float)a.HW, red, mean);
+  ca_sum_partials(a.sums, n, a.sums_rows > 0 ? a.sums_rows : (int)gridDim.y, C, 1.f / (float)a.HW, red, mean);
   if (tid < Cr) {
     float z = a.b1[tid];
     for (int c = 0; c < C; ++c) z += a.w1[tid * C + c] * mean[c];
@@ -165,8 +165,8 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_bwd_kernel(const s
   __shared__ float dpre2[CA_MAXC], dmean[CA_MAXC], sv[CA_MAXC], mean[CA_MAXC], dpre1[CA_MAXCR], zv[CA_MAXCR], red[CA_NT];
   const int n = blockIdx.x, split = blockIdx.y, tid = threadIdx.x;
   const int C = a.C, Cr = a.Cr;
-  ca_sum_partials(a.gsum, n, gridDim.y, C, 1.f, red, dpre2);
-  if (split == 0) ca_sum_partials(a.sums, n, gridDim.y, C, 1.f / (float)a.HW, red, mean);        // block-uniform branch
+  ca_sum_partials(a.gsum, n, a.gsum_rows > 0 ? a.gsum_rows : (int)gridDim.y, C, 1.f, red, dpre2);
+  if (split == 0) ca_sum_partials(a.sums, n, a.sums_rows > 0 ? a.sums_rows : (int)gridDim.y, C, 1.f / (float)a.HW, red, mean);        // block-uniform branch
   if (tid < C) {
     const float s = a.s[(size_t)n * C + tid];
     sv[tid] = s;

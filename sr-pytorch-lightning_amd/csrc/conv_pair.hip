@@ -321,10 +321,28 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   init_acc(bias2);
   // slab b1 is needed from step 10 on (fragments are read two steps ahead), b2 from step 22: this wave's pieces by the
   // counted wait, every other wave's by the barrier
+  // pooling with a second factor (pool_aux): this lane's four 16-byte pieces of it, requested once nothing else is in
+  // flight (conv-2 hand-over at step 22) and used when the output tile leaves
+  u32x4_t au[4] = {};
+  auto load_aux = [&]() {
+    if (a.pool && a.pool_aux) {
+      const __amdgpu_buffer_rsrc_t ra = rsrc_of(a.pool_aux);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = tid + C::NT * k;
+        const int p = i >> 3, c = i & 7;
+        const int row = p / C::TO, col = p - row * C::TO;
+        const int gy = y0 + row, gx = x0 + col;
+        const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
+        const unsigned vo = ok ? (unsigned)((((n * H + gy) * W + gx) * a.pool_aux_pitch + a.pool_aux_coff + c * Tr::CH) * 2) : 0x80000000u;
+        au[k] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, 0, 0);
+      }
+    }
+  };
   if (cw) {
     conv_loop(3, ml, C::MP, [&](int s) {
       if (s == 10) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-      if (s == 22) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+      if (s == 22) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); load_aux(); }
     });
   } else {
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); __builtin_amdgcn_s_barrier();
@@ -345,6 +363,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
       }
     }
+    load_aux();
   }
 
   SRK_PSTAMP(10);
@@ -386,7 +405,9 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   }
   drain_barrier();
   {
+    // lane `tid` copies pieces i = tid + 512 k: chunk c = tid & 7 of pixels (tid >> 3) + 64 k -- the same 8 channels each time
     const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.out);
+    float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = tid + C::NT * k;
@@ -397,6 +418,32 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       const i32x4 q = lds_read16(Xs + (((row + 2) * C::XP + col + 2) << 7) + ((c ^ swz(col + 2)) << 4));
       const unsigned vo = ok ? (unsigned)((((n * H + gy) * W + gx) * a.out_pitch + a.out_coff + c * Tr::CH) * 2) : 0x80000000u;
       __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
+      if (a.pool && ok) {
+        const int qw[4] = {q.x, q.y, q.z, q.w};
+        const uint32_t aw[4] = {au[k].x, au[k].y, au[k].z, au[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v0, v1, t0 = 1.f, t1 = 1.f;
+          unpack2<DT>((uint32_t)qw[e], v0, v1);
+          if (a.pool_aux) unpack2<DT>(aw[e], t0, t1);
+          ps[2 * e] += v0 * t0;
+          ps[2 * e + 1] += v1 * t1;
+        }
+      }
+    }
+    if (a.pool) {
+      // per-lane partials -> LDS (the intermediate tile's place), then thread ch sums its channel over the 64 lanes that
+      // carry it, in lane order: bitwise reproducible
+      float* const P = reinterpret_cast<float*>(Ms);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) P[e * C::NT + tid] = ps[e];
+      __syncthreads();
+      if (tid < 64) {
+        const int c = tid >> 3, e = tid & 7;
+        float u = 0.f;
+        for (int j = 0; j < C::NT / 8; ++j) u += P[e * C::NT + c + 8 * j];
+        a.pool[(size_t)blockIdx.x * 64 + tid] = u;
+      }
     }
   }
 #if SRK_PAIR_STAMPS
@@ -423,6 +470,7 @@ extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(!a->mask || (a->mask_pitch % 8 == 0 && a->mask_coff % 8 == 0), "srk_conv_pair: alignment of mask");
   SRK_CHECK_ARG(!a->res || (a->res_pitch % 8 == 0 && a->res_coff % 8 == 0), "srk_conv_pair: alignment of res");
   SRK_CHECK_ARG(!(a->relu_mid && a->mask), "srk_conv_pair: relu_mid and mask are exclusive");
+  SRK_CHECK_ARG(!a->pool_aux || (a->pool && a->pool_aux_pitch % 8 == 0 && a->pool_aux_coff % 8 == 0), "srk_conv_pair: pool_aux needs pool and 16-byte alignment");
   SRK_CHECK_ARG(!a->res_from_x || (a->res == a->x && a->res_pitch == a->x_pitch && a->res_coff == a->x_coff),
                 "srk_conv_pair: res_from_x needs res to BE x");
   const long long px = (long long)a->N * a->H * a->W;
@@ -431,6 +479,7 @@ extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
   if (a->mid && px * a->mid_pitch > mx) mx = px * a->mid_pitch;
   if (a->mask && px * a->mask_pitch > mx) mx = px * a->mask_pitch;
   if (a->res && px * a->res_pitch > mx) mx = px * a->res_pitch;
+  if (a->pool_aux && px * a->pool_aux_pitch > mx) mx = px * a->pool_aux_pitch;
   SRK_CHECK_ARG(mx * 2 < 0x7fff0000LL, "srk_conv_pair: tensors of 2 GiB and more are not supported (small-batch kernel)");
   typedef PairCfg C;
   static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<SRK_BF16>),

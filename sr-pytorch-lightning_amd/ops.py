@@ -292,7 +292,7 @@ def pair_ok(x, w1, w2):
 
 
 def conv_pair_raw(x, pk1, pk2, *, out, relu_mid=False, scale_mid=1.0, mask=None, mid=None, scale_out=1.0, res=None,
-                  use_bias=True):
+                  use_bias=True, pool=None, pool_aux=None):
     """One srk_conv_pair launch: out = (conv(epi(conv(x, pk1)), pk2)) * scale_out + res (include/srk.h)."""
     _need_gpu(x)
     n, h, wd, _ = x.shape
@@ -305,7 +305,8 @@ def conv_pair_raw(x, pk1, pk2, *, out, relu_mid=False, scale_mid=1.0, mask=None,
         mid=_ptr(mid), mid_pitch=0 if mid is None else _pitch(mid), mid_coff=0,
         scale_out=float(scale_out),
         res=_ptr(res), res_pitch=0 if res is None else _pitch(res), res_coff=0, res_from_x=int(from_x),
-        out=out.data_ptr(), out_pitch=_pitch(out), out_coff=0, dtype=_DT[x.dtype])
+        out=out.data_ptr(), out_pitch=_pitch(out), out_coff=0, dtype=_DT[x.dtype],
+        pool=_ptr(pool), pool_aux=_ptr(pool_aux), pool_aux_pitch=0 if pool_aux is None else _pitch(pool_aux), pool_aux_coff=0)
     L.call("srk_conv_pair", a, _stream())
     return out
 
@@ -886,6 +887,21 @@ def conv_chain(x, convs, relus, scale=1.0):
     return ConvChainFn.apply(x, float(scale), tuple(bool(r) for r in relus), *flat)
 
 
+class _CAHint:
+    """Link between consecutive RCABs of one forward pass (small batches only): block k leaves its conv output `t` here; block
+    k+1 -- whose backward produces the gradient block k receives -- pools t * gradient while that gradient leaves its
+    dgrad launch (srk_conv_pair pool / pool_aux), which is the pooling pass block k's channel-attention backward starts
+    with.  Block k uses the sums only for the very tensor they were formed from (same storage, untouched since)."""
+    __slots__ = ("t", "out_ref", "gsum", "g_ptr", "g_ver", "__weakref__")
+
+    def __init__(self, t, out):
+        self.t, self.out_ref = t, weakref.ref(out)
+        self.gsum = self.g_ptr = self.g_ver = None
+
+
+_LAST_CA_HINT = None
+
+
 class RCABFn(torch.autograd.Function):
     """RCAB (models/rcan.py:33-55): conv -> ReLU -> conv -> CALayer (rcan.py:10-29), += x.
 
@@ -901,15 +917,19 @@ class RCABFn(torch.autograd.Function):
         cr = cw1.shape[0]
         y1 = torch.empty_like(x)
         t = torch.empty_like(x)
-        if pair_ok(x, w1, w2):
-            conv_pair_raw(x, pack_conv(w1, b1, dt), pack_conv(w2, b2, dt), out=t, relu_mid=True, mid=y1)
+        paired = pair_ok(x, w1, w2)
+        if paired:
+            # small batch: both convs in one launch, which also leaves the per-tile channel sums of t (the pooling pass)
+            ns = L.load().srk_conv_pair_tiles(1, h, wd)
+            sums = torch.empty((n, ns, cp), dtype=torch.float32, device=x.device)
+            conv_pair_raw(x, pack_conv(w1, b1, dt), pack_conv(w2, b2, dt), out=t, relu_mid=True, mid=y1, pool=sums)
         else:
             conv_raw(x, pack_conv(w1, b1, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=y1, relu=True)
             conv_raw(y1, pack_conv(w2, b2, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=t)
-        ns = L.load().srk_ca_splits(n, h * wd)
-        sums = torch.empty((n, ns, cp), dtype=torch.float32, device=x.device)      # per-block partials: nothing to zero
-        L.call("srk_ca_pool", L.CaPoolArgs(t=t.data_ptr(), t_pitch=cp, t_coff=0, u=0, u_pitch=0, u_coff=0,
-                                           sums=sums.data_ptr(), N=n, HW=h * wd, C=cp, dtype=_DT[dt]), _stream())
+            ns = L.load().srk_ca_splits(n, h * wd)
+            sums = torch.empty((n, ns, cp), dtype=torch.float32, device=x.device)      # per-block partials: nothing to zero
+            L.call("srk_ca_pool", L.CaPoolArgs(t=t.data_ptr(), t_pitch=cp, t_coff=0, u=0, u_pitch=0, u_coff=0,
+                                               sums=sums.data_ptr(), N=n, HW=h * wd, C=cp, dtype=_DT[dt]), _stream())
         s = torch.empty((n, cp), dtype=torch.float32, device=x.device)
         z = torch.empty((n, cr), dtype=torch.float32, device=x.device)
         out = torch.empty_like(x)
@@ -918,10 +938,18 @@ class RCABFn(torch.autograd.Function):
             t=t.data_ptr(), t_pitch=cp, t_coff=0, res=x.data_ptr(), res_pitch=cp, res_coff=0, sums=sums.data_ptr(),
             w1=w1f.data_ptr(), b1=b1f.data_ptr(), w2=w2f.data_ptr(), b2=b2f.data_ptr(),
             s_out=s.data_ptr(), z_out=z.data_ptr(), out=out.data_ptr(), out_pitch=cp, out_coff=0,
-            N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt]), _stream())
+            N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt], sums_rows=ns), _stream())
         ctx.save_for_backward(x, y1, t, sums, s, z, w1, w2, cw1, cw2)
         ctx.wb = (w1, b1, w2, b2)
         ctx.pg = _tok()
+        global _LAST_CA_HINT
+        prev, ctx.hint_in, ctx.hint_out = _LAST_CA_HINT, None, None
+        if paired:
+            if prev is not None and prev.out_ref() is x and prev.t.shape == x.shape:
+                ctx.hint_in = prev                           # x is the previous RCAB's output
+            ctx.hint_out = _LAST_CA_HINT = _CAHint(t, out)
+        else:
+            _LAST_CA_HINT = None
         return out
 
     @staticmethod
@@ -932,9 +960,15 @@ class RCABFn(torch.autograd.Function):
         dt = x.dtype
         c, cr = w2.shape[0], cw1.shape[0]
         dev = x.device
-        gsum = torch.empty_like(sums)
-        L.call("srk_ca_pool", L.CaPoolArgs(t=t.data_ptr(), t_pitch=cp, t_coff=0, u=g.data_ptr(), u_pitch=_pitch(g), u_coff=0,
-                                           sums=gsum.data_ptr(), N=n, HW=h * wd, C=cp, dtype=_DT[dt]), _stream())
+        ho = ctx.hint_out
+        if ho is not None and ho.gsum is not None and ho.g_ptr == g.data_ptr() and ho.g_ver == g._version and ho.gsum.shape[0] == n:
+            gsum = ho.gsum                                   # sums of t * g formed by the launch that produced g
+            gs_rows = gsum.shape[1]
+        else:
+            gs_rows = L.load().srk_ca_splits(n, h * wd)
+            gsum = torch.empty((n, gs_rows, cp), dtype=torch.float32, device=dev)
+            L.call("srk_ca_pool", L.CaPoolArgs(t=t.data_ptr(), t_pitch=cp, t_coff=0, u=g.data_ptr(), u_pitch=_pitch(g), u_coff=0,
+                                               sums=gsum.data_ptr(), N=n, HW=h * wd, C=cp, dtype=_DT[dt]), _stream())
         w1f, _, w2f, _ = _ca_params(cw1, None, cw2, None, cp)
         # per-sample parameter-gradient contributions [N][dW1 | db1 | dW2 | db2], summed over n below (one reduction
         # instead of a zero-fill + float atomics + per-tensor copies)
@@ -948,15 +982,21 @@ class RCABFn(torch.autograd.Function):
             g=g.data_ptr(), g_pitch=_pitch(g), g_coff=0, gsum=gsum.data_ptr(), sums=sums.data_ptr(), s=s.data_ptr(),
             z=z.data_ptr(), w1=w1f.data_ptr(), w2=w2f.data_ptr(), dw1=dw1.data_ptr(), db1=db1.data_ptr(),
             dw2=dw2.data_ptr(), db2=db2.data_ptr(), gt=gt.data_ptr(), gt_pitch=cp, gt_coff=0,
-            N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt]), _stream())
+            N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt], sums_rows=sums.shape[1], gsum_rows=gs_rows), _stream())
         gw2, gb2 = wgrad(y1, gt, wparam=ctx.wb[2], bparam=ctx.wb[3], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w2.shape[2],
                          w_shape=tuple(w2.shape), want_bias=ctx.wb[3] is not None)
         g1 = torch.empty_like(x)
         gx = torch.empty_like(x)
         paired = pair_ok(gt, w1, w2)
         if paired:
+            hi = ctx.hint_in
+            pool = None
+            if hi is not None and hi.t.shape == gx.shape and hi.t.dtype == dt:
+                pool = torch.empty((n, L.load().srk_conv_pair_tiles(1, h, wd), cp), dtype=torch.float32, device=dev)
             conv_pair_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), pack_conv(w1, None, dt, dgrad=True, token=ctx.pg),
-                          out=gx, mask=y1, mid=g1, res=g, use_bias=False)
+                          out=gx, mask=y1, mid=g1, res=g, use_bias=False, pool=pool, pool_aux=None if pool is None else hi.t)
+            if pool is not None:
+                hi.gsum, hi.g_ptr, hi.g_ver = pool, gx.data_ptr(), gx._version
         else:
             conv_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1, use_bias=False)
         gw1, gb1 = wgrad(x, g1, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w1.shape[2],

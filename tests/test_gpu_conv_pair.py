@@ -73,6 +73,17 @@ def test_pair_is_bit_identical_to_two_launches(A, dt, form):
         A.ops.conv_pair_raw(x, pk1, pk2, out=out2, **kw)
         torch.cuda.synchronize()
         assert torch.equal(out2.view(torch.int16), out_ref.view(torch.int16)), (form, n, h, w, "out, no mid")
+        # channel-attention pooling of the output while it leaves: per-tile partial sums of out (* aux)
+        T = A._lib.load().srk_conv_pair_tiles(1, h, w)
+        for aux in (None, other):
+            pool = torch.full((n, T, 64), float("nan"), dtype=torch.float32, device=dev)
+            out3 = torch.empty_like(x)
+            A.ops.conv_pair_raw(x, pk1, pk2, out=out3, pool=pool, pool_aux=aux, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(out3.view(torch.int16), out_ref.view(torch.int16))
+            want = (out_ref.double() * (1.0 if aux is None else aux.double())).sum(dim=(1, 2))
+            got = pool.double().sum(1)
+            assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6, (form, n, h, w, aux is None)
 
 
 def test_pair_on_channel_slices_of_wider_tensors(A):
@@ -151,7 +162,12 @@ def test_blocks_take_the_pair_at_batch_16_and_agree_with_two_launches(A, kind, m
     assert len(calls) == 2, "one pair launch forward, one backward"
     yt, gxt, gt = _block_grads(A, make, x0, False)
     assert len(calls) == 2
-    assert torch.equal(yp, yt) and torch.equal(gxp, gxt)
+    if kind == "resblock":
+        assert torch.equal(yp, yt) and torch.equal(gxp, gxt)
+    else:       # the pair also pools t for the channel attention: another summation order, a few outputs move by one bf16 ulp
+        for a, b in ((yp, yt), (gxp, gxt)):
+            d = (a - b).abs()
+            assert float(d.max()) <= 2.0 ** -7 * float(b.abs().max()) and float((d > 0).float().mean()) < 0.02
     for a, b in zip(gp, gt):
         assert float((a.float() - b.float()).abs().max()) <= 1e-5 * float(b.float().abs().max()) + 1e-7
 
@@ -166,3 +182,78 @@ def test_pair_threshold_follows_tile_count(A):
     assert A._lib.load().srk_conv_pair_tiles(256, 48, 48) > 2 * cus and not A.ops.pair_ok(big, w, w)
     assert not A.ops.pair_ok(small.float(), w, w)
     assert not A.ops.pair_ok(small, torch.zeros(64, 64, 1, 1, device=dev), w)
+
+
+def test_rcab_chain_pools_inside_the_pair_launches(A, monkeypatch):
+    """Three RCABs in a row at 16 x 48 x 48: the forward pooling passes ride on the conv pairs, the backward ones (sum of
+    t * gradient) on the dgrad pair of the FOLLOWING block; only the last block, whose gradient comes from elsewhere, still
+    launches srk_ca_pool.  Results agree with the unfused path to bf16 rounding."""
+    dev = torch.device("cuda")
+    from sr_amd.models import common, rcan
+
+    def make():
+        m = torch.nn.Sequential(*[rcan.RCAB(common.DefaultConv2d, 64, 3, 16) for _ in range(3)]).to(dev)
+        return m
+
+    def run(paired):
+        prev = A.ops._PAIR_OFF
+        A.ops._PAIR_OFF = not paired
+        try:
+            torch.manual_seed(0)
+            m = make()
+            g = torch.Generator().manual_seed(4)
+            x = A.ops.nchw_to_nhwc(_rand(g, 16, 64, 48, 48, dt=torch.float32, dev=dev), torch.bfloat16).detach().requires_grad_(True)
+            y = x
+            for blk in m:
+                y = blk.nhwc(y)
+            (y.float() * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+            torch.cuda.synchronize()
+            return y.detach().float(), x.grad.float(), [p.grad.clone() for p in m.parameters()]
+        finally:
+            A.ops._PAIR_OFF = prev
+
+    calls = []
+    real = A._lib.call
+    monkeypatch.setattr(A._lib, "call", lambda name, *a, **k: (calls.append(name), real(name, *a, **k))[1])
+    yp, gxp, gp = run(True)
+    assert calls.count("srk_conv_pair") == 6 and calls.count("srk_ca_pool") == 1, calls
+    del calls[:]
+    yt, gxt, gt = run(False)
+    assert calls.count("srk_conv_pair") == 0 and calls.count("srk_ca_pool") == 6
+    for a, b in ((yp, yt), (gxp, gxt)):
+        d = (a - b).abs()
+        assert float(d.max()) <= 2.0 ** -6 * float(b.abs().max()) and float((d > 0).float().mean()) < 0.05
+    for a, b in zip(gp, gt):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6
+
+
+def test_rcab_hint_is_not_used_for_an_accumulated_gradient(A):
+    """The output of an RCAB consumed twice: autograd sums two gradients, the sums pooled from one of them do not apply."""
+    dev = torch.device("cuda")
+    from sr_amd.models import common, rcan
+    torch.manual_seed(1)
+    b1 = rcan.RCAB(common.DefaultConv2d, 64, 3, 16).to(dev)
+    b2 = rcan.RCAB(common.DefaultConv2d, 64, 3, 16).to(dev)
+    g = torch.Generator().manual_seed(8)
+    x0 = A.ops.nchw_to_nhwc(_rand(g, 4, 64, 20, 20, dt=torch.float32, dev=dev), torch.bfloat16).detach()
+
+    def run(paired):
+        prev = A.ops._PAIR_OFF
+        A.ops._PAIR_OFF = not paired
+        try:
+            for p in list(b1.parameters()) + list(b2.parameters()):
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y1 = b1.nhwc(x)
+            y2 = b2.nhwc(y1)
+            (y2.float().sum() + (y1.float() * 0.5).sum()).backward()        # y1 has two consumers
+            torch.cuda.synchronize()
+            return x.grad.float(), [p.grad.clone() for p in b1.parameters()]
+        finally:
+            A.ops._PAIR_OFF = prev
+
+    gxp, gp = run(True)
+    gxt, gt = run(False)
+    assert float((gxp - gxt).abs().max()) <= 2.0 ** -6 * float(gxt.abs().max())
+    for a, b in zip(gp, gt):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6
