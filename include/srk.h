@@ -276,6 +276,11 @@ typedef struct {
   int sums_rows, gsum_rows;             /* partial rows per sample in `sums` / `gsum`; 0 = srk_ca_splits(N, HW)          */
 } srk_ca_bwd_args;
 int srk_ca_bwd_apply(const srk_ca_bwd_args* a, srk_stream_t stream);
+/* dst[i] = sum over r < n of src[r*k + i] (row order: reproducible) for `njobs` entries of a DEVICE table in one launch: the
+ * sums over the batch of the per-sample slots srk_ca_bwd_apply writes, for every CALayer of a backward pass at once
+ * (replaces the conv_du weight / bias gradient reductions autograd performs per layer, models/rcan.py:10-29).        */
+typedef struct { const float* src; float* dst; int n; int k; } srk_rowsum_job;
+int srk_rowsum_group(const srk_rowsum_job* table_dev, int njobs, int max_k, srk_stream_t stream);
 
 /* ---- data step feeding the path ------------------------------------------------
  * _SRDataset._get_item / _get_patch in 'train' mode (srdata.py:64-91,137-169): crop an LR patch and the matching

@@ -46,6 +46,10 @@ class ConvPairArgs(C.Structure):
                 ("pool", _p), ("pool_aux", _p), ("pool_aux_pitch", _i), ("pool_aux_coff", _i)]
 
 
+class RowsumJob(C.Structure):
+    _fields_ = [("src", _p), ("dst", _p), ("n", _i), ("k", _i)]
+
+
 class AdamSlot(C.Structure):
     _fields_ = [("p", _p), ("g", _p), ("state_off", C.c_longlong), ("n", C.c_longlong), ("step_idx", C.c_longlong)]
 
@@ -179,7 +183,7 @@ LAUNCHERS = {
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
-                 "srk_conv_pair_tiles")
+                 "srk_conv_pair_tiles", "srk_rowsum_group")
 
 _lib = None
 
@@ -216,6 +220,8 @@ def load():
     lib.srk_conv2d_wgrad_group.restype = C.c_int
     lib.srk_wgrad_finalize_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.srk_wgrad_finalize_group.restype = C.c_int
+    lib.srk_rowsum_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.srk_rowsum_group.restype = C.c_int
     lib.srk_upload_small.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
     lib.srk_upload_small.restype = C.c_int
     lib.srk_chan_stats_blocks.argtypes = [C.c_longlong]

@@ -217,6 +217,18 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_bwd_kernel(const s
   }
 }
 
+// dst[i] = sum over rows r < n of src[r*k + i], for every job of a device table in one launch (blockIdx.y = job): the sums
+// over the batch of the per-sample parameter-gradient slots of all channel-attention layers of a backward pass
+__global__ __launch_bounds__(CA_NT) void rowsum_group_kernel(const srk_rowsum_job* __restrict__ table) {
+  const srk_rowsum_job j = table[blockIdx.y];
+  for (int i = blockIdx.x * CA_NT + threadIdx.x; i < j.k; i += gridDim.x * CA_NT) {
+    float u = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < j.n; ++r) u += j.src[(size_t)r * j.k + i];
+    j.dst[i] = u;
+  }
+}
+
 inline void split_for(int N, int HW, int* splits, int* ppb) {
   // aim at >= ~1024 blocks but at least 64 pixels per block
   int s = (1024 + N - 1) / N;
@@ -291,6 +303,15 @@ extern "C" int srk_ca_bwd_apply(const srk_ca_bwd_args* a, srk_stream_t stream) {
   int splits, ppb;
   split_for(a->N, a->HW, &splits, &ppb);
   CA_DISPATCH(ca_bwd_kernel, *a, dim3(a->N, splits), reinterpret_cast<hipStream_t>(stream), ppb);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_rowsum_group(const srk_rowsum_job* table_dev, int njobs, int max_k, srk_stream_t stream) {
+  SRK_CHECK_ARG(table_dev && njobs > 0 && njobs <= 65535 && max_k > 0, "srk_rowsum_group: bad table (%d jobs, k <= %d)", njobs, max_k);
+  int bx = (max_k + CA_NT - 1) / CA_NT;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(rowsum_group_kernel, dim3(bx, njobs), dim3(CA_NT), 0, reinterpret_cast<hipStream_t>(stream), table_dev);
   SRK_LAUNCH_CHECK();
   return 0;
 }

@@ -363,6 +363,7 @@ class _WgradQueue:
 
     def __init__(self):
         self.jobs = []          # dicts, see wgrad()
+        self.rjobs = []         # row-sum jobs (channel-attention parameter gradients), see defer_rowsum()
         self.armed = False      # somebody will flush (final callback queued, or inside hold_wgrads)
         self.enabled = True
         self.targets = {}       # address of a dw buffer -> number of jobs queued on it (weight sharing -> rounds)
@@ -419,21 +420,90 @@ def _grad_slot(p, shape):
     return None
 
 
-def _view_of(storage, shape, device):
-    return torch.empty(0, dtype=torch.float32, device=device).set_(storage, 0, tuple(shape))
+def _view_of(storage, shape, device, offset=0):
+    return torch.empty(0, dtype=torch.float32, device=device).set_(storage, int(offset), tuple(shape))
+
+
+def _arm_flush():
+    """Make sure somebody flushes the queues: the autograd engine's final callback of the running backward pass."""
+    if _WQ.armed:
+        return True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+    except RuntimeError:            # not inside a backward pass (a Function's backward called by hand)
+        return False
+    _WQ.armed = True
+    return True
+
+
+def _launch_rowsums(rjobs, st):
+    import ctypes as C
+    n = len(rjobs)
+    host = (L.RowsumJob * n)()
+    for i, j in enumerate(rjobs):
+        host[i].src, host[i].dst, host[i].n, host[i].k = j["src"].data_ptr(), j["dst"], j["n"], j["k"]
+    nbytes = C.sizeof(L.RowsumJob) * n
+    table = torch.empty(_roundup(nbytes, 16), dtype=torch.uint8, device=rjobs[0]["src"].device)
+    L.check(L.load().srk_upload_small(table.data_ptr(), C.addressof(host), nbytes, st), "srk_upload_small")
+    L.check(L.load().srk_rowsum_group(table.data_ptr(), n, max(j["k"] for j in rjobs), st), "srk_rowsum_group")
+
+
+def defer_rowsum(per, params, shapes_offsets):
+    """Sum `per` [n][K] over n into a fresh [K] buffer whose slices become the gradients of `params` -- deferred to the end of
+    the backward pass, where ONE launch serves every queued job (an RCAN backward has 200 of them).
+
+    shapes_offsets[i] = (shape, offset into the K floats) of parameter i's gradient.  Returns the list of gradient tensors
+    (views of the unfilled buffer, which autograd adopts as `.grad`), or None when deferral does not apply (a gradient
+    already exists and autograd would read the unfilled buffer, hooks, a second use of the parameters in this pass...)."""
+    if not _WQ.enabled or per.shape[0] == 0:
+        return None
+    for p, (shape, _) in zip(params, shapes_offsets):
+        sl = _grad_slot(p, shape)
+        if sl is None or sl[0] != "new" or p is None:
+            return None
+        seen = p.__dict__.get("_srk_pending_rs")
+        if seen is not None and seen == _WQ.gen:
+            # used twice in this pass: autograd will ADD this gradient to the (still unfilled) one queued earlier, right
+            # after this backward returns -- fill the queued ones now (stream order puts the sums in front of that add)
+            rj, _WQ.rjobs = _WQ.rjobs, []
+            if rj:
+                with torch.cuda.stream(_WQ.stream):
+                    _launch_rowsums(rj, _WQ.stream.cuda_stream)
+            return None
+    if not _arm_flush():
+        return None
+    n, k = per.shape
+    tot = torch.empty(k, dtype=torch.float32, device=per.device)
+    stg = tot.untyped_storage()
+    outs, new = [], []
+    for p, (shape, off) in zip(params, shapes_offsets):
+        numel = 1
+        for d in shape:
+            numel *= d
+        v = tot[off:off + numel].view(shape)
+        new.append((p, v.data_ptr(), stg, tuple(shape), off))
+        p.__dict__["_srk_pending_rs"] = _WQ.gen
+        outs.append(v)
+    _WQ.rjobs.append(dict(src=per, dst=tot.data_ptr(), n=int(n), k=int(k), keep=[per, stg], new=new))
+    _WQ.stream = torch.cuda.current_stream()
+    del tot
+    return outs
 
 
 def flush_wgrads():
     """Launch every queued weight gradient: ONE grouped slab kernel per dtype and ONE grouped finalize per round."""
     import ctypes as C
     jobs, _WQ.jobs, _WQ.armed, _WQ.targets = _WQ.jobs, [], False, {}
+    rjobs, _WQ.rjobs = _WQ.rjobs, []
     _WQ.gen += 1
-    if not jobs:
+    if not jobs and not rjobs:
         return
     lib = L.load()
     stream = _WQ.stream if _WQ.stream is not None else torch.cuda.current_stream()
     with torch.cuda.stream(stream):         # the flush may run on another thread than the backward nodes: same stream
         st = stream.cuda_stream
+        if rjobs:
+            _launch_rowsums(rjobs, st)
         for dt in sorted({j["a"].dtype for j in jobs}):
             grp = [j for j in jobs if j["a"].dtype == dt]
             n = len(grp)
@@ -472,11 +542,12 @@ def flush_wgrads():
         # a gradient autograd COPIED instead of adopting (create_graph, layout contract) holds the bytes of the then
         # unfilled buffer: refresh it from the filled one.  ('new' jobs only: .grad was None, so the copy is all it holds)
         with torch.no_grad():
-            for j in jobs:
-                for p, ptr, stg, shape in j["new"]:
+            for j in jobs + rjobs:
+                for ent in j["new"]:
+                    p, ptr, stg, shape = ent[:4]
                     g = p.grad if p is not None else None
                     if g is not None and g.data_ptr() != ptr and tuple(g.shape) == tuple(shape):
-                        g.copy_(_view_of(stg, shape, g.device))
+                        g.copy_(_view_of(stg, shape, g.device, ent[4] if len(ent) > 4 else 0))
     # `table`, `scratch`, operands and result storages are referenced by enqueued work only from here on: the caching
     # allocator re-issues a freed block on this stream behind these launches
 
@@ -531,12 +602,8 @@ def wgrad(x, dy, *, wparam=None, bparam=None, **kw):
     _WQ.jobs.append(dict(a=a, dw=dw_ptr, db=db_ptr, Cout=cout, Cin=cin, ps_r=int(kw.get("ps_r", 0)), scale=float(kw.get("scale", 1.0)),
                          acc=acc, round=rnd, keep=keep, new=new))
     _WQ.stream = torch.cuda.current_stream()
-    if not _WQ.armed:
-        _WQ.armed = True
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
-        except RuntimeError:            # not inside a backward pass (a Function's backward called by hand)
-            flush_wgrads()
+    if not _arm_flush():                # not inside a backward pass (a Function's backward called by hand)
+        flush_wgrads()
     return ret_w, ret_b
 
 
@@ -941,6 +1008,7 @@ class RCABFn(torch.autograd.Function):
             N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt], sums_rows=ns), _stream())
         ctx.save_for_backward(x, y1, t, sums, s, z, w1, w2, cw1, cw2)
         ctx.wb = (w1, b1, w2, b2)
+        ctx.ca = (cw1, cb1, cw2, cb2)
         ctx.pg = _tok()
         global _LAST_CA_HINT
         prev, ctx.hint_in, ctx.hint_out = _LAST_CA_HINT, None, None
@@ -1003,8 +1071,15 @@ class RCABFn(torch.autograd.Function):
                          w_shape=tuple(w1.shape), want_bias=ctx.wb[1] is not None)
         if not paired:
             conv_raw(g1, pack_conv(w1, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=gx, res=g, use_bias=False)
-        # (summing the slots inside the launch -- last block by ticket -- was measured: the device-scope release it needs
-        # writes back the L2 of every XCD and costs what this reduction launch costs)
+        # The sum of the slots over n.  No padding channels (C == Cp): deferred, ONE launch at the end of the backward pass
+        # sums the slots of every RCAB (ops.defer_rowsum).  (Summing inside this launch -- last block by ticket -- was
+        # measured: the device-scope release it needs writes back the L2 of every XCD and costs what a reduction launch costs.)
+        if c == cp:
+            o1, o2, o3 = cr * cp, cr * cp + cr, 2 * cr * cp + cr
+            outs = defer_rowsum(per, (ctx.ca[0], ctx.ca[1], ctx.ca[2], ctx.ca[3]),
+                                (((cr, c, 1, 1), 0), ((cr,), o1), ((c, cr, 1, 1), o2), ((c,), o3)))
+            if outs is not None:
+                return (gx, gw1, gb1, gw2, gb2, *outs)
         tot = per.sum(0)
         dw1, db1 = tot[:cr * cp], tot[cr * cp:cr * cp + cr]
         dw2, db2 = tot[cr * cp + cr:2 * cr * cp + cr], tot[2 * cr * cp + cr:]

@@ -153,3 +153,69 @@ def test_upload_small_roundtrip(A):
         assert rc == 0
         torch.cuda.synchronize()
         assert torch.equal(dst[:n].cpu(), src) and int(dst[n:].sum()) == 0
+
+
+def test_channel_attention_gradients_are_summed_by_one_deferred_launch(A, monkeypatch):
+    """RCAB backward: the per-sample slots of the conv_du gradients of every block are summed over the batch by ONE
+    srk_rowsum_group launch when the pass ends; a second pass accumulates into the existing .grad through autograd
+    (immediate sums), and a module applied twice in one pass is handled."""
+    dev = torch.device("cuda")
+    from sr_amd.models import common, rcan
+    torch.manual_seed(3)
+    blocks = [rcan.RCAB(common.DefaultConv2d, 64, 3, 16).to(dev) for _ in range(3)]
+    g = torch.Generator().manual_seed(12)
+    x0 = (torch.rand(8, 40, 40, 64, generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    names = []
+    real = A._lib.load().srk_rowsum_group
+
+    def run(order):
+        x = x0.clone().requires_grad_(True)
+        y = x
+        for i in order:
+            y = blocks[i].nhwc(y)
+        y.float().square().sum().backward()
+        torch.cuda.synchronize()
+
+    def ca_grads():
+        return [p.grad.clone() for b in blocks for p in b.body[3].parameters()]
+
+    calls = []
+    lib = A._lib.load()
+    monkeypatch.setattr(A.ops, "_launch_rowsums", (lambda f: (lambda rj, st: (calls.append(len(rj)), f(rj, st))[1]))(A.ops._launch_rowsums))
+    run([0, 1, 2])
+    assert calls == [3], "one launch for the three blocks"
+    g1 = ca_grads()
+    prev = A.ops.set_defer_wgrad(False)
+    try:
+        for b in blocks:
+            b.zero_grad(set_to_none=True)
+        run([0, 1, 2])
+    finally:
+        A.ops.set_defer_wgrad(prev)
+    g0 = ca_grads()
+    for a, b in zip(g1, g0):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
+    # second pass on top of existing gradients: accumulated, twice the value
+    del calls[:]
+    for b in blocks:
+        for p in b.body[3].parameters():
+            p.grad = None
+    run([0, 1, 2])
+    run([0, 1, 2])
+    assert calls == [3], "the second pass finds gradients in place and sums immediately"
+    for a, b in zip(ca_grads(), g1):
+        assert float((a - 2 * b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
+    # a block applied twice in one pass
+    for b in blocks:
+        b.zero_grad(set_to_none=True)
+    run([0, 0])
+    ga = [p.grad.clone() for p in blocks[0].body[3].parameters()]
+    prev = A.ops.set_defer_wgrad(False)
+    try:
+        for b in blocks:
+            b.zero_grad(set_to_none=True)
+        run([0, 0])
+    finally:
+        A.ops.set_defer_wgrad(prev)
+    for a, b in zip(ga, [p.grad for p in blocks[0].body[3].parameters()]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7

@@ -43,7 +43,7 @@ def _header_struct_fields(name):
         if not stmt:
             continue
         # "const void* x" / "int x_pitch, x_coff" / "float scale"
-        m = re.match(r"(const\s+)?(void|float|int|double|long long|signed char|uint8_t|srk_patch_desc)\s*(\*?)\s*(.*)", stmt)
+        m = re.match(r"(const\s+)?(void|float|int|double|long long|signed char|uint8_t|unsigned int|srk_patch_desc|srk_adam_slot|srk_adam_block)\s*(\*?)\s*(.*)", stmt)
         base, ptr, rest = m.group(2), m.group(3), m.group(4)
         base = {"long long": "q"}.get(base, base)
         for nm in rest.split(","):
@@ -60,7 +60,9 @@ def _header_struct_fields(name):
                                         ("srk_ca_bwd_args", "CaBwdArgs"), ("srk_patch_desc", "PatchDesc"), ("srk_patch_args", "PatchArgs"),
                                         ("srk_sse_args", "SseArgs"), ("srk_ssim_args", "SsimArgs"), ("srk_l1_args", "L1Args"),
                                         ("srk_unfold_nhwc_args", "UnfoldNhwcArgs"), ("srk_fold_nhwc_args", "FoldNhwcArgs"),
-                                        ("srk_chan_stats_args", "ChanStatsArgs"), ("srk_chan_apply_args", "ChanApplyArgs")])
+                                        ("srk_chan_stats_args", "ChanStatsArgs"), ("srk_chan_apply_args", "ChanApplyArgs"),
+                                        ("srk_conv_pair_args", "ConvPairArgs"), ("srk_adam_slot", "AdamSlot"),
+                                        ("srk_adam_block", "AdamBlock"), ("srk_adam_args", "AdamArgs"), ("srk_rowsum_job", "RowsumJob")])
 def test_ctypes_structs_mirror_header(cname, cls):
     want = _header_struct_fields(cname)
     st = getattr(sr_amd._lib, cls)
