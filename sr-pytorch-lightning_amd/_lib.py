@@ -43,7 +43,10 @@ class ConvPairArgs(C.Structure):
                 ("scale_out", _f),
                 ("res", _p), ("res_pitch", _i), ("res_coff", _i), ("res_from_x", _i),
                 ("out", _p), ("out_pitch", _i), ("out_coff", _i), ("dtype", _i),
-                ("pool", _p), ("pool_aux", _p), ("pool_aux_pitch", _i), ("pool_aux_coff", _i)]
+                ("pool", _p), ("pool_aux", _p), ("pool_aux_pitch", _i), ("pool_aux_coff", _i),
+                ("ca_mode", _i), ("ca_cr", _i), ("ca_gsum", _p), ("ca_gsum_rows", _i), ("ca_sums", _p), ("ca_sums_rows", _i),
+                ("ca_s", _p), ("ca_z", _p), ("ca_w1", _p), ("ca_w2", _p), ("ca_slots", _p),
+                ("xo", _p), ("xo_pitch", _i), ("xo_coff", _i)]
 
 
 class RowsumJob(C.Structure):

@@ -87,19 +87,22 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   const unsigned xs_lds = lds_addr_of(Xs), wr_lds = lds_addr_of(Wr);
 
   // ---- prologue: input tile + slabs a0 a1 a2 ---------------------------------------------------------------------------
+  const bool ca = a.ca_mode != 0;                          // the input is transformed on its way in (below): not by DMA
+  if (!ca) {
 #pragma unroll
-  for (int k = 0; k < C::XK; ++k) {
-    const int i = tid + k * C::NT;
-    if (k * C::NT + wave * 64 < C::XPIECES) {             // wave-uniform
-      const int sl = i & 7, p = i >> 3;
-      const int iy = p / C::XT, ix = p - iy * C::XT;
-      const int c = sl ^ swz(ix);
-      const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
-      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * Tr::CH) * (int)sizeof(elem)) : 0x80000000u;
-      // the last 1 KB piece is half tile: its upper lanes are switched off (EXEC), they would land on the intermediate tile
-      if (i < C::XPIECES)
-        dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + ((k * C::NT + wave * 64) << 4))));
+    for (int k = 0; k < C::XK; ++k) {
+      const int i = tid + k * C::NT;
+      if (k * C::NT + wave * 64 < C::XPIECES) {             // wave-uniform
+        const int sl = i & 7, p = i >> 3;
+        const int iy = p / C::XT, ix = p - iy * C::XT;
+        const int c = sl ^ swz(ix);
+        const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
+        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * Tr::CH) * (int)sizeof(elem)) : 0x80000000u;
+        // the last 1 KB piece is half tile: its upper lanes are switched off (EXEC), they would land on the intermediate tile
+        if (i < C::XPIECES)
+          dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + ((k * C::NT + wave * 64) << 4))));
+      }
     }
   }
   // slab g (0..5): taps 3*(g%3)..+2 of conv (g/3); 24 pieces of 1 KB, 3 per wave; a straight copy of the packed layout
@@ -119,6 +122,103 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   dma_slab(1);
   dma_slab(2);
   SRK_PSTAMP(2);
+
+  // ---- channel attention on the way in (RCAN at small batches; ca_mode 1 = backward of CALayer, models/rcan.py:10-29) -------
+  // x' = x * s[n][c] + dmean[n][c] (zero outside the image), s and dmean from the squeeze/excite MLP's backward on this
+  // sample's pooled vectors -- what srk_ca_bwd_apply computes as its own launch, with the same arithmetic in the same order.
+  // The input comes through registers (coalesced 16-byte pieces, requested before the MLP so that it hides their latency),
+  // x' goes to the LDS tile and, for this workgroup's 14x14, to `xo` (the weight gradient of conv 2 reads it).
+  if (ca) {
+    __shared__ float cred[256], cA[64], cB[64], cmean[64], cd2[64], cz[32], cd1[32];
+    u32x4_t xin[C::XK];
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x);
+#pragma unroll
+    for (int k = 0; k < C::XK; ++k) {
+      const int i = tid + k * C::NT;
+      const int sl = i & 7, p = i >> 3;
+      const int iy = p / C::XT, ix = p - iy * C::XT;
+      const int c = sl ^ swz(ix);
+      const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
+      const bool ok = i < C::XPIECES && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * Tr::CH) * 2) : 0x80000000u;
+      xin[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
+    }
+    const int Cr = a.ca_cr;
+    const float invHW = 1.f / (float)(H * W);
+    // sums of the per-block partials, the way srk_ca_*'s ca_sum_partials forms them: four strided partial sums per channel
+    auto partials = [&](const float* src, int rows, float scale, float* out) {
+      if (tid < 256) {
+        const int q = tid >> 6, c = tid & 63;
+        float t = 0.f;
+        const float* pp = src + (size_t)n * rows * 64 + c;
+#pragma unroll 4
+        for (int sp = q; sp < rows; sp += 4) t += pp[(size_t)sp * 64];
+        cred[tid] = t;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float u = 0.f;
+        for (int k = 0; k < 4; ++k) u += cred[k * 64 + tid];
+        out[tid] = u * scale;
+      }
+      __syncthreads();
+    };
+    partials(a.ca_gsum, a.ca_gsum_rows, 1.f, cd2);
+    const bool slot_owner = tX == 0 && tY == 0;             // one workgroup per sample writes the parameter-gradient slot
+    if (slot_owner) partials(a.ca_sums, a.ca_sums_rows, invHW, cmean);
+    if (tid < 64) {
+      const float sg = a.ca_s[(size_t)n * 64 + tid];
+      cA[tid] = sg;
+      cd2[tid] *= sg * (1.f - sg);
+    }
+    if (tid < Cr) cz[tid] = a.ca_z[(size_t)n * Cr + tid];
+    __syncthreads();
+    if (tid < Cr) {
+      float dz = 0.f;
+      for (int c = 0; c < 64; ++c) dz += a.ca_w2[c * Cr + tid] * cd2[c];
+      cd1[tid] = cz[tid] > 0.f ? dz : 0.f;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float dm = 0.f;
+      for (int j = 0; j < Cr; ++j) dm += a.ca_w1[j * 64 + tid] * cd1[j];
+      cB[tid] = dm / (float)(H * W);
+    }
+    __syncthreads();
+    if (slot_owner && a.ca_slots) {
+      float* const sl0 = a.ca_slots + (size_t)n * (2 * 64 * Cr + Cr + 64);      // [dW1 | db1 | dW2 | db2]
+      float* const dw1 = sl0, *const db1 = sl0 + 64 * Cr, *const dw2 = db1 + Cr, *const db2 = dw2 + 64 * Cr;
+      for (int i = tid; i < 64 * Cr; i += C::NT) {
+        dw2[i] = cd2[i / Cr] * cz[i % Cr];
+        dw1[i] = cd1[i / 64] * cmean[i % 64];
+      }
+      if (tid < 64) db2[tid] = cd2[tid];
+      if (tid < Cr) db1[tid] = cd1[tid];
+    }
+#pragma unroll
+    for (int k = 0; k < C::XK; ++k) {
+      const int i = tid + k * C::NT;
+      if (i < C::XPIECES) {
+        const int sl = i & 7, p = i >> 3;
+        const int iy = p / C::XT, ix = p - iy * C::XT;
+        const int c = sl ^ swz(ix);
+        const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
+        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const uint32_t w4[4] = {xin[k].x, xin[k].y, xin[k].z, xin[k].w};
+        uint32_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v0, v1;
+          unpack2<DT>(w4[e], v0, v1);
+          v0 = v0 * cA[8 * c + 2 * e] + cB[8 * c + 2 * e];
+          v1 = v1 * cA[8 * c + 2 * e + 1] + cB[8 * c + 2 * e + 1];
+          o4[e] = ok ? pack2<DT>(v0, v1) : 0u;
+        }
+        lds_write16(Xs + (i << 4), i32x4{(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]});
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
 
   // ---- per-lane constants -----------------------------------------------------------------------------------------------
   // Waves 0..3 compute (one per SIMD), each a 64-channel x 64-pixel tile = pixel blocks 2w, 2w+1 (tile rows 4w .. 4w+3):
@@ -236,6 +336,21 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   } else {
     hand1();
     hand2();
+    // transformed input: this workgroup's 14x14 to HBM, whole 128-byte pixels (the input tile stays until conv 1 is done)
+    if (ca && a.xo) {
+      const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.xo);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int i = (tid - 256) + 256 * k;
+        const int p = i >> 3, c = i & 7;
+        const int row = p / C::TO, col = p - row * C::TO;
+        const int gy = y0 + row, gx = x0 + col;
+        const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
+        const i32x4 q = lds_read16(Xs + (((row + 2) * C::XP + col + 2) << 7) + ((c ^ swz(col + 2)) << 4));
+        const unsigned vo = ok ? (unsigned)((((n * H + gy) * W + gx) * a.xo_pitch + a.xo_coff + c * Tr::CH) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
+      }
+    }
   }
 
   SRK_PSTAMP(6);
@@ -473,6 +588,14 @@ extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(!a->pool_aux || (a->pool && a->pool_aux_pitch % 8 == 0 && a->pool_aux_coff % 8 == 0), "srk_conv_pair: pool_aux needs pool and 16-byte alignment");
   SRK_CHECK_ARG(!a->res_from_x || (a->res == a->x && a->res_pitch == a->x_pitch && a->res_coff == a->x_coff),
                 "srk_conv_pair: res_from_x needs res to BE x");
+  SRK_CHECK_ARG(a->ca_mode == 0 || a->ca_mode == 1, "srk_conv_pair: ca_mode %d", a->ca_mode);
+  if (a->ca_mode) {
+    SRK_CHECK_ARG(!a->res_from_x, "srk_conv_pair: the LDS input tile is transformed in ca_mode, a residual comes from memory");
+    SRK_CHECK_ARG(a->ca_gsum && a->ca_sums && a->ca_s && a->ca_z && a->ca_w1 && a->ca_w2 && a->ca_gsum_rows > 0 && a->ca_sums_rows > 0,
+                  "srk_conv_pair: ca_mode 1 needs gsum, sums, s, z, w1, w2");
+    SRK_CHECK_ARG(a->ca_cr > 0 && a->ca_cr <= 32, "srk_conv_pair: ca_cr=%d", a->ca_cr);
+    SRK_CHECK_ARG(!a->xo || (a->xo_pitch % 8 == 0 && a->xo_coff % 8 == 0), "srk_conv_pair: alignment of xo");
+  }
   const long long px = (long long)a->N * a->H * a->W;
   long long mx = px * a->x_pitch;
   if (px * a->out_pitch > mx) mx = px * a->out_pitch;
@@ -480,6 +603,7 @@ extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
   if (a->mask && px * a->mask_pitch > mx) mx = px * a->mask_pitch;
   if (a->res && px * a->res_pitch > mx) mx = px * a->res_pitch;
   if (a->pool_aux && px * a->pool_aux_pitch > mx) mx = px * a->pool_aux_pitch;
+  if (a->ca_mode && a->xo && px * a->xo_pitch > mx) mx = px * a->xo_pitch;
   SRK_CHECK_ARG(mx * 2 < 0x7fff0000LL, "srk_conv_pair: tensors of 2 GiB and more are not supported (small-batch kernel)");
   typedef PairCfg C;
   static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<SRK_BF16>),

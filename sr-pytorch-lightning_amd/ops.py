@@ -273,6 +273,7 @@ def conv_raw(x, pk, *, N, H, W, Cin, Cout, out, out_mode=L.OUT_NHWC, ps_r=0, rel
 
 
 _PAIR_OFF = os.environ.get("SRK_NO_PAIR", "0") == "1"
+_CA_UNFUSED = os.environ.get("SRK_CA_UNFUSED", "0") == "1"      # A/B knob: the CALayer backward as its own launch
 _PAIR_MAX_TILES = int(os.environ.get("SRK_PAIR_MAX_TILES", "0"))
 
 
@@ -292,11 +293,12 @@ def pair_ok(x, w1, w2):
 
 
 def conv_pair_raw(x, pk1, pk2, *, out, relu_mid=False, scale_mid=1.0, mask=None, mid=None, scale_out=1.0, res=None,
-                  use_bias=True, pool=None, pool_aux=None):
+                  use_bias=True, pool=None, pool_aux=None, ca_bwd=None, xo=None):
     """One srk_conv_pair launch: out = (conv(epi(conv(x, pk1)), pk2)) * scale_out + res (include/srk.h)."""
     _need_gpu(x)
     n, h, wd, _ = x.shape
-    from_x = res is not None and res.data_ptr() == x.data_ptr() and _pitch(res) == _pitch(x)
+    from_x = res is not None and res.data_ptr() == x.data_ptr() and _pitch(res) == _pitch(x) and ca_bwd is None
+    ca = ca_bwd or {}                   # gsum, sums, s, z, w1, w2 (fp32 tensors), slots: the CALayer backward on the way in
     a = L.ConvPairArgs(
         x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, N=n, H=h, W=wd,
         w1=pk1.wpk.data_ptr(), b1=_ptr(pk1.bias) if use_bias else 0, w2=pk2.wpk.data_ptr(), b2=_ptr(pk2.bias) if use_bias else 0,
@@ -306,7 +308,12 @@ def conv_pair_raw(x, pk1, pk2, *, out, relu_mid=False, scale_mid=1.0, mask=None,
         scale_out=float(scale_out),
         res=_ptr(res), res_pitch=0 if res is None else _pitch(res), res_coff=0, res_from_x=int(from_x),
         out=out.data_ptr(), out_pitch=_pitch(out), out_coff=0, dtype=_DT[x.dtype],
-        pool=_ptr(pool), pool_aux=_ptr(pool_aux), pool_aux_pitch=0 if pool_aux is None else _pitch(pool_aux), pool_aux_coff=0)
+        pool=_ptr(pool), pool_aux=_ptr(pool_aux), pool_aux_pitch=0 if pool_aux is None else _pitch(pool_aux), pool_aux_coff=0,
+        ca_mode=1 if ca_bwd is not None else 0, ca_cr=ca["z"].shape[1] if ca else 0,
+        ca_gsum=_ptr(ca.get("gsum")), ca_gsum_rows=ca["gsum"].shape[1] if ca else 0,
+        ca_sums=_ptr(ca.get("sums")), ca_sums_rows=ca["sums"].shape[1] if ca else 0,
+        ca_s=_ptr(ca.get("s")), ca_z=_ptr(ca.get("z")), ca_w1=_ptr(ca.get("w1")), ca_w2=_ptr(ca.get("w2")), ca_slots=_ptr(ca.get("slots")),
+        xo=_ptr(xo), xo_pitch=0 if xo is None else _pitch(xo), xo_coff=0)
     L.call("srk_conv_pair", a, _stream())
     return out
 
@@ -1046,27 +1053,32 @@ class RCABFn(torch.autograd.Function):
         dw1, db1 = per[0, :cr * cp], per[0, cr * cp:cr * cp + cr]
         dw2, db2 = per[0, cr * cp + cr:2 * cr * cp + cr], per[0, 2 * cr * cp + cr:]
         gt = torch.empty_like(x)
-        L.call("srk_ca_bwd_apply", L.CaBwdArgs(
-            g=g.data_ptr(), g_pitch=_pitch(g), g_coff=0, gsum=gsum.data_ptr(), sums=sums.data_ptr(), s=s.data_ptr(),
-            z=z.data_ptr(), w1=w1f.data_ptr(), w2=w2f.data_ptr(), dw1=dw1.data_ptr(), db1=db1.data_ptr(),
-            dw2=dw2.data_ptr(), db2=db2.data_ptr(), gt=gt.data_ptr(), gt_pitch=cp, gt_coff=0,
-            N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt], sums_rows=sums.shape[1], gsum_rows=gs_rows), _stream())
-        gw2, gb2 = wgrad(y1, gt, wparam=ctx.wb[2], bparam=ctx.wb[3], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w2.shape[2],
-                         w_shape=tuple(w2.shape), want_bias=ctx.wb[3] is not None)
+        paired = pair_ok(g, w1, w2) and cp == 64 and not _CA_UNFUSED
+        if not paired:
+            L.call("srk_ca_bwd_apply", L.CaBwdArgs(
+                g=g.data_ptr(), g_pitch=_pitch(g), g_coff=0, gsum=gsum.data_ptr(), sums=sums.data_ptr(), s=s.data_ptr(),
+                z=z.data_ptr(), w1=w1f.data_ptr(), w2=w2f.data_ptr(), dw1=dw1.data_ptr(), db1=db1.data_ptr(),
+                dw2=dw2.data_ptr(), db2=db2.data_ptr(), gt=gt.data_ptr(), gt_pitch=cp, gt_coff=0,
+                N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt], sums_rows=sums.shape[1], gsum_rows=gs_rows), _stream())
         g1 = torch.empty_like(x)
         gx = torch.empty_like(x)
-        paired = pair_ok(gt, w1, w2)
         if paired:
+            # ONE launch: the CALayer backward on the way in (gt = g*s + dmean, parameter-gradient slots), dgrad of conv 2
+            # with the ReLU mask, dgrad of conv 1, + g; gt and g1 are stored for the two weight gradients.  If the previous
+            # RCAB left its t, the launch also pools t * gx for that block's backward.
             hi = ctx.hint_in
             pool = None
             if hi is not None and hi.t.shape == gx.shape and hi.t.dtype == dt:
                 pool = torch.empty((n, L.load().srk_conv_pair_tiles(1, h, wd), cp), dtype=torch.float32, device=dev)
-            conv_pair_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), pack_conv(w1, None, dt, dgrad=True, token=ctx.pg),
-                          out=gx, mask=y1, mid=g1, res=g, use_bias=False, pool=pool, pool_aux=None if pool is None else hi.t)
+            conv_pair_raw(g, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), pack_conv(w1, None, dt, dgrad=True, token=ctx.pg),
+                          out=gx, mask=y1, mid=g1, res=g, use_bias=False, pool=pool, pool_aux=None if pool is None else hi.t,
+                          ca_bwd=dict(gsum=gsum, sums=sums, s=s, z=z, w1=w1f, w2=w2f, slots=per), xo=gt)
             if pool is not None:
                 hi.gsum, hi.g_ptr, hi.g_ver = pool, gx.data_ptr(), gx._version
         else:
             conv_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1, use_bias=False)
+        gw2, gb2 = wgrad(y1, gt, wparam=ctx.wb[2], bparam=ctx.wb[3], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w2.shape[2],
+                         w_shape=tuple(w2.shape), want_bias=ctx.wb[3] is not None)
         gw1, gb1 = wgrad(x, g1, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w1.shape[2],
                          w_shape=tuple(w1.shape), want_bias=ctx.wb[1] is not None)
         if not paired:

@@ -257,3 +257,49 @@ def test_rcab_hint_is_not_used_for_an_accumulated_gradient(A):
     assert float((gxp - gxt).abs().max()) <= 2.0 ** -6 * float(gxt.abs().max())
     for a, b in zip(gp, gt):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(16, 48, 48), (3, 20, 33), (2, 14, 14)])
+def test_ca_backward_on_the_way_in_matches_its_own_launch(A, dt, shape):
+    """ca_mode 1: srk_conv_pair applies the CALayer backward (models/rcan.py:10-29) to its input while loading it.  The
+    transformed input gt, the per-sample parameter-gradient slots, the intermediate and the output must be BIT-identical to
+    srk_ca_bwd_apply followed by the plain pair."""
+    dev = torch.device("cuda")
+    n, h, w = shape
+    cr = 4
+    g = torch.Generator().manual_seed(21)
+    gin = _rand(g, n, h, w, 64, dt=dt, dev=dev)
+    y1 = torch.relu(_rand(g, n, h, w, 64, dt=dt, dev=dev))
+    rows_g, rows_s = 5, A._lib.load().srk_ca_splits(n, h * w)
+    gsum = (torch.rand(n, rows_g, 64, generator=g) - 0.5).to(dev)
+    sums = (torch.rand(n, rows_s, 64, generator=g) * (h * w / rows_s)).to(dev)
+    sg = torch.sigmoid(torch.rand(n, 64, generator=g) * 4 - 2).to(dev)
+    z = torch.relu(torch.rand(n, cr, generator=g) - 0.3).to(dev)
+    w1f = ((torch.rand(cr, 64, generator=g) - 0.5) * 0.5).to(dev)
+    w2f = ((torch.rand(64, cr, generator=g) - 0.5) * 0.5).to(dev)
+    wa = torch.nn.Parameter((torch.rand(64, 64, 3, 3, generator=g) - 0.5).mul(0.1).to(dev))
+    wb = torch.nn.Parameter((torch.rand(64, 64, 3, 3, generator=g) - 0.5).mul(0.1).to(dev))
+    pka, pkb = A.ops.pack_conv(wa, None, dt, dgrad=True), A.ops.pack_conv(wb, None, dt, dgrad=True)
+    K = 2 * 64 * cr + cr + 64
+    L = A._lib
+    # reference: its own launch, then the plain pair
+    per_ref = torch.full((n, K), float("nan"), device=dev)
+    gt_ref = torch.empty_like(gin)
+    L.call("srk_ca_bwd_apply", L.CaBwdArgs(
+        g=gin.data_ptr(), g_pitch=64, g_coff=0, gsum=gsum.data_ptr(), sums=sums.data_ptr(), s=sg.data_ptr(), z=z.data_ptr(),
+        w1=w1f.data_ptr(), w2=w2f.data_ptr(), dw1=per_ref[0, :64 * cr].data_ptr(), db1=per_ref[0, 64 * cr:].data_ptr(),
+        dw2=per_ref[0, 64 * cr + cr:].data_ptr(), db2=per_ref[0, 2 * 64 * cr + cr:].data_ptr(), gt=gt_ref.data_ptr(), gt_pitch=64, gt_coff=0,
+        N=n, HW=h * w, C=64, Cr=cr, dtype=A.ops._DT[dt], sums_rows=rows_s, gsum_rows=rows_g), torch.cuda.current_stream().cuda_stream)
+    mid_ref, out_ref = torch.empty_like(gin), torch.empty_like(gin)
+    A.ops.conv_pair_raw(gt_ref, pka, pkb, out=out_ref, mask=y1, mid=mid_ref, res=gin, use_bias=False)
+    # fused
+    per = torch.full((n, K), float("nan"), device=dev)
+    gt, mid, out = (torch.full_like(gin, float("nan")) for _ in range(3))
+    A.ops.conv_pair_raw(gin, pka, pkb, out=out, mask=y1, mid=mid, res=gin, use_bias=False,
+                        ca_bwd=dict(gsum=gsum, sums=sums, s=sg, z=z, w1=w1f, w2=w2f, slots=per), xo=gt)
+    torch.cuda.synchronize()
+    assert torch.equal(gt.view(torch.int16), gt_ref.view(torch.int16)), "gt"
+    assert torch.equal(per, per_ref), "parameter-gradient slots"
+    assert torch.equal(mid.view(torch.int16), mid_ref.view(torch.int16)), "intermediate"
+    assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)), "output"
