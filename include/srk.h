@@ -136,18 +136,21 @@ typedef struct {
    * T = srk_conv_pair_tiles(1, H, W) partial rows per sample (srk_ca_apply / srk_ca_bwd_apply take them via sums_rows /
    * gsum_rows), summed in a fixed order over the stored (rounded) values                                              */
   float* pool; const void* pool_aux; int pool_aux_pitch, pool_aux_coff;
-  /* optional backward of the channel attention applied to the INPUT while it is loaded (ca_mode 1; 0 = off): what
-   * srk_ca_bwd_apply does as its own launch, same arithmetic and order.  x' = x * s[n][c] + dmean[n][c] (zero outside the
-   * image) feeds conv 1; s, dmean come from the MLP backward on this sample's (ca_gsum [N][ca_gsum_rows][64], ca_sums
-   * [N][ca_sums_rows][64], ca_s [N][64], ca_z [N][ca_cr], ca_w1 [ca_cr][64], ca_w2 [64][ca_cr]).  ca_slots (nullable)
-   * receives the per-sample parameter-gradient slots [dW1 | db1 | dW2 | db2] of srk_ca_bwd_apply (2*64*ca_cr + ca_cr + 64
-   * floats per sample, written by one workgroup per sample); xo (nullable) receives x'.  A residual must come from memory
-   * (res_from_x = 0).                                                                                                      */
+  /* optional channel-attention step applied to the INPUT while it is loaded (0 = off); x' feeds conv 1 and goes to xo
+   * (nullable); a residual must then come from memory (res_from_x = 0).  Same arithmetic and order as the stand-alone launches.
+   * ca_mode 1 = srk_ca_bwd_apply: x' = x * s[n][c] + dmean[n][c] (zero outside the image), s / dmean from the MLP backward on
+   *   this sample's (ca_gsum [N][ca_gsum_rows][64], ca_sums [N][ca_sums_rows][64], ca_s [N][64], ca_z [N][ca_cr], ca_w1
+   *   [ca_cr][64], ca_w2 [64][ca_cr]); ca_slots (nullable): the per-sample parameter-gradient slots [dW1 | db1 | dW2 | db2]
+   *   (2*64*ca_cr + ca_cr + 64 floats per sample, written by one workgroup per sample).
+   * ca_mode 2 = srk_ca_apply of the PREVIOUS block: x' = x * s[n][c] + ca_x2 with s = sigmoid(W2 relu(W1 mean + b1) + b2), mean
+   *   from ca_sums; ca_s_out [N][64] / ca_z_out [N][ca_cr] (nullable) receive s and the hidden activations.            */
   int ca_mode; int ca_cr;
   const float* ca_gsum; int ca_gsum_rows; const float* ca_sums; int ca_sums_rows;
   const float* ca_s; const float* ca_z; const float* ca_w1; const float* ca_w2;
   float* ca_slots;
   void* xo; int xo_pitch, xo_coff;
+  const void* ca_x2; int ca_x2_pitch, ca_x2_coff;
+  const float* ca_b1; const float* ca_b2; float* ca_s_out; float* ca_z_out;
 } srk_conv_pair_args;
 int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream);
 /* workgroups (14x14 output tiles) such a launch has: the host uses the pair while this is about two per CU or less */

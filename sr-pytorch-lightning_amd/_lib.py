@@ -46,7 +46,8 @@ class ConvPairArgs(C.Structure):
                 ("pool", _p), ("pool_aux", _p), ("pool_aux_pitch", _i), ("pool_aux_coff", _i),
                 ("ca_mode", _i), ("ca_cr", _i), ("ca_gsum", _p), ("ca_gsum_rows", _i), ("ca_sums", _p), ("ca_sums_rows", _i),
                 ("ca_s", _p), ("ca_z", _p), ("ca_w1", _p), ("ca_w2", _p), ("ca_slots", _p),
-                ("xo", _p), ("xo_pitch", _i), ("xo_coff", _i)]
+                ("xo", _p), ("xo_pitch", _i), ("xo_coff", _i),
+                ("ca_x2", _p), ("ca_x2_pitch", _i), ("ca_x2_coff", _i), ("ca_b1", _p), ("ca_b2", _p), ("ca_s_out", _p), ("ca_z_out", _p)]
 
 
 class RowsumJob(C.Structure):

@@ -123,9 +123,11 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   dma_slab(2);
   SRK_PSTAMP(2);
 
-  // ---- channel attention on the way in (RCAN at small batches; ca_mode 1 = backward of CALayer, models/rcan.py:10-29) -------
-  // x' = x * s[n][c] + dmean[n][c] (zero outside the image), s and dmean from the squeeze/excite MLP's backward on this
-  // sample's pooled vectors -- what srk_ca_bwd_apply computes as its own launch, with the same arithmetic in the same order.
+  // ---- channel attention on the way in (RCAN at small batches; CALayer models/rcan.py:10-29) ------------------------------
+  // ca_mode 1, backward: x' = x * s[n][c] + dmean[n][c] (zero outside the image), s and dmean from the squeeze/excite MLP's
+  // backward on this sample's pooled vectors -- what srk_ca_bwd_apply computes as its own launch.
+  // ca_mode 2, forward: x' = x * s[n][c] + x2, the PREVIOUS block's `t * s + residual` (rcan.py:52-54), s from the MLP on that
+  // block's pooled sums -- what srk_ca_apply computes as its own launch.  Same arithmetic in the same order, both.
   // The input comes through registers (coalesced 16-byte pieces, requested before the MLP so that it hides their latency),
   // x' goes to the LDS tile and, for this workgroup's 14x14, to `xo` (the weight gradient of conv 2 reads it).
   if (ca) {
@@ -142,6 +144,22 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       const bool ok = i < C::XPIECES && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
       const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * Tr::CH) * 2) : 0x80000000u;
       xin[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
+    }
+    // ca_mode 2: the second operand (the residual of the previous block's `t * s + x`)
+    u32x4_t x2in[C::XK] = {};
+    if (a.ca_mode == 2) {
+      const __amdgpu_buffer_rsrc_t r2 = rsrc_of(a.ca_x2);
+#pragma unroll
+      for (int k = 0; k < C::XK; ++k) {
+        const int i = tid + k * C::NT;
+        const int sl = i & 7, p = i >> 3;
+        const int iy = p / C::XT, ix = p - iy * C::XT;
+        const int c = sl ^ swz(ix);
+        const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
+        const bool ok = i < C::XPIECES && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.ca_x2_pitch + a.ca_x2_coff + c * Tr::CH) * 2) : 0x80000000u;
+        x2in[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
+      }
     }
     const int Cr = a.ca_cr;
     const float invHW = 1.f / (float)(H * W);
@@ -163,38 +181,60 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       }
       __syncthreads();
     };
-    partials(a.ca_gsum, a.ca_gsum_rows, 1.f, cd2);
-    const bool slot_owner = tX == 0 && tY == 0;             // one workgroup per sample writes the parameter-gradient slot
-    if (slot_owner) partials(a.ca_sums, a.ca_sums_rows, invHW, cmean);
-    if (tid < 64) {
-      const float sg = a.ca_s[(size_t)n * 64 + tid];
-      cA[tid] = sg;
-      cd2[tid] *= sg * (1.f - sg);
-    }
-    if (tid < Cr) cz[tid] = a.ca_z[(size_t)n * Cr + tid];
-    __syncthreads();
-    if (tid < Cr) {
-      float dz = 0.f;
-      for (int c = 0; c < 64; ++c) dz += a.ca_w2[c * Cr + tid] * cd2[c];
-      cd1[tid] = cz[tid] > 0.f ? dz : 0.f;
-    }
-    __syncthreads();
-    if (tid < 64) {
-      float dm = 0.f;
-      for (int j = 0; j < Cr; ++j) dm += a.ca_w1[j * 64 + tid] * cd1[j];
-      cB[tid] = dm / (float)(H * W);
-    }
-    __syncthreads();
-    if (slot_owner && a.ca_slots) {
-      float* const sl0 = a.ca_slots + (size_t)n * (2 * 64 * Cr + Cr + 64);      // [dW1 | db1 | dW2 | db2]
-      float* const dw1 = sl0, *const db1 = sl0 + 64 * Cr, *const dw2 = db1 + Cr, *const db2 = dw2 + 64 * Cr;
-      for (int i = tid; i < 64 * Cr; i += C::NT) {
-        dw2[i] = cd2[i / Cr] * cz[i % Cr];
-        dw1[i] = cd1[i / 64] * cmean[i % 64];
+    const bool slot_owner = tX == 0 && tY == 0;             // one workgroup per sample writes the per-sample results
+    if (a.ca_mode == 1) {
+      partials(a.ca_gsum, a.ca_gsum_rows, 1.f, cd2);
+      if (slot_owner) partials(a.ca_sums, a.ca_sums_rows, invHW, cmean);
+      if (tid < 64) {
+        const float sg = a.ca_s[(size_t)n * 64 + tid];
+        cA[tid] = sg;
+        cd2[tid] *= sg * (1.f - sg);
       }
-      if (tid < 64) db2[tid] = cd2[tid];
-      if (tid < Cr) db1[tid] = cd1[tid];
+      if (tid < Cr) cz[tid] = a.ca_z[(size_t)n * Cr + tid];
+      __syncthreads();
+      if (tid < Cr) {
+        float dz = 0.f;
+        for (int c = 0; c < 64; ++c) dz += a.ca_w2[c * Cr + tid] * cd2[c];
+        cd1[tid] = cz[tid] > 0.f ? dz : 0.f;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float dm = 0.f;
+        for (int j = 0; j < Cr; ++j) dm += a.ca_w1[j * 64 + tid] * cd1[j];
+        cB[tid] = dm / (float)(H * W);
+      }
+      __syncthreads();
+      if (slot_owner && a.ca_slots) {
+        float* const sl0 = a.ca_slots + (size_t)n * (2 * 64 * Cr + Cr + 64);      // [dW1 | db1 | dW2 | db2]
+        float* const dw1 = sl0, *const db1 = sl0 + 64 * Cr, *const dw2 = db1 + Cr, *const db2 = dw2 + 64 * Cr;
+        for (int i = tid; i < 64 * Cr; i += C::NT) {
+          dw2[i] = cd2[i / Cr] * cz[i % Cr];
+          dw1[i] = cd1[i / 64] * cmean[i % 64];
+        }
+        if (tid < 64) db2[tid] = cd2[tid];
+        if (tid < Cr) db1[tid] = cd1[tid];
+      }
+    } else {
+      // forward: z = relu(W1 mean + b1), s = sigmoid(W2 z + b2) -- srk_ca_apply's arithmetic
+      partials(a.ca_sums, a.ca_sums_rows, invHW, cmean);
+      if (tid < Cr) {
+        float zz = a.ca_b1[tid];
+        for (int c = 0; c < 64; ++c) zz += a.ca_w1[tid * 64 + c] * cmean[c];
+        zz = fmaxf(zz, 0.f);
+        cz[tid] = zz;
+        if (a.ca_z_out && slot_owner) a.ca_z_out[(size_t)n * Cr + tid] = zz;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float sg = a.ca_b2[tid];
+        for (int j = 0; j < Cr; ++j) sg += a.ca_w2[tid * Cr + j] * cz[j];
+        sg = 1.f / (1.f + expf(-sg));
+        cA[tid] = sg;
+        if (a.ca_s_out && slot_owner) a.ca_s_out[(size_t)n * 64 + tid] = sg;
+      }
+      __syncthreads();
     }
+    const bool fwd = a.ca_mode == 2;
 #pragma unroll
     for (int k = 0; k < C::XK; ++k) {
       const int i = tid + k * C::NT;
@@ -205,13 +245,16 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
         const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         const uint32_t w4[4] = {xin[k].x, xin[k].y, xin[k].z, xin[k].w};
+        const uint32_t r4[4] = {x2in[k].x, x2in[k].y, x2in[k].z, x2in[k].w};
         uint32_t o4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v0, v1;
+          float v0, v1, b0, b1v;
           unpack2<DT>(w4[e], v0, v1);
-          v0 = v0 * cA[8 * c + 2 * e] + cB[8 * c + 2 * e];
-          v1 = v1 * cA[8 * c + 2 * e + 1] + cB[8 * c + 2 * e + 1];
+          if (fwd) unpack2<DT>(r4[e], b0, b1v);
+          else { b0 = cB[8 * c + 2 * e]; b1v = cB[8 * c + 2 * e + 1]; }
+          v0 = v0 * cA[8 * c + 2 * e] + b0;
+          v1 = v1 * cA[8 * c + 2 * e + 1] + b1v;
           o4[e] = ok ? pack2<DT>(v0, v1) : 0u;
         }
         lds_write16(Xs + (i << 4), i32x4{(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]});
@@ -588,11 +631,14 @@ extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(!a->pool_aux || (a->pool && a->pool_aux_pitch % 8 == 0 && a->pool_aux_coff % 8 == 0), "srk_conv_pair: pool_aux needs pool and 16-byte alignment");
   SRK_CHECK_ARG(!a->res_from_x || (a->res == a->x && a->res_pitch == a->x_pitch && a->res_coff == a->x_coff),
                 "srk_conv_pair: res_from_x needs res to BE x");
-  SRK_CHECK_ARG(a->ca_mode == 0 || a->ca_mode == 1, "srk_conv_pair: ca_mode %d", a->ca_mode);
+  SRK_CHECK_ARG(a->ca_mode >= 0 && a->ca_mode <= 2, "srk_conv_pair: ca_mode %d", a->ca_mode);
   if (a->ca_mode) {
     SRK_CHECK_ARG(!a->res_from_x, "srk_conv_pair: the LDS input tile is transformed in ca_mode, a residual comes from memory");
-    SRK_CHECK_ARG(a->ca_gsum && a->ca_sums && a->ca_s && a->ca_z && a->ca_w1 && a->ca_w2 && a->ca_gsum_rows > 0 && a->ca_sums_rows > 0,
+    SRK_CHECK_ARG(a->ca_mode != 1 || (a->ca_gsum && a->ca_sums && a->ca_s && a->ca_z && a->ca_w1 && a->ca_w2 && a->ca_gsum_rows > 0 && a->ca_sums_rows > 0),
                   "srk_conv_pair: ca_mode 1 needs gsum, sums, s, z, w1, w2");
+    SRK_CHECK_ARG(a->ca_mode != 2 || (a->ca_x2 && a->ca_sums && a->ca_w1 && a->ca_w2 && a->ca_b1 && a->ca_b2 && a->ca_sums_rows > 0 &&
+                                      a->ca_x2_pitch % 8 == 0 && a->ca_x2_coff % 8 == 0),
+                  "srk_conv_pair: ca_mode 2 needs x2, sums, w1, b1, w2, b2");
     SRK_CHECK_ARG(a->ca_cr > 0 && a->ca_cr <= 32, "srk_conv_pair: ca_cr=%d", a->ca_cr);
     SRK_CHECK_ARG(!a->xo || (a->xo_pitch % 8 == 0 && a->xo_coff % 8 == 0), "srk_conv_pair: alignment of xo");
   }
@@ -604,6 +650,7 @@ extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
   if (a->res && px * a->res_pitch > mx) mx = px * a->res_pitch;
   if (a->pool_aux && px * a->pool_aux_pitch > mx) mx = px * a->pool_aux_pitch;
   if (a->ca_mode && a->xo && px * a->xo_pitch > mx) mx = px * a->xo_pitch;
+  if (a->ca_mode == 2 && px * a->ca_x2_pitch > mx) mx = px * a->ca_x2_pitch;
   SRK_CHECK_ARG(mx * 2 < 0x7fff0000LL, "srk_conv_pair: tensors of 2 GiB and more are not supported (small-batch kernel)");
   typedef PairCfg C;
   static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<SRK_BF16>),

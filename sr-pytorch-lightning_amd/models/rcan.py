@@ -60,9 +60,12 @@ class ResidualGroup(_NCHWContract, nn.Module):
         return self.body[-1].out_channels
 
     def nhwc(self, x):
-        r = x
+        blocks = []
         for blk in list(self.body)[:-1]:
-            r = blk.nhwc(r)
+            c1, c2, ca = blk.body[0], blk.body[2], blk.body[3]
+            blocks.append((c1.weight, c1.bias, c2.weight, c2.bias,
+                           ca.conv_du[0].weight, ca.conv_du[0].bias, ca.conv_du[2].weight, ca.conv_du[2].bias))
+        r = ops.rcab_chain(x, blocks)
         return self.body[-1].nhwc(r, res=x)
 
 

@@ -293,12 +293,15 @@ def pair_ok(x, w1, w2):
 
 
 def conv_pair_raw(x, pk1, pk2, *, out, relu_mid=False, scale_mid=1.0, mask=None, mid=None, scale_out=1.0, res=None,
-                  use_bias=True, pool=None, pool_aux=None, ca_bwd=None, xo=None):
+                  use_bias=True, pool=None, pool_aux=None, ca_bwd=None, ca_fwd=None, xo=None):
     """One srk_conv_pair launch: out = (conv(epi(conv(x, pk1)), pk2)) * scale_out + res (include/srk.h)."""
     _need_gpu(x)
     n, h, wd, _ = x.shape
-    from_x = res is not None and res.data_ptr() == x.data_ptr() and _pitch(res) == _pitch(x) and ca_bwd is None
-    ca = ca_bwd or {}                   # gsum, sums, s, z, w1, w2 (fp32 tensors), slots: the CALayer backward on the way in
+    from_x = res is not None and res.data_ptr() == x.data_ptr() and _pitch(res) == _pitch(x) and ca_bwd is None and ca_fwd is None
+    # ca_bwd: gsum, sums, s, z, w1, w2, slots -- the CALayer backward on the way in
+    # ca_fwd: x2, sums, w1, b1, w2, b2, s_out, z_out -- the previous block's CALayer forward (t * s + x2) on the way in
+    ca = ca_bwd or ca_fwd or {}
+    x2 = ca.get("x2")
     a = L.ConvPairArgs(
         x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, N=n, H=h, W=wd,
         w1=pk1.wpk.data_ptr(), b1=_ptr(pk1.bias) if use_bias else 0, w2=pk2.wpk.data_ptr(), b2=_ptr(pk2.bias) if use_bias else 0,
@@ -309,11 +312,13 @@ def conv_pair_raw(x, pk1, pk2, *, out, relu_mid=False, scale_mid=1.0, mask=None,
         res=_ptr(res), res_pitch=0 if res is None else _pitch(res), res_coff=0, res_from_x=int(from_x),
         out=out.data_ptr(), out_pitch=_pitch(out), out_coff=0, dtype=_DT[x.dtype],
         pool=_ptr(pool), pool_aux=_ptr(pool_aux), pool_aux_pitch=0 if pool_aux is None else _pitch(pool_aux), pool_aux_coff=0,
-        ca_mode=1 if ca_bwd is not None else 0, ca_cr=ca["z"].shape[1] if ca else 0,
-        ca_gsum=_ptr(ca.get("gsum")), ca_gsum_rows=ca["gsum"].shape[1] if ca else 0,
+        ca_mode=1 if ca_bwd is not None else (2 if ca_fwd is not None else 0), ca_cr=ca["w1"].shape[0] if ca else 0,
+        ca_gsum=_ptr(ca.get("gsum")), ca_gsum_rows=ca["gsum"].shape[1] if ca_bwd else 0,
         ca_sums=_ptr(ca.get("sums")), ca_sums_rows=ca["sums"].shape[1] if ca else 0,
         ca_s=_ptr(ca.get("s")), ca_z=_ptr(ca.get("z")), ca_w1=_ptr(ca.get("w1")), ca_w2=_ptr(ca.get("w2")), ca_slots=_ptr(ca.get("slots")),
-        xo=_ptr(xo), xo_pitch=0 if xo is None else _pitch(xo), xo_coff=0)
+        xo=_ptr(xo), xo_pitch=0 if xo is None else _pitch(xo), xo_coff=0,
+        ca_x2=_ptr(x2), ca_x2_pitch=0 if x2 is None else _pitch(x2), ca_x2_coff=0,
+        ca_b1=_ptr(ca.get("b1")), ca_b2=_ptr(ca.get("b2")), ca_s_out=_ptr(ca.get("s_out")), ca_z_out=_ptr(ca.get("z_out")))
     L.call("srk_conv_pair", a, _stream())
     return out
 
@@ -976,6 +981,18 @@ class _CAHint:
 _LAST_CA_HINT = None
 
 
+class _LazyApply:
+    """The pending last step of an RCAB (out = t * s + x with s from the squeeze/excite MLP on `sums`): everything the next
+    block's launch needs to perform it, and the buffers (`out`, `s`, `z`) it fills."""
+    __slots__ = ("t", "x", "sums", "w", "s", "z", "out")
+
+    def __init__(self, t, x, sums, w, s, z, out):
+        self.t, self.x, self.sums, self.w, self.s, self.z, self.out = t, x, sums, w, s, z, out
+
+
+_LAST_LAZY = None
+
+
 class RCABFn(torch.autograd.Function):
     """RCAB (models/rcan.py:33-55): conv -> ReLU -> conv -> CALayer (rcan.py:10-29), += x.
 
@@ -983,7 +1000,10 @@ class RCABFn(torch.autograd.Function):
     backward: srk_ca_pool(t*g), srk_ca_bwd_apply, dgrad2 (ReLU mask), dgrad1 (+g), 2 wgrads."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, cw1, cb1, cw2, cb2):
+    def forward(ctx, x, w1, b1, w2, b2, cw1, cb1, cw2, cb2, lazy_in=None, lazy_out=False):
+        """lazy_in / lazy_out (rcab_chain, small batches): with lazy_out the block leaves its last step -- out = t * s + x,
+        the srk_ca_apply launch -- to the NEXT block's conv launch, which performs it on its input tile as it loads it
+        (srk_conv_pair ca_mode 2) and fills `out`, `s` and `z`; `lazy_in` is that pending step of the previous block."""
         _need_gpu(x)
         n, h, wd, cp = x.shape
         dt = x.dtype
@@ -992,11 +1012,17 @@ class RCABFn(torch.autograd.Function):
         y1 = torch.empty_like(x)
         t = torch.empty_like(x)
         paired = pair_ok(x, w1, w2)
+        assert paired or (lazy_in is None and not lazy_out), "the lazy channel-attention protocol is for the paired launches"
         if paired:
             # small batch: both convs in one launch, which also leaves the per-tile channel sums of t (the pooling pass)
             ns = L.load().srk_conv_pair_tiles(1, h, wd)
             sums = torch.empty((n, ns, cp), dtype=torch.float32, device=x.device)
-            conv_pair_raw(x, pack_conv(w1, b1, dt), pack_conv(w2, b2, dt), out=t, relu_mid=True, mid=y1, pool=sums)
+            if lazy_in is None:
+                conv_pair_raw(x, pack_conv(w1, b1, dt), pack_conv(w2, b2, dt), out=t, relu_mid=True, mid=y1, pool=sums)
+            else:       # x = lazy_in.t * s + lazy_in.x is formed on the way in and stored to x
+                conv_pair_raw(lazy_in.t, pack_conv(w1, b1, dt), pack_conv(w2, b2, dt), out=t, relu_mid=True, mid=y1, pool=sums,
+                              ca_fwd=dict(x2=lazy_in.x, sums=lazy_in.sums, w1=lazy_in.w[0], b1=lazy_in.w[1], w2=lazy_in.w[2],
+                                          b2=lazy_in.w[3], s_out=lazy_in.s, z_out=lazy_in.z), xo=x)
         else:
             conv_raw(x, pack_conv(w1, b1, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=y1, relu=True)
             conv_raw(y1, pack_conv(w2, b2, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=t)
@@ -1008,11 +1034,16 @@ class RCABFn(torch.autograd.Function):
         z = torch.empty((n, cr), dtype=torch.float32, device=x.device)
         out = torch.empty_like(x)
         w1f, b1f, w2f, b2f = _ca_params(cw1, cb1, cw2, cb2, cp)
-        L.call("srk_ca_apply", L.CaApplyArgs(
-            t=t.data_ptr(), t_pitch=cp, t_coff=0, res=x.data_ptr(), res_pitch=cp, res_coff=0, sums=sums.data_ptr(),
-            w1=w1f.data_ptr(), b1=b1f.data_ptr(), w2=w2f.data_ptr(), b2=b2f.data_ptr(),
-            s_out=s.data_ptr(), z_out=z.data_ptr(), out=out.data_ptr(), out_pitch=cp, out_coff=0,
-            N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt], sums_rows=ns), _stream())
+        global _LAST_LAZY
+        _LAST_LAZY = None
+        if lazy_out:
+            _LAST_LAZY = _LazyApply(t, x, sums, (w1f, b1f, w2f, b2f), s, z, out)
+        else:
+            L.call("srk_ca_apply", L.CaApplyArgs(
+                t=t.data_ptr(), t_pitch=cp, t_coff=0, res=x.data_ptr(), res_pitch=cp, res_coff=0, sums=sums.data_ptr(),
+                w1=w1f.data_ptr(), b1=b1f.data_ptr(), w2=w2f.data_ptr(), b2=b2f.data_ptr(),
+                s_out=s.data_ptr(), z_out=z.data_ptr(), out=out.data_ptr(), out_pitch=cp, out_coff=0,
+                N=n, HW=h * wd, C=cp, Cr=cr, dtype=_DT[dt], sums_rows=ns), _stream())
         ctx.save_for_backward(x, y1, t, sums, s, z, w1, w2, cw1, cw2)
         ctx.wb = (w1, b1, w2, b2)
         ctx.ca = (cw1, cb1, cw2, cb2)
@@ -1091,14 +1122,14 @@ class RCABFn(torch.autograd.Function):
             outs = defer_rowsum(per, (ctx.ca[0], ctx.ca[1], ctx.ca[2], ctx.ca[3]),
                                 (((cr, c, 1, 1), 0), ((cr,), o1), ((c, cr, 1, 1), o2), ((c,), o3)))
             if outs is not None:
-                return (gx, gw1, gb1, gw2, gb2, *outs)
+                return (gx, gw1, gb1, gw2, gb2, *outs, None, None)
         tot = per.sum(0)
         dw1, db1 = tot[:cr * cp], tot[cr * cp:cr * cp + cr]
         dw2, db2 = tot[cr * cp + cr:2 * cr * cp + cr], tot[2 * cr * cp + cr:]
         # un-pad the CA parameter gradients (rows/cols beyond the real C are zero); views of `tot`, no copies when C == Cp
         gcw1 = dw1.view(cr, cp)[:, :c].reshape(cr, c, 1, 1)
         gcw2 = dw2.view(cp, cr)[:c].reshape(c, cr, 1, 1)
-        return gx, gw1, gb1, gw2, gb2, gcw1, db1, gcw2, db2[:c]
+        return gx, gw1, gb1, gw2, gb2, gcw1, db1, gcw2, db2[:c], None, None
 
 
 def _ca_params(cw1, cb1, cw2, cb2, cp):
@@ -1118,6 +1149,28 @@ def _ca_params(cw1, cb1, cw2, cb2, cp):
 
 def rcab(x, w1, b1, w2, b2, cw1, cb1, cw2, cb2):
     return RCABFn.apply(x, w1, b1, w2, b2, cw1, cb1, cw2, cb2)
+
+
+def rcab_chain(x, blocks):
+    """A run of RCABs (a residual group's body, models/rcan.py:59-74); blocks[i] = the nine parameters of `rcab`.
+
+    At small batches (pair_ok) every block is ONE launch forward: the conv pair also pools its output, and the channel
+    attention's last step of block i (t * s + x) is performed by block i+1's launch on its input tile; only the last block
+    runs srk_ca_apply.  Larger batches: the blocks one by one, as `rcab`."""
+    global _LAST_LAZY
+    if not blocks:
+        return x
+    w1, w2 = blocks[0][0], blocks[0][2]
+    lazy_ok = (not _CA_UNFUSED and pair_ok(x, w1, w2) and x.shape[3] == 64
+               and all(tuple(b[0].shape) == (64, 64, 3, 3) and tuple(b[2].shape) == (64, 64, 3, 3) and b[5] is not None and b[7] is not None
+                       and b[4].shape[1] == 64 for b in blocks))
+    lazy = None
+    for i, b in enumerate(blocks):
+        last = i == len(blocks) - 1
+        x = RCABFn.apply(x, *b, lazy, lazy_ok and not last)
+        lazy = _LAST_LAZY if (lazy_ok and not last) else None
+        _LAST_LAZY = None
+    return x
 
 
 class RDBFn(torch.autograd.Function):

@@ -303,3 +303,84 @@ def test_ca_backward_on_the_way_in_matches_its_own_launch(A, dt, shape):
     assert torch.equal(per, per_ref), "parameter-gradient slots"
     assert torch.equal(mid.view(torch.int16), mid_ref.view(torch.int16)), "intermediate"
     assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)), "output"
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(16, 48, 48), (3, 20, 33), (2, 14, 14)])
+def test_ca_forward_on_the_way_in_matches_its_own_launch(A, dt, shape):
+    """ca_mode 2: the previous block's `t * s + x` (srk_ca_apply) formed by the next block's conv launch while it loads its
+    input: x', s, z, the intermediate and the output are BIT-identical to srk_ca_apply followed by the plain pair."""
+    dev = torch.device("cuda")
+    n, h, w = shape
+    cr = 4
+    g = torch.Generator().manual_seed(31)
+    t = _rand(g, n, h, w, 64, dt=dt, dev=dev)
+    xres = _rand(g, n, h, w, 64, dt=dt, dev=dev)
+    rows = 7
+    sums = ((torch.rand(n, rows, 64, generator=g) - 0.3) * (h * w / rows)).to(dev)
+    w1f = ((torch.rand(cr, 64, generator=g) - 0.5) * 0.5).to(dev)
+    w2f = ((torch.rand(64, cr, generator=g) - 0.5) * 2).to(dev)
+    b1f = (torch.rand(cr, generator=g) - 0.5).to(dev)
+    b2f = (torch.rand(64, generator=g) - 0.5).to(dev)
+    wa = torch.nn.Parameter((torch.rand(64, 64, 3, 3, generator=g) - 0.5).mul(0.1).to(dev))
+    wb = torch.nn.Parameter((torch.rand(64, 64, 3, 3, generator=g) - 0.5).mul(0.1).to(dev))
+    ba = torch.nn.Parameter((torch.rand(64, generator=g) - 0.5).to(dev))
+    bb = torch.nn.Parameter((torch.rand(64, generator=g) - 0.5).to(dev))
+    pka, pkb = A.ops.pack_conv(wa, ba, dt), A.ops.pack_conv(wb, bb, dt)
+    L = A._lib
+    s_ref, z_ref = torch.empty(n, 64, device=dev), torch.empty(n, cr, device=dev)
+    x_ref = torch.empty_like(t)
+    L.call("srk_ca_apply", L.CaApplyArgs(
+        t=t.data_ptr(), t_pitch=64, t_coff=0, res=xres.data_ptr(), res_pitch=64, res_coff=0, sums=sums.data_ptr(),
+        w1=w1f.data_ptr(), b1=b1f.data_ptr(), w2=w2f.data_ptr(), b2=b2f.data_ptr(), s_out=s_ref.data_ptr(), z_out=z_ref.data_ptr(),
+        out=x_ref.data_ptr(), out_pitch=64, out_coff=0, N=n, HW=h * w, C=64, Cr=cr, dtype=A.ops._DT[dt], sums_rows=rows),
+        torch.cuda.current_stream().cuda_stream)
+    mid_ref, out_ref = torch.empty_like(t), torch.empty_like(t)
+    A.ops.conv_pair_raw(x_ref, pka, pkb, out=out_ref, relu_mid=True, mid=mid_ref)
+    sv, zv = torch.full((n, 64), float("nan"), device=dev), torch.full((n, cr), float("nan"), device=dev)
+    xo, mid, out = (torch.full_like(t, float("nan")) for _ in range(3))
+    A.ops.conv_pair_raw(t, pka, pkb, out=out, relu_mid=True, mid=mid, xo=xo,
+                        ca_fwd=dict(x2=xres, sums=sums, w1=w1f, b1=b1f, w2=w2f, b2=b2f, s_out=sv, z_out=zv))
+    torch.cuda.synchronize()
+    assert torch.equal(sv, s_ref) and torch.equal(zv, z_ref), "s / z"
+    assert torch.equal(xo.view(torch.int16), x_ref.view(torch.int16)), "t * s + x"
+    assert torch.equal(mid.view(torch.int16), mid_ref.view(torch.int16)), "intermediate"
+    assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)), "output"
+
+
+def test_residual_group_is_one_launch_per_block_and_direction(A, monkeypatch):
+    """A residual group (models/rcan.py:59-74) of 4 RCABs at 16 x 48 x 48: forward 4 pair launches + 1 srk_ca_apply (the last
+    block's), backward 4 pair launches + 1 srk_ca_pool (the last block's gradient comes from the group's conv); no
+    srk_ca_bwd_apply at all.  Output and gradients agree with the launch-per-op path to bf16 rounding."""
+    dev = torch.device("cuda")
+    from sr_amd.models import common, rcan
+
+    def run(fused):
+        prev = A.ops._PAIR_OFF
+        A.ops._PAIR_OFF = not fused
+        try:
+            torch.manual_seed(0)
+            grp = rcan.ResidualGroup(common.DefaultConv2d, 64, 3, 16, act=None, res_scale=1, n_resblocks=4).to(dev)
+            g = torch.Generator().manual_seed(4)
+            x = A.ops.nchw_to_nhwc(_rand(g, 16, 64, 48, 48, dt=torch.float32, dev=dev), torch.bfloat16).detach().requires_grad_(True)
+            y = grp.nhwc(x)
+            (y.float() * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+            torch.cuda.synchronize()
+            return y.detach().float(), x.grad.float(), [p.grad.clone() for p in grp.parameters()]
+        finally:
+            A.ops._PAIR_OFF = prev
+
+    calls = []
+    real = A._lib.call
+    monkeypatch.setattr(A._lib, "call", lambda name, *a, **k: (calls.append(name), real(name, *a, **k))[1])
+    yp, gxp, gp = run(True)
+    cnt = {k: calls.count(k) for k in ("srk_conv_pair", "srk_ca_apply", "srk_ca_pool", "srk_ca_bwd_apply")}
+    assert cnt == {"srk_conv_pair": 8, "srk_ca_apply": 1, "srk_ca_pool": 1, "srk_ca_bwd_apply": 0}, cnt
+    del calls[:]
+    yt, gxt, gt = run(False)
+    assert calls.count("srk_conv_pair") == 0 and calls.count("srk_ca_apply") == 4 and calls.count("srk_ca_bwd_apply") == 4
+    for a, b in ((yp, yt), (gxp, gxt)):
+        d = (a - b).abs()
+        assert float(d.max()) <= 2.0 ** -6 * float(b.abs().max()) and float((d > 0).float().mean()) < 0.05
+    for a, b in zip(gp, gt):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6
