@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   const int r = lane & 31, h = lane >> 5;
   const int H = a.H, W = a.W;
 #if SRK_PAIR_STAMPS
-  unsigned long long* const stamp = (blockIdx.x == 0 && (tid & 255) == 0) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.b2)) + (wave >> 2) * 16 : nullptr;
+  unsigned long long* const stamp = (blockIdx.x == 0 && (tid & 255) == 0) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.b2)) + (wave >> 2) * 32 : nullptr;
 #define SRK_PSTAMP(i) do { if (stamp) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
   const float* const bias2 = nullptr;
 #else
@@ -118,37 +118,35 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     }
   };
   SRK_PSTAMP(1);
-  dma_slab(0);
-  dma_slab(1);
-  dma_slab(2);
+  if (!ca) {
+    dma_slab(0);
+    dma_slab(1);
+    dma_slab(2);
+  }
   SRK_PSTAMP(2);
 
   // ---- channel attention on the way in (RCAN at small batches; CALayer models/rcan.py:10-29) ------------------------------
   // ca_mode 1, backward: x' = x * s[n][c] + dmean[n][c] (zero outside the image), s and dmean from the squeeze/excite MLP's
   // backward on this sample's pooled vectors -- what srk_ca_bwd_apply computes as its own launch.
   // ca_mode 2, forward: x' = x * s[n][c] + x2, the PREVIOUS block's `t * s + residual` (rcan.py:52-54), s from the MLP on that
-  // block's pooled sums -- what srk_ca_apply computes as its own launch.  Same arithmetic in the same order, both.
-  // The input comes through registers (coalesced 16-byte pieces, requested before the MLP so that it hides their latency),
-  // x' goes to the LDS tile and, for this workgroup's 14x14, to `xo` (the weight gradient of conv 2 reads it).
+  // block's pooled sums -- what srk_ca_apply computes as its own launch.  Same arithmetic in the same ORDER, both: results are
+  // bit-identical to the stand-alone launches.
+  // Laid out for latency (a launch spends ~4k cycles in its prologue without this): every global operand is requested at
+  // once and waited for once, BEFORE the weight slabs' LDS-DMA is issued -- the vector-memory counter retires in order, so
+  // any later compiler-inserted wait would sit behind those 74 KB; the slabs then fly while the MLP and the tile
+  // transform run out of LDS and registers.  The 64 x Cr products of a matrix-vector step are formed in parallel, their
+  // sums (serial, for the order) read all operands first.
   if (ca) {
-    __shared__ float cred[256], cA[64], cB[64], cmean[64], cd2[64], cz[32], cd1[32];
-    u32x4_t xin[C::XK];
-    const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x);
-#pragma unroll
-    for (int k = 0; k < C::XK; ++k) {
-      const int i = tid + k * C::NT;
-      const int sl = i & 7, p = i >> 3;
-      const int iy = p / C::XT, ix = p - iy * C::XT;
-      const int c = sl ^ swz(ix);
-      const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
-      const bool ok = i < C::XPIECES && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * Tr::CH) * 2) : 0x80000000u;
-      xin[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
-    }
-    // ca_mode 2: the second operand (the residual of the previous block's `t * s + x`)
-    u32x4_t x2in[C::XK] = {};
-    if (a.ca_mode == 2) {
-      const __amdgpu_buffer_rsrc_t r2 = rsrc_of(a.ca_x2);
+    __shared__ __attribute__((aligned(16))) float cred[512], cW1[512], cW2[512], cA[64], cB[64], cmean[64], cd2[64], cz[8], cd1[8];
+    const bool bwd = a.ca_mode == 1;
+    const int Cr = a.ca_cr;                                  // <= 8 (launcher)
+    const float invHW = 1.f / (float)(H * W);
+    const bool slot_owner = tX == 0 && tY == 0;             // one workgroup per sample writes the per-sample results
+    // input pieces (and, forward, the second operand) through registers: coalesced 16-byte pieces in the tile's LDS order
+    u32x4_t xin[C::XK], x2in[C::XK] = {};
+    {
+      const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x);
+      const __amdgpu_buffer_rsrc_t r2 = rsrc_of(bwd ? a.x : a.ca_x2);
 #pragma unroll
       for (int k = 0; k < C::XK; ++k) {
         const int i = tid + k * C::NT;
@@ -157,50 +155,91 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         const int c = sl ^ swz(ix);
         const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
         const bool ok = i < C::XPIECES && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.ca_x2_pitch + a.ca_x2_coff + c * Tr::CH) * 2) : 0x80000000u;
-        x2in[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
+        const int pix = (n * H + gy) * W + gx;
+        xin[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)((pix * a.x_pitch + a.x_coff + c * Tr::CH) * 2) : 0x80000000u, 0, 0);
+        if (!bwd)
+          x2in[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, ok ? (unsigned)((pix * a.ca_x2_pitch + a.ca_x2_coff + c * Tr::CH) * 2) : 0x80000000u, 0, 0);
       }
     }
-    const int Cr = a.ca_cr;
-    const float invHW = 1.f / (float)(H * W);
-    // sums of the per-block partials, the way srk_ca_*'s ca_sum_partials forms them: four strided partial sums per channel
-    auto partials = [&](const float* src, int rows, float scale, float* out) {
-      if (tid < 256) {
-        const int q = tid >> 6, c = tid & 63;
-        float t = 0.f;
+    SRK_PSTAMP(13);
+    // partial sums, four strided ones per channel, the way ca_sum_partials forms them; loads first, ordered adds after
+    float pg = 0.f, ps = 0.f;
+    if (tid < 256) {
+      const int q = tid >> 6, c = tid & 63;
+      auto strided = [&](const float* src, int rows) {
         const float* pp = src + (size_t)n * rows * 64 + c;
-#pragma unroll 4
-        for (int sp = q; sp < rows; sp += 4) t += pp[(size_t)sp * 64];
-        cred[tid] = t;
-      }
+        float t = 0.f;
+        for (int s0 = q; s0 < rows; s0 += 32) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = s0 + 4 * u < rows ? pp[(size_t)(s0 + 4 * u) * 64] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) if (s0 + 4 * u < rows) t += v[u];
+        }
+        return t;
+      };
+      if (bwd) pg = strided(a.ca_gsum, a.ca_gsum_rows);
+      if (!bwd || slot_owner) ps = strided(a.ca_sums, a.ca_sums_rows);
+    }
+    float w1r = 0.f, w2r = 0.f, sg_in = 0.f, z_in = 0.f, b1_in = 0.f, b2_in = 0.f;
+    if (tid < 64 * Cr) { w1r = a.ca_w1[tid]; w2r = a.ca_w2[tid]; }
+    if (bwd) {
+      if (tid < 64) sg_in = a.ca_s[(size_t)n * 64 + tid];
+      if (tid < Cr) z_in = a.ca_z[(size_t)n * Cr + tid];
+    } else {
+      if (tid < Cr) b1_in = a.ca_b1[tid];
+      if (tid < 64) b2_in = a.ca_b2[tid];
+    }
+    SRK_PSTAMP(14);
+    // everything requested so far is used (= waited for) HERE, then the weight slabs' DMA starts
+#pragma unroll
+    for (int k = 0; k < C::XK; ++k) asm volatile("" : "+v"(xin[k]), "+v"(x2in[k]));
+    asm volatile("" : "+v"(pg), "+v"(ps), "+v"(w1r), "+v"(w2r), "+v"(sg_in), "+v"(z_in), "+v"(b1_in), "+v"(b2_in));
+    SRK_PSTAMP(15);
+    dma_slab(0);
+    dma_slab(1);
+    dma_slab(2);
+    if (tid < 64 * Cr) { cW1[tid] = w1r; cW2[tid] = w2r; }
+    if (tid < 256) cred[tid] = ps;
+    __syncthreads();
+    if (tid < 64) {
+      float u = 0.f;
+      for (int k = 0; k < 4; ++k) u += cred[k * 64 + tid];
+      cmean[tid] = u * invHW;
+    }
+    __syncthreads();
+    // ordered sum of 64 LDS operands (stride `st` floats): all reads first, then the adds
+    auto sum64 = [&](const float* base, int st, float init) {
+      float v[64];
+#pragma unroll
+      for (int c = 0; c < 64; ++c) v[c] = base[c * st];
+      float u = init;
+#pragma unroll
+      for (int c = 0; c < 64; ++c) u += v[c];
+      return u;
+    };
+    if (bwd) {
+      if (tid < 256) cred[tid] = pg;
       __syncthreads();
       if (tid < 64) {
         float u = 0.f;
         for (int k = 0; k < 4; ++k) u += cred[k * 64 + tid];
-        out[tid] = u * scale;
+        cA[tid] = sg_in;
+        cd2[tid] = u * (sg_in * (1.f - sg_in));
       }
+      if (tid < Cr) cz[tid] = z_in;
       __syncthreads();
-    };
-    const bool slot_owner = tX == 0 && tY == 0;             // one workgroup per sample writes the per-sample results
-    if (a.ca_mode == 1) {
-      partials(a.ca_gsum, a.ca_gsum_rows, 1.f, cd2);
-      if (slot_owner) partials(a.ca_sums, a.ca_sums_rows, invHW, cmean);
-      if (tid < 64) {
-        const float sg = a.ca_s[(size_t)n * 64 + tid];
-        cA[tid] = sg;
-        cd2[tid] *= sg * (1.f - sg);
-      }
-      if (tid < Cr) cz[tid] = a.ca_z[(size_t)n * Cr + tid];
+      // dz[j] = sum_c W2[c][j] dpre2[c] (c ascending), dpre1 = relu'(z) dz
+      if (tid < 64 * Cr) cred[tid] = cW2[tid] * cd2[tid / Cr];
       __syncthreads();
       if (tid < Cr) {
-        float dz = 0.f;
-        for (int c = 0; c < 64; ++c) dz += a.ca_w2[c * Cr + tid] * cd2[c];
+        const float dz = sum64(cred + tid, Cr, 0.f);
         cd1[tid] = cz[tid] > 0.f ? dz : 0.f;
       }
       __syncthreads();
       if (tid < 64) {
         float dm = 0.f;
-        for (int j = 0; j < Cr; ++j) dm += a.ca_w1[j * 64 + tid] * cd1[j];
+        for (int j = 0; j < Cr; ++j) dm += cW1[j * 64 + tid] * cd1[j];
         cB[tid] = dm / (float)(H * W);
       }
       __syncthreads();
@@ -215,26 +254,26 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         if (tid < Cr) db1[tid] = cd1[tid];
       }
     } else {
-      // forward: z = relu(W1 mean + b1), s = sigmoid(W2 z + b2) -- srk_ca_apply's arithmetic
-      partials(a.ca_sums, a.ca_sums_rows, invHW, cmean);
+      // forward: z = relu(b1 + W1 mean) (c ascending), s = sigmoid(b2 + W2 z)
+      if (tid < 64 * Cr) cred[tid] = cW1[tid] * cmean[tid & 63];
+      __syncthreads();
       if (tid < Cr) {
-        float zz = a.ca_b1[tid];
-        for (int c = 0; c < 64; ++c) zz += a.ca_w1[tid * 64 + c] * cmean[c];
-        zz = fmaxf(zz, 0.f);
+        const float zz = fmaxf(sum64(cred + tid * 64, 1, b1_in), 0.f);
         cz[tid] = zz;
         if (a.ca_z_out && slot_owner) a.ca_z_out[(size_t)n * Cr + tid] = zz;
       }
       __syncthreads();
       if (tid < 64) {
-        float sg = a.ca_b2[tid];
-        for (int j = 0; j < Cr; ++j) sg += a.ca_w2[tid * Cr + j] * cz[j];
+        float sg = b2_in;
+        for (int j = 0; j < Cr; ++j) sg += cW2[tid * Cr + j] * cz[j];
         sg = 1.f / (1.f + expf(-sg));
         cA[tid] = sg;
+        cB[tid] = 0.f;
         if (a.ca_s_out && slot_owner) a.ca_s_out[(size_t)n * 64 + tid] = sg;
       }
       __syncthreads();
     }
-    const bool fwd = a.ca_mode == 2;
+    SRK_PSTAMP(16);
 #pragma unroll
     for (int k = 0; k < C::XK; ++k) {
       const int i = tid + k * C::NT;
@@ -244,23 +283,28 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         const int c = sl ^ swz(ix);
         const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
         const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const f32x4 A0 = *reinterpret_cast<const f32x4*>(cA + 8 * c), A1 = *reinterpret_cast<const f32x4*>(cA + 8 * c + 4);
+        const f32x4 B0 = *reinterpret_cast<const f32x4*>(cB + 8 * c), B1 = *reinterpret_cast<const f32x4*>(cB + 8 * c + 4);
+        const float Av[8] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w};
+        const float Bv[8] = {B0.x, B0.y, B0.z, B0.w, B1.x, B1.y, B1.z, B1.w};
         const uint32_t w4[4] = {xin[k].x, xin[k].y, xin[k].z, xin[k].w};
         const uint32_t r4[4] = {x2in[k].x, x2in[k].y, x2in[k].z, x2in[k].w};
         uint32_t o4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v0, v1, b0, b1v;
+          float v0, v1, b0 = Bv[2 * e], b1v = Bv[2 * e + 1];
           unpack2<DT>(w4[e], v0, v1);
-          if (fwd) unpack2<DT>(r4[e], b0, b1v);
-          else { b0 = cB[8 * c + 2 * e]; b1v = cB[8 * c + 2 * e + 1]; }
-          v0 = v0 * cA[8 * c + 2 * e] + b0;
-          v1 = v1 * cA[8 * c + 2 * e + 1] + b1v;
+          if (!bwd) unpack2<DT>(r4[e], b0, b1v);
+          v0 = v0 * Av[2 * e] + b0;
+          v1 = v1 * Av[2 * e + 1] + b1v;
           o4[e] = ok ? pack2<DT>(v0, v1) : 0u;
         }
         lds_write16(Xs + (i << 4), i32x4{(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]});
       }
     }
+    SRK_PSTAMP(17);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    SRK_PSTAMP(18);
   }
 
   // ---- per-lane constants -----------------------------------------------------------------------------------------------
@@ -639,7 +683,7 @@ extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
     SRK_CHECK_ARG(a->ca_mode != 2 || (a->ca_x2 && a->ca_sums && a->ca_w1 && a->ca_w2 && a->ca_b1 && a->ca_b2 && a->ca_sums_rows > 0 &&
                                       a->ca_x2_pitch % 8 == 0 && a->ca_x2_coff % 8 == 0),
                   "srk_conv_pair: ca_mode 2 needs x2, sums, w1, b1, w2, b2");
-    SRK_CHECK_ARG(a->ca_cr > 0 && a->ca_cr <= 32, "srk_conv_pair: ca_cr=%d", a->ca_cr);
+    SRK_CHECK_ARG(a->ca_cr > 0 && a->ca_cr <= 8, "srk_conv_pair: ca_cr=%d (1..8)", a->ca_cr);
     SRK_CHECK_ARG(!a->xo || (a->xo_pitch % 8 == 0 && a->xo_coff % 8 == 0), "srk_conv_pair: alignment of xo");
   }
   const long long px = (long long)a->N * a->H * a->W;

@@ -1084,8 +1084,9 @@ class RCABFn(torch.autograd.Function):
         dw1, db1 = per[0, :cr * cp], per[0, cr * cp:cr * cp + cr]
         dw2, db2 = per[0, cr * cp + cr:2 * cr * cp + cr], per[0, 2 * cr * cp + cr:]
         gt = torch.empty_like(x)
-        paired = pair_ok(g, w1, w2) and cp == 64 and not _CA_UNFUSED
-        if not paired:
+        paired = pair_ok(g, w1, w2)
+        fuse_ca = paired and cp == 64 and cr <= 8 and not _CA_UNFUSED
+        if not fuse_ca:
             L.call("srk_ca_bwd_apply", L.CaBwdArgs(
                 g=g.data_ptr(), g_pitch=_pitch(g), g_coff=0, gsum=gsum.data_ptr(), sums=sums.data_ptr(), s=s.data_ptr(),
                 z=z.data_ptr(), w1=w1f.data_ptr(), w2=w2f.data_ptr(), dw1=dw1.data_ptr(), db1=db1.data_ptr(),
@@ -1101,9 +1102,11 @@ class RCABFn(torch.autograd.Function):
             pool = None
             if hi is not None and hi.t.shape == gx.shape and hi.t.dtype == dt:
                 pool = torch.empty((n, L.load().srk_conv_pair_tiles(1, h, wd), cp), dtype=torch.float32, device=dev)
-            conv_pair_raw(g, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), pack_conv(w1, None, dt, dgrad=True, token=ctx.pg),
+            conv_pair_raw(g if fuse_ca else gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg),
+                          pack_conv(w1, None, dt, dgrad=True, token=ctx.pg),
                           out=gx, mask=y1, mid=g1, res=g, use_bias=False, pool=pool, pool_aux=None if pool is None else hi.t,
-                          ca_bwd=dict(gsum=gsum, sums=sums, s=s, z=z, w1=w1f, w2=w2f, slots=per), xo=gt)
+                          ca_bwd=dict(gsum=gsum, sums=sums, s=s, z=z, w1=w1f, w2=w2f, slots=per) if fuse_ca else None,
+                          xo=gt if fuse_ca else None)
             if pool is not None:
                 hi.gsum, hi.g_ptr, hi.g_ver = pool, gx.data_ptr(), gx._version
         else:
@@ -1163,7 +1166,7 @@ def rcab_chain(x, blocks):
     w1, w2 = blocks[0][0], blocks[0][2]
     lazy_ok = (not _CA_UNFUSED and pair_ok(x, w1, w2) and x.shape[3] == 64
                and all(tuple(b[0].shape) == (64, 64, 3, 3) and tuple(b[2].shape) == (64, 64, 3, 3) and b[5] is not None and b[7] is not None
-                       and b[4].shape[1] == 64 for b in blocks))
+                       and b[4].shape[1] == 64 and b[4].shape[0] <= 8 for b in blocks))
     lazy = None
     for i, b in enumerate(blocks):
         last = i == len(blocks) - 1

@@ -14,8 +14,20 @@ stamps = torch.zeros(64, dtype=torch.int64, device=dev)
 class P: pass
 p2 = P(); p2.wpk = pk[1].wpk; p2.bias = stamps.view(torch.float32)
 mid, o = torch.empty_like(x), torch.empty_like(x)
+MODE = int(os.environ.get("STAMP_CA", "0"))
+T = A._lib.load().srk_conv_pair_tiles(1, 48, 48)
+ca = dict(gsum=torch.rand(n, T, 64, device=dev), sums=torch.rand(n, T, 64, device=dev), s=torch.rand(n, 64, device=dev), z=torch.rand(n, 4, device=dev),
+          w1=torch.rand(4, 64, device=dev), w2=torch.rand(64, 4, device=dev), slots=torch.empty(n, 2 * 256 + 68, device=dev),
+          x2=x.clone(), b1=torch.rand(4, device=dev), b2=torch.rand(64, device=dev), s_out=torch.empty(n, 64, device=dev), z_out=torch.empty(n, 4, device=dev))
+xo = torch.empty_like(x)
+pool = torch.empty(n, T, 64, device=dev)
 def run():
-    A.ops.conv_pair_raw(x, pk[0], p2, out=o, relu_mid=True, mid=mid, scale_out=0.1, res=x)
+    if MODE == 1:
+        A.ops.conv_pair_raw(x, pk[0], p2, out=o, mask=x, mid=mid, res=x, use_bias=True, ca_bwd=ca, xo=xo, pool=pool, pool_aux=x)
+    elif MODE == 2:
+        A.ops.conv_pair_raw(x, pk[0], p2, out=o, relu_mid=True, mid=mid, ca_fwd=ca, xo=xo, pool=pool)
+    else:
+        A.ops.conv_pair_raw(x, pk[0], p2, out=o, relu_mid=True, mid=mid, scale_out=0.1, res=x)
 run(); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
@@ -28,5 +40,7 @@ st = stamps.cpu().numpy()
 names = ["entry", "x tile issued", "slabs issued", "mask requested", "own DMA landed", "barrier", "conv1 done", "mid epilogue done",
          "drain barrier", "b0 barrier", "conv2 done", "stores issued", "stores done"]
 for w in (0, 1):
-    t = st[w * 16:(w + 1) * 16]
+    t = st[w * 32:(w + 1) * 32]
     print(("compute wave 0: " if w == 0 else "DMA wave 4:     ") + "; ".join(f"{nm} {t[i]-t[0]}" for i, nm in enumerate(names)))
+    if t[13]:
+        print("      channel-attention block: " + "; ".join(f"{nm} {t[13+i]-t[0]}" for i, nm in enumerate(["input pieces requested", "MLP operands requested", "first operand arrived", "MLP done", "tile transformed", "all landed"])))
