@@ -137,8 +137,10 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   // transform run out of LDS and registers.  The 64 x Cr products of a matrix-vector step are formed in parallel, their
   // sums (serial, for the order) read all operands first.
   if (ca) {
-    __shared__ __attribute__((aligned(16))) float cred[512], cW1[512], cW2[512], cA[64], cB[64], cmean[64], cd2[64], cz[8], cd1[8];
+    __shared__ __attribute__((aligned(16))) float cW1[512], cW2[512], cA[64], cB[64], cmean[64], cd2[64], cz[8], cd1[8];
     const bool bwd = a.ca_mode == 1;
+    // workgroup barrier for LDS traffic only: __syncthreads() would also wait for the weight slabs in flight (vmcnt)
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     const int Cr = a.ca_cr;                                  // <= 8 (launcher)
     const float invHW = 1.f / (float)(H * W);
     const bool slot_owner = tX == 0 && tY == 0;             // one workgroup per sample writes the per-sample results
@@ -162,24 +164,19 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       }
     }
     SRK_PSTAMP(13);
-    // partial sums, four strided ones per channel, the way ca_sum_partials forms them; loads first, ordered adds after
-    float pg = 0.f, ps = 0.f;
-    if (tid < 256) {
-      const int q = tid >> 6, c = tid & 63;
-      auto strided = [&](const float* src, int rows) {
-        const float* pp = src + (size_t)n * rows * 64 + c;
-        float t = 0.f;
-        for (int s0 = q; s0 < rows; s0 += 32) {
-          float v[8];
+    // the per-block partial sums of the pooled vectors ([rows <= 64][64] floats each): 16-byte loads spread over the whole
+    // workgroup -- a CU issues roughly one vector-memory instruction per 16 cycles whoever asks, so their NUMBER is what
+    // costs -- staged raw in the (still unused) intermediate tile's LDS
+    const bool want_s = !bwd || slot_owner;
+    const int rg = bwd ? a.ca_gsum_rows : 0, rs = want_s ? a.ca_sums_rows : 0;
+    float* const rawG = reinterpret_cast<float*>(Ms);
+    float* const rawS = rawG + 64 * 64;
+    f32x4 vg[2], vs[2];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = s0 + 4 * u < rows ? pp[(size_t)(s0 + 4 * u) * 64] : 0.f;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) if (s0 + 4 * u < rows) t += v[u];
-        }
-        return t;
-      };
-      if (bwd) pg = strided(a.ca_gsum, a.ca_gsum_rows);
-      if (!bwd || slot_owner) ps = strided(a.ca_sums, a.ca_sums_rows);
+    for (int u = 0; u < 2; ++u) {
+      const int f = tid + C::NT * u;                         // float4 index: row f >> 4, channels 4 (f & 15) ..
+      vg[u] = f < rg * 16 ? *reinterpret_cast<const f32x4*>(a.ca_gsum + (size_t)n * rg * 64 + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
+      vs[u] = f < rs * 16 ? *reinterpret_cast<const f32x4*>(a.ca_sums + (size_t)n * rs * 64 + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float w1r = 0.f, w2r = 0.f, sg_in = 0.f, z_in = 0.f, b1_in = 0.f, b2_in = 0.f;
     if (tid < 64 * Cr) { w1r = a.ca_w1[tid]; w2r = a.ca_w2[tid]; }
@@ -194,56 +191,95 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     // everything requested so far is used (= waited for) HERE, then the weight slabs' DMA starts
 #pragma unroll
     for (int k = 0; k < C::XK; ++k) asm volatile("" : "+v"(xin[k]), "+v"(x2in[k]));
-    asm volatile("" : "+v"(pg), "+v"(ps), "+v"(w1r), "+v"(w2r), "+v"(sg_in), "+v"(z_in), "+v"(b1_in), "+v"(b2_in));
+    asm volatile("" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vs[0]), "+v"(vs[1]), "+v"(w1r), "+v"(w2r), "+v"(sg_in), "+v"(z_in), "+v"(b1_in), "+v"(b2_in));
     SRK_PSTAMP(15);
     dma_slab(0);
     dma_slab(1);
     dma_slab(2);
-    if (tid < 64 * Cr) { cW1[tid] = w1r; cW2[tid] = w2r; }
-    if (tid < 256) cred[tid] = ps;
-    __syncthreads();
-    if (tid < 64) {
-      float u = 0.f;
-      for (int k = 0; k < 4; ++k) u += cred[k * 64 + tid];
-      cmean[tid] = u * invHW;
+    // (everything beyond the real rows / hidden units is staged as ZERO, so that the sums below run over fixed ranges with
+    // no per-element branch: a +-0 term leaves a sum as it is)
+    cW1[tid] = w1r;
+    cW2[tid] = w2r;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f = tid + C::NT * u;
+      *reinterpret_cast<f32x4*>(rawG + 4 * f) = vg[u];
+      *reinterpret_cast<f32x4*>(rawS + 4 * f) = vs[u];
     }
-    __syncthreads();
-    // ordered sum of 64 LDS operands (stride `st` floats): all reads first, then the adds
-    auto sum64 = [&](const float* base, int st, float init) {
+    lds_barrier();
+    // sum of the partials of channel c the way ca_sum_partials forms it: four strided sums (rows q, q+4, ...), then those in order
+    // (all <= 64 operands are read before the first add: a dependent LDS read per add costs ~100 cycles each; rows beyond
+    // `rows` contribute +0.0, which leaves every partial sum as it is)
+    auto pooled = [&](const float* raw, int c) {
       float v[64];
 #pragma unroll
-      for (int c = 0; c < 64; ++c) v[c] = base[c * st];
-      float u = init;
+      for (int sp = 0; sp < 64; ++sp) v[sp] = raw[sp * 64 + c];
+      float u = 0.f;
 #pragma unroll
-      for (int c = 0; c < 64; ++c) u += v[c];
+      for (int q = 0; q < 4; ++q) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += v[q + 4 * k];
+        u += t;
+      }
       return u;
     };
-    if (bwd) {
-      if (tid < 256) cred[tid] = pg;
-      __syncthreads();
-      if (tid < 64) {
-        float u = 0.f;
-        for (int k = 0; k < 4; ++k) u += cred[k * 64 + tid];
-        cA[tid] = sg_in;
-        cd2[tid] = u * (sg_in * (1.f - sg_in));
+    // The MLP itself on wave 0 alone: LDS operations of one wave execute in order, so its stages need no workgroup barrier
+    // (seven of them cost more than the arithmetic).  lane = channel; lanes < Cr also own one hidden unit.
+    auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    // ordered sum over c of wa[c * sa] * wb[c] (+ init): operands read 16 at a time, products and adds in c order
+    auto dot64 = [&](const float* wa, int sa, const float* wb, float init) {
+      float u = init;
+#pragma unroll
+      for (int c0 = 0; c0 < 64; c0 += 16) {
+        float x[16], y[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { x[c] = wa[(c0 + c) * sa]; y[c] = wb[c0 + c]; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) u += x[c] * y[c];
       }
-      if (tid < Cr) cz[tid] = z_in;
-      __syncthreads();
-      // dz[j] = sum_c W2[c][j] dpre2[c] (c ascending), dpre1 = relu'(z) dz
-      if (tid < 64 * Cr) cred[tid] = cW2[tid] * cd2[tid / Cr];
-      __syncthreads();
-      if (tid < Cr) {
-        const float dz = sum64(cred + tid, Cr, 0.f);
-        cd1[tid] = cz[tid] > 0.f ? dz : 0.f;
-      }
-      __syncthreads();
-      if (tid < 64) {
+      return u;
+    };
+    if (wave == 0) {
+      cmean[lane] = pooled(rawS, lane) * invHW;
+      if (bwd) {
+        const float u = pooled(rawG, lane);
+        cA[lane] = sg_in;
+        cd2[lane] = u * (sg_in * (1.f - sg_in));
+        if (lane < 8) { cz[lane] = lane < Cr ? z_in : 0.f; cd1[lane] = 0.f; }
+        wave_sync();
+        // dz[j] = sum_c W2[c][j] dpre2[c] (c ascending), dpre1 = relu'(z) dz
+        if (lane < Cr) {
+          const float dz = dot64(cW2 + lane, Cr, cd2, 0.f);
+          cd1[lane] = z_in > 0.f ? dz : 0.f;
+        }
+        wave_sync();
+        float wj[8], dj[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wj[j] = cW1[j * 64 + lane]; dj[j] = cd1[j]; }
         float dm = 0.f;
-        for (int j = 0; j < Cr; ++j) dm += cW1[j * 64 + tid] * cd1[j];
-        cB[tid] = dm / (float)(H * W);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dm += wj[j] * dj[j];
+        cB[lane] = dm / (float)(H * W);
+      } else {
+        wave_sync();
+        // forward: z = relu(b1 + W1 mean) (c ascending), s = sigmoid(b2 + W2 z)
+        if (lane < 8) cz[lane] = lane < Cr ? fmaxf(dot64(cW1 + lane * 64, 1, cmean, b1_in), 0.f) : 0.f;
+        wave_sync();
+        float wj[8], zj[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wj[j] = cW2[lane * Cr + j]; zj[j] = cz[j]; }
+        float sg = b2_in;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sg += wj[j] * zj[j];
+        sg = 1.f / (1.f + expf(-sg));
+        cA[lane] = sg;
+        cB[lane] = 0.f;
       }
-      __syncthreads();
-      if (slot_owner && a.ca_slots) {
+    }
+    lds_barrier();
+    if (slot_owner) {                                        // per-sample results: one workgroup per sample
+      if (bwd && a.ca_slots) {
         float* const sl0 = a.ca_slots + (size_t)n * (2 * 64 * Cr + Cr + 64);      // [dW1 | db1 | dW2 | db2]
         float* const dw1 = sl0, *const db1 = sl0 + 64 * Cr, *const dw2 = db1 + Cr, *const db2 = dw2 + 64 * Cr;
         for (int i = tid; i < 64 * Cr; i += C::NT) {
@@ -253,25 +289,10 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         if (tid < 64) db2[tid] = cd2[tid];
         if (tid < Cr) db1[tid] = cd1[tid];
       }
-    } else {
-      // forward: z = relu(b1 + W1 mean) (c ascending), s = sigmoid(b2 + W2 z)
-      if (tid < 64 * Cr) cred[tid] = cW1[tid] * cmean[tid & 63];
-      __syncthreads();
-      if (tid < Cr) {
-        const float zz = fmaxf(sum64(cred + tid * 64, 1, b1_in), 0.f);
-        cz[tid] = zz;
-        if (a.ca_z_out && slot_owner) a.ca_z_out[(size_t)n * Cr + tid] = zz;
+      if (!bwd) {
+        if (a.ca_z_out && tid < Cr) a.ca_z_out[(size_t)n * Cr + tid] = cz[tid];
+        if (a.ca_s_out && tid < 64) a.ca_s_out[(size_t)n * 64 + tid] = cA[tid];
       }
-      __syncthreads();
-      if (tid < 64) {
-        float sg = b2_in;
-        for (int j = 0; j < Cr; ++j) sg += cW2[tid * Cr + j] * cz[j];
-        sg = 1.f / (1.f + expf(-sg));
-        cA[tid] = sg;
-        cB[tid] = 0.f;
-        if (a.ca_s_out && slot_owner) a.ca_s_out[(size_t)n * 64 + tid] = sg;
-      }
-      __syncthreads();
     }
     SRK_PSTAMP(16);
 #pragma unroll
@@ -684,6 +705,7 @@ extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
                                       a->ca_x2_pitch % 8 == 0 && a->ca_x2_coff % 8 == 0),
                   "srk_conv_pair: ca_mode 2 needs x2, sums, w1, b1, w2, b2");
     SRK_CHECK_ARG(a->ca_cr > 0 && a->ca_cr <= 8, "srk_conv_pair: ca_cr=%d (1..8)", a->ca_cr);
+    SRK_CHECK_ARG(a->ca_sums_rows <= 64 && a->ca_gsum_rows <= 64, "srk_conv_pair: more than 64 partial rows per sample");
     SRK_CHECK_ARG(!a->xo || (a->xo_pitch % 8 == 0 && a->xo_coff % 8 == 0), "srk_conv_pair: alignment of xo");
   }
   const long long px = (long long)a->N * a->H * a->W;

@@ -1085,7 +1085,7 @@ class RCABFn(torch.autograd.Function):
         dw2, db2 = per[0, cr * cp + cr:2 * cr * cp + cr], per[0, 2 * cr * cp + cr:]
         gt = torch.empty_like(x)
         paired = pair_ok(g, w1, w2)
-        fuse_ca = paired and cp == 64 and cr <= 8 and not _CA_UNFUSED
+        fuse_ca = paired and cp == 64 and cr <= 8 and gs_rows <= 64 and sums.shape[1] <= 64 and not _CA_UNFUSED
         if not fuse_ca:
             L.call("srk_ca_bwd_apply", L.CaBwdArgs(
                 g=g.data_ptr(), g_pitch=_pitch(g), g_coff=0, gsum=gsum.data_ptr(), sums=sums.data_ptr(), s=s.data_ptr(),
@@ -1164,7 +1164,7 @@ def rcab_chain(x, blocks):
     if not blocks:
         return x
     w1, w2 = blocks[0][0], blocks[0][2]
-    lazy_ok = (not _CA_UNFUSED and pair_ok(x, w1, w2) and x.shape[3] == 64
+    lazy_ok = (not _CA_UNFUSED and pair_ok(x, w1, w2) and x.shape[3] == 64 and L.load().srk_conv_pair_tiles(1, x.shape[1], x.shape[2]) <= 64
                and all(tuple(b[0].shape) == (64, 64, 3, 3) and tuple(b[2].shape) == (64, 64, 3, 3) and b[5] is not None and b[7] is not None
                        and b[4].shape[1] == 64 and b[4].shape[0] <= 8 for b in blocks))
     lazy = None
