@@ -1421,6 +1421,9 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
       if (a.CoutP == 32 && rin == 1 && a.Cin == 64) return launch_ws<DT, 1, 4, false>(a, st);   // e.g. the 64->3 tail conv
     }
   }
+  if constexpr (DTraits<DT>::IS16) {
+    if (srk_conv_ks_ok(a)) return srk_conv_ks_launch(a, st);      // many input channels: conv_ks.hip
+  }
   const int tc = (a.CoutP % 128 == 0) ? 128 : (a.CoutP % 64 == 0) ? 64 : 32;
   if (a.KH == 3) {
     if (tc == 128) return launch<DT, 128, 3>(a, st);

@@ -203,3 +203,8 @@ template <int DT> SRK_DEV void store4(typename DTraits<DT>::elem* p, const float
     *reinterpret_cast<f32x4*>(p) = raw;
   }
 }
+
+// conv_ks.hip: 3x3 conv with >= 2 input blocks of 64 channels (K-streaming kernel); srk_conv2d (conv_igemm.hip) dispatches to it
+bool srk_conv_ks_ok(const srk_conv_args& a);
+int srk_conv_ks_launch(const srk_conv_args& a, hipStream_t st);
+

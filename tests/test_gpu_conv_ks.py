@@ -1,0 +1,97 @@
+"""GPU tests of conv_ks_kernel (csrc/conv_ks.hip): the 3x3 convolution for many input channels (EDSR-large's 256 -> 256
+layers, models/edsr.py; RDN's dense layers, models/rdn.py:9-40) that srk_conv2d dispatches to for Cin = 64 k >= 128, Cout a
+multiple of 64, 16-bit NHWC.  Every epilogue form (bias, ReLU, scale, residual, ReLU mask from a channel on, residual AND mask)
+on aligned and ragged images, forward and data-gradient packs, against a float64 reference on the rounded operands."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import sr_amd
+    assert torch.cuda.is_available()
+    sr_amd._lib.load()
+    return sr_amd
+
+
+def _rnd(g, *shape, scale=1.0):
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+CASES = [(16, 48, 48, 256, 256), (2, 20, 33, 128, 64), (1, 7, 9, 512, 128), (3, 16, 16, 192, 64), (1, 1, 1, 128, 64), (2, 17, 31, 256, 192)]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("form", ["bias_relu", "scale_res", "mask", "res_mask_from", "dgrad_mask"])
+def test_conv_ks_against_float64(A, dt, form):
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(7)
+    for (n, h, w, ci, co) in CASES:
+        x = _rnd(g, n, h, w, ci).to(dt)
+        wt = _rnd(g, co, ci, 3, 3, scale=1.0 / np.sqrt(9 * ci))
+        b = _rnd(g, co, scale=0.2)
+        res = _rnd(g, n, h, w, co).to(dt)
+        mk = torch.relu(_rnd(g, n, h, w, co)).to(dt)
+        dgrad = form == "dgrad_mask"
+        wp, bp = torch.nn.Parameter(wt.to(dev)), torch.nn.Parameter(b.to(dev))
+        kw = dict(relu=False, scale=1.0, res=None, mask=None, mask_from=0, use_bias=not dgrad)
+        if dgrad:      # data gradient of a conv ci -> co' : input has co' = `ci` channels here, weight is [ci_out = ci][co] ...
+            wt2 = _rnd(g, ci, co, 3, 3, scale=1.0 / np.sqrt(9 * ci))          # conv co -> ci ; its dgrad maps ci -> co
+            wp = torch.nn.Parameter(wt2.to(dev))
+            pk = A.ops.pack_conv(wp, None, dt, dgrad=True)
+            kw.update(mask=mk.to(dev))
+            wq = wt2.to(dt).double()
+            ref = F.conv_transpose2d(x.double().permute(0, 3, 1, 2), wq, padding=1)       # [n, co, h, w]
+            ref = torch.where(mk.double().permute(0, 3, 1, 2) > 0, ref, torch.zeros_like(ref))
+        else:
+            pk = A.ops.pack_conv(wp, bp, dt)
+            wq = wt.to(dt).double()
+            ref = F.conv2d(x.double().permute(0, 3, 1, 2), wq, b.double(), padding=1)
+            if form == "bias_relu":
+                kw.update(relu=True)
+                ref = torch.relu(ref)
+            elif form == "scale_res":
+                kw.update(scale=0.1, res=res.to(dev))
+                ref = ref * 0.1 + res.double().permute(0, 3, 1, 2)
+            elif form == "mask":
+                kw.update(mask=mk.to(dev))
+                ref = torch.where(mk.double().permute(0, 3, 1, 2) > 0, ref, torch.zeros_like(ref))
+            elif form == "res_mask_from":
+                mf = 32 if co > 32 else 0
+                kw.update(res=res.to(dev), mask=mk.to(dev), mask_from=mf)
+                ref = ref + res.double().permute(0, 3, 1, 2)
+                m = mk.double().permute(0, 3, 1, 2) > 0
+                m[:, :mf] = True
+                ref = torch.where(m, ref, torch.zeros_like(ref))
+        out = torch.full((n, h, w, co), float("nan"), dtype=dt, device=dev)
+        A.ops.conv_raw(x.to(dev), pk, N=n, H=h, W=w, Cin=ci, Cout=co, out=out, **kw)
+        torch.cuda.synchronize()
+        got = out.double().cpu().permute(0, 3, 1, 2)
+        tol = (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * max(1.0, float(ref.abs().max()))
+        assert torch.isfinite(got).all(), (form, n, h, w, ci, co)
+        assert float((got - ref).abs().max()) <= tol, (form, n, h, w, ci, co, float((got - ref).abs().max()), tol)
+
+
+def test_conv_ks_on_channel_slices(A):
+    """RDN's dense block: the conv reads the first 128 / 192 channels of a wider buffer and writes a 64-channel slice of it."""
+    dev = torch.device("cuda")
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 2, 19, 30
+    feat = _rnd(g, n, h, w, 320).to(dt).to(dev)
+    ref_feat = feat.clone()
+    for cin in (128, 192):
+        wt = _rnd(g, 64, cin, 3, 3, scale=1.0 / np.sqrt(9 * cin))
+        b = _rnd(g, 64, scale=0.2)
+        pk = A.ops.pack_conv(torch.nn.Parameter(wt.to(dev)), torch.nn.Parameter(b.to(dev)), dt)
+        A.ops.conv_raw(feat[..., :cin], pk, N=n, H=h, W=w, Cin=cin, Cout=64, out=feat[..., cin:cin + 64], relu=True)
+        torch.cuda.synchronize()
+        r = torch.relu(F.conv2d(ref_feat[..., :cin].double().cpu().permute(0, 3, 1, 2), wt.to(dt).double(), b.double(), padding=1))
+        got = feat[..., cin:cin + 64].double().cpu().permute(0, 3, 1, 2)
+        assert float((got - r).abs().max()) <= 2.0 ** -7 * max(1.0, float(r.abs().max()))
+        assert torch.equal(feat[..., cin + 64:], ref_feat[..., cin + 64:]) and torch.equal(feat[..., :cin], ref_feat[..., :cin])
+        ref_feat = feat.clone()
