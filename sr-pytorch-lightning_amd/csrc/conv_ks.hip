@@ -63,8 +63,10 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
   const unsigned x_lds = lds_addr_of(X0), wr_lds = lds_addr_of(Wr);
 
   // halo tile of K-block kb -> X[kb & 1]: pieces in the tile's LDS order (pixel-major, chunk slot XOR-swizzled by column)
+  const int rin = a.x_ps > 1 ? a.x_ps : 1, Cs = a.Cin / (rin * rin);
   auto dma_xtile = [&](int kb) {
     const unsigned dst = x_lds + (unsigned)((kb & 1) * C::XS_BYTES);
+    const int xij = (kb * 64) / Cs, xc0 = kb * 64 - xij * Cs, xsi = xij / rin, xsj = xij - xsi * rin;
 #pragma unroll
     for (int k = 0; k < C::XK; ++k) {
       const int i = tid + k * C::NT;
@@ -74,7 +76,10 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
         const int c = sl ^ swz(ix);
         const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
         const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + kb * 64 + c * Tr::CH) * 2) : 0x80000000u;
+        // (pixel-shuffled input, the dgrad of a conv -> PixelShuffle(r): logical channel k = (i*r+j)*Cs + c lives in pixel
+        //  (gy*r+i, gx*r+j), channel c; a 64-channel K-block lies inside one (i, j) plane)
+        const int pix = rin == 1 ? (n * H + gy) * W + gx : (n * H * rin + gy * rin + xsi) * (W * rin) + gx * rin + xsj;
+        const unsigned voff = ok ? (unsigned)((pix * a.x_pitch + a.x_coff + xc0 + c * Tr::CH) * 2) : 0x80000000u;
         if (i < C::XPIECES)                                // the last piece is half tile: its upper lanes are switched off
           dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + ((k * C::NT + wave * 64) << 4))));
       }
@@ -282,6 +287,8 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   {
     const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.out);
+    const int orr = (a.out_mode == SRK_OUT_NHWC_PS && a.ps_r > 1) ? a.ps_r : 1, Cc = a.Cout / (orr * orr);
+    const int oij = (cob * 64) / Cc, ocb = cob * 64 - oij * Cc, osi = oij / orr, osj = oij - osi * orr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = tid + C::NT * k;                       // 2,048 pieces: pixel i >> 3 (row-major 16 x 16), chunk i & 7
@@ -290,7 +297,9 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
       const int gy = y0 + row, gx = x0 + col;
       const bool ok = gy < H && gx < W;
       const i32x4 q = lds_read16(stage + (p << 7) + ((c ^ swz(col)) << 4));
-      const unsigned vo = ok ? (unsigned)((((n * H + gy) * W + gx) * a.out_pitch + a.out_coff + cob * 64 + c * Tr::CH) * 2) : 0x80000000u;
+      // (fused PixelShuffle(r) store: packed channel co' = (i*r+j)*Cc + c goes to pixel (gy*r+i, gx*r+j), channel c)
+      const int opix = orr == 1 ? (n * H + gy) * W + gx : (n * H * orr + gy * orr + osi) * (W * orr) + gx * orr + osj;
+      const unsigned vo = ok ? (unsigned)((opix * a.out_pitch + a.out_coff + ocb + c * Tr::CH) * 2) : 0x80000000u;
       __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
     }
   }
@@ -299,18 +308,22 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
 }  // namespace
 
 // Whether srk_conv2d takes this kernel for `a` (16-bit, 3x3, >= 2 input blocks of 64 channels, 64-channel output blocks,
-// plain NHWC in and out).  SRK_NO_KS=1 keeps the streaming kernel (A/B runs).
+// NHWC in and out, optionally a pixel-shuffled input -- dgrad of an upsampler conv -- or the fused PixelShuffle store).
+// SRK_NO_KS=1 keeps the streaming kernel (A/B runs).
 bool srk_conv_ks_ok(const srk_conv_args& a) {
   static const bool off = [] { const char* e = getenv("SRK_NO_KS"); return e && e[0] == '1'; }();
   if (off || a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3) return false;
-  if (a.x_ps > 1 || a.out_mode != SRK_OUT_NHWC || a.post_add) return false;
+  if (a.out_mode == SRK_OUT_PLANAR || a.post_add) return false;
   if (a.Cin < 128 || a.Cin % 64 != 0 || a.CoutP % 64 != 0 || a.Cout != a.CoutP) return false;
+  const int rin = a.x_ps > 1 ? a.x_ps : 1, rr = (a.out_mode == SRK_OUT_NHWC_PS && a.ps_r > 1) ? a.ps_r : 1;
+  if (rin > 1 && (a.Cin % (rin * rin) != 0 || (a.Cin / (rin * rin)) % 64 != 0)) return false;       // a K-block inside one (i, j) plane
+  if (rr > 1 && (a.Cout % (rr * rr) != 0 || (a.Cout / (rr * rr)) % 64 != 0 || a.res || a.mask)) return false;
   if (a.x_pitch % 8 || a.x_coff % 8 || a.out_pitch % 8 || a.out_coff % 8) return false;
   if (a.res && (a.res_pitch % 8 || a.res_coff % 8)) return false;
   if (a.mask && (a.mask_pitch % 8 || a.mask_coff % 8 || a.mask_from % 16)) return false;
   const long long px = (long long)a.N * a.H * a.W;
-  long long mx = px * a.x_pitch;
-  if (px * a.out_pitch > mx) mx = px * a.out_pitch;
+  long long mx = px * rin * rin * a.x_pitch;
+  if (px * rr * rr * a.out_pitch > mx) mx = px * rr * rr * a.out_pitch;
   if (a.res && px * a.res_pitch > mx) mx = px * a.res_pitch;
   if (a.mask && px * a.mask_pitch > mx) mx = px * a.mask_pitch;
   if (mx * 2 >= 0x7fff0000LL) return false;
@@ -331,7 +344,8 @@ int srk_conv_ks_launch(const srk_conv_args& a, hipStream_t st) {
   const int tilesX = (a.W + C::T - 1) / C::T, tilesY = (a.H + C::T - 1) / C::T, ncob = a.CoutP / 64;
   const long long nb = (long long)a.N * tilesX * tilesY * ncob;
   SRK_CHECK_ARG(nb <= 0x7fffffffLL, "srk_conv2d: %lld workgroups", nb);
-  const unsigned xb = (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2);
+  const int rin = a.x_ps > 1 ? a.x_ps : 1;
+  const unsigned xb = (unsigned)((long long)a.N * a.H * a.W * rin * rin * a.x_pitch * 2);
   const unsigned wb = (unsigned)(9LL * (a.Cin / 8) * a.CoutP * 16);
   if (a.dtype == SRK_BF16) hipLaunchKernelGGL((conv_ks_kernel<SRK_BF16>), dim3((unsigned)nb), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY, ncob, xb, wb);
   else hipLaunchKernelGGL((conv_ks_kernel<SRK_F16>), dim3((unsigned)nb), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY, ncob, xb, wb);

@@ -95,3 +95,30 @@ def test_conv_ks_on_channel_slices(A):
         assert float((got - r).abs().max()) <= 2.0 ** -7 * max(1.0, float(r.abs().max()))
         assert torch.equal(feat[..., cin + 64:], ref_feat[..., cin + 64:]) and torch.equal(feat[..., :cin], ref_feat[..., :cin])
         ref_feat = feat.clone()
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_conv_ks_pixelshuffle_store_and_shuffled_input(A, dt):
+    """The upsampler of the 256-feature models (models/common.py:133: conv 256 -> 1024, PixelShuffle(2)): the fused
+    pixel-shuffle store forward, and the data gradient that reads its incoming gradient through the same addressing."""
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(17)
+    n, h, w, f, r = 2, 11, 13, 128, 2
+    x = _rnd(g, n, f, h, w)
+    wt = _rnd(g, f * r * r, f, 3, 3, scale=1.0 / np.sqrt(9 * f))
+    b = _rnd(g, f * r * r, scale=0.1)
+    xq = x.to(dt).double().requires_grad_(True)
+    y = F.pixel_shuffle(F.conv2d(xq, wt.to(dt).double(), b.double(), padding=1), r)
+    gy = _rnd(g, *y.shape).to(dt).double()
+    y.backward(gy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dt).to(dev).requires_grad_(True)
+    wp, bp = torch.nn.Parameter(wt.to(dev)), torch.nn.Parameter(b.to(dev))
+    calls = []
+    yd = A.ops.conv(xd, wp, bp, ps_r=r)
+    yd.backward(gy.permute(0, 2, 3, 1).contiguous().to(dt).to(dev))
+    torch.cuda.synchronize()
+    tol = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    got = yd.detach().double().cpu().permute(0, 3, 1, 2)
+    assert float((got - y.detach()).abs().max()) <= tol * max(1.0, float(y.abs().max()))
+    gx = xd.grad.double().cpu().permute(0, 3, 1, 2)
+    assert float((gx - xq.grad).abs().max()) <= 2 * tol * max(1.0, float(xq.grad.abs().max()))
