@@ -410,6 +410,26 @@ typedef struct {
 } srk_chan_stats_args;
 int srk_chan_stats_blocks(long long P);
 int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream);
+/* The per-channel step between srk_chan_stats and srk_chan_apply of nn.BatchNorm2d (models/common.py:97-98 in srresnet.py:16-21)
+ * and nn.PReLU, as one launch: the ordered sum over the blocks of `partial` [nblocks][2][C] and the vector arithmetic.
+ *   mode 0: out[0] = mean = sum0 / M
+ *   mode 1 (sums of x - mean): var = max(sum1/M - (sum0/M)^2, 0); running_mean / running_var (nullable, [Creal]) updated with
+ *           `momentum` (unbiased variance, like torch); out rows: invstd = rsqrt(var + eps), gamma (weight padded with 0),
+ *           a = gamma * invstd, d = beta - mean * a            (srk_chan_apply: out = a x + d)
+ *   mode 2 (sum0 = sum dy, sum1 = sum (x - mean) dy; batch statistics): out rows: dgamma = invstd sum1, dbeta = sum0,
+ *           a = gamma invstd, b = -a invstd dgamma / M, d = -a dbeta / M - b mean     (dx = a dy + b x + d)
+ *   mode 3 (running statistics): out rows: dgamma, dbeta, a = gamma invstd
+ *   mode 4: out[0][c] = sum0 (PReLU slope gradients); total = 1: one number, summed over the channels too          */
+typedef struct {
+  const float* partial; int nblocks; int C; int Creal;
+  int mode; int total;
+  float M, eps, momentum;
+  const float* mean; const float* invstd; const float* gamma;
+  const float* weight; const float* bias;
+  float* running_mean; float* running_var;
+  float* out;                             /* [rows][C] fp32 */
+} srk_chan_finalize_args;
+int srk_chan_finalize(const srk_chan_finalize_args* a, srk_stream_t stream);
 
 /* out[p][c] = post( (a[c]*x + b[c]*y + d[c]) * gate ),  gate = (z > 0 ? 1 : slope[c*slope_stride]) when z is given,
  * post = PReLU with the same slope when post_prelu.  a / b / d NULL = 1 / 1 / 0; y NULL = no second input.

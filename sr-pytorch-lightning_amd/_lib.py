@@ -50,6 +50,12 @@ class ConvPairArgs(C.Structure):
                 ("ca_x2", _p), ("ca_x2_pitch", _i), ("ca_x2_coff", _i), ("ca_b1", _p), ("ca_b2", _p), ("ca_s_out", _p), ("ca_z_out", _p)]
 
 
+class ChanFinalizeArgs(C.Structure):
+    _fields_ = [("partial", _p), ("nblocks", _i), ("C", _i), ("Creal", _i), ("mode", _i), ("total", _i),
+                ("M", _f), ("eps", _f), ("momentum", _f), ("mean", _p), ("invstd", _p), ("gamma", _p),
+                ("weight", _p), ("bias", _p), ("running_mean", _p), ("running_var", _p), ("out", _p)]
+
+
 class RowsumJob(C.Structure):
     _fields_ = [("src", _p), ("dst", _p), ("n", _i), ("k", _i)]
 
@@ -166,6 +172,7 @@ LAUNCHERS = {
     "srk_conv2d": ConvArgs,
     "srk_conv_pair": ConvPairArgs,
     "srk_adam_step": AdamArgs,
+    "srk_chan_finalize": ChanFinalizeArgs,
     "srk_conv2d_wgrad": WgradArgs,
     "srk_wgrad_finalize": WgradFinArgs,
     "srk_unfold_nchw": UnfoldArgs,

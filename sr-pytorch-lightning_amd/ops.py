@@ -1328,6 +1328,30 @@ def _pitch4(t):
     return _pitch(t) if t.dim() == 4 else t.shape[-1]
 
 
+def chan_partials(x, y=None, mode=0, shift=None):
+    """The per-block partial sums of srk_chan_stats [blocks][2][C] (see chan_sums), left unsummed for srk_chan_finalize."""
+    _need_gpu(x)
+    c = x.shape[-1]
+    P = x.numel() // c
+    nb = L.load().srk_chan_stats_blocks(P)
+    part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
+    L.call("srk_chan_stats", L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
+                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift)), _stream())
+    return part
+
+
+def chan_finalize(part, mode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None, bias=None,
+                  running_mean=None, running_var=None, total=False):
+    """srk_chan_finalize on the partials of chan_partials: `rows` x [C] fp32 results (include/srk.h lists them per mode)."""
+    nb, _, c = part.shape
+    out = torch.empty((rows, c), dtype=torch.float32, device=part.device)
+    L.call("srk_chan_finalize", L.ChanFinalizeArgs(
+        partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=mode, total=int(total),
+        M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
+        weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr()), _stream())
+    return out
+
+
 def chan_apply(x, *, y=None, z=None, a=None, b=None, d=None, slope=None, post_prelu=False):
     """out = post((a*x + b*y + d) * gate(z)) per channel (srk_chan_apply).  a/b/d/slope: fp32 [C] (slope may have 1 element)."""
     _need_gpu(x)
@@ -1371,8 +1395,12 @@ class PReLUFn(torch.autograd.Function):
         gx = chan_apply(g, z=x, slope=weight) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
-            s = chan_sums(x, g, mode=2)[0]
-            gw = s.sum().view(1) if weight.numel() == 1 else s[:weight.numel()]
+            if x.numel() == 0:
+                gw = torch.zeros_like(weight)
+            else:       # partial sums over x <= 0 of x * g, summed (over the channels too for a single slope) by one small launch
+                one = weight.numel() == 1
+                s = chan_finalize(chan_partials(x, g, mode=2), 4, 1, total=one)[0]
+                gw = s[:1] if one else s[:weight.numel()]
         return gx, gw
 
 
@@ -1392,24 +1420,33 @@ class BatchNormFn(torch.autograd.Function):
         c = weight.numel()
         cp = x.shape[-1]
         M = x.numel() // cp
-        if training:
+        if training and M > 0:
             # two-pass statistics: the mean, then the sums of the CENTRED values (E[x^2] - mean^2 cancels in fp32 when
-            # |mean| >> std, which formula-filled / badly scaled nets do have)
-            mean = (chan_sums(x)[0] / M).contiguous()
-            c1, c2 = chan_sums(x, shift=mean)
-            var = (c2 / M - (c1 / M) ** 2).clamp_min(0.0)
-            if running_mean is not None:
+            # |mean| >> std, which formula-filled / badly scaled nets do have).  The [C]-sized arithmetic between the passes
+            # (mean; variance, running buffers, invstd, scale and shift of the apply pass) is one small launch each.
+            mean = chan_finalize(chan_partials(x), 0, 1, M=M)[0]
+            w32, b32 = _f32c(weight), _f32c(bias)
+            upd = running_mean is not None and running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
+            r = chan_finalize(chan_partials(x, shift=mean), 1, 4, M=M, creal=c, eps=eps, momentum=momentum, mean=mean, weight=w32, bias=b32,
+                              running_mean=running_mean if upd else None, running_var=running_var if upd else None)
+            invstd, gamma, a, d = r[0], r[1], r[2], r[3]
+            if running_mean is not None and not upd:        # buffers in another dtype: torch arithmetic
+                var = 1.0 / (invstd * invstd) - eps
                 with torch.no_grad():
-                    running_mean.mul_(1 - momentum).add_(mean[:c], alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(var[:c] * (M / max(M - 1, 1)), alpha=momentum)
+                    running_mean.mul_(1 - momentum).add_(mean[:c].to(running_mean.dtype), alpha=momentum)
+                    running_var.mul_(1 - momentum).add_((var[:c] * (M / max(M - 1, 1))).to(running_var.dtype), alpha=momentum)
         else:
-            mean = torch.nn.functional.pad(running_mean.float(), (0, cp - c))
-            var = torch.nn.functional.pad(running_var.float(), (0, cp - c), value=1.0)
-        invstd = torch.rsqrt(var + eps)
-        gamma = torch.nn.functional.pad(weight.detach().float(), (0, cp - c))
-        beta = torch.nn.functional.pad(bias.detach().float(), (0, cp - c))
-        a = gamma * invstd
-        out = chan_apply(x, y=res, a=a, d=beta - mean * a)
+            if training:
+                mean, var = torch.zeros(cp, dtype=torch.float32, device=x.device), torch.zeros(cp, dtype=torch.float32, device=x.device)
+            else:
+                mean = torch.nn.functional.pad(running_mean.float(), (0, cp - c))
+                var = torch.nn.functional.pad(running_var.float(), (0, cp - c), value=1.0)
+            invstd = torch.rsqrt(var + eps)
+            gamma = torch.nn.functional.pad(weight.detach().float(), (0, cp - c))
+            beta = torch.nn.functional.pad(bias.detach().float(), (0, cp - c))
+            a = gamma * invstd
+            d = beta - mean * a
+        out = chan_apply(x, y=res, a=a, d=d)
         ctx.save_for_backward(x, mean, invstd, gamma)
         ctx.cfg = (training, c, M, res is not None)
         return out
@@ -1419,16 +1456,19 @@ class BatchNormFn(torch.autograd.Function):
         x, mean, invstd, gamma = ctx.saved_tensors
         training, c, M, has_res = ctx.cfg
         g = g.contiguous()
-        sg, sxg = chan_sums(x, g, shift=mean.contiguous())   # sum dy, sum (x - mean)*dy
-        dbeta = sg
-        dgamma = invstd * sxg                           # sum dy * xhat
+        if M == 0:
+            z = torch.zeros(c, dtype=torch.float32, device=x.device)
+            return torch.empty_like(g), z, z.clone(), None, None, None, None, None, (g if has_res else None)
+        part = chan_partials(x, g, mode=1, shift=mean.contiguous())      # sum dy, sum (x - mean)*dy
         if training:
             # dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M),  xhat = (x - mean)*invstd
-            k = gamma * invstd
-            bx = -k * invstd * dgamma / M
-            gx = chan_apply(g, y=x, a=k, b=bx, d=-k * dbeta / M - bx * mean)
+            r = chan_finalize(part, 2, 5, M=M, mean=mean, invstd=invstd.contiguous(), gamma=gamma.contiguous())
+            dgamma, dbeta = r[0], r[1]
+            gx = chan_apply(g, y=x, a=r[2], b=r[3], d=r[4])
         else:
-            gx = chan_apply(g, a=gamma * invstd)
+            r = chan_finalize(part, 3, 3, M=M, invstd=invstd.contiguous(), gamma=gamma.contiguous())
+            dgamma, dbeta = r[0], r[1]
+            gx = chan_apply(g, a=r[2])
         return gx, dgamma[:c], dbeta[:c], None, None, None, None, None, (g if has_res else None)
 
 

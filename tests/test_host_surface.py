@@ -62,7 +62,8 @@ def _header_struct_fields(name):
                                         ("srk_unfold_nhwc_args", "UnfoldNhwcArgs"), ("srk_fold_nhwc_args", "FoldNhwcArgs"),
                                         ("srk_chan_stats_args", "ChanStatsArgs"), ("srk_chan_apply_args", "ChanApplyArgs"),
                                         ("srk_conv_pair_args", "ConvPairArgs"), ("srk_adam_slot", "AdamSlot"),
-                                        ("srk_adam_block", "AdamBlock"), ("srk_adam_args", "AdamArgs"), ("srk_rowsum_job", "RowsumJob")])
+                                        ("srk_adam_block", "AdamBlock"), ("srk_adam_args", "AdamArgs"), ("srk_rowsum_job", "RowsumJob"),
+                                        ("srk_chan_finalize_args", "ChanFinalizeArgs")])
 def test_ctypes_structs_mirror_header(cname, cls):
     want = _header_struct_fields(cname)
     st = getattr(sr_amd._lib, cls)
