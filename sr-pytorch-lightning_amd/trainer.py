@@ -189,19 +189,118 @@ def synthetic_batch(n, channels, lr_size, scale, seed, device):
     return {"lr": lr.to(device), "hr": hr.to(device), "path": [f"synthetic/{i}" for i in range(n)]}
 
 
+def _eager_step(model, net, optimizer, gsync, scaler, batch):
+    """forward -> losses -> backward -> [gradient average] -> optimizer step, launch by launch."""
+    optimizer.zero_grad(set_to_none=True)
+    img_sr = net(batch["lr"])
+    loss = model._calculate_losses(img_sr=img_sr, img_hr=batch["hr"])["loss"]
+    if scaler is not None:
+        scaler.scale(loss).backward()
+        if gsync is not None:
+            gsync.sync()
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        loss.backward()
+        if gsync is not None:
+            gsync.sync()
+        optimizer.step()
+    # detached: an autograd graph of an eager step that is still referenced when a later step is CAPTURED gets released inside
+    # the capture (when its holder is reassigned), which crashes hipStreamEndCapture on this stack
+    return loss.detach()
+
+
+class GraphedStep:
+    """The training step as hipGraph replays.
+
+    At the reference's batch (16 patches of 48x48 per GPU) a step is hundreds of launches of 5-20 us; issued one by one from
+    Python the host is the bottleneck (RCAN: 60 ms per step eager, 10 ms replayed).  The first `warm_steps` batches run eagerly
+    (they are ordinary training steps: nothing is repeated or skipped); the next batch is copied into static buffers and the
+    step is CAPTURED (capturing records launches, it does not execute them) and then replayed for it and every later batch of
+    the same shape.  One process: one graph (forward, loss, backward, Adam).  Several ranks: forward + backward + gradient
+    packing are one graph, the bucketed all-reduce (RCCL) is issued eagerly between, the optimizer step is a second graph --
+    no collective is ever inside a capture.  A batch of another shape (a short last batch) runs eagerly.  If a capture fails
+    the loop stays eager (and says so once).  Callers must not keep a loss WITH its autograd graph from an earlier eager step
+    alive across the capture (`_eager_step` returns it detached for that reason)."""
+
+    def __init__(self, model, net, optimizer, gsync, warm_steps=3):
+        self.model, self.net, self.opt, self.gsync = model, net, optimizer, gsync
+        self.warm_steps = int(warm_steps)
+        self.seen = 0
+        self.graphs = None
+        self.static = None
+        self.loss = None
+        self.failed = False
+
+    def _fwd_bwd(self):
+        self.opt.zero_grad(set_to_none=True)
+        sr = self.net(self.static["lr"])
+        loss = self.model._calculate_losses(img_sr=sr, img_hr=self.static["hr"])["loss"]
+        loss.backward()
+        return loss
+
+    def _capture(self, batch):
+        self.static = {"lr": batch["lr"].clone(), "hr": batch["hr"].clone()}
+        if self.gsync is not None:
+            self.gsync.remove_hooks()            # no collective from inside backward any more: pack() / reduce() around the graphs
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        cem = "thread_local" if self.gsync is not None else "global"      # RCCL's watchdog polls events while this thread captures
+        if self.gsync is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode=cem):
+                self.loss = self._fwd_bwd()
+                self.opt.step()
+            self.graphs = (g,)
+        else:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, stream=side, capture_error_mode=cem):
+                self.loss = self._fwd_bwd()
+                self.gsync.pack()
+            with torch.cuda.graph(gb, stream=side, capture_error_mode=cem):
+                self.opt.step()
+            self.graphs = (ga, gb)
+
+    def __call__(self, batch):
+        self.seen += 1
+        same = self.static is not None and batch["lr"].shape == self.static["lr"].shape and batch["hr"].shape == self.static["hr"].shape
+        if self.failed or self.seen <= self.warm_steps or (self.graphs is not None and not same):
+            return _eager_step(self.model, self.net, self.opt, self.gsync, None, batch)
+        if self.graphs is None:
+            try:
+                torch.cuda.synchronize()
+                self._capture(batch)
+            except Exception as e:  # noqa: BLE001
+                import sys
+                print(f"[trainer] hipGraph capture failed ({type(e).__name__}: {e}); training continues eagerly", file=sys.stderr)
+                self.failed, self.graphs, self.static = True, None, None
+                torch.cuda.synchronize()
+                return _eager_step(self.model, self.net, self.opt, self.gsync, None, batch)
+        else:
+            self.static["lr"].copy_(batch["lr"], non_blocking=True)
+            self.static["hr"].copy_(batch["hr"], non_blocking=True)
+        self.graphs[0].replay()
+        if len(self.graphs) == 2:
+            self.gsync.reduce()
+            self.graphs[1].replay()
+        return self.loss.detach()
+
+
 class Trainer:
     """`fit(model, batches)`: forward -> losses -> backward -> optimizer.step, DDP when WORLD_SIZE > 1.
 
     Mirrors what Lightning's fit loop does around `SRModel.training_step` (srmodel.py:160-171):
     nothing else (no checkpointing / loggers -- out of scope)."""
 
-    def __init__(self, device=None, max_steps=-1, log_every=0, use_grad_scaler=None):
+    def __init__(self, device=None, max_steps=-1, log_every=0, use_grad_scaler=None, use_graph=None):
         if device is None:
             device = torch.device("cuda", dist_env()[2]) if torch.cuda.is_available() else torch.device("cpu")
         self.device = torch.device(device)
         self.max_steps = max_steps
         self.log_every = log_every
         self.use_grad_scaler = use_grad_scaler
+        # hipGraph replay of the training step (GraphedStep): on by default on a GPU; SRK_TRAIN_GRAPH=0 or use_graph=False: eager
+        self.use_graph = (os.environ.get("SRK_TRAIN_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
         self.rank, self.world, self.local = init_distributed(self.device.type)
         self.losses = []
 
@@ -220,26 +319,19 @@ class Trainer:
             use_scaler = getattr(model, "compute_dtype", torch.float32) == torch.float16 and self.device.type == "cuda"
         if use_scaler:
             scaler = torch.amp.GradScaler("cuda")
+        graphed = None
+        if self.use_graph and scaler is None and self.device.type == "cuda" and not use_ddp:
+            graphed = GraphedStep(model, net, optimizer, gsync, warm_steps=11 if gsync is not None else 3)
         for step, batch in enumerate(batches):
             if 0 <= self.max_steps <= step:
                 break
-            batch = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
-            optimizer.zero_grad(set_to_none=True)
-            img_sr = net(batch["lr"])
-            result = model._calculate_losses(img_sr=img_sr, img_hr=batch["hr"])
-            loss = result["loss"]
-            if scaler is not None:
-                scaler.scale(loss).backward()
-                if gsync is not None:
-                    gsync.sync()
-                scaler.step(optimizer)
-                scaler.update()
+            batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            if graphed is not None:
+                loss = graphed(batch)
             else:
-                loss.backward()
-                if gsync is not None:
-                    gsync.sync()
-                optimizer.step()
+                loss = _eager_step(model, net, optimizer, gsync, scaler, batch)
             self.losses.append(float(loss.detach()))
             if self.log_every and self.rank == 0 and (step + 1) % self.log_every == 0:
                 print(f"step {step + 1}: loss {self.losses[-1]:.6f}", flush=True)
+        self.graphed = graphed
         return model

@@ -538,3 +538,36 @@ def test_srresnet_fullsize_backward_vs_float64_oracle(A):
         worst = max(worst, e)
         assert e < 0.1 and cos > 0.99, f"{n}: rel-L2 {e:.3f} cosine {cos:.4f}"
     print(f"srresnet_full_x4: worst relative L2 deviation of a gradient from the float64 oracle {worst:.3f}")
+
+
+@pytest.mark.parametrize("model_kw", [dict(cls="EDSR", n_feats=64, n_resblocks=2, res_scale=0.1), dict(cls="RCAN", n_feats=64, n_resblocks=3, n_resgroups=2)])
+def test_trainer_graph_replay_follows_the_eager_loop(model_kw):
+    """Trainer.fit replays the training step as a hipGraph after three eager steps (trainer.GraphedStep): same losses, step for
+    step, and the same final weights as the launch-by-launch loop; a batch of another shape falls back to eager."""
+    import sr_amd
+    from sr_amd import trainer as T
+    kw = dict(model_kw)
+    cls = getattr(sr_amd, kw.pop("cls"))
+
+    def batches():
+        for i in range(9):
+            n = 16 if i != 7 else 6                      # one short batch in the middle of the replays
+            yield T.synthetic_batch(n, 3, 24, 2, 100 + i, "cpu")
+
+    out = []
+    for use_graph in (True, False):
+        torch.manual_seed(0)
+        m = cls(scale_factor=2, precision="bf16", **kw)
+        tr = T.Trainer(device="cuda", use_graph=use_graph)
+        tr.fit(m, batches())
+        torch.cuda.synchronize()
+        out.append((tr.losses, [p.detach().clone() for p in m.parameters()], tr.graphed))
+    (lg, pg, g), (le, pe, _) = out
+    assert g is not None and g.graphs is not None and not g.failed, "the step was captured"
+    assert len(lg) == len(le) == 9
+    np.testing.assert_allclose(lg, le, rtol=2e-3)
+    assert lg[:3] == le[:3], "the first steps are the same eager code"
+    # Adam moves a weight by up to lr = 1e-3 per step whatever the size of its gradient, so single weights with near-zero
+    # gradients may part by a few steps' worth; on average the two runs stay together
+    for a, b in zip(pg, pe):
+        assert float((a - b).abs().max()) <= 9.5e-3 and float((a - b).abs().mean()) <= 3e-4
