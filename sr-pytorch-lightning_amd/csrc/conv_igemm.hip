@@ -1423,6 +1423,7 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
   }
   if constexpr (DTraits<DT>::IS16) {
     if (srk_conv_ks_ok(a)) return srk_conv_ks_launch(a, st);      // many input channels: conv_ks.hip
+    if (srk_conv1x1_ok(a)) return srk_conv1x1_launch(a, st);      // pointwise convs: conv1x1.hip
   }
   const int tc = (a.CoutP % 128 == 0) ? 128 : (a.CoutP % 64 == 0) ? 64 : 32;
   if (a.KH == 3) {

@@ -207,4 +207,7 @@ template <int DT> SRK_DEV void store4(typename DTraits<DT>::elem* p, const float
 // conv_ks.hip: 3x3 conv with >= 2 input blocks of 64 channels (K-streaming kernel); srk_conv2d (conv_igemm.hip) dispatches to it
 bool srk_conv_ks_ok(const srk_conv_args& a);
 int srk_conv_ks_launch(const srk_conv_args& a, hipStream_t st);
+// conv1x1.hip: 1x1 conv with Cin <= 384 (all operands in LDS behind one wait)
+bool srk_conv1x1_ok(const srk_conv_args& a);
+int srk_conv1x1_launch(const srk_conv_args& a, hipStream_t st);
 

@@ -122,3 +122,48 @@ def test_conv_ks_pixelshuffle_store_and_shuffled_input(A, dt):
     assert float((got - y.detach()).abs().max()) <= tol * max(1.0, float(y.abs().max()))
     gx = xd.grad.double().cpu().permute(0, 3, 1, 2)
     assert float((gx - xq.grad).abs().max()) <= 2 * tol * max(1.0, float(xq.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("form", ["bias_relu", "scale_res", "mask", "res_mask_from"])
+def test_conv1x1_against_float64(A, dt, form):
+    """conv1x1_kernel (csrc/conv1x1.hip): WDSR-B's pointwise convs (models/wdsr.py:30-51) and their data gradients."""
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(23)
+    # (the last three: WDSR-B at its default width -- 128 -> 768, 768 -> 102 (stored as 112 channels), 102 -> 768 (input padded to 112))
+    for (n, h, w, ci, co) in [(16, 48, 48, 64, 384), (16, 48, 48, 384, 64), (2, 9, 21, 128, 128), (1, 1, 1, 64, 64), (3, 17, 16, 320, 192),
+                              (4, 24, 24, 128, 768), (4, 24, 24, 768, 102), (4, 24, 24, 102, 768)]:
+        cip, cop = (ci + 15) // 16 * 16, (co + 15) // 16 * 16
+        x = torch.zeros(n, h, w, cip, dtype=dt)
+        x[..., :ci] = _rnd(g, n, h, w, ci).to(dt)
+        wt = _rnd(g, co, ci, 1, 1, scale=1.0 / np.sqrt(ci))
+        b = _rnd(g, co, scale=0.2)
+        res = _rnd(g, n, h, w, cop).to(dt)
+        mk = torch.relu(_rnd(g, n, h, w, cop)).to(dt)
+        pk = A.ops.pack_conv(torch.nn.Parameter(wt.to(dev)), torch.nn.Parameter(b.to(dev)), dt)
+        kw = dict(relu=False, scale=1.0, res=None, mask=None, mask_from=0)
+        ref = F.conv2d(x[..., :ci].double().permute(0, 3, 1, 2), wt.to(dt).double(), b.double())
+        resr, mkr = res[..., :co].double().permute(0, 3, 1, 2), mk[..., :co].double().permute(0, 3, 1, 2)
+        if form == "bias_relu":
+            kw.update(relu=True)
+            ref = torch.relu(ref)
+        elif form == "scale_res":
+            kw.update(scale=0.3, res=res.to(dev))
+            ref = ref * 0.3 + resr
+        elif form == "mask":
+            kw.update(mask=mk.to(dev))
+            ref = torch.where(mkr > 0, ref, torch.zeros_like(ref))
+        else:
+            mf = 32
+            kw.update(res=res.to(dev), mask=mk.to(dev), mask_from=mf)
+            ref = ref + resr
+            m = mkr > 0
+            m[:, :mf] = True
+            ref = torch.where(m, ref, torch.zeros_like(ref))
+        out = torch.full((n, h, w, cop), float("nan"), dtype=dt, device=dev)
+        A.ops.conv_raw(x.to(dev), pk, N=n, H=h, W=w, Cin=cip, Cout=cop, out=out, **kw)
+        torch.cuda.synchronize()
+        got = out[..., :co].double().cpu().permute(0, 3, 1, 2)
+        assert torch.isfinite(out.float()).all(), "padding channels are written too"
+        tol = (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * max(1.0, float(ref.abs().max()))
+        assert torch.isfinite(got).all() and float((got - ref).abs().max()) <= tol, (form, n, h, w, ci, co, float((got - ref).abs().max()), tol)
