@@ -299,12 +299,21 @@ dev = torch.device("cuda", local)
 torch.manual_seed(0)
 m = sr_amd.EDSR(n_feats=64, n_resblocks=2, res_scale=0.1, scale_factor=2, precision="bf16").to(dev)
 g = torch.Generator().manual_seed(5)
-full = [{{"lr": torch.rand(4, 3, 24, 24, generator=g), "hr": torch.rand(4, 3, 48, 48, generator=g)}} for _ in range(3)]
+full = [{{"lr": torch.rand(4, 3, 24, 24, generator=g), "hr": torch.rand(4, 3, 48, 48, generator=g)}} for _ in range(6)]
 per = 4 // world
 mode = {mode!r}
-gs = T.GradSync(m, overlap=(mode == "hooks"), bucket_bytes=64 << 10)
+gs = T.GradSync(m, overlap=(mode != "pack_reduce"), bucket_bytes=64 << 10)
 gs.broadcast()
 opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, fused=True)
+if mode == "graphed":
+    # the trainer's loop: eager steps with the overlapped all-reduces, then forward + backward + packing as one hipGraph, the
+    # all-reduce issued eagerly, the optimizer step (the one-launch HIP Adam) as a second graph
+    opt = m.configure_optimizers()[0]
+    gstep = T.GraphedStep(m, m, opt, gs, warm_steps=2)
+    for b in full:
+        gstep({{k: v[rank * per:(rank + 1) * per].to(dev) for k, v in b.items()}})
+    assert gstep.graphs is not None and len(gstep.graphs) == 2 and not gstep.failed
+    full = []
 for b in full:
     sh = {{k: v[rank * per:(rank + 1) * per].to(dev) for k, v in b.items()}}
     opt.zero_grad(set_to_none=True)
@@ -323,9 +332,9 @@ torch.distributed.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["hooks", "pack_reduce"])
+@pytest.mark.parametrize("mode", ["hooks", "pack_reduce", "graphed"])
 def test_gradsync_over_rccl(A, tmp_path, mode):
-    """A HIP EDSR trains 3 steps under trainer.GradSync on an `nccl` (= RCCL) process group: 1 rank always (the
+    """A HIP EDSR trains 6 steps under trainer.GradSync on an `nccl` (= RCCL) process group: 1 rank always (the
     collective path itself), 2 ranks when the box has 2 GPUs (replica equality).  The result must equal the same
     steps without any process group (global batch)."""
     ngpu = torch.cuda.device_count()
@@ -347,15 +356,20 @@ def test_gradsync_over_rccl(A, tmp_path, mode):
     torch.manual_seed(0)
     m = A.EDSR(n_feats=64, n_resblocks=2, res_scale=0.1, scale_factor=2, precision="bf16").cuda()
     g = torch.Generator().manual_seed(5)
-    full = [{"lr": torch.rand(4, 3, 24, 24, generator=g), "hr": torch.rand(4, 3, 48, 48, generator=g)} for _ in range(3)]
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, fused=True)
+    full = [{"lr": torch.rand(4, 3, 24, 24, generator=g), "hr": torch.rand(4, 3, 48, 48, generator=g)} for _ in range(6)]
+    opt = m.configure_optimizers()[0] if mode == "graphed" else torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, fused=True)
     for b in full:
         opt.zero_grad(set_to_none=True)
         m._calculate_losses(img_sr=m(b["lr"].cuda()), img_hr=b["hr"].cuda())["loss"].backward()
         opt.step()
     for k, v in m.state_dict().items():
-        d = float((v.float().cpu() - sds[0][k]).abs().max())
-        assert d <= (2e-6 if world == 1 else 2e-4) * max(1.0, float(v.abs().max())), (k, d)
+        dv = (v.float().cpu() - sds[0][k]).abs()
+        if mode == "graphed":
+            # replayed steps vs launch-by-launch steps: the same kernels, but fp32 atomics of the small weight gradients and
+            # Adam's lr-sized moves on near-zero gradients let single weights part by a few steps' worth
+            assert float(dv.max()) <= 6.5e-3 and float(dv.mean()) <= 3e-4, (k, float(dv.max()), float(dv.mean()))
+        else:
+            assert float(dv.max()) <= (2e-6 if world == 1 else 2e-4) * max(1.0, float(v.abs().max())), (k, float(dv.max()))
 
 
 # ---------------------------------------------------------------------------------------------------------------
