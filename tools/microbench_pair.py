@@ -2,7 +2,8 @@
 depth of EDSR-baseline's body, forward + backward forms).  Usage: python3 tools/microbench_pair.py [N ...]"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sr_amd as A
 
 dev = torch.device("cuda")
