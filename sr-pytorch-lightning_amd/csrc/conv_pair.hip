@@ -193,9 +193,15 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     for (int k = 0; k < C::XK; ++k) asm volatile("" : "+v"(xin[k]), "+v"(x2in[k]));
     asm volatile("" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vs[0]), "+v"(vs[1]), "+v"(w1r), "+v"(w2r), "+v"(sg_in), "+v"(z_in), "+v"(b1_in), "+v"(b2_in));
     SRK_PSTAMP(15);
-    dma_slab(0);
-    dma_slab(1);
-    dma_slab(2);
+    // slabs a0 a1 a2 (72 pieces) by waves 1..7 only: wave 0 carries the MLP below, the longest chain of this prologue
+    if (wave) {
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const int piece = (wave - 1) + 7 * k;                // 0 .. 71 = slab piece / 24, piece % 24
+        if (piece < 72)
+          dma16_hidden(w1rsrc, (unsigned)(piece * 1024 + lane * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(wr_lds + piece * 1024)));
+      }
+    }
     // (everything beyond the real rows / hidden units is staged as ZERO, so that the sums below run over fixed ranges with
     // no per-element branch: a +-0 term leaves a sum as it is)
     cW1[tid] = w1r;
@@ -210,19 +216,21 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     // sum of the partials of channel c the way ca_sum_partials forms it: four strided sums (rows q, q+4, ...), then those in order
     // (all <= 64 operands are read before the first add: a dependent LDS read per add costs ~100 cycles each; rows beyond
     // `rows` contribute +0.0, which leaves every partial sum as it is)
-    auto pooled = [&](const float* raw, int c) {
-      float v[64];
+    auto pooled = [&](const float* raw, int rows, int c) {
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int sp = 0; sp < 64; ++sp) v[sp] = raw[sp * 64 + c];
-      float u = 0.f;
+      for (int k0 = 0; k0 < 16; k0 += 4) {                   // 16 rows at a time (rows q + 4k, k = k0 .. k0+3), reads before adds
+        if (4 * k0 < rows) {
+          float v[16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t = 0.f;
+          for (int i = 0; i < 16; ++i) v[i] = raw[(4 * k0 + i) * 64 + c];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += v[q + 4 * k];
-        u += t;
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] += v[4 * k + q];
+        }
       }
-      return u;
+      return ((t[0] + t[1]) + t[2]) + t[3] + 0.f;
     };
     // The MLP itself on wave 0 alone: LDS operations of one wave execute in order, so its stages need no workgroup barrier
     // (seven of them cost more than the arithmetic).  lane = channel; lanes < Cr also own one hidden unit.
@@ -241,9 +249,9 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       return u;
     };
     if (wave == 0) {
-      cmean[lane] = pooled(rawS, lane) * invHW;
+      cmean[lane] = pooled(rawS, rs, lane) * invHW;
       if (bwd) {
-        const float u = pooled(rawG, lane);
+        const float u = pooled(rawG, rg, lane);
         cA[lane] = sg_in;
         cd2[lane] = u * (sg_in * (1.f - sg_in));
         if (lane < 8) { cz[lane] = lane < Cr ? z_in : 0.f; cd1[lane] = 0.f; }

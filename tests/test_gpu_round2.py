@@ -580,7 +580,8 @@ def test_trainer_graph_replay_follows_the_eager_loop(model_kw):
     assert g is not None and g.graphs is not None and not g.failed, "the step was captured"
     assert len(lg) == len(le) == 9
     np.testing.assert_allclose(lg, le, rtol=2e-3)
-    assert lg[:3] == le[:3], "the first steps are the same eager code"
+    assert lg[0] == le[0], "the first step is the same eager code on the same weights"
+    np.testing.assert_allclose(lg[:3], le[:3], rtol=1e-4)
     # Adam moves a weight by up to lr = 1e-3 per step whatever the size of its gradient, so single weights with near-zero
     # gradients may part by a few steps' worth; on average the two runs stay together
     for a, b in zip(pg, pe):
