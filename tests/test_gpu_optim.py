@@ -163,3 +163,30 @@ def test_model_trajectory_edsr_vs_torch_adam(A):
         assert float((p.detach() - q.detach()).abs().max()) <= 2e-6 * max(1.0, float(q.detach().abs().max()))
     assert losses[-1] < losses[0], "the model trains: forward sees the updated weights"
     assert all(p._version >= 4 for p in ps), "the update is visible to autograd's version counters"
+
+
+def test_param_groups_lr_schedule_and_persistent_grads(A):
+    """Two parameter groups with their own hyper-parameters, a learning rate changed between steps (what an lr scheduler does)
+    and gradients that persist across steps (zero_grad(set_to_none=False)): still torch.optim.Adam's trajectory."""
+    ps, rs = _params(7), _params(7)
+    groups = lambda q: [dict(params=q[:3], lr=1e-2), dict(params=q[3:], lr=1e-3, betas=(0.5, 0.9), weight_decay=0.01)]
+    opt, ropt = A.optim.Adam(groups(ps)), torch.optim.Adam(groups(rs))
+    for step in range(5):
+        _set_grads(ps, step)
+        _set_grads(rs, step)
+        if step == 0:
+            kept = [p.grad for p in ps]
+        else:                                                # same gradient tensors, new values (addresses unchanged: no table rebuild)
+            for k, p in zip(kept, ps):
+                k.copy_(p.grad)
+                p.grad = k
+        if step == 3:
+            for o in (opt, ropt):
+                o.param_groups[0]["lr"] = 5e-3
+        opt.step()
+        ropt.step()
+        opt.zero_grad(set_to_none=False)
+        assert all(float(p.grad.abs().max()) == 0.0 for p in ps)
+    torch.cuda.synchronize()
+    for p, r in zip(ps, rs):
+        assert float((p.detach() - r.detach()).abs().max()) <= 3e-6 * max(1.0, float(r.detach().abs().max())), p.shape
