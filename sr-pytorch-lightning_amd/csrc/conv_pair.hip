@@ -193,15 +193,6 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     for (int k = 0; k < C::XK; ++k) asm volatile("" : "+v"(xin[k]), "+v"(x2in[k]));
     asm volatile("" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vs[0]), "+v"(vs[1]), "+v"(w1r), "+v"(w2r), "+v"(sg_in), "+v"(z_in), "+v"(b1_in), "+v"(b2_in));
     SRK_PSTAMP(15);
-    // slabs a0 a1 a2 (72 pieces) by waves 1..7 only: wave 0 carries the MLP below, the longest chain of this prologue
-    if (wave) {
-#pragma unroll
-      for (int k = 0; k < 11; ++k) {
-        const int piece = (wave - 1) + 7 * k;                // 0 .. 71 = slab piece / 24, piece % 24
-        if (piece < 72)
-          dma16_hidden(w1rsrc, (unsigned)(piece * 1024 + lane * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(wr_lds + piece * 1024)));
-      }
-    }
     // (everything beyond the real rows / hidden units is staged as ZERO, so that the sums below run over fixed ranges with
     // no per-element branch: a +-0 term leaves a sum as it is)
     cW1[tid] = w1r;
@@ -213,6 +204,16 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       *reinterpret_cast<f32x4*>(rawS + 4 * f) = vs[u];
     }
     lds_barrier();
+    // slabs a0 a1 a2 (72 pieces) by waves 1..7 only, AFTER the staging barrier: wave 0 carries the MLP below, the longest chain
+    // of this prologue, and must not wait for their issue (~1.3k cycles); the transfers land well before the tile transform ends
+    if (wave) {
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const int piece = (wave - 1) + 7 * k;                // 0 .. 71 = slab piece / 24, piece % 24
+        if (piece < 72)
+          dma16_hidden(w1rsrc, (unsigned)(piece * 1024 + lane * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(wr_lds + piece * 1024)));
+      }
+    }
     // sum of the partials of channel c the way ca_sum_partials forms it: four strided sums (rows q, q+4, ...), then those in order
     // (all <= 64 operands are read before the first add: a dependent LDS read per add costs ~100 cycles each; rows beyond
     // `rows` contribute +0.0, which leaves every partial sum as it is)
