@@ -46,7 +46,8 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int H = a.H, W = a.W;
-  const int nkb = a.Cin >> 6, nch = a.Cin >> 3;         // K-blocks of 64 input channels; 16-byte chunks per pixel / tap
+  const int nkb = (a.Cin + 63) >> 6, nch = a.Cin >> 3;  // K-blocks of 64 input channels (the last one may be partial: Cin % 16 == 0);
+                                                        // 16-byte chunks per pixel / tap
 
   // output-channel block fastest: the workgroups that share a halo tile run together
   int pt = blockIdx.x;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
         const int iy = p / C::XT, ix = p - iy * C::XT;
         const int c = sl ^ swz(ix);
         const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
-        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && kb * 8 + c < nch;      // chunks beyond Cin: zeros
         // (pixel-shuffled input, the dgrad of a conv -> PixelShuffle(r): logical channel k = (i*r+j)*Cs + c lives in pixel
         //  (gy*r+i, gx*r+j), channel c; a 64-channel K-block lies inside one (i, j) plane)
         const int pix = rin == 1 ? (n * H + gy) * W + gx : (n * H * rin + gy * rin + xsi) * (W * rin) + gx * rin + xsj;
@@ -94,8 +95,8 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     for (int k = 0; k < 3; ++k) {
       const int piece = wave * 3 + k;                      // tap kh*3 + piece / 8, chunk kb*8 + piece % 8
       const int tap = kh * 3 + (piece >> 3), cc = kb * 8 + (piece & 7);
-      dma16_hidden(wrsrc, (unsigned)((((tap * nch + cc) * a.CoutP + cob * 64) << 4) + lane * 16),
-                   (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));
+      dma16_hidden(wrsrc, cc < nch ? (unsigned)((((tap * nch + cc) * a.CoutP + cob * 64) << 4) + lane * 16) : 0x80000000u,
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));      // chunks beyond Cin: zeros
     }
   };
   // residual / mask tile (16x16 pixels x this block's 64 channels) -> a halo buffer, image format with row pitch 16
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
       const int iy = blk >> 1, ix = (blk & 1) * 8 + (lane >> 3);
       const int c = (lane & 7) ^ swz(ix);
       const int gy = y0 + iy, gx = x0 + ix;
-      const bool ok = gy < H && gx < W;
+      const bool ok = gy < H && gx < W && cob * 64 + c * Tr::CH < a.Cout;      // Cout may end inside the last 64-row block
       const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * pitch + coff + cob * 64 + c * Tr::CH) * 2) : 0x80000000u;
       dma16_hidden(rs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (blk << 10))));
     }
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
       const int p = i >> 3, c = i & 7;
       const int row = p >> 4, col = p & 15;
       const int gy = y0 + row, gx = x0 + col;
-      const bool ok = gy < H && gx < W;
+      const bool ok = gy < H && gx < W && cob * 64 + c * Tr::CH < a.Cout;
       const i32x4 q = lds_read16(stage + (p << 7) + ((c ^ swz(col)) << 4));
       // (fused PixelShuffle(r) store: packed channel co' = (i*r+j)*Cc + c goes to pixel (gy*r+i, gx*r+j), channel c)
       const int opix = orr == 1 ? (n * H + gy) * W + gx : (n * H * orr + gy * orr + osi) * (W * orr) + gx * orr + osj;
@@ -307,17 +308,18 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
 
 }  // namespace
 
-// Whether srk_conv2d takes this kernel for `a` (16-bit, 3x3, >= 2 input blocks of 64 channels, 64-channel output blocks,
+// Whether srk_conv2d takes this kernel for `a` (16-bit, 3x3, more than one 64-channel input block -- Cin >= 96, a multiple of 16 --,
+// the stored channels ending inside the last 64-row block of the packed weights,
 // NHWC in and out, optionally a pixel-shuffled input -- dgrad of an upsampler conv -- or the fused PixelShuffle store).
 // SRK_NO_KS=1 keeps the streaming kernel (A/B runs).
 bool srk_conv_ks_ok(const srk_conv_args& a) {
   static const bool off = [] { const char* e = getenv("SRK_NO_KS"); return e && e[0] == '1'; }();
   if (off || a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3) return false;
   if (a.out_mode == SRK_OUT_PLANAR || a.post_add) return false;
-  if (a.Cin < 128 || a.Cin % 64 != 0 || a.CoutP % 64 != 0 || a.Cout != a.CoutP) return false;
+  if (a.Cin < 96 || a.Cin % 16 != 0 || a.CoutP % 64 != 0 || a.Cout % 8 != 0 || a.Cout > a.CoutP || a.Cout <= a.CoutP - 64) return false;
   const int rin = a.x_ps > 1 ? a.x_ps : 1, rr = (a.out_mode == SRK_OUT_NHWC_PS && a.ps_r > 1) ? a.ps_r : 1;
-  if (rin > 1 && (a.Cin % (rin * rin) != 0 || (a.Cin / (rin * rin)) % 64 != 0)) return false;       // a K-block inside one (i, j) plane
-  if (rr > 1 && (a.Cout % (rr * rr) != 0 || (a.Cout / (rr * rr)) % 64 != 0 || a.res || a.mask)) return false;
+  if (rin > 1 && (a.Cin % 64 != 0 || a.Cin % (rin * rin) != 0 || (a.Cin / (rin * rin)) % 64 != 0)) return false;   // a K-block inside one (i, j) plane
+  if (rr > 1 && (a.Cout != a.CoutP || a.Cout % (rr * rr) != 0 || (a.Cout / (rr * rr)) % 64 != 0 || a.res || a.mask)) return false;
   if (a.x_pitch % 8 || a.x_coff % 8 || a.out_pitch % 8 || a.out_coff % 8) return false;
   if (a.res && (a.res_pitch % 8 || a.res_coff % 8)) return false;
   if (a.mask && (a.mask_pitch % 8 || a.mask_coff % 8 || a.mask_from % 16)) return false;

@@ -167,3 +167,36 @@ def test_conv1x1_against_float64(A, dt, form):
         assert torch.isfinite(out.float()).all(), "padding channels are written too"
         tol = (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * max(1.0, float(ref.abs().max()))
         assert torch.isfinite(got).all() and float((got - ref).abs().max()) <= tol, (form, n, h, w, ci, co, float((got - ref).abs().max()), tol)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_conv_ks_partial_blocks_wdsr_shapes(A, dt):
+    """WDSR-B's 3x3 conv 102 -> 128 (models/wdsr.py:30-51; the 102 channels live in 112-channel tensors) and its data gradient
+    128 -> 102: a partial last 64-channel input block and stored channels that end inside the last 64-row output block."""
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(29)
+    n, h, w, ci, co = 4, 24, 24, 102, 128
+    wt = _rnd(g, co, ci, 3, 3, scale=1.0 / np.sqrt(9 * ci))
+    b = _rnd(g, co, scale=0.2)
+    wp, bp = torch.nn.Parameter(wt.to(dev)), torch.nn.Parameter(b.to(dev))
+    tol = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    # forward: x [.., 112] (last 10 channels zero), scale + residual
+    x = torch.zeros(n, h, w, 112, dtype=dt)
+    x[..., :ci] = _rnd(g, n, h, w, ci).to(dt)
+    res = _rnd(g, n, h, w, co).to(dt)
+    out = torch.full((n, h, w, co), float("nan"), dtype=dt, device=dev)
+    A.ops.conv_raw(x.to(dev), A.ops.pack_conv(wp, bp, dt), N=n, H=h, W=w, Cin=112, Cout=co, out=out, scale=0.5, res=res.to(dev))
+    ref = F.conv2d(x[..., :ci].double().permute(0, 3, 1, 2), wt.to(dt).double(), b.double(), padding=1) * 0.5 + res.double().permute(0, 3, 1, 2)
+    torch.cuda.synchronize()
+    assert float((out.double().cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    # data gradient: dy [.., 128] -> dx [.., 112] with a ReLU mask; the 10 padding channels of dx come out as zeros
+    dy = _rnd(g, n, h, w, co).to(dt)
+    mk = torch.relu(_rnd(g, n, h, w, 112)).to(dt)
+    dx = torch.full((n, h, w, 112), float("nan"), dtype=dt, device=dev)
+    A.ops.conv_raw(dy.to(dev), A.ops.pack_conv(wp, None, dt, dgrad=True), N=n, H=h, W=w, Cin=co, Cout=112, out=dx, mask=mk.to(dev), use_bias=False)
+    refd = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), wt.to(dt).double(), padding=1)
+    refd = torch.where(mk[..., :ci].double().permute(0, 3, 1, 2) > 0, refd, torch.zeros_like(refd))
+    torch.cuda.synchronize()
+    got = dx.double().cpu()
+    assert float((got[..., :ci].permute(0, 3, 1, 2) - refd).abs().max()) <= tol * max(1.0, float(refd.abs().max()))
+    assert float(got[..., ci:].abs().max()) == 0.0
