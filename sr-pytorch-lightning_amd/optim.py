@@ -31,6 +31,8 @@ class _Plan:
         self.key = None
         self.grads = None       # the gradient tensors the table was built for (kept alive: their addresses are in it)
         self.live = []          # the parameters in the table
+        self.live_ids = None    # their identities (same set, moved addresses: only the pointer fields are rewritten)
+        self.slots = None
         self.nslots = self.nblocks = self.blocks_off = 0
 
 
@@ -114,24 +116,33 @@ class Adam(torch.optim.Adam):
         key = tuple((p.data_ptr(), g.data_ptr(), g.numel()) for p, g in live)
         if key == plan.key:
             return
-        slots = (L.AdamSlot * max(len(live), 1))()
-        blocks = []
-        for i, (p, g) in enumerate(live):
+        for p, g in live:
             if g.is_sparse:
                 raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
             if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device or g.numel() != p.numel():
                 raise RuntimeError("HIP Adam needs contiguous fp32 gradients on the parameter's device")
-            n = p.numel()
-            slots[i].p, slots[i].g, slots[i].state_off, slots[i].n, slots[i].step_idx = p.data_ptr(), g.data_ptr(), plan.offsets[p], n, plan.index[p]
-            for s0 in range(0, n, _CHUNK):
-                blocks.append((i, min(_CHUNK, n - s0), s0))
-        barr = (L.AdamBlock * max(len(blocks), 1))()
-        for j, (i, cnt, s0) in enumerate(blocks):
-            barr[j].slot, barr[j].count, barr[j].start = i, cnt, s0
+        ids = tuple(id(p) for p, _ in live)
+        same_set = ids == plan.live_ids                      # only addresses moved (eager steps re-allocate the gradients)
+        if not same_set:
+            plan.slots = (L.AdamSlot * max(len(live), 1))()
+            blocks = []
+            for i, (p, g) in enumerate(live):
+                n = p.numel()
+                plan.slots[i].state_off, plan.slots[i].n, plan.slots[i].step_idx = plan.offsets[p], n, plan.index[p]
+                for s0 in range(0, n, _CHUNK):
+                    blocks.append((i, min(_CHUNK, n - s0), s0))
+            barr = (L.AdamBlock * max(len(blocks), 1))()
+            for j, (i, cnt, s0) in enumerate(blocks):
+                barr[j].slot, barr[j].count, barr[j].start = i, cnt, s0
+            plan.nblocks = len(blocks)
+        slots = plan.slots
+        for i, (p, g) in enumerate(live):
+            slots[i].p, slots[i].g = p.data_ptr(), g.data_ptr()
         ssz = C.sizeof(L.AdamSlot) * len(live)
         boff = (ssz + 15) // 16 * 16
-        total = boff + C.sizeof(L.AdamBlock) * len(blocks)
-        if total:
+        total = boff + C.sizeof(L.AdamBlock) * plan.nblocks
+        upto = total if not same_set else ssz                # the block list depends on the sizes only
+        if upto:
             # one host-to-device copy from a page-locked staging buffer sized when the plan was made (so nothing is
             # allocated here): captured into a hipGraph it is ONE memcpy node that replays the same bytes
             assert total <= plan.host.numel()
@@ -139,13 +150,14 @@ class Adam(torch.optim.Adam):
             if plan.copied is not None and not capturing:
                 plan.copied.synchronize()                   # the previous table may still be on its way out of `host`
             C.memmove(plan.host.data_ptr(), C.addressof(slots), ssz)
-            C.memmove(plan.host.data_ptr() + boff, C.addressof(barr), total - boff)
-            plan.table[:total].copy_(plan.host[:total], non_blocking=True)
+            if not same_set:
+                C.memmove(plan.host.data_ptr() + boff, C.addressof(barr), total - boff)
+            plan.table[:upto].copy_(plan.host[:upto], non_blocking=True)
             if not capturing:
                 plan.copied = torch.cuda.Event()
                 plan.copied.record()
-        plan.key, plan.grads, plan.live = key, [g for _, g in live], [p for p, _ in live]
-        plan.nslots, plan.nblocks, plan.blocks_off = len(live), len(blocks), boff
+        plan.key, plan.grads, plan.live, plan.live_ids = key, [g for _, g in live], [p for p, _ in live], ids
+        plan.nslots, plan.blocks_off = len(live), boff
 
     # -- step -------------------------------------------------------------------------------------
     @torch.no_grad()
