@@ -213,11 +213,16 @@ class SRModel(_Base):
         raise NotImplementedError
 
     def _pack_group(self):
-        """Lazily created `ops.PackGroup`: one launch per step re-packs every conv's shadow weights."""
-        g = self.__dict__.get("_srk_packs")
+        """Lazily created `ops.PackGroup` of the CURRENT storage dtype: one launch per step re-packs every conv's shadow
+        weights.  One group per dtype, so the fp16 evaluation forward of a bf16 model (`_eval_forward`) never adds its
+        entries to the group the (possibly hipGraph-captured) training step refreshes."""
+        groups = self.__dict__.get("_srk_packs")
+        if groups is None:
+            groups = self.__dict__["_srk_packs"] = {}
+        g = groups.get(self.compute_dtype)
         if g is None:
             from .. import ops
-            g = self.__dict__["_srk_packs"] = ops.PackGroup()
+            g = groups[self.compute_dtype] = ops.PackGroup()
         return g
 
     # -- srmodel.py:160-171 ---------------------------------------------------------------------------

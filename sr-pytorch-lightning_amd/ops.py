@@ -127,7 +127,10 @@ class PackGroup:
             arr = (L.PackArgs * len(self.entries))(*[e[0] for e in self.entries.values()])
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             dev = next(iter(self.entries.values()))[2].device
-            self.table = raw.to(dev)
+            # the table keeps its ADDRESS while it fits (a captured step points at it): grown in place, with head room
+            if self.table is None or self.table.device != dev or self.table.numel() < raw.numel():
+                self.table = torch.empty(max(2 * raw.numel(), 4096), dtype=torch.uint8, device=dev)
+            self.table[:raw.numel()].copy_(raw)
             self.dirty = False
         rc = L.load().srk_pack_conv_weights_group(self.table.data_ptr(), len(self.entries), _stream())
         if rc != 0:
@@ -320,6 +323,7 @@ def conv_pair_raw(x, pk1, pk2, *, out, relu_mid=False, scale_mid=1.0, mask=None,
         ca_x2=_ptr(x2), ca_x2_pitch=0 if x2 is None else _pitch(x2), ca_x2_coff=0,
         ca_b1=_ptr(ca.get("b1")), ca_b2=_ptr(ca.get("b2")), ca_s_out=_ptr(ca.get("s_out")), ca_z_out=_ptr(ca.get("z_out")))
     L.call("srk_conv_pair", a, _stream())
+    PAIR_LAUNCHES[a.ca_mode] += 1
     return out
 
 
@@ -500,6 +504,14 @@ def defer_rowsum(per, params, shapes_offsets):
     _WQ.stream = torch.cuda.current_stream()
     del tot
     return outs
+
+
+def discard_wgrads():
+    """Drop whatever a backward pass that did NOT end normally left queued (an exception inside backward, a failed hipGraph
+    capture: the engine's final callback may never have run, so `armed` would stay set and later passes would queue jobs
+    nobody flushes).  Call before starting a fresh step."""
+    _WQ.jobs, _WQ.rjobs, _WQ.armed, _WQ.targets = [], [], False, {}
+    _WQ.gen += 1
 
 
 def flush_wgrads():
@@ -978,9 +990,6 @@ class _CAHint:
         self.gsum = self.g_ptr = self.g_ver = None
 
 
-_LAST_CA_HINT = None
-
-
 class _LazyApply:
     """The pending last step of an RCAB (out = t * s + x with s from the squeeze/excite MLP on `sums`): everything the next
     block's launch needs to perform it, and the buffers (`out`, `s`, `z`) it fills."""
@@ -990,7 +999,18 @@ class _LazyApply:
         self.t, self.x, self.sums, self.w, self.s, self.z, self.out = t, x, sums, w, s, z, out
 
 
-_LAST_LAZY = None
+def _fwd_state():
+    """Per-thread hand-over slots between consecutive RCABFn.forward calls (`ca_hint`: the previous block's _CAHint,
+    `lazy`: its pending _LazyApply).  Thread-local: two models stepping on two Python threads never see each other's."""
+    st = _TLS
+    if not hasattr(st, "ca_hint"):
+        st.ca_hint = st.lazy = None
+    return st
+
+
+#: launches of srk_conv_pair by ca_mode (0 plain, 1 CALayer backward on the way in, 2 CALayer forward on the way in):
+#: tests assert from it that a model run really took the fused flavours
+PAIR_LAUNCHES = [0, 0, 0]
 
 
 class RCABFn(torch.autograd.Function):
@@ -1034,10 +1054,10 @@ class RCABFn(torch.autograd.Function):
         z = torch.empty((n, cr), dtype=torch.float32, device=x.device)
         out = torch.empty_like(x)
         w1f, b1f, w2f, b2f = _ca_params(cw1, cb1, cw2, cb2, cp)
-        global _LAST_LAZY
-        _LAST_LAZY = None
+        fst = _fwd_state()
+        fst.lazy = None
         if lazy_out:
-            _LAST_LAZY = _LazyApply(t, x, sums, (w1f, b1f, w2f, b2f), s, z, out)
+            fst.lazy = _LazyApply(t, x, sums, (w1f, b1f, w2f, b2f), s, z, out)
         else:
             L.call("srk_ca_apply", L.CaApplyArgs(
                 t=t.data_ptr(), t_pitch=cp, t_coff=0, res=x.data_ptr(), res_pitch=cp, res_coff=0, sums=sums.data_ptr(),
@@ -1048,14 +1068,13 @@ class RCABFn(torch.autograd.Function):
         ctx.wb = (w1, b1, w2, b2)
         ctx.ca = (cw1, cb1, cw2, cb2)
         ctx.pg = _tok()
-        global _LAST_CA_HINT
-        prev, ctx.hint_in, ctx.hint_out = _LAST_CA_HINT, None, None
+        prev, ctx.hint_in, ctx.hint_out = fst.ca_hint, None, None
         if paired:
             if prev is not None and prev.out_ref() is x and prev.t.shape == x.shape:
                 ctx.hint_in = prev                           # x is the previous RCAB's output
-            ctx.hint_out = _LAST_CA_HINT = _CAHint(t, out)
+            ctx.hint_out = fst.ca_hint = _CAHint(t, out)
         else:
-            _LAST_CA_HINT = None
+            fst.ca_hint = None
         return out
 
     @staticmethod
@@ -1160,9 +1179,9 @@ def rcab_chain(x, blocks):
     At small batches (pair_ok) every block is ONE launch forward: the conv pair also pools its output, and the channel
     attention's last step of block i (t * s + x) is performed by block i+1's launch on its input tile; only the last block
     runs srk_ca_apply.  Larger batches: the blocks one by one, as `rcab`."""
-    global _LAST_LAZY
     if not blocks:
         return x
+    fst = _fwd_state()
     w1, w2 = blocks[0][0], blocks[0][2]
     lazy_ok = (not _CA_UNFUSED and pair_ok(x, w1, w2) and x.shape[3] == 64 and L.load().srk_conv_pair_tiles(1, x.shape[1], x.shape[2]) <= 64
                and all(tuple(b[0].shape) == (64, 64, 3, 3) and tuple(b[2].shape) == (64, 64, 3, 3) and b[5] is not None and b[7] is not None
@@ -1171,8 +1190,8 @@ def rcab_chain(x, blocks):
     for i, b in enumerate(blocks):
         last = i == len(blocks) - 1
         x = RCABFn.apply(x, *b, lazy, lazy_ok and not last)
-        lazy = _LAST_LAZY if (lazy_ok and not last) else None
-        _LAST_LAZY = None
+        lazy = fst.lazy if (lazy_ok and not last) else None
+        fst.lazy = None
     return x
 
 
@@ -1476,7 +1495,12 @@ def batch_norm(x, bn, res=None):
     """`bn`: an nn.BatchNorm2d (parameters, running buffers, training flag, momentum, eps) applied to NHWC `x`."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    mom = 0.1 if bn.momentum is None else bn.momentum
+    if bn.momentum is not None:
+        mom = bn.momentum
+    elif bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        mom = 1.0 / float(bn.num_batches_tracked)           # torch: cumulative moving average (a host read, as in torch)
+    else:
+        mom = 0.0
     use_batch = bn.training or bn.running_mean is None
     return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, res)
 

@@ -17,16 +17,14 @@ from . import _lib as L
 _CHUNK = 4096           # elements per workgroup (256 threads x 4 x float4)
 
 
-class _Plan:
-    """Per parameter group: flat moment buffers, the device step counter and the device table of (parameter, gradient)."""
+class _Table:
+    """One device copy of the (parameter, gradient) table with its page-locked staging buffer.  The eager steps own one;
+    every hipGraph capture gets ITS OWN (a captured upload is a memcpy node that re-reads the staging buffer on every
+    replay, so nothing an eager step does later may touch the bytes a live graph points at: ADVICE r2)."""
 
-    def __init__(self):
-        self.offsets = {}       # param -> offset (floats) into the flat moment buffers
-        self.index = {}         # param -> index into `steps`
-        self.m = self.v = None
-        self.steps = self.ticket = None  # per-parameter update counts (torch counts per parameter)
-        self.table = None       # device bytes: slots | blocks
-        self.host = None        # page-locked staging copy of the table
+    def __init__(self, cap, dev):
+        self.table = torch.empty(cap, dtype=torch.uint8, device=dev)   # device bytes: slots | blocks
+        self.host = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
         self.copied = None      # event behind the last eager upload from `host`
         self.key = None
         self.grads = None       # the gradient tensors the table was built for (kept alive: their addresses are in it)
@@ -34,6 +32,20 @@ class _Plan:
         self.live_ids = None    # their identities (same set, moved addresses: only the pointer fields are rewritten)
         self.slots = None
         self.nslots = self.nblocks = self.blocks_off = 0
+
+
+class _Plan:
+    """Per parameter group: flat moment buffers, the device step counter and the device tables of (parameter, gradient)."""
+
+    def __init__(self):
+        self.offsets = {}       # param -> offset (floats) into the flat moment buffers
+        self.index = {}         # param -> index into `steps`
+        self.m = self.v = None
+        self.steps = self.ticket = None  # per-parameter update counts (torch counts per parameter)
+        self.cap = 0
+        self.eager = None       # _Table of the launch-by-launch steps
+        self.captured = []      # _Tables owned by hipGraph captures: written once, kept alive as long as the plan
+        self.spare = None       # allocated OUTSIDE any capture (page-locked allocations are not capturable) for the next one
 
 
 class Adam(torch.optim.Adam):
@@ -84,8 +96,8 @@ class Adam(torch.optim.Adam):
         plan.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         # table of the largest case (every parameter has a gradient): tensors | 16-byte gap | blocks
         cap = C.sizeof(L.AdamSlot) * len(params) + 16 + C.sizeof(L.AdamBlock) * sum((p.numel() + _CHUNK - 1) // _CHUNK for p in params)
-        plan.table = torch.empty(cap, dtype=torch.uint8, device=dev)
-        plan.host = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        plan.cap = cap
+        plan.eager, plan.spare = _Table(cap, dev), _Table(cap, dev)
         host_steps = [0.0] * len(params)
         for k, p in enumerate(params):
             st = self.state[p]
@@ -112,52 +124,64 @@ class Adam(torch.optim.Adam):
 
     # -- device table --------------------------------------------------------------------------------
     def _table(self, plan, group):
+        """The table this step's launch reads: the eager one (rebuilt / re-pointed when gradient addresses moved), or a
+        fresh one owned by the capture in progress."""
         live = [(p, p.grad) for p in group["params"] if p.requires_grad and p.grad is not None]
         key = tuple((p.data_ptr(), g.data_ptr(), g.numel()) for p, g in live)
-        if key == plan.key:
-            return
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # owned by this capture and never rewritten: eager steps between replays (a short last batch, validation-time
+            # fallbacks) keep using `plan.eager`
+            t, plan.spare = (plan.spare or _Table(plan.cap, plan.m.device)), None
+            plan.captured.append(t)
+        else:
+            t = plan.eager
+            if plan.spare is None:
+                plan.spare = _Table(plan.cap, plan.m.device)
+            if key == t.key:
+                return t
         for p, g in live:
             if g.is_sparse:
                 raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
             if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device or g.numel() != p.numel():
                 raise RuntimeError("HIP Adam needs contiguous fp32 gradients on the parameter's device")
         ids = tuple(id(p) for p, _ in live)
-        same_set = ids == plan.live_ids                      # only addresses moved (eager steps re-allocate the gradients)
+        same_set = ids == t.live_ids                         # only addresses moved (eager steps re-allocate the gradients)
         if not same_set:
-            plan.slots = (L.AdamSlot * max(len(live), 1))()
+            t.slots = (L.AdamSlot * max(len(live), 1))()
             blocks = []
             for i, (p, g) in enumerate(live):
                 n = p.numel()
-                plan.slots[i].state_off, plan.slots[i].n, plan.slots[i].step_idx = plan.offsets[p], n, plan.index[p]
+                t.slots[i].state_off, t.slots[i].n, t.slots[i].step_idx = plan.offsets[p], n, plan.index[p]
                 for s0 in range(0, n, _CHUNK):
                     blocks.append((i, min(_CHUNK, n - s0), s0))
             barr = (L.AdamBlock * max(len(blocks), 1))()
             for j, (i, cnt, s0) in enumerate(blocks):
                 barr[j].slot, barr[j].count, barr[j].start = i, cnt, s0
-            plan.nblocks = len(blocks)
-        slots = plan.slots
+            t.nblocks = len(blocks)
+        slots = t.slots
         for i, (p, g) in enumerate(live):
             slots[i].p, slots[i].g = p.data_ptr(), g.data_ptr()
         ssz = C.sizeof(L.AdamSlot) * len(live)
         boff = (ssz + 15) // 16 * 16
-        total = boff + C.sizeof(L.AdamBlock) * plan.nblocks
+        total = boff + C.sizeof(L.AdamBlock) * t.nblocks
         upto = total if not same_set else ssz                # the block list depends on the sizes only
         if upto:
-            # one host-to-device copy from a page-locked staging buffer sized when the plan was made (so nothing is
+            # one host-to-device copy from a page-locked staging buffer sized when the table was made (so nothing is
             # allocated here): captured into a hipGraph it is ONE memcpy node that replays the same bytes
-            assert total <= plan.host.numel()
-            capturing = torch.cuda.is_current_stream_capturing()
-            if plan.copied is not None and not capturing:
-                plan.copied.synchronize()                   # the previous table may still be on its way out of `host`
-            C.memmove(plan.host.data_ptr(), C.addressof(slots), ssz)
+            assert total <= t.host.numel()
+            if t.copied is not None and not capturing:
+                t.copied.synchronize()                      # the previous table may still be on its way out of `host`
+            C.memmove(t.host.data_ptr(), C.addressof(slots), ssz)
             if not same_set:
-                C.memmove(plan.host.data_ptr() + boff, C.addressof(barr), total - boff)
-            plan.table[:upto].copy_(plan.host[:upto], non_blocking=True)
+                C.memmove(t.host.data_ptr() + boff, C.addressof(barr), total - boff)
+            t.table[:upto].copy_(t.host[:upto], non_blocking=True)
             if not capturing:
-                plan.copied = torch.cuda.Event()
-                plan.copied.record()
-        plan.key, plan.grads, plan.live, plan.live_ids = key, [g for _, g in live], [p for p, _ in live], ids
-        plan.nslots, plan.blocks_off = len(live), boff
+                t.copied = torch.cuda.Event()
+                t.copied.record()
+        t.key, t.grads, t.live, t.live_ids = key, [g for _, g in live], [p for p, _ in live], ids
+        t.nslots, t.blocks_off = len(live), boff
+        return t
 
     # -- step -------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -177,12 +201,12 @@ class Adam(torch.optim.Adam):
                 continue
             with torch.cuda.device(plan.m.device):
                 stream = torch.cuda.current_stream().cuda_stream
-                self._table(plan, group)
-                if plan.nblocks == 0:
+                t = self._table(plan, group)
+                if t.nblocks == 0:
                     continue
                 b1, b2 = group["betas"]
-                a = L.AdamArgs(slots=plan.table.data_ptr(), blocks=plan.table.data_ptr() + plan.blocks_off,
-                               nslots=plan.nslots, nblocks=plan.nblocks,
+                a = L.AdamArgs(slots=t.table.data_ptr(), blocks=t.table.data_ptr() + t.blocks_off,
+                               nslots=t.nslots, nblocks=t.nblocks,
                                m=plan.m.data_ptr(), v=plan.v.data_ptr(), steps=plan.steps.data_ptr(), ticket=plan.ticket.data_ptr(),
                                lr=float(group["lr"]), beta1=float(b1), beta2=float(b2), eps=float(group["eps"]),
                                weight_decay=float(group["weight_decay"]), maximize=int(bool(group["maximize"])),
@@ -190,5 +214,5 @@ class Adam(torch.optim.Adam):
                 L.call("srk_adam_step", a, stream)
                 # the kernel wrote through raw pointers: tell autograd (and the packed-weight cache, which keys on it) that
                 # the parameters changed, as an in-place torch op would
-                torch.autograd.graph.increment_version(plan.live)
+                torch.autograd.graph.increment_version(t.live)
         return loss

@@ -49,13 +49,22 @@ def wrap_ddp(model, device, force=False):
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return model
     from . import ops
-    ops.set_defer_wgrad(False)
+    ops.set_defer_wgrad(False)           # process-wide while a DDP-wrapped model trains; `unwrap_ddp` restores it
     nbytes = sum(p.numel() * 4 for p in model.parameters() if p.requires_grad)
     cap_mb = max(1, int(nbytes / 2 ** 20) + 1)
     kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=cap_mb, broadcast_buffers=False, find_unused_parameters=False)
     if device.type == "cuda":
         return DDP(model, device_ids=[device.index], output_device=device.index, **kw)
     return DDP(model, **kw)
+
+
+def unwrap_ddp(net):
+    """Undo `wrap_ddp`'s process-wide switch once the wrapped model is done training."""
+    from . import ops
+    if isinstance(net, DDP):
+        ops.set_defer_wgrad(True)
+        return net.module
+    return net
 
 
 class GradSync:
@@ -191,17 +200,21 @@ def synthetic_batch(n, channels, lr_size, scale, seed, device):
 
 def _eager_step(model, net, optimizer, gsync, scaler, batch):
     """forward -> losses -> backward -> [gradient average] -> optimizer step, launch by launch."""
+    from . import ops
+    ops.discard_wgrads()                 # nothing of an earlier pass that ended abnormally may linger in the deferred queue
     optimizer.zero_grad(set_to_none=True)
     img_sr = net(batch["lr"])
     loss = model._calculate_losses(img_sr=img_sr, img_hr=batch["hr"])["loss"]
     if scaler is not None:
         scaler.scale(loss).backward()
+        ops.flush_wgrads()
         if gsync is not None:
             gsync.sync()
         scaler.step(optimizer)
         scaler.update()
     else:
         loss.backward()
+        ops.flush_wgrads()               # normally a no-op: the engine's final callback already ran
         if gsync is not None:
             gsync.sync()
         optimizer.step()
@@ -231,6 +244,14 @@ class GraphedStep:
         self.static = None
         self.loss = None
         self.failed = False
+        self.hyper = None
+
+    def _hyper(self):
+        """The optimizer's hyper-parameters travel BY VALUE in the captured launch (srk_adam_args): a scheduler or a manual
+        change after the capture would be ignored by a replay, so a change re-captures."""
+        keys = ("lr", "betas", "eps", "weight_decay", "maximize", "momentum", "alpha")
+        return tuple(tuple((k, tuple(g[k]) if isinstance(g[k], (tuple, list)) else float(g[k])) for k in keys if k in g)
+                     for g in self.opt.param_groups)
 
     def _fwd_bwd(self):
         self.opt.zero_grad(set_to_none=True)
@@ -241,6 +262,7 @@ class GraphedStep:
 
     def _capture(self, batch):
         self.static = {"lr": batch["lr"].clone(), "hr": batch["hr"].clone()}
+        self.hyper = self._hyper()
         if self.gsync is not None:
             self.gsync.remove_hooks()            # no collective from inside backward any more: pack() / reduce() around the graphs
         side = torch.cuda.Stream()
@@ -266,12 +288,16 @@ class GraphedStep:
         same = self.static is not None and batch["lr"].shape == self.static["lr"].shape and batch["hr"].shape == self.static["hr"].shape
         if self.failed or self.seen <= self.warm_steps or (self.graphs is not None and not same):
             return _eager_step(self.model, self.net, self.opt, self.gsync, None, batch)
+        if self.graphs is not None and self._hyper() != self.hyper:
+            self.graphs = None                   # lr / betas / ... changed: capture again with the new values
         if self.graphs is None:
             try:
                 torch.cuda.synchronize()
                 self._capture(batch)
             except Exception as e:  # noqa: BLE001
                 import sys
+                from . import ops
+                ops.discard_wgrads()
                 print(f"[trainer] hipGraph capture failed ({type(e).__name__}: {e}); training continues eagerly", file=sys.stderr)
                 self.failed, self.graphs, self.static = True, None, None
                 torch.cuda.synchronize()
@@ -302,7 +328,16 @@ class Trainer:
         # hipGraph replay of the training step (GraphedStep): on by default on a GPU; SRK_TRAIN_GRAPH=0 or use_graph=False: eager
         self.use_graph = (os.environ.get("SRK_TRAIN_GRAPH", "1") != "0") if use_graph is None else bool(use_graph)
         self.rank, self.world, self.local = init_distributed(self.device.type)
-        self.losses = []
+        self._loss_host = []             # floats already fetched
+        self._loss_dev = []              # device scalars of the latest steps (no host sync per step: replays queue ahead)
+
+    @property
+    def losses(self):
+        """Per-step loss values.  Reading them synchronises with the device (once per read, not once per step)."""
+        if self._loss_dev:
+            self._loss_host += torch.stack(self._loss_dev).float().cpu().tolist()
+            self._loss_dev = []
+        return self._loss_host
 
     def fit(self, model, batches):
         model = model.to(self.device)
@@ -330,8 +365,14 @@ class Trainer:
                 loss = graphed(batch)
             else:
                 loss = _eager_step(model, net, optimizer, gsync, scaler, batch)
-            self.losses.append(float(loss.detach()))
-            if self.log_every and self.rank == 0 and (step + 1) % self.log_every == 0:
-                print(f"step {step + 1}: loss {self.losses[-1]:.6f}", flush=True)
+            # a replayed step returns the graph's static loss tensor: clone (one tiny asynchronous launch), never float()
+            self._loss_dev.append(loss.detach().clone())
+            if self.log_every and (step + 1) % self.log_every == 0:
+                last = self.losses[-1]
+                if self.rank == 0:
+                    print(f"step {step + 1}: loss {last:.6f}", flush=True)
+            elif len(self._loss_dev) >= 1024:
+                self.losses  # noqa: B018  (drain to the host list)
         self.graphed = graphed
+        unwrap_ddp(net)
         return model

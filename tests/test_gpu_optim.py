@@ -118,6 +118,55 @@ def test_graph_replay_advances_the_step(A):
         assert float((p.detach() - r.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max()))
 
 
+def test_eager_steps_between_replays_do_not_touch_the_captured_table(A):
+    """a captured step uploads its (parameter, gradient) table through a memcpy node that re-reads the staging
+    buffer on every replay.  An eager step with NEW gradient tensors between replays (trainer: the short last batch of an epoch)
+    must not redirect the replays to its own gradients: capture, eager step with fresh gradients, >= 3 replays, compared
+    tightly with torch.optim.Adam on the same gradient sequence."""
+    ps, rs = _params(5), _params(5)
+    opt, ropt = A.optim.Adam(ps), torch.optim.Adam(rs)
+    _set_grads(ps, 0)
+    _set_grads(rs, 0)
+    static = [p.grad for p in ps]
+    opt.step()
+    ropt.step()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            opt.step()
+    torch.cuda.current_stream().wait_stream(s)
+
+    def fresh(step):
+        gen = torch.Generator().manual_seed(900 + step)
+        return [(torch.rand(*sg.shape, generator=gen) - 0.5).cuda() for sg in static]
+
+    for step in range(1, 9):
+        new = fresh(step)
+        for r, n in zip(rs, new):
+            r.grad = n.clone()
+        if step in (1, 5):                                   # eager fallback: brand-new gradient tensors, p.grad re-pointed
+            for p, n in zip(ps, new):
+                p.grad = n.clone()
+            opt.step()
+            for p, sg in zip(ps, static):                    # what GraphedStep's graph sees again afterwards
+                p.grad = sg
+        else:
+            for sg, n in zip(static, new):
+                sg.copy_(n)
+            g.replay()
+        ropt.step()
+    torch.cuda.synchronize()
+    assert float(opt.state[ps[0]]["step"]) == 9.0
+    for p, r in zip(ps, rs):
+        assert float((p.detach() - r.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max()))
+    plan = opt._plans[0]
+    cap = plan.captured[-1]
+    assert [g_.data_ptr() for g_ in cap.grads] == [sg.data_ptr() for sg in static], "the capture's table still names the static gradients"
+    assert cap.table.data_ptr() != plan.eager.table.data_ptr() and cap.host.data_ptr() != plan.eager.host.data_ptr()
+
+
 def test_errors(A):
     with pytest.raises(NotImplementedError):
         A.optim.Adam(_params(4), amsgrad=True)

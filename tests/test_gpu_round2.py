@@ -554,6 +554,50 @@ def test_srresnet_fullsize_backward_vs_float64_oracle(A):
     print(f"srresnet_full_x4: worst relative L2 deviation of a gradient from the float64 oracle {worst:.3f}")
 
 
+def test_trainer_short_batch_right_after_the_capture_then_replays():
+    """the eager fallback for a batch of another shape (4 -> the first batch after the capture) is followed by
+    six replays; with fp32 storage the replayed loop must stay on the eager loop's trajectory step for step (a replay that
+    applied the short batch's stale gradients would not), and an lr change after the capture must reach the replays."""
+    import sr_amd
+    from sr_amd import trainer as T
+
+    def batches():
+        for i in range(12):
+            n = 8 if i != 4 else 3                       # steps 0-2 eager, 3 = capture + first replay, 4 = short batch
+            yield T.synthetic_batch(n, 3, 24, 2, 300 + i, "cpu")
+
+    out = []
+    for use_graph in (True, False):
+        torch.manual_seed(0)
+        m = sr_amd.EDSR(scale_factor=2, precision=32, n_feats=32, n_resblocks=2, res_scale=0.1)
+        tr = T.Trainer(device="cuda", use_graph=use_graph)
+
+        class Sched:                                     # a manual "scheduler": lr drops after step 8
+            def __iter__(self_):
+                for i, b in enumerate(batches()):
+                    if i == 8:
+                        for grp in self_.opt.param_groups:
+                            grp["lr"] = 2.5e-4
+                    yield b
+        sch = Sched()
+        orig = m.configure_optimizers
+
+        def conf():
+            r = orig()
+            sch.opt = r[0]
+            return r
+        m.configure_optimizers = conf
+        tr.fit(m, sch)
+        torch.cuda.synchronize()
+        out.append((tr.losses, [p.detach().clone() for p in m.parameters()], tr.graphed))
+    (lg, pg, g), (le, pe, _) = out
+    assert g is not None and g.graphs is not None and not g.failed
+    assert len(lg) == len(le) == 12
+    np.testing.assert_allclose(lg, le, rtol=2e-4)
+    for a, b in zip(pg, pe):
+        assert float((a - b).abs().max()) <= 2e-4, float((a - b).abs().max())
+
+
 @pytest.mark.parametrize("model_kw", [dict(cls="EDSR", n_feats=64, n_resblocks=2, res_scale=0.1), dict(cls="RCAN", n_feats=64, n_resblocks=3, n_resgroups=2)])
 def test_trainer_graph_replay_follows_the_eager_loop(model_kw):
     """Trainer.fit replays the training step as a hipGraph after three eager steps (trainer.GraphedStep): same losses, step for

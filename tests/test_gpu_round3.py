@@ -1,0 +1,108 @@
+"""Round-3 GPU parity tests: the batch-16 flavours of the path -- two convs per launch with the CALayer
+steps inside the launches (`srk_conv_pair` ca_mode 1 / 2, models/rcan.py:10-74) -- compared with the ORACLE (the CPU restatement
+pinned to the reference's own outputs), not with the stand-alone launches they replace.
+
+All citations relative to /root/reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import functional as OF, train as OT
+
+pytestmark = pytest.mark.gpu
+
+PREC = {torch.float16: 16, torch.bfloat16: "bf16"}
+
+
+@pytest.fixture(scope="module")
+def A():
+    import sr_amd
+    assert torch.cuda.is_available()
+    sr_amd._lib.load()
+    return sr_amd
+
+
+RCAN_KW = dict(n_feats=64, n_resgroups=2, n_resblocks=3, reduction=16, scale_factor=2)
+
+
+@pytest.mark.parametrize("dt,min_psnr,min_cos", [(torch.bfloat16, 50.0, 0.99), (torch.float16, 62.0, 0.999)])
+def test_rcan_64_feature_chain_16bit_vs_oracle(A, dt, min_psnr, min_cos):
+    """BASELINE config 3's own shape per launch: RCAN with 64 features at 16 x 3 x 48 x 48 (one 14x14 tile per CU, the pair
+    kernel with pooling, `ca_mode 2` forward and `ca_mode 1` backward through `ops.rcab_chain`), forward PSNR and the cosine
+    of every sizeable parameter gradient against the fp32 oracle (rcan.py:33-74), plus the channel-attention parameters'
+    gradients (conv_du: 64 -> 4 -> 64), which only the fused backward produces."""
+    from sr_amd import ops
+    torch.manual_seed(0)
+    m = A.RCAN(precision=PREC[dt], **RCAN_KW)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    trainable = {k for k, p in m.named_parameters() if p.requires_grad}
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    m = m.cuda()
+    gen = torch.Generator().manual_seed(777)
+    x = torch.rand(16, 3, 48, 48, generator=gen)
+    hr = torch.rand(16, 3, 96, 96, generator=gen)
+    y_ref = OF.forward("RCAN", sd, x, **RCAN_KW)
+    torch.nn.functional.l1_loss(y_ref, hr).backward()
+    before = list(ops.PAIR_LAUNCHES)
+    y = m(x.cuda())
+    loss = torch.nn.functional.l1_loss(y, hr.cuda())
+    (loss * 1024.0).backward()                      # loss scaling keeps fp16 gradients out of the subnormals
+    torch.cuda.synchronize()
+    took = [a - b for a, b in zip(ops.PAIR_LAUNCHES, before)]
+    # 2 groups x 3 RCABs: forward = per group 1 plain + 2 with the previous block's CALayer forward (ca_mode 2);
+    # backward = 6 launches with the CALayer backward on the way in (ca_mode 1)
+    assert took[2] == 4 and took[1] == 6 and took[0] >= 2, f"pair launches by ca_mode: {took}"
+    mse = float(((y.detach().cpu().double() - y_ref.detach().double()) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
+    assert psnr > min_psnr, f"RCAN 64 {dt}: PSNR(build, oracle) = {psnr:.1f} dB"
+    assert abs(float(loss) - float(torch.nn.functional.l1_loss(y_ref, hr))) < 2e-3
+    params = dict(m.named_parameters())
+    worst = 1.0
+    for k in sorted(trainable):
+        ref = sd[k].grad.double().flatten()
+        if ref.numel() < 256:
+            continue
+        got = params[k].grad.cpu().double().flatten() / 1024.0
+        cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos > min_cos, f"RCAN 64 {dt} grad {k}: cosine {cos:.5f}"
+        ratio = float(got.norm() / (ref.norm() + 1e-30))
+        assert 0.9 < ratio < 1.1, f"RCAN 64 {dt} grad {k}: norm ratio {ratio:.3f}"
+    ca_keys = [k for k in trainable if "conv_du" in k and k.endswith("weight")]
+    assert len(ca_keys) == 12
+    print(f"RCAN 64 {dt}: PSNR {psnr:.1f} dB, worst gradient cosine {worst:.5f}, pair launches {took}")
+
+
+@pytest.mark.parametrize("cls,kw", [("RCAN", dict(n_feats=64, n_resgroups=2, n_resblocks=3, reduction=16, scale_factor=2)),
+                                    ("EDSR", dict(n_feats=64, n_resblocks=4, res_scale=0.1, scale_factor=2))])
+def test_graph_replayed_steps_follow_the_oracle_trajectory(A, cls, kw):
+    """Trainer.fit (3 eager steps, then hipGraph replays of the pair-kernel step) against the ORACLE's Adam trajectory on the
+    same batches (srmodel.py:145-171): the loss of every step, computed from weights that all earlier steps produced."""
+    from sr_amd import trainer as T
+    torch.manual_seed(0)
+    m = getattr(A, cls)(precision="bf16", **kw)
+    om = OT.OracleModel(cls, **kw)
+    om.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    steps = 8
+    data = [T.synthetic_batch(16, 3, 48, 2, 500 + i, "cpu") for i in range(steps)]
+    # learnable targets (HR = bilinear upsampling of LR) so that the loss moves by far more than the comparison tolerance
+    for b in data:
+        b["hr"] = torch.nn.functional.interpolate(b["lr"], scale_factor=2, mode="bilinear", align_corners=False)
+    opt = om.configure_optimizers()[0]
+    ref = []
+    for b in data:
+        opt.zero_grad()
+        loss = om.training_step(b)["loss"]
+        loss.backward()
+        opt.step()
+        ref.append(float(loss))
+    tr = T.Trainer(device="cuda", use_graph=True)
+    tr.fit(m, iter(data))
+    torch.cuda.synchronize()
+    assert tr.graphed is not None and tr.graphed.graphs is not None and not tr.graphed.failed
+    got = tr.losses
+    assert len(got) == steps
+    assert ref[0] - ref[-1] > 0.05 * ref[0], f"the oracle's loss should fall on learnable data: {ref}"
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-3)
