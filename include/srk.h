@@ -156,6 +156,55 @@ int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream);
 /* workgroups (14x14 output tiles) such a launch has: the host uses the pair while this is about two per CU or less */
 int srk_conv_pair_tiles(int N, int H, int W);
 
+/* ---- two chained pointwise convolutions with the wide intermediate kept on chip -----------------------------------
+ * Replaces the opening of WDSR's _Block_B (models/wdsr.py:30-51):
+ *     h = relu(conv1x1(x; Cin -> Chid) + b1);   z = conv1x1(h; Chid -> Cmid) + b2
+ * (wn(nn.Conv2d(F, 6F, 1)), ReLU, wn(nn.Conv2d(6F, int(.8F), 1))) and its backward
+ *     gh = (W2^T gz) * (h > 0);   gx = W1^T gh [+ res]
+ * without the Chid-channel tensor ever reaching HBM: the hidden channels are walked in slices of 64 whose activations
+ * live in MFMA accumulator registers and become the next GEMM's operand in place.  Pixels are a flat list of P = N*H*W
+ * NHWC rows (pitch / channel offset in elements).  Supported shapes: srk_pw_shape_ok(Cin, Chid, CoutP) -- 16-bit storage,
+ * (Cin, CoutP) = (128, 128) or (64, 64), Chid a multiple of 64 (WDSR-B at n_feats 128 / 64).
+ * srk_pw_pack converts the fp32 matrices of record (w1 [Chid][Cin], w2 [Cmid][Chid], biases) into the two streamed
+ * layouts (sizes: srk_pw_pack_bytes(..., bwd = 0 / 1)); h is rounded to the storage dtype exactly like a stored
+ * activation would be.  The backward RE-computes the pre-activation with the forward's instruction sequence, so its
+ * sign is the forward's ReLU mask bit for bit; with h_out / gh_out (both or neither, [P][Chid] storage dtype) the slices
+ * of h and gh are also written for the weight-gradient GEMMs (srk_conv2d_wgrad, KH = KW = 1).                       */
+typedef struct {
+  const float* w1; const float* b1;     /* [Chid][Cin], [Chid] or NULL */
+  const float* w2; const float* b2;     /* [Cmid][Chid], [Cmid] or NULL */
+  int Cin, Chid, Cmid, CoutP;           /* CoutP: padded rows of conv 2 (multiple of 64, >= Cmid) */
+  void* fwd; void* bwd;                 /* out: srk_pw_pack_bytes(Cin, Chid, CoutP, 0 / 1) bytes each */
+  int dtype;
+} srk_pw_pack_args;
+int srk_pw_shape_ok(int Cin, int Chid, int CoutP);
+long long srk_pw_pack_bytes(int Cin, int Chid, int CoutP, int bwd);
+int srk_pw_pack(const srk_pw_pack_args* a, srk_stream_t stream);
+
+typedef struct {
+  const void* x; int x_pitch, x_coff;   /* [P] pixels x Cin channels */
+  long long P;
+  int Cin, Chid, CoutP;
+  int Cout;                             /* channels of z to store (multiple of 8, <= CoutP; channels >= Cmid are zeros) */
+  const void* wpk;                      /* srk_pw_pack's `fwd` */
+  void* out; int out_pitch, out_coff;
+  int dtype;
+} srk_pw_args;
+int srk_pw_forward(const srk_pw_args* a, srk_stream_t stream);
+
+typedef struct {
+  const void* x; int x_pitch, x_coff;   /* the forward's input */
+  const void* gz; int gz_pitch, gz_coff; int Cz;   /* gradient of z: Cz stored channels (multiple of 8, <= CoutP) */
+  long long P;
+  int Cin, Chid, CoutP;
+  const void* wpk;                      /* srk_pw_pack's `bwd` */
+  const void* res; int res_pitch, res_coff;        /* added to gx (the skip connection's gradient) or NULL */
+  void* gx; int gx_pitch, gx_coff;
+  void* h_out; void* gh_out;            /* [P][Chid] or NULL (both) */
+  int dtype;
+} srk_pw_bwd_args;
+int srk_pw_backward(const srk_pw_bwd_args* a, srk_stream_t stream);
+
 /* ---- weight / bias gradient -------------------------------------------------------------------
  * Replaces autograd's conv weight-gradient for the convs above:
  *     dwp[tap][ci][co] += sum_{n,y,x} x[n][y+kh-ph][x+kw-pw][ci] * dy[n][y][x][co]   (fp32 atomics)

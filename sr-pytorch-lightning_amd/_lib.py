@@ -50,6 +50,23 @@ class ConvPairArgs(C.Structure):
                 ("ca_x2", _p), ("ca_x2_pitch", _i), ("ca_x2_coff", _i), ("ca_b1", _p), ("ca_b2", _p), ("ca_s_out", _p), ("ca_z_out", _p)]
 
 
+class PwPackArgs(C.Structure):
+    _fields_ = [("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p), ("Cin", _i), ("Chid", _i), ("Cmid", _i), ("CoutP", _i),
+                ("fwd", _p), ("bwd", _p), ("dtype", _i)]
+
+
+class PwArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("P", C.c_longlong), ("Cin", _i), ("Chid", _i), ("CoutP", _i), ("Cout", _i),
+                ("wpk", _p), ("out", _p), ("out_pitch", _i), ("out_coff", _i), ("dtype", _i)]
+
+
+class PwBwdArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("gz", _p), ("gz_pitch", _i), ("gz_coff", _i), ("Cz", _i),
+                ("P", C.c_longlong), ("Cin", _i), ("Chid", _i), ("CoutP", _i), ("wpk", _p),
+                ("res", _p), ("res_pitch", _i), ("res_coff", _i), ("gx", _p), ("gx_pitch", _i), ("gx_coff", _i),
+                ("h_out", _p), ("gh_out", _p), ("dtype", _i)]
+
+
 class ChanFinalizeArgs(C.Structure):
     _fields_ = [("partial", _p), ("nblocks", _i), ("C", _i), ("Creal", _i), ("mode", _i), ("total", _i),
                 ("M", _f), ("eps", _f), ("momentum", _f), ("mean", _p), ("invstd", _p), ("gamma", _p),
@@ -171,6 +188,9 @@ LAUNCHERS = {
     "srk_pack_conv_weights": PackArgs,
     "srk_conv2d": ConvArgs,
     "srk_conv_pair": ConvPairArgs,
+    "srk_pw_pack": PwPackArgs,
+    "srk_pw_forward": PwArgs,
+    "srk_pw_backward": PwBwdArgs,
     "srk_adam_step": AdamArgs,
     "srk_chan_finalize": ChanFinalizeArgs,
     "srk_conv2d_wgrad": WgradArgs,
@@ -194,7 +214,7 @@ LAUNCHERS = {
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
-                 "srk_conv_pair_tiles", "srk_rowsum_group")
+                 "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes")
 
 _lib = None
 
@@ -241,6 +261,10 @@ def load():
     lib.srk_ca_splits.restype = C.c_int
     lib.srk_l1_blocks.argtypes = [C.c_longlong]
     lib.srk_l1_blocks.restype = C.c_int
+    lib.srk_pw_shape_ok.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.srk_pw_shape_ok.restype = C.c_int
+    lib.srk_pw_pack_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.srk_pw_pack_bytes.restype = C.c_longlong
     lib.srk_last_error.restype = C.c_char_p
     lib.srk_version.restype = C.c_int
     lib.srk_device_cus.restype = C.c_int

@@ -1,0 +1,580 @@
+// Two chained pointwise (1x1) convolutions with the WIDE intermediate kept on chip: WDSR-B's block opens with
+//     h = relu(conv1x1(x; F -> 6F) + b1);   z = conv1x1(h; 6F -> int(0.8 F)) + b2          (models/wdsr.py:30-51)
+// Launched one by one the 6F-channel tensor (768 channels at F = 128: 1.5 KB per pixel) is written and re-read, ~6x the traffic of
+// the block's input and output together, and the two GEMMs run HBM-bound.  Here the hidden channels are walked in SLICES of 64:
+// a wave owns 32 pixels, keeps their input fragments in registers for the whole tile, computes one slice of h with MFMAs
+// (lane = pixel, accumulator registers = hidden channels), applies bias / ReLU, packs it -- and the packed registers ARE the
+// B operand of the second GEMM's next K-steps (the weight ROWS of conv 1 are permuted at pack time so that the accumulator
+// registers of a lane half are two 8-channel K-chunks): h never exists outside the register file.
+//   forward  (pw_fwd_kernel)  : z = W2 relu(W1 x + b1) + b2                               32 MFMAs per wave and slice
+//   backward (pw_bwd_kernel)  : recompute the slice of h (its sign is the ReLU mask), gh = (W2^T gz) * (h > 0), gx = W1^T gh [+ res];
+//                               optionally h and gh leave for the weight-gradient GEMMs               48 MFMAs per wave and slice
+// Workgroup = 8 waves x 32 pixels = 256 pixels (pixels are a flat list: a 1x1 conv has no geometry).  The weights of a slice
+// (forward 32 KB, backward 48 KB at F = 128) stream through an LDS ring by hidden LDS-DMA (srk_common.h), all waves issuing and
+// all waves computing (two per SIMD: one's convert / wait gaps are the other's MFMA time); the pixel tiles arrive once by
+// LDS-DMA into ring slots that are still empty and go to registers.  Results leave by per-lane 16-byte stores (a lane holds 32
+// contiguous channels of its pixel).
+#include "srk_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+// MFMA row rho (0..63) of a 64-row hidden slice -> hidden channel inside the slice.  After a 32x32 MFMA lane half hh holds rows
+// 8i + 4hh + e (i, e = 0..3) in accumulator register 4i + e; the next GEMM wants lane half hh to supply channels 16j + 8hh + t
+// (t = 0..7) of K-step j.  So: block b = rho >> 5 feeds K-steps 2b (registers i = 0, 1) and 2b + 1 (i = 2, 3).
+__host__ __device__ inline int pw_hid_of_row(int rho) {
+  const int b = rho >> 5, rp = rho & 31;
+  const int i = rp >> 3, hh = (rp >> 2) & 1, e = rp & 3;
+  return 16 * (2 * b + (i >> 1)) + 8 * hh + 4 * (i & 1) + e;
+}
+// MFMA row -> stored channel for output rows (64-row blocks, as every conv kernel here: a lane half holds 32 contiguous channels)
+__host__ __device__ inline int pw_chan_of_row(int rho) {
+  const int e = rho & 3, hh = (rho >> 2) & 1, i = (rho >> 3) & 3, r64 = rho & 63;
+  return (rho >> 6) * 64 + 32 * hh + 16 * (r64 >> 5) + 4 * i + e;
+}
+
+template <int KC1, int NRB> struct PwCfg {
+  static constexpr int NT = 512;
+  static constexpr int PXW = 32, PX = 8 * PXW;                   // pixels per wave / workgroup
+  static constexpr int RI = 16 * KC1;                            // input channels = rows of the W1^T GEMM
+  static constexpr int R2 = 32 * NRB;                            // padded output rows of conv 2 = K of the W2^T GEMM
+  static constexpr int W1_BYTES = 2 * KC1 * 64 * 16;             // [chunk][64 hidden rows][16 B]
+  static constexpr int W2_BYTES = 8 * R2 * 16;                   // [chunk (64 hidden / 8)][R2 rows][16 B]
+  static constexpr int W2T_BYTES = (R2 / 8) * 64 * 16;           // [chunk (R2 / 8)][64 hidden rows][16 B]
+  static constexpr int W1T_BYTES = 8 * RI * 16;                  // [chunk (64 hidden / 8)][RI rows][16 B]
+  static constexpr int FWD_SLICE = W1_BYTES + W2_BYTES;
+  static constexpr int BWD_SLICE = W1_BYTES + W2T_BYTES + W1T_BYTES;
+  static constexpr int FWD_SLOTS = 4, BWD_SLOTS = 3;
+  static constexpr int XT_BYTES = PX * RI * 2;                   // staged input tile
+  static constexpr int ZT_BYTES = PX * R2 * 2;                   // staged gz tile (backward)
+  static_assert(FWD_SLICE % 8192 == 0 && BWD_SLICE % 8192 == 0, "whole 1 KB pieces per wave");
+  static_assert(XT_BYTES <= 2 * FWD_SLICE, "the input tile is staged in two empty ring slots");
+};
+
+// swizzle of the staged pixel tiles: 16-byte slot of chunk c of pixel r = c ^ f(r), chosen so that the 16 lanes one
+// ds_read_b128 group serves ({0-3,12-15,20-27} and its shifts) hit 16 different 16-byte columns of the 256-byte bank row
+template <int CHUNKS> SRK_DEV int pw_swz(int r) {
+  if constexpr (CHUNKS >= 16) return r & 15;
+  else return (r >> 1) & 7;        // 8 chunks (128 B) per pixel: two pixels per bank row
+}
+
+// one pixel tile (this wave's 32 pixels x CHUNKS 16-byte chunks) -> LDS at `dst` (wave-uniform), swizzled
+template <int CHUNKS> SRK_DEV void pw_dma_pixels(i32x4 rsrc, long long p0, long long P, int pitch, int coff, int cvalid, unsigned dst, int lane) {
+  constexpr int PIECES = 32 * CHUNKS / 64;                       // 1 KB pieces
+#pragma unroll
+  for (int k = 0; k < PIECES; ++k) {
+    const int idx = k * 64 + lane;
+    const int pl = idx / CHUNKS, slot = idx % CHUNKS;
+    const int c = slot ^ pw_swz<CHUNKS>(pl);
+    const long long p = p0 + pl;
+    const bool ok = p < P && c * 8 < cvalid;
+    const unsigned voff = ok ? (unsigned)((p * pitch + coff + c * 8) * 2) : 0x80000000u;
+    dma16_hidden(rsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + k * 1024)));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int DT, int KC1, int NRB>
+__global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsigned x_bytes, unsigned w_bytes, int cst_pieces) {
+  typedef DTraits<DT> Tr;
+  typedef PwCfg<KC1, NRB> C;
+  constexpr int SL = C::FWD_SLICE, NSLOT = C::FWD_SLOTS, PPW = SL / 8192;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ring = smem;
+  char* const cst = smem + NSLOT * SL;                          // b1 (permuted, Chid floats) | b2 (permuted, R2 floats)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int NS = a.Chid >> 6;
+  const long long P = a.P;
+  const long long p0 = (long long)blockIdx.x * C::PX + wave * C::PXW;
+
+  const i32x4 xrsrc = make_rsrc4(a.x, x_bytes);
+  const i32x4 wrsrc = make_rsrc4(a.wpk, w_bytes);
+  const unsigned ring_lds = lds_addr_of(ring), cst_lds = lds_addr_of(cst);
+  const unsigned cst_bytes = (unsigned)cst_pieces * 1024u;
+
+  auto dma_slice = [&](int s) {
+    const unsigned dst = ring_lds + (unsigned)((s % NSLOT) * SL);
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int piece = wave * PPW + k;
+      dma16_hidden(wrsrc, cst_bytes + (unsigned)s * SL + piece * 1024 + lane * 16,
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));
+    }
+  };
+
+  // ---- prologue: constants, this wave's pixels (into ring slots 2, 3: still empty), slices 0 and 1 ------------------------------
+  if (wave < cst_pieces)
+    dma16_hidden(wrsrc, (unsigned)(wave * 1024 + lane * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(cst_lds + wave * 1024)));
+  const unsigned xs_lds = ring_lds + 2 * SL + (unsigned)wave * (C::PXW * C::RI * 2);
+  pw_dma_pixels<2 * KC1>(xrsrc, p0, P, a.x_pitch, a.x_coff, a.Cin, xs_lds, lane);
+  dma_slice(0);
+  dma_slice(1);
+  if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  i32x4 xf[KC1];
+  {
+    const char* xs = ring + 2 * SL + wave * (C::PXW * C::RI * 2) + r * (C::RI * 2);
+    const int g = pw_swz<2 * KC1>(r);
+#pragma unroll
+    for (int j = 0; j < KC1; ++j) xf[j] = lds_read16(xs + (((2 * j + h) ^ g) << 4));
+  }
+  f32x16 acc2[NRB];
+  {
+    const float* b2 = reinterpret_cast<const float*>(cst) + a.Chid;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(b2 + (rb * 2 + h) * 16 + 4 * q);
+        acc2[rb][4 * q] = v.x; acc2[rb][4 * q + 1] = v.y; acc2[rb][4 * q + 2] = v.z; acc2[rb][4 * q + 3] = v.w;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has its pixels in registers: slots 2, 3 are free
+  dma_slice(2);
+  dma_slice(3);
+
+  const int lane_a = (h * 64 + r) << 4;                          // A fragments of the 64-row W1 part
+  const int lane_a2 = (h * C::R2 + r) << 4;                      // ... of the R2-row W2 part
+  auto gemm1 = [&](int s, f32x16 (&acc)[2]) {
+    const float* b1 = reinterpret_cast<const float*>(cst) + s * 64;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(b1 + (b * 2 + h) * 16 + 4 * q);
+        acc[b][4 * q] = v.x; acc[b][4 * q + 1] = v.y; acc[b][4 * q + 2] = v.z; acc[b][4 * q + 3] = v.w;
+      }
+    const char* w = ring + (s % NSLOT) * SL + lane_a;
+#pragma unroll
+    for (int j = 0; j < KC1; ++j)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[b] = Tr::mma(lds_read16(w + j * 2048 + b * 512), xf[j], acc[b]);
+  };
+  auto convert = [&](const f32x16 (&acc)[2], i32x4 (&hf)[4]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        i32x4 q;
+        q.x = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 0], acc[b][8 * m + 1]));
+        q.y = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 2], acc[b][8 * m + 3]));
+        q.z = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 4], acc[b][8 * m + 5]));
+        q.w = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 6], acc[b][8 * m + 7]));
+        hf[2 * b + m] = q;
+      }
+  };
+  auto gemm2 = [&](int s, const i32x4 (&hf)[4]) {
+    const char* w = ring + (s % NSLOT) * SL + C::W1_BYTES + lane_a2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) acc2[rb] = Tr::mma(lds_read16(w + j * (2 * C::R2 * 16) + rb * 512), hf[j], acc2[rb]);
+  };
+
+  f32x16 acc1[2];
+  i32x4 hfa[4], hfb[4];
+  gemm1(0, acc1);
+  convert(acc1, hfa);
+  // iteration s: conv 1 of slice s + 1 and conv 2 of slice s (the ring holds slices s .. s + 3)
+  for (int s = 0; s < NS; s += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ss = s + u;
+      if (ss < NS) {
+        // slice ss + 1 must have landed; younger transfers: slices ss + 2 (and, in the first iteration, 3)
+        if (ss == 0) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else if (ss + 2 < NS) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ss >= 1 && ss + 3 < NS) dma_slice(ss + 3);           // into the slot slice ss - 1 left
+        if (u == 0) {
+          if (ss + 1 < NS) gemm1(ss + 1, acc1);
+          gemm2(ss, hfa);
+          if (ss + 1 < NS) convert(acc1, hfb);
+        } else {
+          if (ss + 1 < NS) gemm1(ss + 1, acc1);
+          gemm2(ss, hfb);
+          if (ss + 1 < NS) convert(acc1, hfa);
+        }
+      }
+    }
+  }
+
+  // ---- store: lane (pixel r, half h) holds channels 64 B + 32 h .. + 32 of its pixel ---------------------------------------------
+  const long long p = p0 + r;
+  if (p < P) {
+    typename Tr::elem* const o = reinterpret_cast<typename Tr::elem*>(a.out) + p * a.out_pitch + a.out_coff;
+#pragma unroll
+    for (int B = 0; B < NRB / 2; ++B)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ch = 64 * B + 32 * h + 8 * k;
+        if (ch < a.Cout) {
+          const f32x16& v = acc2[2 * B + (k >> 1)];
+          const int q0 = 8 * (k & 1);
+          i32x4 q;
+          q.x = (int)pack2<DT>(v[q0 + 0], v[q0 + 1]);
+          q.y = (int)pack2<DT>(v[q0 + 2], v[q0 + 3]);
+          q.z = (int)pack2<DT>(v[q0 + 4], v[q0 + 5]);
+          q.w = (int)pack2<DT>(v[q0 + 6], v[q0 + 7]);
+          *reinterpret_cast<i32x4*>(o + ch) = q;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// backward (data): gx = W1^T ((W2^T gz) * (W1 x + b1 > 0)) [+ res]; WH: the slices of h and gh also go to HBM (operands of the
+// weight-gradient GEMMs).  The hidden pre-activation is RE-computed from x with the forward's instruction sequence (same
+// fragments, same accumulation order: bit-identical), so its sign is exactly the forward's ReLU mask.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int DT, int KC1, int NRB, bool WH>
+__global__ __launch_bounds__(512) void pw_bwd_kernel(const srk_pw_bwd_args a, unsigned x_bytes, unsigned gz_bytes, unsigned w_bytes, int cst_pieces) {
+  typedef DTraits<DT> Tr;
+  typedef PwCfg<KC1, NRB> C;
+  constexpr int SL = C::BWD_SLICE, NSLOT = C::BWD_SLOTS, PPW = SL / 8192;
+  constexpr int KCZ = NRB * 2;                                   // K-steps of the W2^T GEMM (R2 / 16)
+  constexpr int NIB = KC1 / 2;                                   // 32-row blocks of the W1^T GEMM (RI / 32)
+  constexpr int NST = WH ? 8 : 0;                                // per-lane stores per slice (they count in vmcnt too)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ring = smem;
+  char* const cst = smem + NSLOT * SL;                          // b1 (permuted)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int NS = a.Chid >> 6;
+  const long long P = a.P;
+  const long long p0 = (long long)blockIdx.x * C::PX + wave * C::PXW;
+
+  const i32x4 xrsrc = make_rsrc4(a.x, x_bytes);
+  const i32x4 zrsrc = make_rsrc4(a.gz, gz_bytes);
+  const i32x4 wrsrc = make_rsrc4(a.wpk, w_bytes);
+  const unsigned ring_lds = lds_addr_of(ring), cst_lds = lds_addr_of(cst);
+  const unsigned cst_bytes = (unsigned)cst_pieces * 1024u;
+
+  auto dma_slice = [&](int s) {
+    const unsigned dst = ring_lds + (unsigned)((s % NSLOT) * SL);
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int piece = wave * PPW + k;
+      dma16_hidden(wrsrc, cst_bytes + (unsigned)s * SL + piece * 1024 + lane * 16,
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));
+    }
+  };
+
+  // ---- prologue: constants, slice 0, then this wave's x and gz pixels one after the other through its own staging area (slots 1, 2) --
+  if (wave < cst_pieces)
+    dma16_hidden(wrsrc, (unsigned)(wave * 1024 + lane * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(cst_lds + wave * 1024)));
+  dma_slice(0);
+  constexpr int STG = C::PXW * (C::RI > C::R2 ? C::RI : C::R2) * 2;      // per-wave staging bytes
+  static_assert(8 * STG <= 2 * SL, "staging fits the two empty slots");
+  const unsigned st_lds = ring_lds + SL + (unsigned)wave * STG;
+  const char* const st = ring + SL + wave * STG;
+  pw_dma_pixels<2 * KC1>(xrsrc, p0, P, a.x_pitch, a.x_coff, a.Cin, st_lds, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  i32x4 xf[KC1], zf[KCZ];
+  {
+    const int g = pw_swz<2 * KC1>(r);
+#pragma unroll
+    for (int j = 0; j < KC1; ++j) xf[j] = lds_read16(st + r * (C::RI * 2) + (((2 * j + h) ^ g) << 4));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  pw_dma_pixels<2 * KCZ>(zrsrc, p0, P, a.gz_pitch, a.gz_coff, a.Cz, st_lds, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    const int g = pw_swz<2 * KCZ>(r);
+#pragma unroll
+    for (int j = 0; j < KCZ; ++j) zf[j] = lds_read16(st + r * (C::R2 * 2) + (((2 * j + h) ^ g) << 4));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // staging areas free, slice 0 and the constants have landed everywhere
+  dma_slice(1);
+  dma_slice(2);
+
+  const int lane_a = (h * 64 + r) << 4;
+  const int lane_ai = (h * C::RI + r) << 4;
+  f32x16 gx[NIB];
+#pragma unroll
+  for (int ib = 0; ib < NIB; ++ib)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gx[ib][q] = 0.f;
+
+  const long long p = p0 + r;
+  typename Tr::elem* const ho = WH ? reinterpret_cast<typename Tr::elem*>(a.h_out) + p * a.Chid : nullptr;
+  typename Tr::elem* const go = WH ? reinterpret_cast<typename Tr::elem*>(a.gh_out) + p * a.Chid : nullptr;
+
+  for (int s = 0; s < NS; ++s) {
+    const char* const slot = ring + (s % NSLOT) * SL;
+    // (1) pre-activation of the slice, exactly as the forward computed it
+    f32x16 acc[2];
+    {
+      const float* b1 = reinterpret_cast<const float*>(cst) + s * 64;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(b1 + (b * 2 + h) * 16 + 4 * q);
+          acc[b][4 * q] = v.x; acc[b][4 * q + 1] = v.y; acc[b][4 * q + 2] = v.z; acc[b][4 * q + 3] = v.w;
+        }
+      const char* w = slot + lane_a;
+#pragma unroll
+      for (int j = 0; j < KC1; ++j)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[b] = Tr::mma(lds_read16(w + j * 2048 + b * 512), xf[j], acc[b]);
+    }
+    bool on[2][16];
+    i32x4 hf[4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) on[b][q] = acc[b][q] > 0.f;
+      if (WH) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          i32x4 q;
+          q.x = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 0], acc[b][8 * m + 1]));
+          q.y = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 2], acc[b][8 * m + 3]));
+          q.z = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 4], acc[b][8 * m + 5]));
+          q.w = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 6], acc[b][8 * m + 7]));
+          hf[2 * b + m] = q;
+        }
+      }
+    }
+    if (WH && p < P) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<i32x4*>(ho + 64 * s + 16 * j + 8 * h) = hf[j];
+    }
+    // (2) gh = (W2^T gz) masked
+    {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+      const char* w = slot + C::W1_BYTES + lane_a;
+#pragma unroll
+      for (int j = 0; j < KCZ; ++j)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[b] = Tr::mma(lds_read16(w + j * 2048 + b * 512), zf[j], acc[b]);
+    }
+    i32x4 gf[4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = on[b][8 * m + t] ? acc[b][8 * m + t] : 0.f;
+        i32x4 q;
+        q.x = (int)pack2<DT>(v[0], v[1]); q.y = (int)pack2<DT>(v[2], v[3]); q.z = (int)pack2<DT>(v[4], v[5]); q.w = (int)pack2<DT>(v[6], v[7]);
+        gf[2 * b + m] = q;
+      }
+    if (WH && p < P) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<i32x4*>(go + 64 * s + 16 * j + 8 * h) = gf[j];
+    }
+    // (3) gx += W1^T gh
+    {
+      const char* w = slot + C::W1_BYTES + C::W2T_BYTES + lane_ai;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ib = 0; ib < NIB; ++ib) gx[ib] = Tr::mma(lds_read16(w + j * (2 * C::RI * 16) + ib * 512), gf[j], gx[ib]);
+    }
+    // hand-over: slice s + 1 has landed (younger: slice s + 2 and this iteration's stores), slot s % 3 is free for slice s + 3
+    if (s + 2 < NS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (s + 3 < NS) dma_slice(s + 3);
+  }
+
+  // ---- store: gx (+ res); lane (pixel r, half h) holds channels 64 B + 32 h .. + 32 ----------------------------------------------
+  if (p < P) {
+    typename Tr::elem* const o = reinterpret_cast<typename Tr::elem*>(a.gx) + p * a.gx_pitch + a.gx_coff;
+    const typename Tr::elem* const rs = a.res ? reinterpret_cast<const typename Tr::elem*>(a.res) + p * a.res_pitch + a.res_coff : nullptr;
+#pragma unroll
+    for (int B = 0; B < NIB / 2; ++B)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ch = 64 * B + 32 * h + 8 * k;
+        const f32x16& v = gx[2 * B + (k >> 1)];
+        const int q0 = 8 * (k & 1);
+        float f[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) f[t] = v[q0 + t];
+        if (rs) {
+          const i32x4 q = *reinterpret_cast<const i32x4*>(rs + ch);
+          const int qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float f0, f1;
+            unpack2<DT>((uint32_t)qw[e], f0, f1);
+            f[2 * e] += f0; f[2 * e + 1] += f1;
+          }
+        }
+        i32x4 q;
+        q.x = (int)pack2<DT>(f[0], f[1]); q.y = (int)pack2<DT>(f[2], f[3]); q.z = (int)pack2<DT>(f[4], f[5]); q.w = (int)pack2<DT>(f[6], f[7]);
+        *reinterpret_cast<i32x4*>(o + ch) = q;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// packing: fp32 [Chid][Cin] / [Cmid][Chid] weights (+ biases) -> constant block + per-slice blocks of both directions
+//   fwd : cst = b1p[Chid] | b2p[R2] (padded to whole KB) ; slice s = W1 part | W2 part
+//   bwd : cst = b1p[Chid]           (padded to whole KB) ; slice s = W1 part | W2^T part | W1^T part
+// one work item = one 16-byte chunk
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int DT> __global__ void pw_pack_kernel(const srk_pw_pack_args a) {
+  typedef DTraits<DT> Tr;
+  const int KC1 = a.Cin / 16, R2 = a.CoutP, RI = a.Cin, NS = a.Chid / 64;
+  const int w1c = 2 * KC1 * 64, w2c = 8 * R2, w2tc = (R2 / 8) * 64, w1tc = 8 * RI;       // chunks per part
+  const int fsl = w1c + w2c, bsl = w1c + w2tc + w1tc;
+  const int fcst = ((a.Chid + R2) * 4 + 1023) / 1024 * 1024, bcst = (a.Chid * 4 + 1023) / 1024 * 1024;
+  const long long nf = (long long)NS * fsl, nb = (long long)NS * bsl;
+  const long long stride = (long long)gridDim.x * blockDim.x, first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  auto put = [&](void* base, long long byte_off, const float (&v)[8]) {
+    i32x4 q;
+    q.x = (int)pack2<DT>(v[0], v[1]); q.y = (int)pack2<DT>(v[2], v[3]); q.z = (int)pack2<DT>(v[4], v[5]); q.w = (int)pack2<DT>(v[6], v[7]);
+    *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(base) + byte_off) = q;
+  };
+  auto w1_chunk = [&](int s, int q, float (&v)[8]) {            // q = c * 64 + rho
+    const int c = q >> 6, hid = 64 * s + pw_hid_of_row(q & 63);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = a.w1[(size_t)hid * a.Cin + 8 * c + t];
+  };
+  for (long long it = first; it < nf + nb; it += stride) {
+    float v[8];
+    if (it < nf) {
+      const int s = (int)(it / fsl), q = (int)(it % fsl);
+      if (q < w1c) w1_chunk(s, q, v);
+      else {
+        const int q2 = q - w1c, c = q2 / R2, ch = pw_chan_of_row(q2 % R2);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = ch < a.Cmid ? a.w2[(size_t)ch * a.Chid + 64 * s + 8 * c + t] : 0.f;
+      }
+      put(a.fwd, fcst + it * 16, v);
+    } else {
+      const long long ib = it - nf;
+      const int s = (int)(ib / bsl), q = (int)(ib % bsl);
+      if (q < w1c) w1_chunk(s, q, v);
+      else if (q < w1c + w2tc) {
+        const int q2 = q - w1c, c = q2 >> 6, hid = 64 * s + pw_hid_of_row(q2 & 63);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = (8 * c + t) < a.Cmid ? a.w2[(size_t)(8 * c + t) * a.Chid + hid] : 0.f;
+      } else {
+        const int q2 = q - w1c - w2tc, c = q2 / RI, ch = pw_chan_of_row(q2 % RI);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = a.w1[(size_t)(64 * s + 8 * c + t) * a.Cin + ch];
+      }
+      put(a.bwd, bcst + ib * 16, v);
+    }
+  }
+  // constants: b1 in accumulator order [s][b][h][4i + e], b2 [rb][h][4i + e]
+  for (long long i = first; i < a.Chid + R2; i += stride) {
+    if (i < a.Chid) {
+      const int s = (int)i >> 6, k = (int)i & 63, b = k >> 5, hh = (k >> 4) & 1, q = k & 15, ii = q >> 2, e = q & 3;
+      const float bv = a.b1 ? a.b1[64 * s + pw_hid_of_row(32 * b + 8 * ii + 4 * hh + e)] : 0.f;
+      reinterpret_cast<float*>(a.fwd)[i] = bv;
+      reinterpret_cast<float*>(a.bwd)[i] = bv;
+    } else {
+      const int k = (int)(i - a.Chid), rb = k >> 5, hh = (k >> 4) & 1, q = k & 15, ii = q >> 2, e = q & 3;
+      const int ch = pw_chan_of_row(32 * rb + 8 * ii + 4 * hh + e);
+      reinterpret_cast<float*>(a.fwd)[i] = (a.b2 && ch < a.Cmid) ? a.b2[ch] : 0.f;
+    }
+  }
+}
+
+bool pw_shape_ok(int Cin, int Chid, int CoutP) {
+  return ((Cin == 128 && CoutP == 128) || (Cin == 64 && CoutP == 64)) && Chid % 64 == 0 && Chid >= 256 && Chid <= 4096;
+}
+
+template <int DT, int KC1, int NRB> int pw_fwd_launch(const srk_pw_args& a, hipStream_t st) {
+  typedef PwCfg<KC1, NRB> C;
+  const int cst_bytes = ((a.Chid + C::R2) * 4 + 1023) / 1024 * 1024;
+  const int lds = C::FWD_SLOTS * C::FWD_SLICE + cst_bytes;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_fwd_kernel<DT, KC1, NRB>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) { srk_set_error("srk_pw_forward: cannot reserve LDS"); return (int)attr; }
+  SRK_CHECK_ARG(lds <= 160 * 1024 && cst_bytes <= 8 * 1024, "srk_pw_forward: %d bytes of LDS", lds);
+  const long long nb = (a.P + C::PX - 1) / C::PX;
+  const unsigned xb = (unsigned)(a.P * a.x_pitch * 2);
+  const unsigned wb = (unsigned)(cst_bytes + (long long)(a.Chid / 64) * C::FWD_SLICE);
+  hipLaunchKernelGGL((pw_fwd_kernel<DT, KC1, NRB>), dim3((unsigned)nb), dim3(C::NT), lds, st, a, xb, wb, cst_bytes / 1024);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int DT, int KC1, int NRB> int pw_bwd_launch(const srk_pw_bwd_args& a, hipStream_t st) {
+  typedef PwCfg<KC1, NRB> C;
+  const int cst_bytes = (a.Chid * 4 + 1023) / 1024 * 1024;
+  const int lds = C::BWD_SLOTS * C::BWD_SLICE + cst_bytes;
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_kernel<DT, KC1, NRB, false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_kernel<DT, KC1, NRB, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr0 != hipSuccess || attr1 != hipSuccess) { srk_set_error("srk_pw_backward: cannot reserve LDS"); return (int)(attr0 != hipSuccess ? attr0 : attr1); }
+  SRK_CHECK_ARG(lds <= 160 * 1024 && cst_bytes <= 8 * 1024, "srk_pw_backward: %d bytes of LDS", lds);
+  const long long nb = (a.P + C::PX - 1) / C::PX;
+  const unsigned xb = (unsigned)(a.P * a.x_pitch * 2), zb = (unsigned)(a.P * a.gz_pitch * 2);
+  const unsigned wb = (unsigned)(cst_bytes + (long long)(a.Chid / 64) * C::BWD_SLICE);
+  if (a.h_out) hipLaunchKernelGGL((pw_bwd_kernel<DT, KC1, NRB, true>), dim3((unsigned)nb), dim3(C::NT), lds, st, a, xb, zb, wb, cst_bytes / 1024);
+  else hipLaunchKernelGGL((pw_bwd_kernel<DT, KC1, NRB, false>), dim3((unsigned)nb), dim3(C::NT), lds, st, a, xb, zb, wb, cst_bytes / 1024);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int srk_pw_shape_ok(int Cin, int Chid, int CoutP) { return pw_shape_ok(Cin, Chid, CoutP) ? 1 : 0; }
+
+extern "C" long long srk_pw_pack_bytes(int Cin, int Chid, int CoutP, int bwd) {
+  if (!pw_shape_ok(Cin, Chid, CoutP)) return -1;
+  const int KC1 = Cin / 16, R2 = CoutP, RI = Cin, NS = Chid / 64;
+  const long long w1 = 2LL * KC1 * 64 * 16, w2 = 8LL * R2 * 16, w2t = (R2 / 8) * 64LL * 16, w1t = 8LL * RI * 16;
+  if (!bwd) return ((Chid + R2) * 4 + 1023) / 1024 * 1024 + NS * (w1 + w2);
+  return (Chid * 4 + 1023) / 1024 * 1024 + NS * (w1 + w2t + w1t);
+}
+
+extern "C" int srk_pw_pack(const srk_pw_pack_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->w1 && a->w2 && a->fwd && a->bwd, "srk_pw_pack: null pointer");
+  SRK_CHECK_ARG(pw_shape_ok(a->Cin, a->Chid, a->CoutP) && a->Cmid <= a->CoutP && a->dtype != SRK_F32,
+                "srk_pw_pack: unsupported shape %d -> %d -> %d (rows %d)", a->Cin, a->Chid, a->Cmid, a->CoutP);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(pw_pack_kernel<SRK_BF16>, dim3(128), dim3(256), 0, st, *a);
+  else hipLaunchKernelGGL(pw_pack_kernel<SRK_F16>, dim3(128), dim3(256), 0, st, *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_pw_forward(const srk_pw_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->wpk && a->out, "srk_pw_forward: null pointer");
+  SRK_CHECK_ARG(pw_shape_ok(a->Cin, a->Chid, a->CoutP) && a->dtype != SRK_F32, "srk_pw_forward: unsupported shape %d -> %d -> rows %d",
+                a->Cin, a->Chid, a->CoutP);
+  SRK_CHECK_ARG(a->P > 0 && a->P * (long long)a->x_pitch * 2 < 0x7fff0000LL && a->x_pitch % 8 == 0 && a->x_coff % 8 == 0 &&
+                a->out_pitch % 8 == 0 && a->out_coff % 8 == 0 && a->Cout % 8 == 0 && a->Cout <= a->CoutP,
+                "srk_pw_forward: addressing (P=%lld pitch %d)", a->P, a->x_pitch);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->Cin == 128) return a->dtype == SRK_BF16 ? pw_fwd_launch<SRK_BF16, 8, 4>(*a, st) : pw_fwd_launch<SRK_F16, 8, 4>(*a, st);
+  return a->dtype == SRK_BF16 ? pw_fwd_launch<SRK_BF16, 4, 2>(*a, st) : pw_fwd_launch<SRK_F16, 4, 2>(*a, st);
+}
+
+extern "C" int srk_pw_backward(const srk_pw_bwd_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->gz && a->wpk && a->gx, "srk_pw_backward: null pointer");
+  SRK_CHECK_ARG(pw_shape_ok(a->Cin, a->Chid, a->CoutP) && a->dtype != SRK_F32, "srk_pw_backward: unsupported shape %d -> %d -> rows %d",
+                a->Cin, a->Chid, a->CoutP);
+  SRK_CHECK_ARG((a->h_out == nullptr) == (a->gh_out == nullptr), "srk_pw_backward: h_out and gh_out come together");
+  SRK_CHECK_ARG(a->P > 0 && a->P * (long long)a->x_pitch * 2 < 0x7fff0000LL && a->P * (long long)a->gz_pitch * 2 < 0x7fff0000LL &&
+                a->x_pitch % 8 == 0 && a->x_coff % 8 == 0 && a->gz_pitch % 8 == 0 && a->gz_coff % 8 == 0 && a->Cz % 8 == 0 && a->Cz <= a->CoutP &&
+                a->gx_pitch % 8 == 0 && a->gx_coff % 8 == 0 && (!a->res || (a->res_pitch % 8 == 0 && a->res_coff % 8 == 0)),
+                "srk_pw_backward: addressing (P=%lld)", a->P);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->Cin == 128) return a->dtype == SRK_BF16 ? pw_bwd_launch<SRK_BF16, 8, 4>(*a, st) : pw_bwd_launch<SRK_F16, 8, 4>(*a, st);
+  return a->dtype == SRK_BF16 ? pw_bwd_launch<SRK_BF16, 4, 2>(*a, st) : pw_bwd_launch<SRK_F16, 4, 2>(*a, st);
+}

@@ -49,8 +49,7 @@ class _Block_B(_NCHWContract, nn.Module):
 
     def nhwc(self, x):
         c1, c2, c3 = self.body[0], self.body[2], self.body[3]
-        return ops.conv_chain(x, [(_wn_weight(c1), c1.bias), (_wn_weight(c2), c2.bias), (_wn_weight(c3), c3.bias)],
-                              [True, False, False], scale=self.res_scale)
+        return ops.wdsr_block_b(x, [(_wn_weight(c1), c1.bias), (_wn_weight(c2), c2.bias), (_wn_weight(c3), c3.bias)], scale=self.res_scale)
 
 
 class WDSR(SRModel):

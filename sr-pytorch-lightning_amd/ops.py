@@ -978,6 +978,117 @@ def conv_chain(x, convs, relus, scale=1.0):
     return ConvChainFn.apply(x, float(scale), tuple(bool(r) for r in relus), *flat)
 
 
+# --------------------------------------------------------------------------------------------
+# WDSR _Block_B with the 6F-channel intermediate kept on chip (csrc/pw_chain.hip)
+# --------------------------------------------------------------------------------------------
+_PW_OFF = os.environ.get("SRK_NO_PW", "0") == "1"        # A/B knob: the block as three srk_conv2d launches (ConvChainFn)
+
+
+def pw_ok(x, w1, w2):
+    """Whether `conv1x1(w1) -> ReLU -> conv1x1(w2)` on NHWC `x` runs as ONE srk_pw_forward launch (16-bit storage,
+    WDSR-B's shapes at n_feats 128 / 64: srk_pw_shape_ok)."""
+    if _PW_OFF or x.dtype not in (torch.bfloat16, torch.float16) or x.numel() == 0:
+        return False
+    if w1.shape[2] != 1 or w2.shape[2] != 1 or w1.shape[1] != x.shape[3] or w2.shape[1] != w1.shape[0]:
+        return False
+    if x.numel() // x.shape[3] * max(x.shape[3], _roundup(w2.shape[0], 64)) * 2 >= _ADDR_LIMIT:
+        return False
+    return bool(L.load().srk_pw_shape_ok(int(w1.shape[1]), int(w1.shape[0]), _roundup(int(w2.shape[0]), 64)))
+
+
+class PwPacked:
+    __slots__ = ("fwd", "bwd", "cin", "chid", "cmid", "coutp")
+
+
+def pw_pack(w1, b1, w2, b2, dtype):
+    """fp32 [Chid][Cin][1][1] / [Cmid][Chid][1][1] (+ biases) -> the forward and backward slice streams of srk_pw_*."""
+    _need_gpu(w1)
+    lib = L.load()
+    p = PwPacked()
+    p.cin, p.chid, p.cmid = int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])
+    p.coutp = _roundup(p.cmid, 64)
+    p.fwd = torch.empty(lib.srk_pw_pack_bytes(p.cin, p.chid, p.coutp, 0), dtype=torch.uint8, device=w1.device)
+    p.bwd = torch.empty(lib.srk_pw_pack_bytes(p.cin, p.chid, p.coutp, 1), dtype=torch.uint8, device=w1.device)
+    w1f, w2f = _f32c(w1.detach()), _f32c(w2.detach())
+    b1f = None if b1 is None else _f32c(b1.detach())
+    b2f = None if b2 is None else _f32c(b2.detach())
+    L.call("srk_pw_pack", L.PwPackArgs(w1=w1f.data_ptr(), b1=_ptr(b1f), w2=w2f.data_ptr(), b2=_ptr(b2f), Cin=p.cin, Chid=p.chid,
+                                       Cmid=p.cmid, CoutP=p.coutp, fwd=p.fwd.data_ptr(), bwd=p.bwd.data_ptr(), dtype=_DT[dtype]), _stream())
+    return p
+
+
+def pw_forward_raw(x, pk, out):
+    n, h, wd, _ = x.shape
+    L.call("srk_pw_forward", L.PwArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, P=n * h * wd, Cin=pk.cin, Chid=pk.chid, CoutP=pk.coutp,
+                                      Cout=out.shape[3], wpk=pk.fwd.data_ptr(), out=out.data_ptr(), out_pitch=_pitch(out), out_coff=0,
+                                      dtype=_DT[x.dtype]), _stream())
+    return out
+
+
+def pw_backward_raw(x, gz, pk, gx, *, res=None, h_out=None, gh_out=None):
+    n, h, wd, _ = x.shape
+    L.call("srk_pw_backward", L.PwBwdArgs(
+        x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, gz=gz.data_ptr(), gz_pitch=_pitch(gz), gz_coff=0, Cz=gz.shape[3], P=n * h * wd,
+        Cin=pk.cin, Chid=pk.chid, CoutP=pk.coutp, wpk=pk.bwd.data_ptr(), res=_ptr(res), res_pitch=0 if res is None else _pitch(res), res_coff=0,
+        gx=gx.data_ptr(), gx_pitch=_pitch(gx), gx_coff=0, h_out=_ptr(h_out), gh_out=_ptr(gh_out), dtype=_DT[x.dtype]), _stream())
+    return gx
+
+
+class WdsrBlockBFn(torch.autograd.Function):
+    """WDSR _Block_B (models/wdsr.py:30-51): out = conv3x3(conv1x1(relu(conv1x1(x)))) * res_scale + x.
+
+    forward : srk_pw_forward (both pointwise convs, the 6F-channel tensor never leaves the chip) + one srk_conv2d (3x3, * scale, + x)
+    backward: dgrad 3x3 (* scale), srk_pw_backward (re-computes the ReLU mask, + g of the skip connection; also leaves h and gh
+              for the pointwise weight gradients), three weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, scale, w1, b1, w2, b2, w3, b3):
+        _need_gpu(x)
+        n, h, wd, cp = x.shape
+        dt = x.dtype
+        pk = pw_pack(w1, b1, w2, b2, dt)
+        z = torch.empty((n, h, wd, pad16(w2.shape[0])), dtype=dt, device=x.device)
+        pw_forward_raw(x, pk, z)
+        out = torch.empty_like(x)
+        conv_raw(z, pack_conv(w3, b3, dt), N=n, H=h, W=wd, Cin=z.shape[3], Cout=cp, out=out, scale=scale, res=x)
+        ctx.save_for_backward(x, z, w1, w2, w3)
+        ctx.pk, ctx.scale = pk, scale
+        ctx.wb = (w1, b1, w2, b2, w3, b3)
+        ctx.pg = _tok()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, z, w1, w2, w3 = ctx.saved_tensors
+        pk, scale = ctx.pk, ctx.scale
+        _, b1, _, b2, _, b3 = ctx.wb
+        g = g.contiguous()
+        n, h, wd, cp = x.shape
+        dt = x.dtype
+        gz = torch.empty_like(z)
+        conv_raw(g, pack_conv(w3, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=z.shape[3], out=gz, scale=scale, use_bias=False)
+        gw3, gb3 = wgrad(z, g, wparam=ctx.wb[4], bparam=b3, N=n, H=h, W=wd, Cin=z.shape[3], Cout=cp, k=3, w_shape=tuple(w3.shape),
+                         scale=scale, want_bias=b3 is not None)
+        hid = torch.empty((n, h, wd, pk.chid), dtype=dt, device=x.device)
+        ghid = torch.empty_like(hid)
+        gx = torch.empty_like(x)
+        pw_backward_raw(x, gz, pk, gx, res=g, h_out=hid, gh_out=ghid)
+        gw2, gb2 = wgrad(hid, gz, wparam=ctx.wb[2], bparam=b2, N=n, H=h, W=wd, Cin=pk.chid, Cout=gz.shape[3], k=1, w_shape=tuple(w2.shape),
+                         want_bias=b2 is not None)
+        gw1, gb1 = wgrad(x, ghid, wparam=ctx.wb[0], bparam=b1, N=n, H=h, W=wd, Cin=cp, Cout=pk.chid, k=1, w_shape=tuple(w1.shape),
+                         want_bias=b1 is not None)
+        return gx, None, gw1, gb1, gw2, gb2, gw3, gb3
+
+
+def wdsr_block_b(x, convs, scale=1.0):
+    """convs = [(w1, b1), (w2, b2), (w3, b3)] of a _Block_B; the fused form when the shapes allow, else the conv chain."""
+    (w1, b1), (w2, b2), (w3, b3) = convs
+    if pw_ok(x, w1, w2) and w3.shape[2] == 3 and w3.shape[0] == x.shape[3]:
+        return WdsrBlockBFn.apply(x, float(scale), w1, b1, w2, b2, w3, b3)
+    return conv_chain(x, convs, [True, False, False], scale=scale)
+
+
+
 class _CAHint:
     """Link between consecutive RCABs of one forward pass (small batches only): block k leaves its conv output `t` here; block
     k+1 -- whose backward produces the gradient block k receives -- pools t * gradient while that gradient leaves its
