@@ -181,6 +181,23 @@ int srk_pw_shape_ok(int Cin, int Chid, int CoutP);
 long long srk_pw_pack_bytes(int Cin, int Chid, int CoutP, int bwd);
 int srk_pw_pack(const srk_pw_pack_args* a, srk_stream_t stream);
 
+/* ---- weight normalisation of all weight-normed convs of a model in one launch per direction ----------------------
+ * Replaces nn.utils.weight_norm (models/wdsr.py:62, applied to all 51 convs of WDSR): forward w = v * (g / ||v||) per output
+ * row (torch._weight_norm, dim 0) and its backward (dv, dg from dw).  `table_dev` is a DEVICE array of jobs (srk_upload_small
+ * gets it there); `row0` = number of rows of all earlier jobs, `total_rows` their sum.  forward writes w and inv (1 / ||v||,
+ * kept for the backward); backward reads v, g, inv, dw and writes dv, dg.                                            */
+typedef struct {
+  const float* v; const float* g;   /* [rows][cols], [rows] */
+  float* w; float* inv;             /* forward out: [rows][cols], [rows] */
+  const float* dw;                  /* backward in */
+  float* dv; float* dg;             /* backward out */
+  int rows, cols, row0, pad_;
+} srk_wn_job;
+int srk_weight_norm_group(const srk_wn_job* table_dev, int njobs, int total_rows, int backward, srk_stream_t stream);
+
+/* same as srk_pw_pack for `n` blocks in ONE launch; `table_dev` is a DEVICE array */
+int srk_pw_pack_group(const srk_pw_pack_args* table_dev, int n, srk_stream_t stream);
+
 typedef struct {
   const void* x; int x_pitch, x_coff;   /* [P] pixels x Cin channels */
   long long P;

@@ -55,6 +55,11 @@ class PwPackArgs(C.Structure):
                 ("fwd", _p), ("bwd", _p), ("dtype", _i)]
 
 
+class WnJob(C.Structure):
+    _fields_ = [("v", _p), ("g", _p), ("w", _p), ("inv", _p), ("dw", _p), ("dv", _p), ("dg", _p),
+                ("rows", _i), ("cols", _i), ("row0", _i), ("pad_", _i)]
+
+
 class PwArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("P", C.c_longlong), ("Cin", _i), ("Chid", _i), ("CoutP", _i), ("Cout", _i),
                 ("wpk", _p), ("out", _p), ("out_pitch", _i), ("out_coff", _i), ("dtype", _i)]
@@ -214,7 +219,7 @@ LAUNCHERS = {
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
-                 "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes")
+                 "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group")
 
 _lib = None
 
@@ -265,6 +270,10 @@ def load():
     lib.srk_pw_shape_ok.restype = C.c_int
     lib.srk_pw_pack_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.srk_pw_pack_bytes.restype = C.c_longlong
+    lib.srk_pw_pack_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.srk_pw_pack_group.restype = C.c_int
+    lib.srk_weight_norm_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.srk_weight_norm_group.restype = C.c_int
     lib.srk_last_error.restype = C.c_char_p
     lib.srk_version.restype = C.c_int
     lib.srk_device_cus.restype = C.c_int

@@ -431,14 +431,13 @@ __global__ __launch_bounds__(512) void pw_bwd_kernel(const srk_pw_bwd_args a, un
 //   bwd : cst = b1p[Chid]           (padded to whole KB) ; slice s = W1 part | W2^T part | W1^T part
 // one work item = one 16-byte chunk
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int DT> __global__ void pw_pack_kernel(const srk_pw_pack_args a) {
+template <int DT> __device__ void pw_pack_body(const srk_pw_pack_args& a, long long stride, long long first) {
   typedef DTraits<DT> Tr;
   const int KC1 = a.Cin / 16, R2 = a.CoutP, RI = a.Cin, NS = a.Chid / 64;
   const int w1c = 2 * KC1 * 64, w2c = 8 * R2, w2tc = (R2 / 8) * 64, w1tc = 8 * RI;       // chunks per part
   const int fsl = w1c + w2c, bsl = w1c + w2tc + w1tc;
   const int fcst = ((a.Chid + R2) * 4 + 1023) / 1024 * 1024, bcst = (a.Chid * 4 + 1023) / 1024 * 1024;
   const long long nf = (long long)NS * fsl, nb = (long long)NS * bsl;
-  const long long stride = (long long)gridDim.x * blockDim.x, first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   auto put = [&](void* base, long long byte_off, const float (&v)[8]) {
     i32x4 q;
     q.x = (int)pack2<DT>(v[0], v[1]); q.y = (int)pack2<DT>(v[2], v[3]); q.z = (int)pack2<DT>(v[4], v[5]); q.w = (int)pack2<DT>(v[6], v[7]);
@@ -489,6 +488,16 @@ template <int DT> __global__ void pw_pack_kernel(const srk_pw_pack_args a) {
       reinterpret_cast<float*>(a.fwd)[i] = (a.b2 && ch < a.Cmid) ? a.b2[ch] : 0.f;
     }
   }
+}
+
+template <int DT> __global__ void pw_pack_kernel(const srk_pw_pack_args a) {
+  pw_pack_body<DT>(a, (long long)gridDim.x * blockDim.x, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void pw_pack_group_kernel(const srk_pw_pack_args* __restrict__ table) {
+  const srk_pw_pack_args a = table[blockIdx.y];
+  const long long stride = (long long)gridDim.x * blockDim.x, first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.dtype == SRK_BF16) pw_pack_body<SRK_BF16>(a, stride, first);
+  else pw_pack_body<SRK_F16>(a, stride, first);
 }
 
 bool pw_shape_ok(int Cin, int Chid, int CoutP) {
@@ -549,6 +558,13 @@ extern "C" int srk_pw_pack(const srk_pw_pack_args* a, srk_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == SRK_BF16) hipLaunchKernelGGL(pw_pack_kernel<SRK_BF16>, dim3(128), dim3(256), 0, st, *a);
   else hipLaunchKernelGGL(pw_pack_kernel<SRK_F16>, dim3(128), dim3(256), 0, st, *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_pw_pack_group(const srk_pw_pack_args* table_dev, int n, srk_stream_t stream) {
+  SRK_CHECK_ARG(table_dev && n > 0 && n <= 65535, "srk_pw_pack_group: bad table (%d entries)", n);
+  hipLaunchKernelGGL(pw_pack_group_kernel, dim3(64, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table_dev);
   SRK_LAUNCH_CHECK();
   return 0;
 }

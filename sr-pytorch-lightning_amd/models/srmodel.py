@@ -319,6 +319,7 @@ class SRModel(_Base):
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_srk_packs", None)
+        state.pop("_srk_wn", None)
         return state
 
     # -- srmodel.py:435-501 ------------------------------------------------------------------------------

@@ -28,9 +28,13 @@ class _Block_A(_NCHWContract, nn.Module):
     def _cout(self):
         return self.body[0].in_channels
 
-    def nhwc(self, x):
+    def wn_convs(self):
+        return [self.body[0], self.body[2]]
+
+    def nhwc(self, x, ws=None):
         c1, c2 = self.body[0], self.body[2]
-        return ops.conv_chain(x, [(_wn_weight(c1), c1.bias), (_wn_weight(c2), c2.bias)], [True, False], scale=self.res_scale)
+        w1, w2 = ws if ws is not None else (_wn_weight(c1), _wn_weight(c2))
+        return ops.conv_chain(x, [(w1, c1.bias), (w2, c2.bias)], [True, False], scale=self.res_scale)
 
 
 class _Block_B(_NCHWContract, nn.Module):
@@ -47,9 +51,13 @@ class _Block_B(_NCHWContract, nn.Module):
     def _cout(self):
         return self.body[0].in_channels
 
-    def nhwc(self, x):
+    def wn_convs(self):
+        return [self.body[0], self.body[2], self.body[3]]
+
+    def nhwc(self, x, ws=None):
         c1, c2, c3 = self.body[0], self.body[2], self.body[3]
-        return ops.wdsr_block_b(x, [(_wn_weight(c1), c1.bias), (_wn_weight(c2), c2.bias), (_wn_weight(c3), c3.bias)], scale=self.res_scale)
+        w1, w2, w3 = ws if ws is not None else (_wn_weight(c1), _wn_weight(c2), _wn_weight(c3))
+        return ops.wdsr_block_b(x, [(w1, c1.bias), (w2, c2.bias), (w3, c3.bias)], scale=self.res_scale)
 
 
 class WDSR(SRModel):
@@ -76,14 +84,26 @@ class WDSR(SRModel):
 
     def forward(self, x):
         """wdsr.py:102-117: x - mean; s = PS(skip(x)); x = PS(tail(body(head(x)))); x += s; x + mean."""
-        with ops.forward_scope(None):      # weight-norm weights are fresh tensors every step: packed per use
+        # all 51 effective weights w = g * v / ||v|| in ONE launch, into a buffer with a stable address (ops.WeightNormGroup):
+        # they join the grouped pack launch and the grouped weight gradients like leaf parameters do
+        grp = self.__dict__.get("_srk_wn")
+        if grp is None:
+            convs = [self.skip[0], self.head[0]]
+            for blk in self.body:
+                convs += blk.wn_convs()
+            grp = self.__dict__["_srk_wn"] = ops.WeightNormGroup(convs + [self.tail[0]])
+        ws = grp.weights()
+        with ops.forward_scope(self._pack_group()):
             mean = None
             if self._channels == 3:
                 self.rgb_mean = self.rgb_mean.to(x.device)
                 mean = self.rgb_mean.view(3).contiguous()
             r = self._scale_factor
-            s = ops.skip_conv(x, _wn_weight(self.skip[0]), self.skip[0].bias, mean, r, self.compute_dtype)
-            f = ops.head_conv(x, _wn_weight(self.head[0]), self.head[0].bias, mean, self.compute_dtype)
+            s = ops.skip_conv(x, ws[0], self.skip[0].bias, mean, r, self.compute_dtype)
+            f = ops.head_conv(x, ws[1], self.head[0].bias, mean, self.compute_dtype)
+            k = 2
             for blk in self.body:
-                f = blk.nhwc(f)
-            return ops.tail_conv(f, _wn_weight(self.tail[0]), self.tail[0].bias, res=s, post_add=mean, ps_r=r)
+                nb = len(blk.wn_convs())
+                f = blk.nhwc(f, ws[k:k + nb])
+                k += nb
+            return ops.tail_conv(f, ws[k], self.tail[0].bias, res=s, post_add=mean, ps_r=r)

@@ -100,6 +100,9 @@ class PackGroup:
 
     def __init__(self):
         self.entries = {}       # key -> [PackArgs, Packed, w, b]
+        self.pw_entries = {}    # key -> [PwPackArgs, PwPacked, (w1, b1, w2, b2)]  (fused pointwise pairs, csrc/pw_chain.hip)
+        self.pw_table = None
+        self.pw_dirty = False
         self.table = None
         self.dirty = False
         self.epoch = 0          # number of refreshes so far
@@ -113,8 +116,35 @@ class PackGroup:
         self.entries[key] = [args, packed, w, b]
         self.dirty = True
 
+    def lookup_pw(self, key):
+        e = self.pw_entries.get(key)
+        return e[1] if e is not None else None
+
+    def add_pw(self, key, args, packed, tensors):
+        self.pw_entries[key] = [args, packed, tensors]
+        self.pw_dirty = True
+
+    def _refresh_pw(self):
+        for e in self.pw_entries.values():
+            a, _, (w1, b1, w2, b2) = e
+            ptrs = (w1.data_ptr(), _ptr(b1), w2.data_ptr(), _ptr(b2))
+            if (a.w1, a.b1 or 0, a.w2, a.b2 or 0) != ptrs:
+                a.w1, a.b1, a.w2, a.b2 = ptrs
+                self.pw_dirty = True
+        if self.pw_dirty:
+            arr = (L.PwPackArgs * len(self.pw_entries))(*[e[0] for e in self.pw_entries.values()])
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            dev = next(iter(self.pw_entries.values()))[2][0].device
+            if self.pw_table is None or self.pw_table.device != dev or self.pw_table.numel() < raw.numel():
+                self.pw_table = torch.empty(max(2 * raw.numel(), 4096), dtype=torch.uint8, device=dev)
+            self.pw_table[:raw.numel()].copy_(raw)
+            self.pw_dirty = False
+        L.check(L.load().srk_pw_pack_group(self.pw_table.data_ptr(), len(self.pw_entries), _stream()), "srk_pw_pack_group")
+
     def refresh(self):
         self.epoch += 1
+        if self.pw_entries:
+            self._refresh_pw()
         if not self.entries:
             return
         for e in self.entries.values():          # parameters moved / re-allocated since the table was built?
@@ -183,8 +213,11 @@ def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False, tok
     as_1x1: present the OIHW weight as the 1x1 conv over Cin*KH*KW unfolded channels (head / skip convs).
     token: the (group, epoch) a Function's forward was built under (backward calls pass it: see PackGroup)."""
     _need_gpu(w)
-    is_param = isinstance(w, torch.nn.Parameter)
-    key = (id(w), dtype, bool(dgrad), int(ps_r), bool(as_1x1))
+    # a weight-normed conv's effective weight (WeightNormGroup) is a non-leaf tensor in a buffer with a STABLE address: it joins
+    # the grouped pack launch under the identity of its `weight_v` parameter
+    kobj = None if isinstance(w, torch.nn.Parameter) else w.__dict__.get("_srk_pack_key")
+    is_param = isinstance(w, torch.nn.Parameter) or kobj is not None
+    key = (id(w) if kobj is None else kobj, dtype, bool(dgrad), int(ps_r), bool(as_1x1))
     group = _group_for(token) if is_param else None
     if group is not None:
         hit = group.lookup(key)
@@ -192,7 +225,7 @@ def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False, tok
             return hit
     ver = (w._version, -1 if b is None else b._version, w.data_ptr())
     store = None
-    if cache and _PACK_CACHE_ENABLED and is_param:
+    if cache and _PACK_CACHE_ENABLED and is_param and kobj is None:
         store = w.__dict__.setdefault("_srk_pack", {})
         hit = store.get(key)
         if hit is not None and hit[0] == ver:
@@ -421,6 +454,8 @@ def _grad_slot(p, shape):
     ('acc', tensor) -> accumulate into the existing fp32 gradient, autograd gets None;  None -> cannot defer."""
     if p is None:
         return ("new", None)
+    if isinstance(p, torch.Tensor) and p.__dict__.get("_srk_wn_proxy", False):
+        return ("new", None)            # effective weight of a weight-normed conv: its consumer (WeightNormGroup's backward) flushes first
     if not (isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad):
         return None
     if getattr(p, "_backward_hooks", None):
@@ -569,6 +604,8 @@ def flush_wgrads():
             for j in jobs + rjobs:
                 for ent in j["new"]:
                     p, ptr, stg, shape = ent[:4]
+                    if p is not None and p.__dict__.get("_srk_wn_proxy", False):
+                        continue                    # non-leaf: the gradient went to WeightNormGroup's backward by address
                     g = p.grad if p is not None else None
                     if g is not None and g.data_ptr() != ptr and tuple(g.shape) == tuple(shape):
                         g.copy_(_view_of(stg, shape, g.device, ent[4] if len(ent) > 4 else 0))
@@ -979,6 +1016,102 @@ def conv_chain(x, convs, relus, scale=1.0):
 
 
 # --------------------------------------------------------------------------------------------
+# weight normalisation of all weight-normed convs of a model in one launch per direction (csrc/wn.hip)
+# --------------------------------------------------------------------------------------------
+class _WnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grp, *params):
+        grp._launch(params, backward=False)
+        ctx.grp = grp
+        ctx.save_for_backward(*params)
+        return tuple(grp.flat[o:o + n].view(shape) for (o, n, shape, _, _) in grp.layout)     # fresh view objects every pass
+
+    @staticmethod
+    def backward(ctx, *grads):
+        grp, params = ctx.grp, ctx.saved_tensors
+        flush_wgrads()          # the deferred weight gradients of this pass are this node's inputs: compute them first
+        dev = params[0].device
+        dflat = torch.empty(grp.total, dtype=torch.float32, device=dev)
+        dg = torch.empty(grp.rows, dtype=torch.float32, device=dev)
+        gs = []
+        for gr, (off, n, shape, r0, rows) in zip(grads, grp.layout):
+            if gr is None:
+                gr = torch.zeros(shape, dtype=torch.float32, device=dev)
+            elif gr.dtype != torch.float32 or not gr.is_contiguous():
+                gr = gr.float().contiguous()
+            gs.append(gr)
+        grp._launch(params, backward=True, dws=gs, dv=dflat, dg=dg)
+        out = [None]
+        for (off, n, shape, r0, rows) in grp.layout:
+            out += [dflat[off:off + n].view(shape), dg[r0:r0 + rows].view(rows, *([1] * (len(shape) - 1)))]
+        return tuple(out)
+
+
+class WeightNormGroup:
+    """The effective weights w = g * v / ||v|| (nn.utils.weight_norm, models/wdsr.py:62) of a list of weight-normed convs:
+    ONE launch computes all of them into one flat buffer whose address never changes (so the grouped pack launch and a captured
+    hipGraph can name the weights), ONE launch turns their gradients into those of `weight_v` / `weight_g`.  `weights()`
+    returns one tensor per conv; each carries the identity of its `weight_v` for the packed-weight group and is accepted by
+    the deferred (grouped) weight gradients although it is not a leaf."""
+
+    def __init__(self, convs):
+        self.convs = list(convs)
+        self.flat = self.inv = None
+        self.layout = []
+        self.total = self.rows = 0
+        self.key = None
+
+    def _build(self, params):
+        dev = params[0].device
+        off = r0 = 0
+        self.layout = []
+        for v in params[0::2]:
+            n, rows = v.numel(), v.shape[0]
+            self.layout.append((off, n, tuple(v.shape), r0, rows))
+            off += _roundup(n, 4)
+            r0 += rows
+        self.total, self.rows = off, r0
+        self.flat = torch.empty(off, dtype=torch.float32, device=dev)
+        self.inv = torch.empty(r0, dtype=torch.float32, device=dev)
+
+    def _launch(self, params, backward, dws=None, dv=None, dg=None):
+        import ctypes as C
+        key = tuple(p.data_ptr() for p in params)
+        if self.flat is None or self.key != key or self.flat.device != params[0].device:
+            for p in params:
+                if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+                    raise RuntimeError("WeightNormGroup needs contiguous fp32 weight_v / weight_g on the GPU")
+            if self.flat is None or self.flat.device != params[0].device or [tuple(v.shape) for v in params[0::2]] != [l[2] for l in self.layout]:
+                self._build(params)
+            self.key = key
+        n = len(self.layout)
+        host = (L.WnJob * n)()
+        for i, (off, cnt, shape, r0, rows) in enumerate(self.layout):
+            v, g = params[2 * i], params[2 * i + 1]
+            j = host[i]
+            j.v, j.g, j.w, j.inv = v.data_ptr(), g.data_ptr(), self.flat.data_ptr() + 4 * off, self.inv.data_ptr() + 4 * r0
+            j.rows, j.cols, j.row0 = rows, cnt // rows, r0
+            if backward:
+                j.dw, j.dv, j.dg = dws[i].data_ptr(), dv.data_ptr() + 4 * off, dg.data_ptr() + 4 * r0
+        nbytes = C.sizeof(L.WnJob) * n
+        table = torch.empty(_roundup(nbytes, 16), dtype=torch.uint8, device=params[0].device)
+        st = _stream()
+        L.check(L.load().srk_upload_small(table.data_ptr(), C.addressof(host), nbytes, st), "srk_upload_small")
+        L.check(L.load().srk_weight_norm_group(table.data_ptr(), n, self.rows, 1 if backward else 0, st), "srk_weight_norm_group")
+
+    def weights(self):
+        params = []
+        for c in self.convs:
+            params += [c.weight_v, c.weight_g]
+        _need_gpu(params[0])
+        ws = _WnFn.apply(self, *params)
+        for w, c in zip(ws, self.convs):
+            w.__dict__["_srk_wn_proxy"] = True
+            w.__dict__["_srk_pack_key"] = ("wn", id(c.weight_v))
+        return list(ws)
+
+
+# --------------------------------------------------------------------------------------------
 # WDSR _Block_B with the 6F-channel intermediate kept on chip (csrc/pw_chain.hip)
 # --------------------------------------------------------------------------------------------
 _PW_OFF = os.environ.get("SRK_NO_PW", "0") == "1"        # A/B knob: the block as three srk_conv2d launches (ConvChainFn)
@@ -1000,10 +1133,20 @@ class PwPacked:
     __slots__ = ("fwd", "bwd", "cin", "chid", "cmid", "coutp")
 
 
-def pw_pack(w1, b1, w2, b2, dtype):
-    """fp32 [Chid][Cin][1][1] / [Cmid][Chid][1][1] (+ biases) -> the forward and backward slice streams of srk_pw_*."""
+def pw_pack(w1, b1, w2, b2, dtype, token=None):
+    """fp32 [Chid][Cin][1][1] / [Cmid][Chid][1][1] (+ biases) -> the forward and backward slice streams of srk_pw_*.
+    Weights with a stable identity (parameters, WeightNormGroup proxies) are served by / registered with the open PackGroup."""
     _need_gpu(w1)
     lib = L.load()
+    ids = []
+    for w in (w1, w2):
+        ids.append(id(w) if isinstance(w, torch.nn.Parameter) else w.__dict__.get("_srk_pack_key"))
+    group = _group_for(token) if all(i is not None for i in ids) else None
+    key = (ids[0], ids[1], dtype)
+    if group is not None:
+        hit = group.lookup_pw(key)
+        if hit is not None:
+            return hit
     p = PwPacked()
     p.cin, p.chid, p.cmid = int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])
     p.coutp = _roundup(p.cmid, 64)
@@ -1012,8 +1155,12 @@ def pw_pack(w1, b1, w2, b2, dtype):
     w1f, w2f = _f32c(w1.detach()), _f32c(w2.detach())
     b1f = None if b1 is None else _f32c(b1.detach())
     b2f = None if b2 is None else _f32c(b2.detach())
-    L.call("srk_pw_pack", L.PwPackArgs(w1=w1f.data_ptr(), b1=_ptr(b1f), w2=w2f.data_ptr(), b2=_ptr(b2f), Cin=p.cin, Chid=p.chid,
-                                       Cmid=p.cmid, CoutP=p.coutp, fwd=p.fwd.data_ptr(), bwd=p.bwd.data_ptr(), dtype=_DT[dtype]), _stream())
+    a = L.PwPackArgs(w1=w1f.data_ptr(), b1=_ptr(b1f), w2=w2f.data_ptr(), b2=_ptr(b2f), Cin=p.cin, Chid=p.chid,
+                     Cmid=p.cmid, CoutP=p.coutp, fwd=p.fwd.data_ptr(), bwd=p.bwd.data_ptr(), dtype=_DT[dtype])
+    L.call("srk_pw_pack", a, _stream())
+    if (group is not None and w1f.data_ptr() == w1.data_ptr() and w2f.data_ptr() == w2.data_ptr()
+            and (b1 is None or b1f.data_ptr() == b1.data_ptr()) and (b2 is None or b2f.data_ptr() == b2.data_ptr())):
+        group.add_pw(key, a, p, (w1, b1, w2, b2))
     return p
 
 
@@ -1047,6 +1194,7 @@ class WdsrBlockBFn(torch.autograd.Function):
         n, h, wd, cp = x.shape
         dt = x.dtype
         pk = pw_pack(w1, b1, w2, b2, dt)
+        ctx.pg = _tok()
         z = torch.empty((n, h, wd, pad16(w2.shape[0])), dtype=dt, device=x.device)
         pw_forward_raw(x, pk, z)
         out = torch.empty_like(x)
@@ -1060,11 +1208,14 @@ class WdsrBlockBFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, z, w1, w2, w3 = ctx.saved_tensors
-        pk, scale = ctx.pk, ctx.scale
+        scale = ctx.scale
         _, b1, _, b2, _, b3 = ctx.wb
         g = g.contiguous()
         n, h, wd, cp = x.shape
         dt = x.dtype
+        # a pack that lives in the model's PackGroup is refreshed in place by later forwards: take it through the token like
+        # every dgrad pack (re-packed from the current weights if the window has moved on); a private pack is immutable
+        pk = ctx.pk if ctx.pg is None else pw_pack(ctx.wb[0], b1, ctx.wb[2], b2, dt, token=ctx.pg)
         gz = torch.empty_like(z)
         conv_raw(g, pack_conv(w3, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=z.shape[3], out=gz, scale=scale, use_bias=False)
         gw3, gb3 = wgrad(z, g, wparam=ctx.wb[4], bparam=b3, N=n, H=h, W=wd, Cin=z.shape[3], Cout=cp, k=3, w_shape=tuple(w3.shape),

@@ -147,3 +147,63 @@ def test_fused_block_equals_the_three_launch_chain(A):
     assert l2err(gxf, gxc.cpu()) < 1e-2
     for a_, b_ in zip(gpf, gpc):
         assert l2err(a_, b_.cpu()) < 1e-2
+
+
+def test_weight_norm_group_matches_torch(A):
+    """ops.WeightNormGroup (csrc/wn.hip: every weight-normed conv of a model in one launch per direction) against
+    torch._weight_norm and its autograd backward (nn.utils.weight_norm, models/wdsr.py:62)."""
+    import torch.nn as nn
+    torch.manual_seed(3)
+    convs = [nn.utils.weight_norm(nn.Conv2d(ci, co, k, padding=k // 2)).cuda() for ci, co, k in [(3, 48, 5), (128, 768, 1), (768, 102, 1), (102, 128, 3), (7, 5, 3)]]
+    with torch.no_grad():
+        for c in convs:
+            c.weight_g.mul_(torch.rand_like(c.weight_g) + 0.5)
+    grp = A.ops.WeightNormGroup(convs)
+    ws = grp.weights()
+    gens = [torch.randn_like(w) for w in ws]
+    torch.autograd.backward(ws, gens)
+    got = [(w.detach().clone(), c.weight_v.grad.clone(), c.weight_g.grad.clone()) for w, c in zip(ws, convs)]
+    for c in convs:
+        c.weight_v.grad = c.weight_g.grad = None
+    for (w, gv, gg), c, gen in zip(got, convs, gens):
+        ref = torch._weight_norm(c.weight_v, c.weight_g, 0)
+        ref.backward(gen)
+        assert float((w - ref.detach()).abs().max()) <= 2e-6 * float(ref.abs().max())
+        assert float((gv - c.weight_v.grad).abs().max()) <= 1e-5 * float(c.weight_v.grad.abs().max())
+        assert float((gg - c.weight_g.grad).abs().max()) <= 1e-5 * float(c.weight_g.grad.abs().max()) + 1e-6
+    p0 = ws[0].data_ptr()
+    assert grp.weights()[0].data_ptr() == p0, "the effective weights keep their address from step to step"
+
+
+def test_wdsr_step_uses_grouped_parameter_launches(A):
+    """A WDSR-B training step issues ONE weight-norm launch per direction and serves the packed weights of its 51 convs from the
+    model's PackGroup (was: ~100 torch weight-norm launches + ~100 per-use packs), and two steps give the same result as the
+    per-conv torch path (SRK_NO_PW-independent: compared through the parameters' gradients)."""
+    torch.manual_seed(0)
+    m = A.WDSR(type="B", n_feats=128, n_resblocks=2, scale_factor=2, precision="bf16").cuda()
+    x, hr = torch.rand(2, 3, 24, 24).cuda(), torch.rand(2, 3, 48, 48).cuda()
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        m.training_step({"lr": x, "hr": hr}, 0)["loss"].backward()
+    torch.cuda.synchronize()
+    grp = m._pack_group()
+    assert len(grp.pw_entries) == 2 and len(grp.entries) >= 2 * 2 + 3, (len(grp.pw_entries), len(grp.entries))
+    got = {k: p.grad.clone() for k, p in m.named_parameters()}
+    # reference: the same model with torch's weight norm per conv and per-use packs
+    from sr_amd.models import wdsr as W
+    for p in m.parameters():
+        p.grad = None
+    y = None
+    with A.ops.forward_scope(None):
+        mean = m.rgb_mean.view(3).contiguous()
+        s = A.ops.skip_conv(x, W._wn_weight(m.skip[0]), m.skip[0].bias, mean, 2, m.compute_dtype)
+        f = A.ops.head_conv(x, W._wn_weight(m.head[0]), m.head[0].bias, mean, m.compute_dtype)
+        for blk in m.body:
+            f = blk.nhwc(f)
+        y = A.ops.tail_conv(f, W._wn_weight(m.tail[0]), m.tail[0].bias, res=s, post_add=mean, ps_r=2)
+    m._calculate_losses(img_sr=y, img_hr=hr)["loss"].backward()
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        ref = p.grad
+        assert l2err(got[k], ref.cpu()) < 2e-3, k

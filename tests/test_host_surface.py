@@ -20,7 +20,7 @@ HEADER = open(os.path.join(ROOT, "include", "srk.h")).read()
 
 
 def _declared_functions():
-    return sorted(set(re.findall(r"^(?:int|const char\*)\s+(srk_\w+)\s*\(", HEADER, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|long long|const char\*)\s+(srk_\w+)\s*\(", HEADER, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():
