@@ -72,6 +72,12 @@ class PwBwdArgs(C.Structure):
                 ("h_out", _p), ("gh_out", _p), ("dtype", _i)]
 
 
+class PwWgradArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("gz", _p), ("gz_pitch", _i), ("gz_coff", _i), ("Cz", _i),
+                ("P", C.c_longlong), ("Cin", _i), ("Chid", _i), ("Cmid", _i), ("CoutP", _i), ("wpk", _p),
+                ("dw1p", _p), ("dw2p", _p), ("db1p", _p), ("nranges", _i), ("dw1", _p), ("db1", _p), ("dw2", _p), ("dtype", _i)]
+
+
 class ChanFinalizeArgs(C.Structure):
     _fields_ = [("partial", _p), ("nblocks", _i), ("C", _i), ("Creal", _i), ("mode", _i), ("total", _i),
                 ("M", _f), ("eps", _f), ("momentum", _f), ("mean", _p), ("invstd", _p), ("gamma", _p),
@@ -196,6 +202,7 @@ LAUNCHERS = {
     "srk_pw_pack": PwPackArgs,
     "srk_pw_forward": PwArgs,
     "srk_pw_backward": PwBwdArgs,
+    "srk_pw_wgrad": PwWgradArgs,
     "srk_adam_step": AdamArgs,
     "srk_chan_finalize": ChanFinalizeArgs,
     "srk_conv2d_wgrad": WgradArgs,
@@ -219,7 +226,7 @@ LAUNCHERS = {
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
-                 "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group")
+                 "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges")
 
 _lib = None
 
@@ -270,6 +277,8 @@ def load():
     lib.srk_pw_shape_ok.restype = C.c_int
     lib.srk_pw_pack_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.srk_pw_pack_bytes.restype = C.c_longlong
+    lib.srk_pw_wgrad_ranges.argtypes = [C.c_longlong, C.c_int]
+    lib.srk_pw_wgrad_ranges.restype = C.c_int
     lib.srk_pw_pack_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.srk_pw_pack_group.restype = C.c_int
     lib.srk_weight_norm_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]

@@ -426,6 +426,221 @@ __global__ __launch_bounds__(512) void pw_bwd_kernel(const srk_pw_bwd_args a, un
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// backward (weights): dW2[hid][z] = sum_p h[p][hid] gz[p][z],  dW1[hid][in] = sum_p gh[p][hid] x[p][in],  db1[hid] = sum_p gh[p][hid]
+// Neither h nor gh exists in HBM: a workgroup owns ONE slice of 64 hidden channels (its W1 / W2^T fragments stay in registers for
+// the whole launch) and a range of pixels, which it walks in tiles of 128.  Per tile: x and gz arrive by LDS-DMA as images in the
+// conv kernels' swizzled format (double-buffered); phase 1 re-computes the slice of h and gh for the tile (lane = pixel) and writes
+// both as 16-bit images; phase 2 reads the four images with the transposing LDS read (K = pixels) and accumulates the slice's
+// rows of dW2 and dW1 in registers.  At the end every workgroup stores its partial sums to its own slab (no atomics: fixed order,
+// reproducible); pw_wgrad_finalize_kernel adds the slabs of the pixel ranges.
+//   wave w, phase 1: pixel block w & 3, hidden 32-row block w >> 2                      16 MFMAs per tile
+//           phase 2: 64 x 64 tile w % NT64 of [dW2 | dW1], K part w / NT64               16 MFMAs per tile
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int DT, int KC1, int NRB>
+__global__ __launch_bounds__(512) void pw_wgrad_kernel(const srk_pw_wgrad_args a, unsigned x_bytes, unsigned gz_bytes, int NR, int tq, int trem) {
+  typedef DTraits<DT> Tr;
+  typedef PwCfg<KC1, NRB> C;
+  constexpr int TP = 128;                                        // pixels per tile
+  constexpr int PLANE = TP * 128;                                // one 64-channel block of a tile: 16 KB
+  constexpr int XPL = C::RI / 64, ZPL = C::R2 / 64;              // planes of x / gz
+  constexpr int BUF = (XPL + ZPL) * PLANE;
+  constexpr int NT64 = XPL + ZPL, KSPLIT = 8 / NT64, ROWS = 8 / KSPLIT;      // phase 2: tiles, K parts, 16-pixel rows per part
+  constexpr int KCZ = NRB * 2;
+  constexpr int PPW = (XPL + ZPL) * 16 / 8;                      // DMA pieces per wave and tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const hs = smem + 2 * BUF;                               // h image [128 px][64 hidden]
+  char* const gs = hs + PLANE;                                   // gh image
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int NS = a.Chid >> 6;
+  const int s = blockIdx.x % NS, rg = blockIdx.x / NS;
+  const long long P = a.P;
+  const int t0 = rg * tq + min(rg, trem), nt = tq + (rg < trem ? 1 : 0);
+
+  const i32x4 xrsrc = make_rsrc4(a.x, x_bytes), zrsrc = make_rsrc4(a.gz, gz_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+  auto dma_tile = [&](int tile, int b) {
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int q = wave * PPW + k, plane = q >> 4, pc = q & 15;
+      const int pl = 8 * pc + (lane >> 3), c8 = (lane & 7) ^ swz(pl & 15);
+      const long long p = (long long)tile * TP + pl;
+      const bool isx = plane < XPL;
+      const int ch = (isx ? plane : plane - XPL) * 64 + c8 * 8;
+      const bool ok = p < P && ch < (isx ? a.Cin : a.Cz);
+      const unsigned voff = ok ? (unsigned)((p * (isx ? a.x_pitch : a.gz_pitch) + (isx ? a.x_coff : a.gz_coff) + ch) * 2) : 0x80000000u;
+      dma16_hidden(isx ? xrsrc : zrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * BUF + plane * PLANE + pc * 1024)));
+    }
+  };
+
+  // ---- this wave's weight fragments (phase 1: hidden rows 32 rb .. + 32 of the slice) and bias, for the whole launch ----------
+  const int pb = wave & 3, rb = wave >> 2;
+  const int cst_bytes = (a.Chid * 4 + 1023) / 1024 * 1024;
+  const char* const slice = reinterpret_cast<const char*>(a.wpk) + cst_bytes + (size_t)s * C::BWD_SLICE;
+  i32x4 w1r[KC1], w2r[KCZ];
+#pragma unroll
+  for (int j = 0; j < KC1; ++j) w1r[j] = gload16(slice + (((2 * j + h) * 64 + rb * 32 + r) << 4));
+#pragma unroll
+  for (int j = 0; j < KCZ; ++j) w2r[j] = gload16(slice + C::W1_BYTES + (((2 * j + h) * 64 + rb * 32 + r) << 4));
+  float b1r[16], bsum[16];
+  {
+    const float* b1 = reinterpret_cast<const float*>(a.wpk) + s * 64 + (rb * 2 + h) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { b1r[q] = b1[q]; bsum[q] = 0.f; }
+  }
+  asm volatile("" : "+v"(w1r[0]), "+v"(w2r[0]), "+v"(b1r[0]));       // (the loads are waited for here, before any hidden DMA is queued)
+#pragma unroll
+  for (int j = 1; j < KC1; ++j) asm volatile("" : "+v"(w1r[j]));
+#pragma unroll
+  for (int j = 1; j < KCZ; ++j) asm volatile("" : "+v"(w2r[j]));
+#pragma unroll
+  for (int q = 1; q < 16; ++q) asm volatile("" : "+v"(b1r[q]));
+
+  const int t2 = wave % NT64, kq = wave / NT64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][o][e] = 0.f;
+  int aoff[2][2], boff[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) aoff[i][rd] = boff[i][rd] = tr_lane_off(0, rd, i, lane);
+  const char* const a_img = t2 < ZPL ? hs : gs;                  // dW2 tiles read h, dW1 tiles read gh
+  const int b_plane = t2 < ZPL ? XPL + t2 : t2 - ZPL;            // ... against gz plane t2 / x plane t2 - ZPL
+
+  const int pl = 32 * pb + r, g = swz(pl & 15);
+  if (nt > 0) dma_tile(t0, 0);
+#pragma unroll 1
+  for (int it = 0; it < nt; ++it) {
+    const char* const B0 = smem + (it & 1) * BUF;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // tile `it` has landed ...
+    __builtin_amdgcn_s_barrier();                                // ... for every wave; phase 2 of the previous tile is over
+    if (it + 1 < nt) dma_tile(t0 + it + 1, (it + 1) & 1);
+    // ---- phase 1 ------------------------------------------------------------------------------------------------------------
+    {
+      f32x16 pre, gh;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { pre[q] = b1r[q]; gh[q] = 0.f; }
+      const char* const xp = B0 + (pl << 7);
+#pragma unroll
+      for (int j = 0; j < KC1; ++j)
+        pre = Tr::mma(w1r[j], lds_read16(xp + (j >> 2) * PLANE + (((((2 * j) & 7) + h) ^ g) << 4)), pre);
+      const char* const zp = B0 + XPL * PLANE + (pl << 7);
+#pragma unroll
+      for (int j = 0; j < KCZ; ++j)
+        gh = Tr::mma(w2r[j], lds_read16(zp + (j >> 2) * PLANE + (((((2 * j) & 7) + h) ^ g) << 4)), gh);
+      const bool valid = (long long)(t0 + it) * TP + pl < P;     // pixels beyond P: x and gz are zeros, but h = relu(b1) is not
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float hv[8], gv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const bool on = pre[8 * m + t] > 0.f;
+          hv[t] = (on && valid) ? pre[8 * m + t] : 0.f;
+          gv[t] = on ? gh[8 * m + t] : 0.f;
+          bsum[8 * m + t] += gv[t];
+        }
+        const int off = (pl << 7) + (((4 * rb + 2 * m + h) ^ g) << 4);
+        lds_write16(hs + off, i32x4{(int)pack2<DT>(hv[0], hv[1]), (int)pack2<DT>(hv[2], hv[3]), (int)pack2<DT>(hv[4], hv[5]), (int)pack2<DT>(hv[6], hv[7])});
+        lds_write16(gs + off, i32x4{(int)pack2<DT>(gv[0], gv[1]), (int)pack2<DT>(gv[2], gv[3]), (int)pack2<DT>(gv[4], gv[5]), (int)pack2<DT>(gv[6], gv[7])});
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- phase 2 ------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int row = kq * ROWS + rr;
+      i32x4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = tr_read2(a_img + row * 2048 + aoff[i][0], a_img + row * 2048 + aoff[i][1]);
+        bf[i] = tr_read2(B0 + b_plane * PLANE + row * 2048 + boff[i][0], B0 + b_plane * PLANE + row * 2048 + boff[i][1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) acc[i][o] = Tr::mma(af[i], bf[o], acc[i][o]);
+    }
+  }
+
+  // ---- the K parts of a tile are added through LDS (fixed order), part 0 stores the workgroup's slab -----------------------------
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  float* const red = reinterpret_cast<float*>(smem);             // [KSPLIT - 1][NT64][64 regs][64 lanes]
+  if (kq > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[(((kq - 1) * NT64 + t2) * 64 + (i * 2 + o) * 16 + e) * 64 + lane] = acc[i][o][e];
+  }
+  // db1: the lanes of a half hold the same 16 hidden channels for 32 different pixels
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float v = bsum[q];
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    bsum[q] = v;
+  }
+  float* const bred = red + (KSPLIT - 1) * NT64 * 64 * 64;       // [4 pixel blocks][64 hidden]
+  if (r == 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bred[pb * 64 + pw_hid_of_row(32 * rb + 8 * (q >> 2) + 4 * h + (q & 3))] = bsum[q];
+  }
+  __syncthreads();
+  if (kq == 0) {
+    const int hq = lane >> 5;
+    const bool is2 = t2 < ZPL;
+    const int ncol = is2 ? C::R2 : C::RI;
+    float* const slab = (is2 ? a.dw2p : a.dw1p) + (size_t)rg * a.Chid * ncol;
+    const int col0 = 64 * (is2 ? t2 : t2 - ZPL);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[i][o][e];
+#pragma unroll
+          for (int k = 1; k < KSPLIT; ++k) v += red[(((k - 1) * NT64 + t2) * 64 + (i * 2 + o) * 16 + e) * 64 + lane];
+          const int row = 64 * s + 32 * i + 4 * hq + (e & 3) + 8 * (e >> 2);
+          slab[(size_t)row * ncol + col0 + 32 * o + (lane & 31)] = v;
+        }
+  }
+  if (tid < 64) a.db1p[(size_t)rg * a.Chid + 64 * s + tid] = bred[tid] + bred[64 + tid] + bred[128 + tid] + bred[192 + tid];
+}
+
+// dW1 [Chid][Cin] and dW2 [Cmid][Chid] (the parameters' row-major fp32 layouts) and db1 from the NR slabs of pw_wgrad_kernel
+__global__ __launch_bounds__(256) void pw_wgrad_finalize_kernel(const srk_pw_wgrad_args a, int NR, int RI, int R2) {
+  const long long n1 = (long long)a.Chid * RI, n2 = (long long)a.Chid * R2;
+  const long long total = n1 + n2 + a.Chid;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    float v = 0.f;
+    if (i < n1) {
+      for (int k = 0; k < NR; ++k) v += a.dw1p[(size_t)k * n1 + i];
+      a.dw1[i] = v;                                               // [hid][in], RI == Cin
+    } else if (i < n1 + n2) {
+      const long long j = i - n1;
+      const int hid = (int)(j / R2), z = (int)(j % R2);
+      if (z < a.Cmid) {
+        for (int k = 0; k < NR; ++k) v += a.dw2p[(size_t)k * n2 + j];
+        a.dw2[(size_t)z * a.Chid + hid] = v;
+      }
+    } else {
+      const int hid = (int)(i - n1 - n2);
+      for (int k = 0; k < NR; ++k) v += a.db1p[(size_t)k * a.Chid + hid];
+      if (a.db1) a.db1[hid] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // packing: fp32 [Chid][Cin] / [Cmid][Chid] weights (+ biases) -> constant block + per-slice blocks of both directions
 //   fwd : cst = b1p[Chid] | b2p[R2] (padded to whole KB) ; slice s = W1 part | W2 part
 //   bwd : cst = b1p[Chid]           (padded to whole KB) ; slice s = W1 part | W2^T part | W1^T part
@@ -539,6 +754,33 @@ template <int DT, int KC1, int NRB> int pw_bwd_launch(const srk_pw_bwd_args& a, 
   return 0;
 }
 
+template <int DT, int KC1, int NRB> int pw_wgrad_launch(const srk_pw_wgrad_args& a, hipStream_t st, int NR) {
+  typedef PwCfg<KC1, NRB> C;
+  constexpr int PLANE = 128 * 128, NT64 = C::RI / 64 + C::R2 / 64, BUF = NT64 * PLANE, IMG = 2 * BUF + 2 * PLANE;
+  constexpr int RED = (8 / NT64 - 1) * NT64 * 64 * 64 * 4 + 1024;       // the end-of-launch reduction re-uses the image area
+  constexpr int LDS = IMG > RED ? IMG : RED;
+  static_assert(LDS <= 160 * 1024, "LDS");
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<DT, KC1, NRB>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) { srk_set_error("srk_pw_wgrad: cannot reserve LDS"); return (int)attr; }
+  const long long ntiles = (a.P + 127) / 128;
+  const int NS = a.Chid / 64;
+  hipLaunchKernelGGL((pw_wgrad_kernel<DT, KC1, NRB>), dim3((unsigned)(NS * NR)), dim3(512), LDS, st, a,
+                     (unsigned)(a.P * a.x_pitch * 2), (unsigned)(a.P * a.gz_pitch * 2), NR, (int)(ntiles / NR), (int)(ntiles % NR));
+  hipLaunchKernelGGL(pw_wgrad_finalize_kernel, dim3(256), dim3(256), 0, st, a, NR, C::RI, C::R2);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+int pw_wgrad_ranges(long long P, int Chid) {
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  const long long ntiles = (P + 127) / 128;
+  long long nr = cus / (Chid / 64);
+  if (nr < 1) nr = 1;
+  if (nr > ntiles) nr = ntiles;
+  return (int)nr;
+}
+
 }  // namespace
 
 extern "C" int srk_pw_shape_ok(int Cin, int Chid, int CoutP) { return pw_shape_ok(Cin, Chid, CoutP) ? 1 : 0; }
@@ -593,4 +835,20 @@ extern "C" int srk_pw_backward(const srk_pw_bwd_args* a, srk_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->Cin == 128) return a->dtype == SRK_BF16 ? pw_bwd_launch<SRK_BF16, 8, 4>(*a, st) : pw_bwd_launch<SRK_F16, 8, 4>(*a, st);
   return a->dtype == SRK_BF16 ? pw_bwd_launch<SRK_BF16, 4, 2>(*a, st) : pw_bwd_launch<SRK_F16, 4, 2>(*a, st);
+}
+
+extern "C" int srk_pw_wgrad_ranges(long long P, int Chid) { return (P > 0 && Chid >= 64) ? pw_wgrad_ranges(P, Chid) : 0; }
+
+extern "C" int srk_pw_wgrad(const srk_pw_wgrad_args* a, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->x && a->gz && a->wpk && a->dw1p && a->dw2p && a->db1p && a->dw1 && a->dw2, "srk_pw_wgrad: null pointer");
+  SRK_CHECK_ARG(pw_shape_ok(a->Cin, a->Chid, a->CoutP) && a->dtype != SRK_F32 && a->Cmid <= a->CoutP, "srk_pw_wgrad: unsupported shape %d -> %d -> rows %d",
+                a->Cin, a->Chid, a->CoutP);
+  SRK_CHECK_ARG(a->P > 0 && a->P * (long long)a->x_pitch * 2 < 0x7fff0000LL && a->P * (long long)a->gz_pitch * 2 < 0x7fff0000LL &&
+                a->x_pitch % 8 == 0 && a->x_coff % 8 == 0 && a->gz_pitch % 8 == 0 && a->gz_coff % 8 == 0 && a->Cz % 8 == 0 && a->Cz <= a->CoutP,
+                "srk_pw_wgrad: addressing (P=%lld)", a->P);
+  const int NR = pw_wgrad_ranges(a->P, a->Chid);
+  SRK_CHECK_ARG(a->nranges == NR, "srk_pw_wgrad: nranges=%d but srk_pw_wgrad_ranges() is %d", a->nranges, NR);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->Cin == 128) return a->dtype == SRK_BF16 ? pw_wgrad_launch<SRK_BF16, 8, 4>(*a, st, NR) : pw_wgrad_launch<SRK_F16, 8, 4>(*a, st, NR);
+  return a->dtype == SRK_BF16 ? pw_wgrad_launch<SRK_BF16, 4, 2>(*a, st, NR) : pw_wgrad_launch<SRK_F16, 4, 2>(*a, st, NR);
 }

@@ -204,6 +204,27 @@ template <int DT> SRK_DEV void store4(typename DTraits<DT>::elem* p, const float
   }
 }
 
+// 16-bit operand fetch with the transposing LDS read.  For a 32x32x16 MFMA operand whose M/N index is a
+// channel (32 channels of 32-block ch32) and whose K index is 16 consecutive pixels of one image row,
+// lane l of 16-lane group G = l>>4 supplies the address of pixel k = 8*(G>>1) + 4*rd + q (q = (l&15)>>2),
+// channels 16*(G&1) + 4p .. +3 (p = l&3), and receives channel 16*(G&1) + (l&15) of pixels 8*(G>>1)+4*rd+0..3.
+// tr_lane_off() is the per-lane byte offset inside an image row for column shift col0 and read rd;
+// the row offset (row * pitch * 128) is a compile-time immediate in the unrolled K loop.
+SRK_DEV int tr_lane_off(int col0, int rd, int ch32, int lane) {
+  const int G = lane >> 4, hh = G >> 1, rowblk = G & 1, q = (lane & 15) >> 2, p = lane & 3;
+  const int chunk = ch32 * 4 + rowblk * 2 + (p >> 1);
+  const int col = col0 + 8 * hh + 4 * rd + q;
+  return (col << 7) + ((chunk ^ swz(col)) << 4) + ((p & 1) << 3);
+}
+
+SRK_DEV i32x4 tr_read2(const char* a0, const char* a1) {
+  typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+  const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(a0));
+  const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(a1));
+  const i32x2 l2 = __builtin_bit_cast(i32x2, lo), h2 = __builtin_bit_cast(i32x2, hi);
+  return i32x4{l2.x, l2.y, h2.x, h2.y};
+}
+
 // conv_ks.hip: 3x3 conv with >= 2 input blocks of 64 channels (K-streaming kernel); srk_conv2d (conv_igemm.hip) dispatches to it
 bool srk_conv_ks_ok(const srk_conv_args& a);
 int srk_conv_ks_launch(const srk_conv_args& a, hipStream_t st);

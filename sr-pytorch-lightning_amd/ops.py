@@ -1181,6 +1181,29 @@ def pw_backward_raw(x, gz, pk, gx, *, res=None, h_out=None, gh_out=None):
     return gx
 
 
+def pw_wgrad_raw(x, gz, pk, w1_shape, w2_shape, want_b1=True):
+    """dW1, db1, dW2 of the pointwise pair from x and gz alone (srk_pw_wgrad: h and gh are re-computed tile by tile)."""
+    n, h, wd, _ = x.shape
+    P = n * h * wd
+    dev = x.device
+    nr = L.load().srk_pw_wgrad_ranges(P, pk.chid)
+    scratch = torch.empty(nr * pk.chid * (pk.cin + pk.coutp + 1), dtype=torch.float32, device=dev)
+    dw1 = torch.empty(w1_shape, dtype=torch.float32, device=dev)
+    dw2 = torch.empty(w2_shape, dtype=torch.float32, device=dev)
+    db1 = torch.empty(pk.chid, dtype=torch.float32, device=dev) if want_b1 else None
+    o2 = nr * pk.chid * pk.cin
+    o3 = o2 + nr * pk.chid * pk.coutp
+    L.call("srk_pw_wgrad", L.PwWgradArgs(
+        x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, gz=gz.data_ptr(), gz_pitch=_pitch(gz), gz_coff=0, Cz=gz.shape[3], P=P,
+        Cin=pk.cin, Chid=pk.chid, Cmid=pk.cmid, CoutP=pk.coutp, wpk=pk.bwd.data_ptr(),
+        dw1p=scratch.data_ptr(), dw2p=scratch.data_ptr() + 4 * o2, db1p=scratch.data_ptr() + 4 * o3, nranges=nr,
+        dw1=dw1.data_ptr(), db1=_ptr(db1), dw2=dw2.data_ptr(), dtype=_DT[x.dtype]), _stream())
+    return dw1, db1, dw2
+
+
+_PW_WG_OFF = os.environ.get("SRK_NO_PW_WGRAD", "0") == "1"      # A/B knob: h / gh through HBM + the two 1x1 weight-gradient GEMMs
+
+
 class WdsrBlockBFn(torch.autograd.Function):
     """WDSR _Block_B (models/wdsr.py:30-51): out = conv3x3(conv1x1(relu(conv1x1(x)))) * res_scale + x.
 
@@ -1220,14 +1243,19 @@ class WdsrBlockBFn(torch.autograd.Function):
         conv_raw(g, pack_conv(w3, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=z.shape[3], out=gz, scale=scale, use_bias=False)
         gw3, gb3 = wgrad(z, g, wparam=ctx.wb[4], bparam=b3, N=n, H=h, W=wd, Cin=z.shape[3], Cout=cp, k=3, w_shape=tuple(w3.shape),
                          scale=scale, want_bias=b3 is not None)
-        hid = torch.empty((n, h, wd, pk.chid), dtype=dt, device=x.device)
-        ghid = torch.empty_like(hid)
         gx = torch.empty_like(x)
-        pw_backward_raw(x, gz, pk, gx, res=g, h_out=hid, gh_out=ghid)
-        gw2, gb2 = wgrad(hid, gz, wparam=ctx.wb[2], bparam=b2, N=n, H=h, W=wd, Cin=pk.chid, Cout=gz.shape[3], k=1, w_shape=tuple(w2.shape),
-                         want_bias=b2 is not None)
-        gw1, gb1 = wgrad(x, ghid, wparam=ctx.wb[0], bparam=b1, N=n, H=h, W=wd, Cin=cp, Cout=pk.chid, k=1, w_shape=tuple(w1.shape),
-                         want_bias=b1 is not None)
+        if _PW_WG_OFF:
+            hid = torch.empty((n, h, wd, pk.chid), dtype=dt, device=x.device)
+            ghid = torch.empty_like(hid)
+            pw_backward_raw(x, gz, pk, gx, res=g, h_out=hid, gh_out=ghid)
+            gw2, gb2 = wgrad(hid, gz, wparam=ctx.wb[2], bparam=b2, N=n, H=h, W=wd, Cin=pk.chid, Cout=gz.shape[3], k=1, w_shape=tuple(w2.shape),
+                             want_bias=b2 is not None)
+            gw1, gb1 = wgrad(x, ghid, wparam=ctx.wb[0], bparam=b1, N=n, H=h, W=wd, Cin=cp, Cout=pk.chid, k=1, w_shape=tuple(w1.shape),
+                             want_bias=b1 is not None)
+            return gx, None, gw1, gb1, gw2, gb2, gw3, gb3
+        pw_backward_raw(x, gz, pk, gx, res=g)
+        gw1, gb1, gw2 = pw_wgrad_raw(x, gz, pk, tuple(w1.shape), tuple(w2.shape), want_b1=b1 is not None)
+        gb2 = chan_sums(gz)[0][:pk.cmid] if b2 is not None else None
         return gx, None, gw1, gb1, gw2, gb2, gw3, gb3
 
 

@@ -207,3 +207,31 @@ def test_wdsr_step_uses_grouped_parameter_launches(A):
     for k, p in m.named_parameters():
         ref = p.grad
         assert l2err(got[k], ref.cpu()) < 2e-3, k
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("f,npix", [(128, 128), (128, 5000), (128, 37), (64, 700), (64, 36864)])
+def test_pw_wgrad_raw(A, dt, f, npix):
+    """srk_pw_wgrad (h and gh re-computed per 128-pixel tile, never in HBM) against float64: dW1, db1, dW2 incl. ragged last tiles and
+    pixel ranges of unequal length."""
+    ops = A.ops
+    chid, cmid = 6 * f, int(0.8 * f)
+    cz = ops.pad16(cmid)
+    x = rnd(1, 1, npix, f, seed=1)
+    w1, b1 = rnd(chid, f, 1, 1, seed=2, scale=1.0 / np.sqrt(f)), rnd(chid, seed=3, scale=0.1)
+    w2, b2 = rnd(cmid, chid, 1, 1, seed=4, scale=1.0 / np.sqrt(chid)), rnd(cmid, seed=5, scale=0.1)
+    gz = rnd(1, 1, npix, cz, seed=6)
+    gz[..., cmid:] = 0
+    xr = q(x, dt).view(npix, f)
+    w1r, w2r = q(w1, dt).view(chid, f), q(w2, dt).view(cmid, chid)
+    pre = xr @ w1r.t() + b1.double()
+    hr = torch.relu(pre).to(dt).double()
+    gzr = q(gz, dt).view(npix, cz)[:, :cmid]
+    ghr = ((gzr @ w2r) * (pre > 0)).to(dt).double()
+    dw1r, db1r, dw2r = ghr.t() @ xr, ghr.sum(0), gzr.t() @ hr
+    pk = ops.pw_pack(torch.nn.Parameter(w1.cuda()), b1.cuda(), torch.nn.Parameter(w2.cuda()), b2.cuda(), dt)
+    dw1, db1, dw2 = ops.pw_wgrad_raw(x.to(dt).cuda(), gz.to(dt).cuda(), pk, (chid, f, 1, 1), (cmid, chid, 1, 1))
+    torch.cuda.synchronize()
+    assert l2err(dw1.view(chid, f), dw1r) < L2TOL[dt] / 4
+    assert l2err(db1, db1r) < L2TOL[dt] / 4
+    assert l2err(dw2.view(cmid, chid), dw2r) < L2TOL[dt] / 4
