@@ -224,16 +224,16 @@ int srk_pw_backward(const srk_pw_bwd_args* a, srk_stream_t stream);
 
 /* weight gradients of the pointwise pair, again without h / gh in HBM (both are re-computed per 128-pixel tile):
  *     dw1[hid][in] = sum_p gh[p][hid] x[p][in];  db1[hid] = sum_p gh[p][hid];  dw2[z][hid] = sum_p h[p][hid] gz[p][z]
- * (db2 = sum_p gz is a plain channel sum: srk_chan_stats).  Scratch: nranges = srk_pw_wgrad_ranges(P, Chid) slabs of
- * [Chid][Cin] (dw1p), [Chid][CoutP] (dw2p) and [Chid] (db1p) fp32 that the launch fills and then sums in a fixed order.   */
+ * and db2[z] = sum_p gz[p][z].  Scratch: nranges = srk_pw_wgrad_ranges(P, Chid) slabs of [Chid][Cin] (dw1p), [Chid][CoutP]
+ * (dw2p), [Chid] (db1p) and [CoutP] (db2p) fp32 that the launch fills and then sums in a fixed order.                   */
 typedef struct {
   const void* x; int x_pitch, x_coff;
   const void* gz; int gz_pitch, gz_coff; int Cz;
   long long P;
   int Cin, Chid, Cmid, CoutP;
   const void* wpk;                      /* srk_pw_pack's `bwd` */
-  float* dw1p; float* dw2p; float* db1p; int nranges;
-  float* dw1; float* db1; float* dw2;   /* out: [Chid][Cin], [Chid] (nullable), [Cmid][Chid] */
+  float* dw1p; float* dw2p; float* db1p; float* db2p; int nranges;   /* db2p / db2: both or neither */
+  float* dw1; float* db1; float* dw2; float* db2;   /* out: [Chid][Cin], [Chid] (nullable), [Cmid][Chid], [Cmid] (nullable) */
   int dtype;
 } srk_pw_wgrad_args;
 int srk_pw_wgrad_ranges(long long P, int Chid);

@@ -75,7 +75,8 @@ class PwBwdArgs(C.Structure):
 class PwWgradArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("gz", _p), ("gz_pitch", _i), ("gz_coff", _i), ("Cz", _i),
                 ("P", C.c_longlong), ("Cin", _i), ("Chid", _i), ("Cmid", _i), ("CoutP", _i), ("wpk", _p),
-                ("dw1p", _p), ("dw2p", _p), ("db1p", _p), ("nranges", _i), ("dw1", _p), ("db1", _p), ("dw2", _p), ("dtype", _i)]
+                ("dw1p", _p), ("dw2p", _p), ("db1p", _p), ("db2p", _p), ("nranges", _i), ("dw1", _p), ("db1", _p), ("dw2", _p), ("db2", _p),
+                ("dtype", _i)]
 
 
 class ChanFinalizeArgs(C.Structure):

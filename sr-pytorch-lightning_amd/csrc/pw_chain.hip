@@ -142,47 +142,66 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
 
   const int lane_a = (h * 64 + r) << 4;                          // A fragments of the 64-row W1 part
   const int lane_a2 = (h * C::R2 + r) << 4;                      // ... of the R2-row W2 part
-  auto gemm1 = [&](int s, f32x16 (&acc)[2]) {
+  // One iteration = ONE stream of MFMAs: conv 1 of slice s + 1 (2 KC1 steps: K-step j = k >> 1, row block k & 1), then conv 2 of
+  // slice s (4 NRB steps).  The weight fragment of step k + PF is requested before the MFMA of step k and the order is pinned
+  // (sched_barrier), so the compiler's counted lgkmcnt waits leave PF reads in flight; the bias / ReLU / pack of slice s + 1
+  // rides in the gaps of conv 2 (two 16-bit pairs per step, starting two steps in: the accumulators are complete by then).
+  constexpr int G1 = 2 * KC1, G2 = 4 * NRB, PF = 3, NBF = 4;
+  constexpr int CPS = (16 + G2 - 3) / (G2 - 2);                   // packed dwords per conv-2 step
+  f32x16 acc1[2];
+  i32x4 hfa[4], hfb[4];
+  auto bias1 = [&](int s) {
     const float* b1 = reinterpret_cast<const float*>(cst) + s * 64;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(b1 + (b * 2 + h) * 16 + 4 * q);
-        acc[b][4 * q] = v.x; acc[b][4 * q + 1] = v.y; acc[b][4 * q + 2] = v.z; acc[b][4 * q + 3] = v.w;
-      }
-    const char* w = ring + (s % NSLOT) * SL + lane_a;
-#pragma unroll
-    for (int j = 0; j < KC1; ++j)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[b] = Tr::mma(lds_read16(w + j * 2048 + b * 512), xf[j], acc[b]);
-  };
-  auto convert = [&](const f32x16 (&acc)[2], i32x4 (&hf)[4]) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        i32x4 q;
-        q.x = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 0], acc[b][8 * m + 1]));
-        q.y = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 2], acc[b][8 * m + 3]));
-        q.z = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 4], acc[b][8 * m + 5]));
-        q.w = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 6], acc[b][8 * m + 7]));
-        hf[2 * b + m] = q;
+        acc1[b][4 * q] = v.x; acc1[b][4 * q + 1] = v.y; acc1[b][4 * q + 2] = v.z; acc1[b][4 * q + 3] = v.w;
       }
   };
-  auto gemm2 = [&](int s, const i32x4 (&hf)[4]) {
-    const char* w = ring + (s % NSLOT) * SL + C::W1_BYTES + lane_a2;
+  auto pack_piece = [&](int d, i32x4 (&hf)[4]) {                 // dword d of the 16 that hold the slice: block d >> 3, K-step half (d >> 2) & 1
+    const int b = d >> 3, m = (d >> 2) & 1, w = d & 3;
+    const int v = (int)relu_pk16(pack2<DT>(acc1[b][8 * m + 2 * w], acc1[b][8 * m + 2 * w + 1]));
+    if (w == 0) hf[2 * b + m].x = v; else if (w == 1) hf[2 * b + m].y = v; else if (w == 2) hf[2 * b + m].z = v; else hf[2 * b + m].w = v;
+  };
+  // first: first step of the stream (0: conv 1 + conv 2; G1: conv 2 only, the last iteration); w1 / w2: fragment bases of the lane
+  auto stream = [&](const int first, const char* w1, const char* w2, const i32x4 (&hc)[4], i32x4 (&hn)[4]) {
+    auto rd = [&](int k) {
+      return k < G1 ? lds_read16(w1 + (k >> 1) * 2048 + (k & 1) * 512)
+                    : lds_read16(w2 + ((k - G1) / NRB) * (2 * C::R2 * 16) + ((k - G1) % NRB) * 512);
+    };
+    i32x4 fa[NBF];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int k = 0; k < PF; ++k) fa[k] = rd(first + k);
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) acc2[rb] = Tr::mma(lds_read16(w + j * (2 * C::R2 * 16) + rb * 512), hf[j], acc2[rb]);
+    for (int k = 0; k < G1 + G2; ++k) {
+      if (k >= first) {
+        if (k + PF < G1 + G2) fa[(k - first + PF) % NBF] = rd(k + PF);
+        if (k < G1) acc1[k & 1] = Tr::mma(fa[(k - first) % NBF], xf[k >> 1], acc1[k & 1]);
+        else {
+          const int kk = k - G1;
+          acc2[kk % NRB] = Tr::mma(fa[(k - first) % NBF], hc[kk / NRB], acc2[kk % NRB]);
+          if (first == 0 && kk >= 2) {
+#pragma unroll
+            for (int c = 0; c < CPS; ++c)
+              if ((kk - 2) * CPS + c < 16) pack_piece((kk - 2) * CPS + c, hn);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   };
 
-  f32x16 acc1[2];
-  i32x4 hfa[4], hfb[4];
-  gemm1(0, acc1);
-  convert(acc1, hfa);
-  // iteration s: conv 1 of slice s + 1 and conv 2 of slice s (the ring holds slices s .. s + 3)
+  // slice 0's conv 1 alone (its weights are there: the prologue waited for slice 0)
+  bias1(0);
+  {
+    const char* w1 = ring + lane_a;
+#pragma unroll
+    for (int k = 0; k < G1; ++k) acc1[k & 1] = Tr::mma(lds_read16(w1 + (k >> 1) * 2048 + (k & 1) * 512), xf[k >> 1], acc1[k & 1]);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) pack_piece(d, hfa);
+  }
   for (int s = 0; s < NS; s += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -194,14 +213,13 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (ss >= 1 && ss + 3 < NS) dma_slice(ss + 3);           // into the slot slice ss - 1 left
-        if (u == 0) {
-          if (ss + 1 < NS) gemm1(ss + 1, acc1);
-          gemm2(ss, hfa);
-          if (ss + 1 < NS) convert(acc1, hfb);
+        const char* const w1 = ring + ((ss + 1) % NSLOT) * SL + lane_a;
+        const char* const w2 = ring + (ss % NSLOT) * SL + C::W1_BYTES + lane_a2;
+        if (ss + 1 < NS) {
+          bias1(ss + 1);
+          if (u == 0) stream(0, w1, w2, hfa, hfb); else stream(0, w1, w2, hfb, hfa);
         } else {
-          if (ss + 1 < NS) gemm1(ss + 1, acc1);
-          gemm2(ss, hfb);
-          if (ss + 1 < NS) convert(acc1, hfa);
+          if (u == 0) stream(G1, w1, w2, hfa, hfb); else stream(G1, w1, w2, hfb, hfa);
         }
       }
     }
@@ -511,6 +529,9 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(const srk_pw_wgrad_args a
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) aoff[i][rd] = boff[i][rd] = tr_lane_off(0, rd, i, lane);
+  // db2 = sum_p gz: the slice-0 workgroups' dW2 waves add up the gz fragments they fetch anyway (lane = channel, 8 pixels per read)
+  const bool do_db2 = s == 0 && t2 < ZPL && a.db2p != nullptr;
+  float dbz[2] = {0.f, 0.f};
   const char* const a_img = t2 < ZPL ? hs : gs;                  // dW2 tiles read h, dW1 tiles read gh
   const int b_plane = t2 < ZPL ? XPL + t2 : t2 - ZPL;            // ... against gz plane t2 / x plane t2 - ZPL
 
@@ -566,6 +587,18 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(const srk_pw_wgrad_args a
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int o = 0; o < 2; ++o) acc[i][o] = Tr::mma(af[i], bf[o], acc[i][o]);
+      if (do_db2) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const int qw[4] = {bf[o].x, bf[o].y, bf[o].z, bf[o].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float f0, f1;
+            unpack2<DT>((uint32_t)qw[e], f0, f1);
+            dbz[o] += f0 + f1;
+          }
+        }
+      }
     }
   }
 
@@ -588,7 +621,11 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(const srk_pw_wgrad_args a
     for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     bsum[q] = v;
   }
-  float* const bred = red + (KSPLIT - 1) * NT64 * 64 * 64;       // [4 pixel blocks][64 hidden]
+  float* const bred = red + (KSPLIT - 1) * NT64 * 64 * 64;       // [4 pixel blocks][64 hidden] | [KSPLIT][ZPL tiles][2 blocks][64 lanes]
+  if (do_db2) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o) bred[256 + ((kq * ZPL + t2) * 2 + o) * 64 + lane] = dbz[o];
+  }
   if (r == 0) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) bred[pb * 64 + pw_hid_of_row(32 * rb + 8 * (q >> 2) + 4 * h + (q & 3))] = bsum[q];
@@ -614,28 +651,47 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(const srk_pw_wgrad_args a
         }
   }
   if (tid < 64) a.db1p[(size_t)rg * a.Chid + 64 * s + tid] = bred[tid] + bred[64 + tid] + bred[128 + tid] + bred[192 + tid];
+  if (s == 0 && a.db2p != nullptr && tid < C::R2) {               // channel tid = 64 t + 32 o + c: lanes c and c + 32 hold the two K halves of a read
+    const int t = tid >> 6, o = (tid >> 5) & 1, c = tid & 31;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < KSPLIT; ++k) v += bred[256 + ((k * ZPL + t) * 2 + o) * 64 + c] + bred[256 + ((k * ZPL + t) * 2 + o) * 64 + 32 + c];
+    a.db2p[(size_t)rg * C::R2 + tid] = v;
+  }
 }
 
-// dW1 [Chid][Cin] and dW2 [Cmid][Chid] (the parameters' row-major fp32 layouts) and db1 from the NR slabs of pw_wgrad_kernel
+// dW1 [Chid][Cin] and dW2 [Cmid][Chid] (the parameters' row-major fp32 layouts), db1 and db2 from the NR slabs of pw_wgrad_kernel:
+// one thread per 4 consecutive slab elements, the NR loads of a thread independent of each other, slabs added in index order
 __global__ __launch_bounds__(256) void pw_wgrad_finalize_kernel(const srk_pw_wgrad_args a, int NR, int RI, int R2) {
-  const long long n1 = (long long)a.Chid * RI, n2 = (long long)a.Chid * R2;
-  const long long total = n1 + n2 + a.Chid;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    float v = 0.f;
-    if (i < n1) {
-      for (int k = 0; k < NR; ++k) v += a.dw1p[(size_t)k * n1 + i];
-      a.dw1[i] = v;                                               // [hid][in], RI == Cin
-    } else if (i < n1 + n2) {
-      const long long j = i - n1;
+  const long long n1 = (long long)a.Chid * RI / 4, n2 = (long long)a.Chid * R2 / 4;
+  const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gi < n1 + n2) {
+    const bool one = gi < n1;
+    const long long j = 4 * (one ? gi : gi - n1);
+    const float* src = (one ? a.dw1p : a.dw2p) + j;
+    const size_t stride = (size_t)a.Chid * (one ? RI : R2);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k = 0; k < NR; ++k) v += *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+    if (one) *reinterpret_cast<f32x4*>(a.dw1 + j) = v;            // [hid][in], RI == Cin
+    else {
       const int hid = (int)(j / R2), z = (int)(j % R2);
-      if (z < a.Cmid) {
-        for (int k = 0; k < NR; ++k) v += a.dw2p[(size_t)k * n2 + j];
-        a.dw2[(size_t)z * a.Chid + hid] = v;
-      }
-    } else {
-      const int hid = (int)(i - n1 - n2);
-      for (int k = 0; k < NR; ++k) v += a.db1p[(size_t)k * a.Chid + hid];
-      if (a.db1) a.db1[hid] = v;
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (z + t < a.Cmid) a.dw2[(size_t)(z + t) * a.Chid + hid] = e[t];
+    }
+  } else {
+    const long long i = gi - n1 - n2;
+    if (i < a.Chid) {
+      float v = 0.f;
+      for (int k = 0; k < NR; ++k) v += a.db1p[(size_t)k * a.Chid + i];
+      if (a.db1) a.db1[i] = v;
+    } else if (i < a.Chid + a.Cmid && a.db2) {
+      const int z = (int)(i - a.Chid);
+      float v = 0.f;
+      for (int k = 0; k < NR; ++k) v += a.db2p[(size_t)k * R2 + z];
+      a.db2[z] = v;
     }
   }
 }
@@ -757,7 +813,7 @@ template <int DT, int KC1, int NRB> int pw_bwd_launch(const srk_pw_bwd_args& a, 
 template <int DT, int KC1, int NRB> int pw_wgrad_launch(const srk_pw_wgrad_args& a, hipStream_t st, int NR) {
   typedef PwCfg<KC1, NRB> C;
   constexpr int PLANE = 128 * 128, NT64 = C::RI / 64 + C::R2 / 64, BUF = NT64 * PLANE, IMG = 2 * BUF + 2 * PLANE;
-  constexpr int RED = (8 / NT64 - 1) * NT64 * 64 * 64 * 4 + 1024;       // the end-of-launch reduction re-uses the image area
+  constexpr int RED = (8 / NT64 - 1) * NT64 * 64 * 64 * 4 + 1024 + 8 * 2 * 64 * 4;       // the end-of-launch reduction re-uses the image area
   constexpr int LDS = IMG > RED ? IMG : RED;
   static_assert(LDS <= 160 * 1024, "LDS");
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<DT, KC1, NRB>),
@@ -767,7 +823,8 @@ template <int DT, int KC1, int NRB> int pw_wgrad_launch(const srk_pw_wgrad_args&
   const int NS = a.Chid / 64;
   hipLaunchKernelGGL((pw_wgrad_kernel<DT, KC1, NRB>), dim3((unsigned)(NS * NR)), dim3(512), LDS, st, a,
                      (unsigned)(a.P * a.x_pitch * 2), (unsigned)(a.P * a.gz_pitch * 2), NR, (int)(ntiles / NR), (int)(ntiles % NR));
-  hipLaunchKernelGGL(pw_wgrad_finalize_kernel, dim3(256), dim3(256), 0, st, a, NR, C::RI, C::R2);
+  const long long fin = (long long)a.Chid * (C::RI + C::R2) / 4 + a.Chid + C::R2;
+  hipLaunchKernelGGL(pw_wgrad_finalize_kernel, dim3((unsigned)((fin + 255) / 256)), dim3(256), 0, st, a, NR, C::RI, C::R2);
   SRK_LAUNCH_CHECK();
   return 0;
 }

@@ -1181,24 +1181,27 @@ def pw_backward_raw(x, gz, pk, gx, *, res=None, h_out=None, gh_out=None):
     return gx
 
 
-def pw_wgrad_raw(x, gz, pk, w1_shape, w2_shape, want_b1=True):
-    """dW1, db1, dW2 of the pointwise pair from x and gz alone (srk_pw_wgrad: h and gh are re-computed tile by tile)."""
+def pw_wgrad_raw(x, gz, pk, w1_shape, w2_shape, want_b1=True, want_b2=True):
+    """dW1, db1, dW2, db2 of the pointwise pair from x and gz alone (srk_pw_wgrad: h and gh are re-computed tile by tile)."""
     n, h, wd, _ = x.shape
     P = n * h * wd
     dev = x.device
     nr = L.load().srk_pw_wgrad_ranges(P, pk.chid)
-    scratch = torch.empty(nr * pk.chid * (pk.cin + pk.coutp + 1), dtype=torch.float32, device=dev)
+    scratch = torch.empty(nr * (pk.chid * (pk.cin + pk.coutp + 1) + pk.coutp), dtype=torch.float32, device=dev)
     dw1 = torch.empty(w1_shape, dtype=torch.float32, device=dev)
     dw2 = torch.empty(w2_shape, dtype=torch.float32, device=dev)
     db1 = torch.empty(pk.chid, dtype=torch.float32, device=dev) if want_b1 else None
+    db2 = torch.empty(pk.cmid, dtype=torch.float32, device=dev) if want_b2 else None
     o2 = nr * pk.chid * pk.cin
     o3 = o2 + nr * pk.chid * pk.coutp
+    o4 = o3 + nr * pk.chid
     L.call("srk_pw_wgrad", L.PwWgradArgs(
         x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, gz=gz.data_ptr(), gz_pitch=_pitch(gz), gz_coff=0, Cz=gz.shape[3], P=P,
         Cin=pk.cin, Chid=pk.chid, Cmid=pk.cmid, CoutP=pk.coutp, wpk=pk.bwd.data_ptr(),
-        dw1p=scratch.data_ptr(), dw2p=scratch.data_ptr() + 4 * o2, db1p=scratch.data_ptr() + 4 * o3, nranges=nr,
-        dw1=dw1.data_ptr(), db1=_ptr(db1), dw2=dw2.data_ptr(), dtype=_DT[x.dtype]), _stream())
-    return dw1, db1, dw2
+        dw1p=scratch.data_ptr(), dw2p=scratch.data_ptr() + 4 * o2, db1p=scratch.data_ptr() + 4 * o3,
+        db2p=(scratch.data_ptr() + 4 * o4) if want_b2 else 0, nranges=nr,
+        dw1=dw1.data_ptr(), db1=_ptr(db1), dw2=dw2.data_ptr(), db2=_ptr(db2), dtype=_DT[x.dtype]), _stream())
+    return dw1, db1, dw2, db2
 
 
 _PW_WG_OFF = os.environ.get("SRK_NO_PW_WGRAD", "0") == "1"      # A/B knob: h / gh through HBM + the two 1x1 weight-gradient GEMMs
@@ -1254,8 +1257,7 @@ class WdsrBlockBFn(torch.autograd.Function):
                              want_bias=b1 is not None)
             return gx, None, gw1, gb1, gw2, gb2, gw3, gb3
         pw_backward_raw(x, gz, pk, gx, res=g)
-        gw1, gb1, gw2 = pw_wgrad_raw(x, gz, pk, tuple(w1.shape), tuple(w2.shape), want_b1=b1 is not None)
-        gb2 = chan_sums(gz)[0][:pk.cmid] if b2 is not None else None
+        gw1, gb1, gw2, gb2 = pw_wgrad_raw(x, gz, pk, tuple(w1.shape), tuple(w2.shape), want_b1=b1 is not None, want_b2=b2 is not None)
         return gx, None, gw1, gb1, gw2, gb2, gw3, gb3
 
 

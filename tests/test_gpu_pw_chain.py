@@ -228,10 +228,11 @@ def test_pw_wgrad_raw(A, dt, f, npix):
     hr = torch.relu(pre).to(dt).double()
     gzr = q(gz, dt).view(npix, cz)[:, :cmid]
     ghr = ((gzr @ w2r) * (pre > 0)).to(dt).double()
-    dw1r, db1r, dw2r = ghr.t() @ xr, ghr.sum(0), gzr.t() @ hr
+    dw1r, db1r, dw2r, db2r = ghr.t() @ xr, ghr.sum(0), gzr.t() @ hr, gzr.sum(0)
     pk = ops.pw_pack(torch.nn.Parameter(w1.cuda()), b1.cuda(), torch.nn.Parameter(w2.cuda()), b2.cuda(), dt)
-    dw1, db1, dw2 = ops.pw_wgrad_raw(x.to(dt).cuda(), gz.to(dt).cuda(), pk, (chid, f, 1, 1), (cmid, chid, 1, 1))
+    dw1, db1, dw2, db2 = ops.pw_wgrad_raw(x.to(dt).cuda(), gz.to(dt).cuda(), pk, (chid, f, 1, 1), (cmid, chid, 1, 1))
     torch.cuda.synchronize()
     assert l2err(dw1.view(chid, f), dw1r) < L2TOL[dt] / 4
     assert l2err(db1, db1r) < L2TOL[dt] / 4
     assert l2err(dw2.view(cmid, chid), dw2r) < L2TOL[dt] / 4
+    assert l2err(db2, db2r) < 1e-3
