@@ -63,6 +63,8 @@ def parse():
     p.add_argument("--sustain-seconds", type=float, default=2.0,
                    help="after the timed steps, keep stepping this long and report sustained_ms_per_step (0 = skip)")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="skip the batch-16 runs of the five BASELINE models that follow the timed region of the default line")
     return p.parse_args()
 
 
@@ -125,22 +127,21 @@ def cpu_baseline(model_name, scale, patch, seconds=15.0, max_steps=8, model=None
                 m.load_state_dict({k_: v.detach().float().cpu() for k_, v in model.state_dict().items()})
                 y_ref = m.forward(lr[:np_].float().cpu())
             mse = float(((y_hip - y_ref) ** 2).mean())
-            tgt = hr[:np_].float().cpu().clamp(0, 1)
-
-            def ps(y):
-                return 10.0 * math.log10(1.0 / max(float(((y.clamp(0, 1) - tgt) ** 2).mean()), 1e-12))
             out["parity"] = {"patches": np_, "psnr_build_vs_oracle_db": round(10.0 * math.log10(1.0 / max(mse, 1e-20)), 2),
                              "max_abs_err": float((y_hip - y_ref).abs().max()),
-                             "delta_psnr_db": round(ps(y_hip) - ps(y_ref), 5),
-                             "note": "HIP forward in the bench dtype vs fp32 CPU oracle, the model's current weights, synthetic (uniform) patches"}
+                             "note": "HIP forward in the bench dtype vs fp32 CPU oracle, the model's current weights, synthetic (uniform) patches; "
+                                     "north_star's 0.01 dB criterion needs a TRAINED net and smooth images: tests/test_gpu_round2.py::"
+                                     "test_psnr_within_0p01_db_of_reference_path"}
         except Exception as e:  # noqa: BLE001
             out["parity"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
-def _time_replays(fn, iters):
+def _time_replays(fn, iters, sustain_s=0.0):
     """Average duration (us) of one call of `fn`: `iters` calls are captured into one hipGraph and replayed between two
-    HIP events on the launch stream, so the Python launch rate (~10 us) does not enter."""
+    HIP events on the launch stream, so the Python launch rate (~10 us) does not enter.  Returns (burst, sustained):
+    burst = one replay right after a warm-up replay; sustained = the replays of the second half of `sustain_s` seconds of
+    back-to-back replays (the chip lowers its clock under these kernels within ~1 s: DESIGN.md section 7), None if 0."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -161,82 +162,223 @@ def _time_replays(fn, iters):
     g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters
+    burst = e0.elapsed_time(e1) * 1e3 / iters
+    if sustain_s <= 0:
+        return burst, None
+    nrep = max(4, int(sustain_s * 1e6 / max(burst * iters, 1.0)))
+    for _ in range(nrep // 2):
+        g.replay()
+    e0.record()
+    for _ in range(nrep - nrep // 2):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return burst, e0.elapsed_time(e1) * 1e3 / (iters * (nrep - nrep // 2))
 
 
 def csrc_sha():
-    """Fingerprint of the kernel sources a PMC measurement belongs to (profiles/r2_pmc_traffic.json carries the same)."""
+    """Fingerprint of the kernel sources a PMC measurement belongs to (profiles/r3_pmc_traffic.json carries the same)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sr-pytorch-lightning_amd", "csrc")
-    for f in ("conv_igemm.hip", "srk_common.h"):
-        with open(os.path.join(d, f), "rb") as fh:
-            h.update(fh.read())
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".hip") or f == "srk_common.h":
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(feats, patch, batch, dtype):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, KiB -> B; MI355X_MICROARCH.md "HBM"), written by tools/pmc_traffic.sh.  None unless an entry exists
-    for this exact shape AND was measured on the kernel sources being timed now."""
+def pmc_traffic(key):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    KiB -> B; MI355X_MICROARCH.md "HBM"), written by tools/pmc_traffic.sh.  None unless an entry exists for this exact
+    kernel / shape AND was measured on the kernel sources being timed now."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")) as fh:
             tab = json.load(fh)
     except (OSError, ValueError):
         return None
-    e = tab.get(f"{feats}x{patch}x{batch}x{dtype}")
+    e = tab.get(key)
     if not e or e.get("csrc_sha") != csrc_sha():
         return None
     return (2.0 * e["fetch_kib"] + e["write_kib"]) * 1024.0
 
 
-def dominant_kernel_roofline(A, batch, patch, feats, dtype, iters=100):
-    """The dominant kernel = the F->F 3x3 implicit-GEMM conv on [batch, patch, patch, F].  `achieved` / `frac` are
-    quoted on its conv + bias + ReLU launch (the line's historical definition); `variants` times every flavour a
-    training step issues -- residual epilogue, ReLU-mask (data-gradient) epilogue, weight gradient incl. its share of
-    the grouped finalize -- and `step_weighted_frac` weights them by their launch counts in one ResBlock
-    (forward: ReLU conv + residual conv; backward: mask dgrad + residual dgrad + 2 weight gradients)."""
+def _flavours(A, model_name, batch, patch, feats, dtype):
+    """The launches that carry the model's residual blocks at this batch: (kernel name, [flavour dicts]).  A flavour =
+    name, fn (one launch, or `per` layers' worth of launches), flops per layer (ALGORITHMIC: 2 x MACs of the reference
+    convs, no padding / halo / recompute work), count = launches of it per block (forward + backward)."""
+    ops = A.ops
     dt = TDT[dtype]
     dev = torch.device("cuda", torch.cuda.current_device())
-    x = (torch.rand(batch, patch, patch, feats, device=dev) - 0.5).to(dt)
-    x2 = (torch.rand(batch, patch, patch, feats, device=dev) - 0.5).to(dt)
-    w = torch.nn.Parameter((torch.rand(feats, feats, 3, 3, device=dev) - 0.5) * 0.05)
-    b = torch.nn.Parameter(torch.zeros(feats, device=dev))
-    pk = A.ops.pack_conv(w, b, dt)
-    pkd = A.ops.pack_conv(w, None, dt, dgrad=True)
-    out = torch.empty_like(x)
-    kw = dict(N=batch, H=patch, W=patch, Cin=feats, Cout=feats, out=out)
-    flops = 2.0 * batch * patch * patch * feats * feats * 9
-    peak = PEAK_TFLOPS[dtype]
-    esz = 4 if dtype == "f32" else 2
-    variants = {}
-    us = _time_replays(lambda: A.ops.conv_raw(x, pk, relu=True, **kw), iters)
-    variants["conv_bias_relu"] = us
-    if dtype != "f32":
-        variants["conv_scale_residual"] = _time_replays(lambda: A.ops.conv_raw(x, pk, scale=0.1, res=x2, **kw), iters)
-        variants["dgrad_relu_mask"] = _time_replays(lambda: A.ops.conv_raw(x, pkd, mask=x2, use_bias=False, **kw), iters)
-        # weight gradient the way a step runs it: 8 layers queued, one grouped launch + one grouped finalize
-        ws = [torch.nn.Parameter(torch.zeros(feats, feats, 3, 3, device=dev)) for _ in range(8)]
-        bs = [torch.nn.Parameter(torch.zeros(feats, device=dev)) for _ in range(8)]
+    n, hw = batch, patch
+
+    def act(c):
+        return (torch.rand(n, hw, hw, c, device=dev) - 0.5).to(dt)
+
+    def par(co, ci, k):
+        return torch.nn.Parameter((torch.rand(co, ci, k, k, device=dev) - 0.5) * (1.0 / (ci * k * k) ** 0.5)), torch.nn.Parameter(torch.zeros(co, device=dev))
+
+    def wg_flavour(xin, dy, cin, cout, k, flops, count):
+        ws = [par(cout, cin, k) for _ in range(8)]
 
         def wg():
-            with A.ops.hold_wgrads():
-                for wi, bi in zip(ws, bs):
-                    A.ops.wgrad(x, x2, wparam=wi, bparam=bi, N=batch, H=patch, W=patch, Cin=feats, Cout=feats, k=3,
-                                w_shape=(feats, feats, 3, 3))
-        variants["wgrad_grouped_per_layer"] = _time_replays(wg, max(4, iters // 8)) / 8.0
-    ach = flops / (us * 1e-6) / 1e12
-    alg_bytes = 2.0 * batch * patch * patch * feats * esz            # one read + one write of the activation
-    r = {"bound": "mfma", "kernel": f"conv_ws_kernel 3x3 {feats}->{feats} @{patch}x{patch} x{batch} ({dtype}), fwd = dgrad kernel",
+            with ops.hold_wgrads():
+                for wi, bi in ws:
+                    ops.wgrad(xin, dy, wparam=wi, bparam=bi, N=n, H=hw, W=hw, Cin=xin.shape[3], Cout=dy.shape[3], k=k, w_shape=(cout, cin, k, k))
+        return dict(name="wgrad_grouped_per_layer", fn=wg, flops=flops, count=count, per=8)
+
+    px = n * hw * hw
+    if model_name == "wdsr_b" and dtype != "f32":
+        f, chid, cmid = 128, 768, 102
+        x, g, z, gz = act(f), act(f), act(112), act(112)
+        gz[..., cmid:] = 0
+        (w1, b1), (w2, b2), (w3, b3) = par(chid, f, 1), par(cmid, chid, 1), par(f, cmid, 3)
+        pk = ops.pw_pack(w1, b1, w2, b2, dt)
+        pk3, pk3d = ops.pack_conv(w3, b3, dt), ops.pack_conv(w3, None, dt, dgrad=True)
+        out, gx = torch.empty_like(x), torch.empty_like(x)
+        fpw, f3 = 2.0 * px * chid * (f + cmid), 2.0 * px * cmid * f * 9
+        fl = [dict(name="pw_pair_fwd", fn=lambda: ops.pw_forward_raw(x, pk, z), flops=fpw, count=1),
+              dict(name="pw_pair_bwd_data", fn=lambda: ops.pw_backward_raw(x, gz, pk, gx, res=g), flops=fpw, count=1),
+              dict(name="pw_pair_wgrad", fn=lambda: ops.pw_wgrad_raw(x, gz, pk, tuple(w1.shape), tuple(w2.shape)), flops=fpw, count=1),
+              dict(name="conv3x3_scale_residual", fn=lambda: ops.conv_raw(z, pk3, N=n, H=hw, W=hw, Cin=112, Cout=f, out=out, scale=1.0, res=x), flops=f3, count=1),
+              dict(name="dgrad3x3", fn=lambda: ops.conv_raw(g, pk3d, N=n, H=hw, W=hw, Cin=f, Cout=112, out=gz, use_bias=False), flops=f3, count=1),
+              wg_flavour(z, g, cmid, f, 3, f3, 1)]
+        return "pw_fwd_kernel + pw_bwd_kernel + pw_wgrad_kernel (WDSR-B pointwise pair 128->768->102, csrc/pw_chain.hip) and conv_ks_kernel 3x3 102->128", fl
+    if model_name == "rdn_b" and dtype != "f32":
+        cin, g0 = 320, 64                  # the middle dense layer of an RDB (rdn.py:9-21: Cin = 64 + 64 c)
+        x, y, gy = act(cin), act(g0), act(g0)
+        w, b = par(g0, cin, 3)
+        pkf, pkd = ops.pack_conv(w, b, dt), ops.pack_conv(w, None, dt, dgrad=True)
+        gx = torch.empty_like(x)
+        fl0 = 2.0 * px * cin * g0 * 9
+        fl = [dict(name="dense_conv_relu", fn=lambda: ops.conv_raw(x, pkf, N=n, H=hw, W=hw, Cin=cin, Cout=g0, out=y, relu=True), flops=fl0, count=1),
+              dict(name="dense_dgrad_accumulate", fn=lambda: ops.conv_raw(gy, pkd, N=n, H=hw, W=hw, Cin=g0, Cout=cin, out=gx, res=gx, use_bias=False), flops=fl0, count=1),
+              wg_flavour(x, gy, cin, g0, 3, fl0, 1)]
+        return f"conv_ks_kernel 3x3 {cin}->{g0} (RDN dense layer)", fl
+    x, x2 = act(feats), act(feats)
+    out = torch.empty_like(x)
+    w, b = par(feats, feats, 3)
+    flops = 2.0 * px * feats * feats * 9
+    pk = ops.pack_conv(w, b, dt)
+    if dtype == "f32":
+        kwc = dict(N=n, H=hw, W=hw, Cin=feats, Cout=feats, out=out)
+        return f"conv_igemm_kernel 3x3 {feats}->{feats} (fp32 MFMA)", [dict(name="conv_bias_relu", fn=lambda: ops.conv_raw(x, pk, relu=True, **kwc), flops=flops, count=1)]
+    pkd = ops.pack_conv(w, None, dt, dgrad=True)
+    if feats == 64 and ops.pair_ok(x, w, w):
+        # the reference's batch: two convs per launch (csrc/conv_pair.hip); RCAN: the CALayer steps ride on the launches
+        w2, b2 = par(feats, feats, 3)
+        pk2, pk2d = ops.pack_conv(w2, b2, dt), ops.pack_conv(w2, None, dt, dgrad=True)
+        mid, g1 = torch.empty_like(x), torch.empty_like(x)
+        if model_name == "rcan":
+            lib = A._lib.load()
+            ns, cr = lib.srk_conv_pair_tiles(1, hw, hw), 4
+            f32 = dict(dtype=torch.float32, device=dev)
+            sums, sums2, gsum = torch.rand(n, ns, 64, **f32), torch.empty(n, ns, 64, **f32), torch.rand(n, ns, 64, **f32)
+            cw1, cb1, cw2, cb2 = torch.rand(cr, 64, **f32) * 0.1, torch.zeros(cr, **f32), torch.rand(64, cr, **f32) * 0.1, torch.zeros(64, **f32)
+            s_, z_ = torch.rand(n, 64, **f32), torch.rand(n, cr, **f32)
+            per = torch.empty(n, 2 * cr * 64 + cr + 64, **f32)
+            xo, t = torch.empty_like(x), act(64)
+            fwd = lambda: ops.conv_pair_raw(x, pk, pk2, out=out, relu_mid=True, mid=mid, pool=sums2, xo=xo,
+                                            ca_fwd=dict(x2=x2, sums=sums, w1=cw1, b1=cb1, w2=cw2, b2=cb2, s_out=s_, z_out=z_))
+            bwd = lambda: ops.conv_pair_raw(x, pk2d, pkd, out=out, mask=x2, mid=g1, res=x, use_bias=False, pool=sums2, pool_aux=t, xo=xo,
+                                            ca_bwd=dict(gsum=gsum, sums=sums, s=s_, z=z_, w1=cw1, w2=cw2, slots=per))
+            names = ("pair_rcab_fwd_ca_in_pool", "pair_rcab_bwd_ca_in_pool")
+        else:
+            fwd = lambda: ops.conv_pair_raw(x, pk, pk2, out=out, relu_mid=True, mid=mid, scale_out=0.1, res=x)
+            bwd = lambda: ops.conv_pair_raw(x, pk2d, pkd, out=out, scale_mid=0.1, mask=x2, mid=g1, res=x, use_bias=False)
+            names = ("pair_resblock_fwd", "pair_resblock_bwd")
+        fl = [dict(name=names[0], fn=fwd, flops=2 * flops, count=1), dict(name=names[1], fn=bwd, flops=2 * flops, count=1),
+              wg_flavour(x, x2, feats, feats, 3, flops, 2)]
+        return f"conv_pair_kernel: two 3x3 {feats}->{feats} convs per launch (csrc/conv_pair.hip)", fl
+    kwc = dict(N=n, H=hw, W=hw, Cin=feats, Cout=feats, out=out)
+    fl = [dict(name="conv_bias_relu", fn=lambda: ops.conv_raw(x, pk, relu=True, **kwc), flops=flops, count=1),
+          dict(name="conv_scale_residual", fn=lambda: ops.conv_raw(x, pk, scale=0.1, res=x2, **kwc), flops=flops, count=2),
+          dict(name="dgrad_relu_mask", fn=lambda: ops.conv_raw(x, pkd, mask=x2, use_bias=False, **kwc), flops=flops, count=1),
+          wg_flavour(x, x2, feats, feats, 3, flops, 2)]
+    kern = "conv_ws_kernel" if feats == 64 else "conv_ks_kernel"
+    return f"{kern} 3x3 {feats}->{feats}, fwd = dgrad kernel", fl
+
+
+def dominant_kernel_roofline(A, model_name, batch, patch, feats, dtype, iters=100, sustain_s=1.0):
+    """The kernel(s) that carry the model's residual blocks AT THIS BATCH (`_flavours`), each flavour a training step issues timed
+    by HIP events on the launch stream: a burst (one graph of `iters` launches right after a warm-up replay) and SUSTAINED
+    (>= `sustain_s` seconds of back-to-back replays, the second half timed: the clock has dropped by then, which is what a
+    rocprofv3 run of the same launches sees -- profiles/r3_variants_*.txt).  `achieved` / `frac` / `variants_us` /
+    `step_weighted_frac` are the SUSTAINED figures; the `_burst` twins are reported next to them.  step-weighted = the block's
+    algorithmic FLOPs over the sum of its launches' times (forward + data gradient + weight gradients)."""
+    kernel, fl = _flavours(A, model_name, batch, patch, feats, dtype)
+    peak = PEAK_TFLOPS[dtype]
+    esz = 4 if dtype == "f32" else 2
+    burst, sust = {}, {}
+    for f in fl:
+        per = f.get("per", 1)
+        b_, s_ = _time_replays(f["fn"], max(4, iters // per), sustain_s)
+        burst[f["name"]], sust[f["name"]] = b_ / per, (s_ if s_ is not None else b_) / per
+    f0 = fl[0]
+    us = sust[f0["name"]]
+    ach = f0["flops"] / (us * 1e-6) / 1e12
+    px = batch * patch * patch
+    alg_bytes = 2.0 * px * feats * esz                              # one read + one write of the block's activation
+    r = {"bound": "mfma", "kernel": f"{kernel} @{patch}x{patch} x{batch} ({dtype}); quoted flavour: {f0['name']}",
          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-         "us_per_launch": round(us, 2), "flops_per_launch": flops,
+         "frac_burst": round(f0["flops"] / (burst[f0["name"]] * 1e-6) / 1e12 / peak, 4),
+         "us_per_launch": round(us, 2), "flops_per_launch": f0["flops"],
          "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": round(alg_bytes / (us * 1e-6) / 1e9, 1),
-         "traffic": pmc_traffic(feats, patch, batch, dtype),
-         "variants_us": {k: round(v, 2) for k, v in variants.items()}}
-    if len(variants) == 4:
-        t = (variants["conv_bias_relu"] + 2 * variants["conv_scale_residual"] + variants["dgrad_relu_mask"]
-             + 2 * variants["wgrad_grouped_per_layer"])
-        r["step_weighted_frac"] = round(6 * flops / (t * 1e-6) / 1e12 / peak, 4)
+         "traffic": pmc_traffic(f"{f0['name']}:{model_name}:{feats}x{patch}x{batch}x{dtype}"),
+         "variants_us": {k: round(v, 2) for k, v in sust.items()},
+         "variants_us_burst": {k: round(v, 2) for k, v in burst.items()},
+         "timing": f"HIP events around hipGraph replays; sustained = second half of {sustain_s:g} s of replays per flavour"}
+    if len(fl) > 1:
+        tot = sum(f["count"] * f["flops"] for f in fl)
+        r["step_weighted_frac"] = round(tot / (sum(f["count"] * sust[f["name"]] for f in fl) * 1e-6) / 1e12 / peak, 4)
+        r["step_weighted_frac_burst"] = round(tot / (sum(f["count"] * burst[f["name"]] for f in fl) * 1e-6) / 1e12 / peak, 4)
+        r["launches_per_block"] = {f["name"]: f["count"] for f in fl}
     return r
+
+
+def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5):
+    """One more BASELINE config in this process (after the timed region): the training step of `name` at `batch` as one
+    hipGraph, replayed for >= `seconds`; returns patches/s and the model-level MFMA fraction."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cls, kw, gflop_fwd, _ = MODELS[name]
+    torch.manual_seed(0)
+    model = getattr(A, cls)(scale_factor=scale, precision=PREC[dtype], **kw).to(dev)
+    batch_t = T.synthetic_batch(batch, 3, patch, scale, 4321, dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt = A.optim.Adam([p for p in model.parameters() if p.requires_grad])
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = model._calculate_losses(img_sr=model(batch_t["lr"]), img_hr=batch_t["hr"])["loss"]
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        loss = step()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = 0
+    while k < 10 or time.perf_counter() - t0 < seconds:
+        for _ in range(5):
+            g.replay()
+        k += 5
+        torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    value = batch * k / el
+    flop = gflop_fwd * 3.0 * (patch / 48.0) ** 2
+    out = {"model": name, "batch": batch, "value": round(value, 1), "unit": "LR patches/s", "ms_per_step": round(el / k * 1e3, 4), "steps": k,
+           "model_mfma_frac": round(value * flop / 1e3 / PEAK_TFLOPS[dtype], 4), "loss": float(loss.detach().float())}
+    del g, model, opt, batch_t
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -406,9 +548,20 @@ def main():
             out["sustained_value"] = round(a.batch * world / sustained, 2)
         if not a.no_roofline:
             try:
-                out["roofline"] = dominant_kernel_roofline(A, a.batch, a.patch, feats, a.dtype)
+                out["roofline"] = dominant_kernel_roofline(A, a.model, a.batch, a.patch, feats, a.dtype)
             except Exception as e:  # noqa: BLE001
                 out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not a.no_other_configs and not a.inference and a.model == "edsr_baseline" and a.batch == 256:
+            # BASELINE.json configs 2-5 at the reference's batch (16 patches per GPU), a few seconds each, after the timed region
+            oc = []
+            graphs = None                      # (frees the default line's graph and its private memory pool)
+            torch.cuda.empty_cache()
+            for name in ("edsr_baseline", "rcan", "edsr_large", "wdsr_b", "rdn_b"):
+                try:
+                    oc.append(quick_train_rate(A, T, name, 16, a.patch, a.scale, a.dtype))
+                except Exception as e:  # noqa: BLE001
+                    oc.append({"model": name, "batch": 16, "error": f"{type(e).__name__}: {e}"})
+            out["other_configs"] = oc
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.model, a.scale, a.patch, model=model, lr=batch["lr"], hr=batch["hr"])

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Isolated launches of ONE flavour of the dominant kernel at the bench shape (for rocprofv3 --kernel-trace):
 plain = conv+bias+ReLU, residual = conv*0.1 + residual, mask = data gradient with ReLU mask, wgrad = 8 queued weight
-gradients per flush (grouped launch + grouped finalize).  usage: microbench_variants.py --n 256 --variant plain --iters 30"""
+gradients per flush (grouped launch + grouped finalize).  `--seconds S`: keep replaying for S seconds (the sustained state bench.py's
+`variants_us` is quoted on).  usage: microbench_variants.py --n 256 --variant plain --iters 30 --seconds 1.5"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sr_amd as A
 p = argparse.ArgumentParser()
 p.add_argument("--n", type=int, default=256); p.add_argument("--variant", default="plain"); p.add_argument("--iters", type=int, default=30)
+p.add_argument("--seconds", type=float, default=0.0)
 a = p.parse_args()
 dev, dt, F = torch.device("cuda"), torch.bfloat16, 64
 x = (torch.rand(a.n, 48, 48, F, device=dev) - 0.5).to(dt)
@@ -34,4 +36,9 @@ with torch.cuda.graph(g):
     for _ in range(a.iters): fn()
 for _ in range(3): g.replay()
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < a.seconds:
+    for _ in range(4): g.replay()
+    torch.cuda.synchronize()
 print(a.variant, "done")
