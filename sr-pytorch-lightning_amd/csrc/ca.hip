@@ -117,7 +117,20 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_apply_kernel(const
   const int n = blockIdx.x, split = blockIdx.y, tid = threadIdx.x;
   const int C = a.C, Cr = a.Cr;
   ca_sum_partials(a.sums, n, a.sums_rows > 0 ? a.sums_rows : (int)gridDim.y, C, 1.f / (float)a.HW, red, mean);
-  if (tid < Cr) {
+  if (C == 64) {
+    // 64 channels (RCAN): lane = channel, the 64-term sum as a wave butterfly (srk_common.h wave_sum64: the order the conv-pair
+    // launches use too), z = relu(b1 + sum)
+    if (tid < 64) {
+      const float m = mean[tid];
+      for (int j = 0; j < Cr; ++j) {
+        const float z = fmaxf(a.b1[j] + wave_sum64(a.w1[j * 64 + tid] * m), 0.f);
+        if (tid == 0) {
+          zv[j] = z;
+          if (a.z_out && split == 0) a.z_out[(size_t)n * Cr + j] = z;
+        }
+      }
+    }
+  } else if (tid < Cr) {
     float z = a.b1[tid];
     for (int c = 0; c < C; ++c) z += a.w1[tid * C + c] * mean[c];
     z = fmaxf(z, 0.f);
@@ -174,7 +187,15 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_bwd_kernel(const s
   }
   if (tid < Cr) zv[tid] = a.z[(size_t)n * Cr + tid];
   __syncthreads();
-  if (tid < Cr) {
+  if (C == 64) {
+    if (tid < 64) {
+      const float d2 = dpre2[tid];
+      for (int j = 0; j < Cr; ++j) {
+        const float dz = wave_sum64(a.w2[tid * Cr + j] * d2);
+        if (tid == 0) dpre1[j] = zv[j] > 0.f ? dz : 0.f;
+      }
+    }
+  } else if (tid < Cr) {
     float dz = 0.f;
     for (int c = 0; c < C; ++c) dz += a.w2[c * Cr + tid] * dpre2[c];
     dpre1[tid] = zv[tid] > 0.f ? dz : 0.f;

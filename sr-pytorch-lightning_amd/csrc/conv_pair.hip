@@ -233,54 +233,41 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       }
       return ((t[0] + t[1]) + t[2]) + t[3] + 0.f;
     };
-    // The MLP itself on wave 0 alone: LDS operations of one wave execute in order, so its stages need no workgroup barrier
-    // (seven of them cost more than the arithmetic).  lane = channel; lanes < Cr also own one hidden unit.
-    auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    // ordered sum over c of wa[c * sa] * wb[c] (+ init): operands read 16 at a time, products and adds in c order
-    auto dot64 = [&](const float* wa, int sa, const float* wb, float init) {
-      float u = init;
-#pragma unroll
-      for (int c0 = 0; c0 < 64; c0 += 16) {
-        float x[16], y[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) { x[c] = wa[(c0 + c) * sa]; y[c] = wb[c0 + c]; }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) u += x[c] * y[c];
-      }
-      return u;
-    };
+    // The MLP itself on wave 0 alone (LDS operations of one wave execute in order, so its stages need no workgroup barrier):
+    // lane = channel; the 64-term sums are wave butterflies (wave_sum64, srk_common.h: the order of the stand-alone kernels
+    // for 64 channels), their results uniform over the wave, so the hidden units live in registers of every lane.
     if (wave == 0) {
-      cmean[lane] = pooled(rawS, rs, lane) * invHW;
+      const float mean_c = pooled(rawS, rs, lane) * invHW;
+      cmean[lane] = mean_c;
       if (bwd) {
         const float u = pooled(rawG, rg, lane);
+        const float d2 = u * (sg_in * (1.f - sg_in));
         cA[lane] = sg_in;
-        cd2[lane] = u * (sg_in * (1.f - sg_in));
-        if (lane < 8) { cz[lane] = lane < Cr ? z_in : 0.f; cd1[lane] = 0.f; }
-        wave_sync();
-        // dz[j] = sum_c W2[c][j] dpre2[c] (c ascending), dpre1 = relu'(z) dz
-        if (lane < Cr) {
-          const float dz = dot64(cW2 + lane, Cr, cd2, 0.f);
-          cd1[lane] = z_in > 0.f ? dz : 0.f;
-        }
-        wave_sync();
-        float wj[8], dj[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { wj[j] = cW1[j * 64 + lane]; dj[j] = cd1[j]; }
+        cd2[lane] = d2;
+        // dz[j] = sum_c W2[c][j] dpre2[c], dpre1 = relu'(z) dz; dmean[c] = sum_j W1[j][c] dpre1[j] (j ascending)
         float dm = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dm += wj[j] * dj[j];
+        for (int j = 0; j < 8; ++j) {
+          if (j < Cr) {
+            const float dz = wave_sum64(cW2[lane * Cr + j] * d2);
+            const float zj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_in), j));
+            const float d1 = zj > 0.f ? dz : 0.f;
+            dm += cW1[j * 64 + lane] * d1;
+            if (lane == 0) { cz[j] = zj; cd1[j] = d1; }
+          } else if (lane == 0) { cz[j] = 0.f; cd1[j] = 0.f; }
+        }
         cB[lane] = dm / (float)(H * W);
       } else {
-        wave_sync();
-        // forward: z = relu(b1 + W1 mean) (c ascending), s = sigmoid(b2 + W2 z)
-        if (lane < 8) cz[lane] = lane < Cr ? fmaxf(dot64(cW1 + lane * 64, 1, cmean, b1_in), 0.f) : 0.f;
-        wave_sync();
-        float wj[8], zj[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { wj[j] = cW2[lane * Cr + j]; zj[j] = cz[j]; }
+        // forward: z = relu(b1 + W1 mean), s = sigmoid(b2 + W2 z) (j ascending)
         float sg = b2_in;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sg += wj[j] * zj[j];
+        for (int j = 0; j < 8; ++j) {
+          if (j < Cr) {
+            const float zj = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1_in), j)) + wave_sum64(cW1[j * 64 + lane] * mean_c), 0.f);
+            sg += cW2[lane * Cr + j] * zj;
+            if (lane == 0) cz[j] = zj;
+          } else if (lane == 0) cz[j] = 0.f;
+        }
         sg = 1.f / (1.f + expf(-sg));
         cA[lane] = sg;
         cB[lane] = 0.f;

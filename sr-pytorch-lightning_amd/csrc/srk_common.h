@@ -124,6 +124,24 @@ SRK_DEV void dma16_hidden(i32x4 rsrc, unsigned voff, unsigned lds_addr) {
                :: "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory", "m0");
 }
 
+// Sum of one value per lane over the 64 lanes of a wave in ONE fixed order, returned uniformly (from lane 63): the GFX9 DPP
+// reduction -- quad swaps, half-row and row mirrors, then row_bcast15 / row_bcast31 across the four rows of 16 -- six vector
+// instructions and no LDS traffic (a ds_bpermute butterfly measured SLOWER than the serial 64-term sum it was to replace: six
+// dependent LDS round trips per sum).  The channel-attention MLP's 64-term sums use it in the stand-alone kernels (ca.hip) AND
+// inside the conv-pair launches (conv_pair.hip), so both forms stay bit-identical.
+template <int CTRL, int ROWS> SRK_DEV float dpp_take(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
+}
+SRK_DEV float wave_sum64(float v) {
+  v += dpp_take<0xB1, 0xf>(v);       // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E, 0xf>(v);       // quad_perm [2,3,0,1]
+  v += dpp_take<0x141, 0xf>(v);      // row_half_mirror
+  v += dpp_take<0x140, 0xf>(v);      // row_mirror: every lane of a row holds the row's sum
+  v += dpp_take<0x142, 0xa>(v);      // row_bcast15 into rows 1, 3
+  v += dpp_take<0x143, 0xc>(v);      // row_bcast31 into rows 2, 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // XCD-contiguous block remap: blocks b and b+8 share an XCD under round-robin dispatch, so give each
 // XCD a contiguous range of the linear work index (neighbouring tiles then share that XCD's L2).
 // Bijective for every grid size; placement only affects speed, never results.

@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline "$@" > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs "$@" > "$OUT/trace.log" 2>&1
 tail -2 "$OUT/trace.log"
 # summarise: per-kernel calls / total / average
 python3 - "$OUT" <<'PY'
