@@ -360,9 +360,22 @@ def conv_pair_raw(x, pk1, pk2, *, out, relu_mid=False, scale_mid=1.0, mask=None,
     return out
 
 
-def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=0, dy_ps=0, want_bias=True):
+def _grad_target(p, shape, dev):
+    """Where the gradient of parameter `p` is to be WRITTEN, or None (a fresh tensor).  trainer.GradSync keeps all gradients in
+    one flat fp32 buffer (what the bucket all-reduces run on) and names each parameter's slice here: the weight-gradient
+    kernels then write the slice directly and autograd adopts a view of it as `.grad` -- no per-step pack copy.  Only while the
+    parameter has no gradient yet (an existing one is accumulated into, as before)."""
+    if p is None or not isinstance(p, torch.Tensor) or p.grad is not None:
+        return None
+    t = p.__dict__.get("_srk_grad_target")
+    if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
+        return None
+    return t.detach()           # a fresh tensor object on the same memory (AccumulateGrad adopts a gradient nobody else references)
+
+
+def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=0, dy_ps=0, want_bias=True, out_w=None, out_b=None):
     """dW (OIHW fp32) and db for a conv whose input was `x` and output gradient is `dy`.
-    Cin/Cout are the padded storage channel counts of x / dy; w_shape the real OIHW shape."""
+    Cin/Cout are the padded storage channel counts of x / dy; w_shape the real OIHW shape.  out_w / out_b: write there."""
     _need_gpu(x)
     dev = x.device
     cout, cin, kh, kw = w_shape
@@ -379,6 +392,10 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
                                scale=scale, x_ps=x_ps, dy_ps=dy_ps, want_bias=want_bias)
             dw = w_ if dw is None else dw.add_(w_)
             db = b_ if (db is None or b_ is None) else db.add_(b_)
+        if out_w is not None:
+            dw = out_w.copy_(dw)
+        if out_b is not None and db is not None:
+            db = out_b.copy_(db)
         return dw, db
     a = L.WgradArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(x_ps),
                     dy=dy.data_ptr(), dy_pitch=_pitch(dy), dy_coff=0, dy_ps=int(dy_ps),
@@ -393,8 +410,8 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
     dbp = scratch[ns * per:]
     a.dwp, a.dbp, a.nslabs = scratch.data_ptr(), (dbp.data_ptr() if want_bias else 0), nslabs
     L.call("srk_conv2d_wgrad", a, _stream())
-    dw = torch.empty(w_shape, dtype=torch.float32, device=dev)
-    db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+    dw = out_w if out_w is not None else torch.empty(w_shape, dtype=torch.float32, device=dev)
+    db = (out_b if out_b is not None else torch.empty(cout, dtype=torch.float32, device=dev)) if want_bias else None
     # the unfolded head conv presents its OIHW weight as a 1x1 conv over Cin*KH*KW channels
     f = L.WgradFinArgs(dwp=scratch.data_ptr(), dbp=dbp.data_ptr() if want_bias else 0, nslabs=nslabs, dw=dw.data_ptr(), db=_ptr(db),
                        Cout=cout, Cin=(cin * kh * kw) // (k * k), KH=k, KW=k, CinP=Cin, CoutP=Cout,
@@ -622,18 +639,20 @@ def wgrad(x, dy, *, wparam=None, bparam=None, **kw):
     references); the queue keeps their storages -- not the tensors -- alive and the flush fills them by address."""
     want_bias = kw.get("want_bias", True)
     k, w_shape = kw["k"], kw["w_shape"]
+    tw = _grad_target(wparam, w_shape, x.device)
+    tb = _grad_target(bparam, (w_shape[0],), x.device) if want_bias else None
     if not (_WQ.enabled and k == 3 and x.dtype in (torch.bfloat16, torch.float16) and kw["N"] > 0 and kw.get("x_ps", 0) <= 1):
-        return wgrad_raw(x, dy, **kw)
+        return wgrad_raw(x, dy, out_w=tw, out_b=tb, **kw)
     sw = _grad_slot(wparam, w_shape)
     sb = _grad_slot(bparam, (w_shape[0],)) if want_bias else ("new", None)
     if sw is None or sb is None or wparam is None or (want_bias and sb[0] != sw[0]) or _batch_chunks(kw["N"], x, dy) > 1:
-        return wgrad_raw(x, dy, **kw)
+        return wgrad_raw(x, dy, out_w=tw, out_b=tb, **kw)
     a = L.WgradArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(kw.get("x_ps", 0)),
                     dy=dy.data_ptr(), dy_pitch=_pitch(dy), dy_coff=0, dy_ps=int(kw.get("dy_ps", 0)),
                     N=kw["N"], H=kw["H"], W=kw["W"], Cin=kw["Cin"], Cout=kw["Cout"], KH=3, KW=3, dwp=0, dbp=1 if want_bias else 0,
                     nslabs=0, dtype=_DT[x.dtype])
     if not L.load().srk_wgrad_group_ok(a):
-        return wgrad_raw(x, dy, **kw)
+        return wgrad_raw(x, dy, out_w=tw, out_b=tb, **kw)
     cout, cin = w_shape[0], w_shape[1]
     dev = x.device
     ret_w = ret_b = None
@@ -644,16 +663,16 @@ def wgrad(x, dy, *, wparam=None, bparam=None, **kw):
         if seen is not None and seen[0] == _WQ.gen:
             dw_ptr, db_ptr, acc = seen[1], seen[2], 1
         else:
-            ret_w = torch.empty(w_shape, dtype=torch.float32, device=dev)
-            ret_b = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+            ret_w = tw if tw is not None else torch.empty(w_shape, dtype=torch.float32, device=dev)
+            ret_b = (tb if tb is not None else torch.empty(cout, dtype=torch.float32, device=dev)) if want_bias else None
             dw_ptr, db_ptr, acc = ret_w.data_ptr(), _ptr(ret_b), 0
             sw_stg = ret_w.untyped_storage()
             keep.append(sw_stg)
-            new.append((wparam, dw_ptr, sw_stg, w_shape))
+            new.append((wparam, dw_ptr, sw_stg, w_shape, ret_w.storage_offset()))
             if ret_b is not None:
                 sb_stg = ret_b.untyped_storage()
                 keep.append(sb_stg)
-                new.append((bparam, db_ptr, sb_stg, (cout,)))
+                new.append((bparam, db_ptr, sb_stg, (cout,), ret_b.storage_offset()))
             wparam.__dict__["_srk_pending"] = (_WQ.gen, dw_ptr, db_ptr)
     else:
         dw_ptr, db_ptr, acc = sw[1].data_ptr(), (sb[1].data_ptr() if want_bias else 0), 1

@@ -78,7 +78,7 @@ class GradSync:
 
     `overlap=False` registers no hooks: `sync()` then packs all gradients and issues the bucket all-reduces after
     backward -- the form a hipGraph-captured step uses (bench.py captures forward + backward + `pack()` in one graph,
-    calls `reduce()` eagerly, and replays the optimizer step as a second graph: no collective inside a capture).
+    calls `reduce()` eagerly and then issues the optimizer step's three launches: no collective inside a capture).
     Replicas start identical: `broadcast()` sends rank 0's parameters and buffers."""
 
     def __init__(self, module, overlap=True, bucket_bytes=32 << 20):
@@ -103,6 +103,10 @@ class GradSync:
                 cur[1] = off + n
                 cur[2].append(p)
                 off += n
+        # the HIP weight-gradient kernels write a parameter's gradient straight into its slice (ops._grad_target): what is left
+        # for `_pack_bucket` are the few gradients produced elsewhere (channel attention, PReLU, BatchNorm, torch ops)
+        for p, v in self.views.items():
+            p.__dict__["_srk_grad_target"] = v
         self._bucket_of = {p: i for i, b in enumerate(self.buckets) for p in b[2]}
         self._ready = [0] * len(self.buckets)
         self._next = 0                                   # first bucket not launched yet
@@ -120,6 +124,12 @@ class GradSync:
         self._hooks = []
         for p in self.params:
             p.__dict__.pop("_srk_flush_aware", None)
+
+    def detach(self):
+        """Undo everything this object attached to the parameters (hooks, gradient targets)."""
+        self.remove_hooks()
+        for p in self.params:
+            p.__dict__.pop("_srk_grad_target", None)
 
     def broadcast(self):
         if self.world > 1:
@@ -231,7 +241,7 @@ class GraphedStep:
     (they are ordinary training steps: nothing is repeated or skipped); the next batch is copied into static buffers and the
     step is CAPTURED (capturing records launches, it does not execute them) and then replayed for it and every later batch of
     the same shape.  One process: one graph (forward, loss, backward, Adam).  Several ranks: forward + backward + gradient
-    packing are one graph, the bucketed all-reduce (RCCL) is issued eagerly between, the optimizer step is a second graph --
+    packing are one graph, the bucketed all-reduce (RCCL) and the optimizer step (three launches) are issued eagerly behind it --
     no collective is ever inside a capture.  A batch of another shape (a short last batch) runs eagerly.  If a capture fails
     the loop stays eager (and says so once).  Callers must not keep a loss WITH its autograd graph from an earlier eager step
     alive across the capture (`_eager_step` returns it detached for that reason)."""
@@ -275,13 +285,14 @@ class GraphedStep:
                 self.opt.step()
             self.graphs = (g,)
         else:
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # forward + backward (+ the few gradients that still need packing) are ONE graph; the bucket all-reduces and the
+            # optimizer step (three launches) are issued eagerly behind it: a second graph would cost its ~15 us launch floor
+            # per step, more than the launches it holds
+            ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=side, capture_error_mode=cem):
                 self.loss = self._fwd_bwd()
                 self.gsync.pack()
-            with torch.cuda.graph(gb, stream=side, capture_error_mode=cem):
-                self.opt.step()
-            self.graphs = (ga, gb)
+            self.graphs = (ga, None)
 
     def __call__(self, batch):
         self.seen += 1
@@ -308,7 +319,7 @@ class GraphedStep:
         self.graphs[0].replay()
         if len(self.graphs) == 2:
             self.gsync.reduce()
-            self.graphs[1].replay()
+            self.opt.step()
         return self.loss.detach()
 
 
@@ -374,5 +385,7 @@ class Trainer:
             elif len(self._loss_dev) >= 1024:
                 self.losses  # noqa: B018  (drain to the host list)
         self.graphed = graphed
+        if gsync is not None:
+            gsync.detach()
         unwrap_ddp(net)
         return model
