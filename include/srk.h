@@ -430,6 +430,8 @@ typedef struct srk_l1_args {
 int srk_l1_blocks(long long n);
 int srk_l1_loss_fwd(const srk_l1_args* a, srk_stream_t stream);
 int srk_l1_loss_bwd(const srk_l1_args* a, srk_stream_t stream);
+/* *out = (partial[0] + ... + partial[nb-1]) / n: the forward's partial sums -> the loss value, one launch */
+int srk_l1_loss_mean(const double* partial, int nb, long long n, float* out, srk_stream_t stream);
 
 /* ---- SSIM with piq.ssim's defaults (reference srmodel.py:52-53,567-593 -> piq.ssim): images are average-pooled by
  * `pool` = max(1, round(min(H, W) / 256)) (floor division of the extent, as F.avg_pool2d), filtered with the separable

@@ -187,6 +187,14 @@ __global__ __launch_bounds__(256) void l1_fwd_kernel(const srk_l1_args a) {
   __syncthreads();
   if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// mean = (sum of the partials in index order) / n as ONE small launch (torch: a double reduction, a division and a cast)
+__global__ __launch_bounds__(64) void l1_mean_kernel(const double* __restrict__ partial, int nb, long long n, float* __restrict__ out) {
+  double t = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 64) t += partial[i];   // lane-strided, then a fixed shuffle tree: reproducible
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if (threadIdx.x == 0) *out = (float)(t / (double)n);
+}
 __global__ __launch_bounds__(256) void l1_bwd_kernel(const srk_l1_args a) {
   const float g = *a.gout * a.scale;
   const long long n4 = a.n >> 2;
@@ -215,6 +223,12 @@ extern "C" int srk_l1_loss_fwd(const srk_l1_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a && a->sr && a->hr && a->sign && a->partial && a->n > 0, "srk_l1_loss_fwd: null pointer / empty");
   SRK_CHECK_ARG(((uintptr_t)a->sr | (uintptr_t)a->hr | (uintptr_t)a->sign) % 16 == 0, "srk_l1_loss_fwd: 16-byte alignment");
   hipLaunchKernelGGL(l1_fwd_kernel, dim3(srk_l1_blocks(a->n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int srk_l1_loss_mean(const double* partial, int nb, long long n, float* out, srk_stream_t stream) {
+  SRK_CHECK_ARG(partial && out && nb > 0 && n > 0, "srk_l1_loss_mean: null pointer / empty");
+  hipLaunchKernelGGL(l1_mean_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), partial, nb, n, out);
   SRK_LAUNCH_CHECK();
   return 0;
 }

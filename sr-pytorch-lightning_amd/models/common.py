@@ -112,6 +112,15 @@ class MeanShift(nn.Conv2d):
             self._checked = key
         return self.bias
 
+    def neg_shift(self):
+        """-shift(), cached (the parameter is frozen; a load_state_dict or an in-place edit bumps its version): the head kernels
+        SUBTRACT this vector, and a `-bias` per step is one more parameter-sized launch."""
+        b = self.shift()
+        key = (b._version, b.data_ptr())
+        if self.__dict__.get("_neg_key") != key:
+            self.__dict__["_neg"], self.__dict__["_neg_key"] = (-b.detach()), key
+        return self.__dict__["_neg"]
+
     def forward(self, x):
         """The reference's op on an NCHW image (3 multiply-adds per pixel; inside the models the shift is fused into the
         head / tail kernels instead)."""

@@ -89,7 +89,7 @@ class DDBPN(SRModel):
         with ops.forward_scope(self._pack_group()):
             rgb = self._channels == 3
             i0, a0, i2, a2 = self.initial
-            x = ops.prelu(ops.head_conv(x, i0.weight, i0.bias, -self.sub_mean.shift() if rgb else None, self.compute_dtype), a0.weight)
+            x = ops.prelu(ops.head_conv(x, i0.weight, i0.bias, self.sub_mean.neg_shift() if rgb else None, self.compute_dtype), a0.weight)
             x = ops.prelu(ops.conv(x, i2.weight, i2.bias), a2.weight)
             h_list, l_list = [], []
             for i in range(self.depth - 1):

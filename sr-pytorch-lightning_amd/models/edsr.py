@@ -28,7 +28,7 @@ class EDSR(SRModel):
         """NCHW float in [0,1] -> NCHW fp32, x scale_factor (edsr.py:40-54)."""
         with ops.forward_scope(self._pack_group()):
             rgb = self._channels == 3
-            f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, -self.sub_mean.shift() if rgb else None,
+            f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, self.sub_mean.neg_shift() if rgb else None,
                               self.compute_dtype)
             r = f
             for blk in list(self.body)[:-1]:

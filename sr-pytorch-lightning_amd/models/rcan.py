@@ -92,7 +92,7 @@ class RCAN(SRModel):
         """rcan.py:115-129"""
         with ops.forward_scope(self._pack_group()):
             rgb = self._channels == 3
-            f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, -self.sub_mean.shift() if rgb else None,
+            f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, self.sub_mean.neg_shift() if rgb else None,
                               self.compute_dtype)
             r = f
             for grp in list(self.body)[:-1]:

@@ -1900,7 +1900,9 @@ class L1LossFn(torch.autograd.Function):
         L.call("srk_l1_loss_fwd", a, _stream())
         ctx.save_for_backward(sign)
         ctx.shape = tuple(sr.shape)
-        return (partial.sum() / n).float()
+        out = torch.empty((), dtype=torch.float32, device=s.device)
+        L.check(L.load().srk_l1_loss_mean(partial.data_ptr(), nb, n, out.data_ptr(), _stream()), "srk_l1_loss_mean")
+        return out
 
     @staticmethod
     def backward(ctx, g):
