@@ -30,8 +30,8 @@ class _RDB(_NCHWContract, nn.Module):
     def _cout(self):
         return self.LFF.out_channels
 
-    def nhwc(self, x):
-        return ops.rdb(x, [(m.conv[0].weight, m.conv[0].bias) for m in self.convs], (self.LFF.weight, self.LFF.bias))
+    def nhwc(self, x, dest=None):
+        return ops.rdb(x, [(m.conv[0].weight, m.conv[0].bias) for m in self.convs], (self.LFF.weight, self.LFF.bias), dest=dest)
 
 
 class RDN(SRModel):
@@ -65,11 +65,13 @@ class RDN(SRModel):
         with ops.forward_scope(self._pack_group()):
             f1 = ops.head_conv(x, self.SFENet1.weight, self.SFENet1.bias, None, self.compute_dtype)
             x = ops.conv(f1, self.SFENet2.weight, self.SFENet2.bias)
-            outs = []
-            for blk in self._RDBs:
-                x = blk.nhwc(x)
+            # `torch.cat(RDBs_out, 1)` (rdn.py:108) without the copy: every block writes its output into its channel slice of ONE
+            # buffer, which the 1x1 global feature fusion then reads whole
+            outs, cat = [], ops.SliceBuffer(len(self._RDBs))
+            for i, blk in enumerate(self._RDBs):
+                x = blk.nhwc(x, dest=(cat, i))
                 outs.append(x)
-            x = ops.conv(torch.cat(outs, dim=3), self.GFF[0].weight, self.GFF[0].bias)    # 1x1 over D*G0 channels
+            x = ops.conv(ops.concat_slices(cat, outs), self.GFF[0].weight, self.GFF[0].bias)    # 1x1 over D*G0 channels
             x = ops.conv(x, self.GFF[1].weight, self.GFF[1].bias, res=f1)                  # `x += f__1`
             mods = list(self.UPNet)
             for conv, ps in zip(mods[0:-1:2], mods[1:-1:2]):

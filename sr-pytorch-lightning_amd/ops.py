@@ -1516,7 +1516,10 @@ class RDBFn(torch.autograd.Function):
     of the newest slice it completes."""
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, dest, *params):
+        """dest: None, or (SliceBuffer, index): the block's output is WRITTEN into channel slice `index` of that pre-allocated
+        buffer (RDN's global feature fusion reads the concatenation of all block outputs, rdn.py:108: no torch.cat copy) and
+        the returned tensor is that slice (a pitched NHWC view)."""
         _need_gpu(x)
         n, h, wd, g0 = x.shape
         nconv = (len(params) - 2) // 2
@@ -1531,7 +1534,7 @@ class RDBFn(torch.autograd.Function):
             cin = g0 + c * g
             conv_raw(feat[..., :cin], pack_conv(ws[c], bs[c], x.dtype), N=n, H=h, W=wd, Cin=cin, Cout=g,
                      out=feat[..., cin:cin + g], relu=True)
-        out = torch.empty_like(x)
+        out = torch.empty_like(x) if dest is None else dest[0].slice(dest[1], x)
         conv_raw(feat, pack_conv(wl, bl, x.dtype), N=n, H=h, W=wd, Cin=ctot, Cout=g0, out=out, res=x)
         ctx.save_for_backward(feat, *ws, wl)
         ctx.cfg = (nconv, g0, g)
@@ -1565,14 +1568,50 @@ class RDBFn(torch.autograd.Function):
             conv_raw(dy, pack_conv(ws[c], None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=g, Cout=cin, out=pref, res=pref,
                      mask=feat[..., :cin] if c > 0 else None, mask_from=cin - g if c > 0 else 0, use_bias=False)
         gx = gfeat[..., :g0] + gout
-        return (gx, *grads)
+        return (gx, None, *grads)
 
 
-def rdb(x, convs, lff):
+class SliceBuffer:
+    """One [N, H, W, count * C] NHWC buffer whose channel slices are the outputs of `count` blocks (RDN: the D residual dense
+    blocks feeding the global feature fusion, models/rdn.py:99-108).  A plain Python object, so autograd sees neither the
+    buffer nor the in-place slice writes: every block returns its slice as a fresh output tensor, `ConcatSlicesFn` returns the
+    whole buffer as the concatenation and hands each block its slice of the gradient (views, no copy either way)."""
+
+    def __init__(self, count):
+        self.count, self.buf = int(count), None
+
+    def slice(self, i, like):
+        n, h, w, c = like.shape
+        if self.buf is None:
+            self.buf = torch.empty((n, h, w, self.count * c), dtype=like.dtype, device=like.device)
+        return self.buf[..., i * c:(i + 1) * c]
+
+
+class ConcatSlicesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        ctx.c = parts[0].shape[3]
+        for i, p_ in enumerate(parts):
+            assert p_.numel() == 0 or p_.data_ptr() == holder.buf.data_ptr() + i * ctx.c * p_.element_size(), \
+                "part %d is not slice %d of the buffer" % (i, i)
+        return holder.buf.view(holder.buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        c = ctx.c
+        return (None, *[g[..., i * c:(i + 1) * c] for i in range(g.shape[3] // c)])
+
+
+def concat_slices(holder, parts):
+    """torch.cat(parts, dim=3) for parts that already ARE the consecutive channel slices of `holder` (no copy)."""
+    return ConcatSlicesFn.apply(holder, *parts)
+
+
+def rdb(x, convs, lff, dest=None):
     flat = []
     for w, b in convs:
         flat += [w, b]
-    return RDBFn.apply(x, *flat, lff[0], lff[1])
+    return RDBFn.apply(x, dest, *flat, lff[0], lff[1])
 
 
 # --------------------------------------------------------------------------------------------
