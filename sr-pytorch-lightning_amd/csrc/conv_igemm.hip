@@ -1448,7 +1448,9 @@ extern "C" int srk_conv_tile(int Cout) {
 extern "C" int srk_conv2d(const srk_conv_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a && a->x && a->wpk && a->out, "srk_conv2d: null pointer");
   SRK_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0, "srk_conv2d: bad dims N=%d H=%d W=%d", a->N, a->H, a->W);
-  SRK_CHECK_ARG(a->KH == a->KW && (a->KH == 1 || a->KH == 3), "srk_conv2d: kernel %dx%d not supported (1x1, 3x3)", a->KH, a->KW);
+  const bool lk = srk_conv_lk_ok(*a);                   // direct 5x5 / 7x7 / 9x9 conv (conv_lk.hip)
+  SRK_CHECK_ARG(a->KH == a->KW && (a->KH == 1 || a->KH == 3 || lk), "srk_conv2d: kernel %dx%d not supported for this shape (1x1, 3x3; "
+                "5x5 .. 9x9 with 64 -> <= 32 or 16 -> 64 channels, 16-bit)", a->KH, a->KW);
   SRK_CHECK_ARG(a->Cin > 0 && a->Cin % 16 == 0, "srk_conv2d: Cin=%d must be a positive multiple of 16", a->Cin);
   SRK_CHECK_ARG(a->CoutP > 0 && a->CoutP % 32 == 0, "srk_conv2d: CoutP=%d must be a multiple of 32", a->CoutP);
   SRK_CHECK_ARG(a->Cout > 0 && a->Cout <= a->CoutP, "srk_conv2d: Cout=%d CoutP=%d", a->Cout, a->CoutP);
@@ -1472,6 +1474,7 @@ extern "C" int srk_conv2d(const srk_conv_args* a, srk_stream_t stream) {
     SRK_CHECK_ARG(a->res_pitch % 4 == 0 && a->res_coff % 4 == 0, "srk_conv2d: residual alignment");
   if (a->mask) SRK_CHECK_ARG(a->mask_pitch % 4 == 0 && a->mask_coff % 4 == 0 && a->mask_from % 4 == 0, "srk_conv2d: mask alignment");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (lk) return srk_conv_lk_launch(*a, st);
   switch (a->dtype) {
     case SRK_BF16: return dispatch_tc<SRK_BF16>(*a, st);
     case SRK_F16: return dispatch_tc<SRK_F16>(*a, st);

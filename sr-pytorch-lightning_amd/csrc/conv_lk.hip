@@ -1,0 +1,337 @@
+// Direct large-kernel convolution (5x5, 7x7, 9x9, stride 1, 'same' padding) for few channels on one side: SRResNet's 9x9 tail
+// conv 64 -> 3 at HR resolution (models/srresnet.py:29: DefaultConv2d(n_feats, channels, 9)) forward, data gradient and weight
+// gradient.  The generic path (generic.hip) materialises the K*K-times larger column tensor in HBM (6.1 GB per batch of 16 for
+// this layer: 8 of SRResNet's 11.9 ms per step); here the (16 + K - 1)^2 halo tile sits in LDS once and all K*K taps read it at
+// shifted addresses, exactly as the 3x3 kernels do, with the weights of one KERNEL ROW (K taps) at a time streaming through a
+// two-slot LDS ring by hidden LDS-DMA.
+//   lk_conv_kernel<DT, CPP, NRB>  forward (CPP = 8: 64 input channels, NRB = 1: <= 32 output rows) and, with data-gradient packs,
+//                                 dgrad (CPP = 2: 16 stored gradient channels, NRB = 2: 64 rows).  4 waves x 64 pixels of a 16x16 tile.
+//   lk_wgrad_kernel<DT>           dW[tap][ci][co]: a workgroup owns ONE kernel row (K taps x 64 input channels x 16 gradient
+//                                 channels = 18 accumulator tiles over its 4 waves) and a range of tiles; K = the 16 pixels of a tile
+//                                 row, both operands by the transposing LDS read; partial sums to per-workgroup slabs
+//                                 (srk_wgrad_finalize's layout).
+// Packed weights, epilogue order and slab format are srk_conv2d's / srk_conv2d_wgrad's: those entry points dispatch here.
+#include "srk_common.h"
+
+namespace {
+
+template <int DT, int CPP, int NRB>
+__global__ __launch_bounds__(256) void lk_conv_kernel(const srk_conv_args a, int tilesX, int tilesY, unsigned x_bytes, unsigned w_bytes, int K) {
+  typedef DTraits<DT> Tr;
+  constexpr int PXB = CPP * 16;                                  // bytes per pixel in the LDS tile
+  constexpr int ROWS = 32 * NRB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int XT = 16 + K - 1, XTP = (XT + 1) & ~1;               // halo tile edge, even row pitch
+  const int xs_bytes = XT * XTP * PXB;
+  const int slab = K * CPP * ROWS * 16;                          // one kernel row of packed weights
+  char* const Xs = smem;
+  char* const Wr = smem + ((xs_bytes + 1023) & ~1023);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W, P = K / 2;
+  int pt = blockIdx.x;
+  const int tX = pt % tilesX;
+  pt /= tilesX;
+  const int tY = pt % tilesY;
+  const int n = pt / tilesY;
+  const int y0 = tY * 16, x0 = tX * 16;
+
+  const i32x4 xrsrc = make_rsrc4(a.x, x_bytes), wrsrc = make_rsrc4(a.wpk, w_bytes);
+  const unsigned xs_lds = lds_addr_of(Xs), wr_lds = lds_addr_of(Wr);
+
+  // bias = initial accumulators (loaded before any hidden DMA is queued: the vector-memory counter retires in order)
+  f32x16 acc[NRB][2];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + rb * 32 + 4 * h + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        acc[rb][pb][4 * i + 0] = b.x; acc[rb][pb][4 * i + 1] = b.y; acc[rb][pb][4 * i + 2] = b.z; acc[rb][pb][4 * i + 3] = b.w;
+      }
+    }
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) asm volatile("" : "+v"(acc[rb][0]), "+v"(acc[rb][1]));
+
+  // halo tile: 1 KB pieces of 64 / CPP pixels; chunk slot XOR-swizzled by the tile column when a pixel is a whole 128-byte row
+  {
+    const int npieces = (XT * XTP * CPP + 63) / 64;
+    for (int k = wave; k < npieces; k += 4) {
+      const int i = k * 64 + lane;
+      const int sl = i % CPP, p = i / CPP;
+      const int iy = p / XTP, ix = p - iy * XTP;
+      const int c = CPP == 8 ? (sl ^ swz(ix)) : sl;
+      const int gy = y0 - P + iy, gx = x0 - P + ix;
+      const bool ok = iy < XT && ix < XT && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c * 8 < a.Cin;
+      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * 8) * 2) : 0x80000000u;
+      dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + (k << 10))));
+    }
+  }
+  const int spieces = slab >> 10;                                // whole KB: K * CPP * ROWS * 16 is a multiple of 1024 for ROWS >= 32, CPP >= 2
+  auto dma_slab = [&](int kh) {
+    const unsigned dst = wr_lds + (unsigned)((kh & 1) * slab);
+    for (int k = wave; k < spieces; k += 4)
+      dma16_hidden(wrsrc, (unsigned)(kh * slab + (k << 10) + lane * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (k << 10))));
+  };
+  dma_slab(0);
+
+  const int px = r & 15;
+  int prow[2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) prow[pb] = 4 * wave + 2 * pb + (r >> 4);
+  const char* const wl = Wr + ((h * ROWS + r) << 4);
+
+  for (int kh = 0; kh < K; ++kh) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // slab kh (and, first, the tile) landed; slot (kh + 1) & 1 is free
+    if (kh + 1 < K) dma_slab(kh + 1);
+    const char* const ws = wl + (kh & 1) * slab;
+    for (int kw = 0; kw < K; ++kw) {
+      const int g = CPP == 8 ? swz(px + kw) : 0;
+#pragma unroll
+      for (int ks = 0; ks < CPP / 2; ++ks) {
+        i32x4 bf[2], af[NRB];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+          bf[pb] = lds_read16(Xs + ((prow[pb] + kh) * XTP + px + kw) * PXB + (((2 * ks + h) ^ g) << 4));
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) af[rb] = lds_read16(ws + (((kw * CPP + 2 * ks) * ROWS + rb * 32) << 4));
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) acc[rb][pb] = Tr::mma(af[rb], bf[pb], acc[rb][pb]);
+      }
+    }
+  }
+
+  // epilogue: v = acc (+ bias already); relu; * scale; + res; store.  Lane (pixel, half h) holds 16 (NRB = 1) / 32 (NRB = 2) contiguous
+  // channels of its pixel: channel = 16 h + 4 i + e  resp.  32 h + 16 rb + 4 i + e  (row_to_chan, srk_common.h)
+  const float sc = a.scale;
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const int gy = y0 + prow[pb], gx = x0 + px;
+    if (gy >= H || gx >= W) continue;
+    const size_t pix = (size_t)(n * H + gy) * W + gx;
+    typename Tr::elem* const o = reinterpret_cast<typename Tr::elem*>(a.out) + pix * a.out_pitch + a.out_coff;
+    const typename Tr::elem* const rs = a.res ? reinterpret_cast<const typename Tr::elem*>(a.res) + pix * a.res_pitch + a.res_coff : nullptr;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {                              // 8 channels = one 16-byte store
+        const int ch = (NRB == 1 ? 16 * h : 32 * h + 16 * rb) + 8 * q;
+        if (ch >= a.Cout) continue;
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          float u = acc[rb][pb][8 * q + t];
+          if (a.relu) u = fmaxf(u, 0.f);
+          v[t] = u * sc;
+        }
+        if (rs) {
+          const i32x4 qv = *reinterpret_cast<const i32x4*>(rs + ch);
+          const int qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float f0, f1;
+            unpack2<DT>((uint32_t)qw[e], f0, f1);
+            v[2 * e] += f0; v[2 * e + 1] += f1;
+          }
+        }
+        i32x4 ov;
+        ov.x = (int)pack2<DT>(v[0], v[1]); ov.y = (int)pack2<DT>(v[2], v[3]); ov.z = (int)pack2<DT>(v[4], v[5]); ov.w = (int)pack2<DT>(v[6], v[7]);
+        *reinterpret_cast<i32x4*>(o + ch) = ov;
+      }
+  }
+}
+
+// ---- weight gradient ---------------------------------------------------------------------------------------------------------
+// blockIdx = (slab, kernel row kh).  Per tile: the 16 x (16 + K - 1) pixels of x the kernel row touches (128 bytes per pixel,
+// swizzled image) and the 16 x 16 gradient tile as a 128-byte-per-pixel image whose channels beyond Cout are zero-filled by the
+// DMA; one K-step = one 16-pixel tile row; pair p = 2 kw + rb of (tap column, 32-row input-channel block) belongs to wave p & 3.
+template <int DT>
+__global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int ntiles, int tq, int trem,
+                                                       unsigned x_bytes, unsigned dy_bytes, int K) {
+  typedef DTraits<DT> Tr;
+  constexpr int MAXP = 5;                                        // pairs per wave: ceil(2 * 9 / 4)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int XW = 16 + K - 1, XWP = (XW + 1) & ~1;
+  const int xbuf = 16 * XWP * 128, dbuf = 16 * 16 * 128, buf = xbuf + dbuf;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = blockIdx.x, kh = blockIdx.y;
+  const int H = a.H, W = a.W, P = K / 2;
+  const int t0 = slot * tq + min(slot, trem), nt = tq + (slot < trem ? 1 : 0);
+  const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+
+  auto dma_tile = [&](int tile, int b) {
+    int pt = tile;
+    const int tX = pt % tilesX;
+    pt /= tilesX;
+    const int tY = pt % tilesY;
+    const int n = pt / tilesY;
+    const int y0 = tY * 16, x0 = tX * 16;
+    const int npx = 16 * XWP * 8 / 64;                           // pieces of the x rows (8 pixels each)
+    for (int k = wave; k < npx + 32; k += 4) {
+      const int i = (k < npx ? k : k - npx) * 64 + lane;
+      const int sl = i & 7, p = i >> 3;
+      if (k < npx) {
+        const int iy = p / XWP, ix = p - iy * XWP;
+        const int c = sl ^ swz(ix);
+        const int gy = y0 + iy + kh - P, gx = x0 + ix - P;
+        const bool ok = ix < XW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c * 8 < a.Cin;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * 8) * 2) : 0x80000000u;
+        dma16_hidden(xrs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * buf + (k << 10))));
+      } else {
+        const int iy = p >> 4, ix = p & 15;
+        const int c = sl ^ swz(ix);
+        const int gy = y0 + iy, gx = x0 + ix;
+        const bool ok = gy < H && gx < W && c * 8 < a.Cout;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.dy_pitch + a.dy_coff + c * 8) * 2) : 0x80000000u;
+        dma16_hidden(drs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * buf + xbuf + ((k - npx) << 10))));
+      }
+    }
+  };
+
+  const int npairs = 2 * K;
+  f32x16 acc[MAXP];
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  int aoff[MAXP][2], boff[2];
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) {
+    const int p = wave + 4 * j;                                  // kw = p >> 1, rb = p & 1
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) aoff[j][rd] = tr_lane_off(p >> 1, rd, p & 1, lane);
+  }
+  boff[0] = tr_lane_off(0, 0, 0, lane);
+  boff[1] = tr_lane_off(0, 1, 0, lane);
+
+  const bool do_bias = a.dbp != nullptr && kh == 0 && wave == 0;     // db = sum of the gradient: from the fragments wave 0 fetches anyway
+  float dbz = 0.f;
+  if (nt > 0) dma_tile(t0, 0);
+  for (int it = 0; it < nt; ++it) {
+    const char* const X = smem + (it & 1) * buf;
+    const char* const D = X + xbuf;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (it + 1 < nt) dma_tile(t0 + it + 1, (it + 1) & 1);
+#pragma unroll 2
+    for (int y = 0; y < 16; ++y) {
+      const i32x4 bf = tr_read2(D + y * 2048 + boff[0], D + y * 2048 + boff[1]);
+      if (do_bias) {                                             // lane = channel (lane & 31), 8 pixels of it per read
+        const int qw[4] = {bf.x, bf.y, bf.z, bf.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float f0, f1;
+          unpack2<DT>((uint32_t)qw[e], f0, f1);
+          dbz += f0 + f1;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MAXP; ++j)
+        if (wave + 4 * j < npairs) {
+          const i32x4 af = tr_read2(X + y * (XWP * 128) + aoff[j][0], X + y * (XWP * 128) + aoff[j][1]);
+          acc[j] = Tr::mma(af, bf, acc[j]);
+        }
+    }
+  }
+
+  if (do_bias) {
+    dbz += __shfl_xor(dbz, 32, 64);                              // the two K halves of a read
+    if (lane < a.Cout) a.dbp[(size_t)slot * a.Cout + lane] = dbz;
+  }
+  // slab [tap][ci][co] fp32 (srk_wgrad_finalize's layout, Cout = the gradient's stored channels): rows = input channels
+  {
+    const int hq = lane >> 5, co = lane & 31;
+    const size_t per = (size_t)K * K * a.Cin * a.Cout;
+    float* const sl = a.dwp + (size_t)slot * per;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      const int p = wave + 4 * j;
+      if (p >= npairs) continue;
+      const int kw = p >> 1, rb = p & 1, tap = kh * K + kw;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = rb * 32 + 4 * hq + (e & 3) + 8 * (e >> 2);
+        if (ci < a.Cin && co < a.Cout) sl[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[j][e];
+      }
+    }
+  }
+}
+
+int lk_wgrad_slabs_for(const srk_wgrad_args& a) {
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  const long long ntiles = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+  long long s = cus / a.KH;
+  if (s < 1) s = 1;
+  if (s > ntiles) s = ntiles;
+  return (int)s;
+}
+
+}  // namespace
+
+// 16-bit, K in {5, 7, 9}, plain NHWC in / out, (Cin <= 64, <= 32 output rows) or (16 input channels, 64 rows): srk_conv2d
+bool srk_conv_lk_ok(const srk_conv_args& a) {
+  if (a.dtype == SRK_F32 || a.KH != a.KW || a.KH < 5 || a.KH > 9 || !(a.KH & 1)) return false;
+  if (a.x_ps > 1 || a.out_mode != SRK_OUT_NHWC || a.post_add || a.mask) return false;
+  const bool fwd = a.Cin == 64 && a.CoutP == 32;
+  const bool bwd = a.Cin == 16 && a.CoutP == 64;
+  if (!fwd && !bwd) return false;
+  if (a.x_pitch % 8 || a.x_coff % 8 || a.out_pitch % 8 || a.out_coff % 8 || a.Cout % 8 || (a.res && (a.res_pitch % 8 || a.res_coff % 8))) return false;
+  const long long px = (long long)a.N * a.H * a.W;
+  long long mx = px * a.x_pitch;
+  if (px * a.out_pitch > mx) mx = px * a.out_pitch;
+  return mx * 2 < 0x7fff0000LL;
+}
+
+template <int DT, int CPP, int NRB> static int lk_launch(const srk_conv_args& a, hipStream_t st) {
+  const int K = a.KH, XT = 16 + K - 1, XTP = (XT + 1) & ~1;
+  const int xs = (XT * XTP * CPP * 16 + 1023) & ~1023, slab = K * CPP * 32 * NRB * 16;
+  const int lds = xs + 2 * slab;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_conv_kernel<DT, CPP, NRB>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) { srk_set_error("srk_conv2d: cannot reserve LDS for the large-kernel conv"); return (int)attr; }
+  SRK_CHECK_ARG(lds <= 160 * 1024, "srk_conv2d: %dx%d kernel needs %d bytes of LDS", K, K, lds);
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
+  const long long nb = (long long)a.N * tilesX * tilesY;
+  SRK_CHECK_ARG(nb <= 0x7fffffffLL, "srk_conv2d: %lld workgroups", nb);
+  hipLaunchKernelGGL((lk_conv_kernel<DT, CPP, NRB>), dim3((unsigned)nb), dim3(256), lds, st, a, tilesX, tilesY,
+                     (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2), (unsigned)((long long)K * slab), K);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st) {
+  if (a.Cin == 16) return a.dtype == SRK_BF16 ? lk_launch<SRK_BF16, 2, 2>(a, st) : lk_launch<SRK_F16, 2, 2>(a, st);
+  return a.dtype == SRK_BF16 ? lk_launch<SRK_BF16, 8, 1>(a, st) : lk_launch<SRK_F16, 8, 1>(a, st);
+}
+
+bool srk_wgrad_lk_ok(const srk_wgrad_args& a) {
+  if (a.dtype == SRK_F32 || a.KH != a.KW || a.KH < 5 || a.KH > 9 || !(a.KH & 1)) return false;
+  if (a.x_ps > 1 || a.dy_ps > 1 || a.Cin > 64 || a.Cin % 16 || a.Cout > 32 || a.Cout % 8) return false;
+  const long long px = (long long)a.N * a.H * a.W;
+  return px * a.x_pitch * 2 < 0x7fff0000LL && px * a.dy_pitch * 2 < 0x7fff0000LL;
+}
+int srk_wgrad_lk_slabs(const srk_wgrad_args& a) { return lk_wgrad_slabs_for(a); }
+
+int srk_wgrad_lk_launch(const srk_wgrad_args& a, hipStream_t st) {
+  const int K = a.KH, XWP = (16 + K - 1 + 1) & ~1;
+  const int lds = 2 * (16 * XWP * 128 + 16 * 16 * 128);
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_wgrad_kernel<SRK_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_wgrad_kernel<SRK_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr0 != hipSuccess || attr1 != hipSuccess) { srk_set_error("srk_conv2d_wgrad: cannot reserve LDS"); return (int)(attr0 != hipSuccess ? attr0 : attr1); }
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
+  const long long ntiles = (long long)a.N * tilesX * tilesY;
+  const int slabs = a.nslabs;
+  const unsigned xb = (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2), db = (unsigned)((long long)a.N * a.H * a.W * a.dy_pitch * 2);
+  if (a.dtype == SRK_BF16)
+    hipLaunchKernelGGL(lk_wgrad_kernel<SRK_BF16>, dim3(slabs, K), dim3(256), lds, st, a, tilesX, tilesY, (int)ntiles, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db, K);
+  else
+    hipLaunchKernelGGL(lk_wgrad_kernel<SRK_F16>, dim3(slabs, K), dim3(256), lds, st, a, tilesX, tilesY, (int)ntiles, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db, K);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}

@@ -636,6 +636,7 @@ static int wgrad1x1_slabs(const srk_wgrad_args& a) {
 
 static int wgrad_ws_slabs(const srk_wgrad_args& a) {
   if (a.KH == 1 && a.KW == 1) return wgrad1x1_slabs(a);
+  if (a.KH > 3) return srk_wgrad_lk_ok(a) ? srk_wgrad_lk_slabs(a) : 0;
   if (a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3 || a.x_ps > 1) return 0;
   static const bool no_ws = getenv("SRK_NO_WS") != nullptr;      // diagnostics knob, read once
   if (no_ws) return 0;
@@ -727,7 +728,7 @@ template <int DT> int dispatch(const srk_wgrad_args& a, hipStream_t st) {
 extern "C" int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a && a->x && a->dy && a->dwp, "srk_conv2d_wgrad: null pointer");
   SRK_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0, "srk_conv2d_wgrad: bad dims");
-  SRK_CHECK_ARG(a->KH == a->KW && (a->KH == 1 || a->KH == 3), "srk_conv2d_wgrad: kernel %dx%d not supported", a->KH, a->KW);
+  SRK_CHECK_ARG(a->KH == a->KW && (a->KH == 1 || a->KH == 3 || srk_wgrad_lk_ok(*a)), "srk_conv2d_wgrad: kernel %dx%d not supported", a->KH, a->KW);
   SRK_CHECK_ARG(a->Cin % 16 == 0 && a->Cout % 16 == 0 && a->Cin > 0 && a->Cout > 0, "srk_conv2d_wgrad: Cin=%d Cout=%d must be multiples of 16", a->Cin, a->Cout);
   SRK_CHECK_ARG(a->dtype >= SRK_BF16 && a->dtype <= SRK_F32, "srk_conv2d_wgrad: dtype %d", a->dtype);
   const int ch = a->dtype == SRK_F32 ? 4 : 8;
@@ -739,6 +740,7 @@ extern "C" int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int slabs = wgrad_ws_slabs(*a);
   SRK_CHECK_ARG(a->nslabs == slabs, "srk_conv2d_wgrad: nslabs=%d but srk_wgrad_slabs() is %d for these arguments", a->nslabs, slabs);
+  if (a->KH > 3) return srk_wgrad_lk_launch(*a, st);
   if (slabs > 0 && a->KH == 1) return a->dtype == SRK_BF16 ? launch_1x1_any<SRK_BF16>(*a, st, slabs) : launch_1x1_any<SRK_F16>(*a, st, slabs);
   if (slabs > 0) return a->dtype == SRK_BF16 ? launch_ws<SRK_BF16>(*a, st, slabs) : launch_ws<SRK_F16>(*a, st, slabs);
   switch (a->dtype) {

@@ -246,6 +246,12 @@ SRK_DEV i32x4 tr_read2(const char* a0, const char* a1) {
 // conv_ks.hip: 3x3 conv with >= 2 input blocks of 64 channels (K-streaming kernel); srk_conv2d (conv_igemm.hip) dispatches to it
 bool srk_conv_ks_ok(const srk_conv_args& a);
 int srk_conv_ks_launch(const srk_conv_args& a, hipStream_t st);
+// conv_lk.hip: direct 5x5 / 7x7 / 9x9 convs with few channels on one side (forward, dgrad, weight gradient)
+bool srk_conv_lk_ok(const srk_conv_args& a);
+int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st);
+bool srk_wgrad_lk_ok(const srk_wgrad_args& a);
+int srk_wgrad_lk_slabs(const srk_wgrad_args& a);
+int srk_wgrad_lk_launch(const srk_wgrad_args& a, hipStream_t st);
 // conv1x1.hip: 1x1 conv with Cin <= 384 (all operands in LDS behind one wait)
 bool srk_conv1x1_ok(const srk_conv_args& a);
 int srk_conv1x1_launch(const srk_conv_args& a, hipStream_t st);

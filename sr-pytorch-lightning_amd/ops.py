@@ -1855,12 +1855,19 @@ def batch_norm(x, bn, res=None):
     return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, res)
 
 
+_LK_OFF = os.environ.get("SRK_NO_LK", "0") == "1"        # A/B knob: large kernels through im2col as in round 2
+
+
 def conv_general(x, w, b, *, stride=1, pad=0):
     """nn.Conv2d with any square kernel / stride / zero padding on NHWC `x`: im2col (srk_unfold_nhwc) + the 1x1 MFMA conv
     with the OIHW weight presented as a [Cout][K*K*Cin] matrix in (kh, kw, ci) order.  The permute / reshape of the
     parameter is a view-level torch op, so its gradient flows back to the OIHW parameter through autograd."""
     cout, cin, k, _ = w.shape
     cp = x.shape[-1]
+    if (stride == 1 and pad == k // 2 and k in (5, 7, 9) and cin == cp == 64 and cout <= 16 and x.dtype in (torch.bfloat16, torch.float16)
+            and x.numel() * 2 < _ADDR_LIMIT and not _LK_OFF):
+        # SRResNet's 9x9 tail conv (srresnet.py:29): the direct large-kernel kernels (csrc/conv_lk.hip), no column tensor
+        return conv(x, w, b)
     if cp != cin:                                   # zero-padded storage channels: pad the weight's input channels too
         w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cp - cin))
     wm = w.permute(0, 2, 3, 1).reshape(cout, k * k * cp, 1, 1)
