@@ -15,15 +15,15 @@
 
 namespace {
 
-template <int DT, int CPP, int NRB>
-__global__ __launch_bounds__(256) void lk_conv_kernel(const srk_conv_args a, int tilesX, int tilesY, unsigned x_bytes, unsigned w_bytes, int K) {
+template <int DT, int CPP, int NRB, int K>
+__global__ __launch_bounds__(256) void lk_conv_kernel(const srk_conv_args a, int tilesX, int tilesY, unsigned x_bytes, unsigned w_bytes) {
   typedef DTraits<DT> Tr;
   constexpr int PXB = CPP * 16;                                  // bytes per pixel in the LDS tile
   constexpr int ROWS = 32 * NRB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int XT = 16 + K - 1, XTP = (XT + 1) & ~1;               // halo tile edge, even row pitch
-  const int xs_bytes = XT * XTP * PXB;
-  const int slab = K * CPP * ROWS * 16;                          // one kernel row of packed weights
+  constexpr int XT = 16 + K - 1, XTP = (XT + 1) & ~1;           // halo tile edge, even row pitch
+  constexpr int xs_bytes = XT * XTP * PXB;
+  constexpr int slab = K * CPP * ROWS * 16;                      // one kernel row of packed weights
   char* const Xs = smem;
   char* const Wr = smem + ((xs_bytes + 1023) & ~1023);
 
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void lk_conv_kernel(const srk_conv_args a, int
 
   // halo tile: 1 KB pieces of 64 / CPP pixels; chunk slot XOR-swizzled by the tile column when a pixel is a whole 128-byte row
   {
-    const int npieces = (XT * XTP * CPP + 63) / 64;
+    constexpr int npieces = (XT * XTP * CPP + 63) / 64;
+#pragma unroll 4
     for (int k = wave; k < npieces; k += 4) {
       const int i = k * 64 + lane;
       const int sl = i % CPP, p = i / CPP;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void lk_conv_kernel(const srk_conv_args a, int
       dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + (k << 10))));
     }
   }
-  const int spieces = slab >> 10;                                // whole KB: K * CPP * ROWS * 16 is a multiple of 1024 for ROWS >= 32, CPP >= 2
+  constexpr int spieces = slab >> 10;                            // whole KB: K * CPP * ROWS * 16 is a multiple of 1024 for ROWS >= 32, CPP >= 2
   auto dma_slab = [&](int kh) {
     const unsigned dst = wr_lds + (unsigned)((kh & 1) * slab);
     for (int k = wave; k < spieces; k += 4)
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void lk_conv_kernel(const srk_conv_args a, int
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // slab kh (and, first, the tile) landed; slot (kh + 1) & 1 is free
     if (kh + 1 < K) dma_slab(kh + 1);
     const char* const ws = wl + (kh & 1) * slab;
+#pragma unroll
     for (int kw = 0; kw < K; ++kw) {
       const int g = CPP == 8 ? swz(px + kw) : 0;
 #pragma unroll
@@ -150,14 +152,14 @@ __global__ __launch_bounds__(256) void lk_conv_kernel(const srk_conv_args a, int
 // blockIdx = (slab, kernel row kh).  Per tile: the 16 x (16 + K - 1) pixels of x the kernel row touches (128 bytes per pixel,
 // swizzled image) and the 16 x 16 gradient tile as a 128-byte-per-pixel image whose channels beyond Cout are zero-filled by the
 // DMA; one K-step = one 16-pixel tile row; pair p = 2 kw + rb of (tap column, 32-row input-channel block) belongs to wave p & 3.
-template <int DT>
+template <int DT, int K>
 __global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int ntiles, int tq, int trem,
-                                                       unsigned x_bytes, unsigned dy_bytes, int K) {
+                                                       unsigned x_bytes, unsigned dy_bytes) {
   typedef DTraits<DT> Tr;
-  constexpr int MAXP = 5;                                        // pairs per wave: ceil(2 * 9 / 4)
+  constexpr int MAXP = (2 * K + 3) / 4;                          // pairs per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int XW = 16 + K - 1, XWP = (XW + 1) & ~1;
-  const int xbuf = 16 * XWP * 128, dbuf = 16 * 16 * 128, buf = xbuf + dbuf;
+  constexpr int XW = 16 + K - 1, XWP = (XW + 1) & ~1;
+  constexpr int xbuf = 16 * XWP * 128, dbuf = 16 * 16 * 32 + 1024, buf = xbuf + dbuf;   // gradient tile: 32 bytes per pixel (16 channels) + 1 KB of zeros
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = blockIdx.x, kh = blockIdx.y;
@@ -166,6 +168,21 @@ __global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, i
   const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
   const unsigned lds0 = lds_addr_of(smem);
 
+  // per-lane piece constants (tile-independent): x piece k = wave + 4 j covers pixels (iy, ix) of the 16 x XWP rows, chunk c;
+  // packed iy | ix << 8 | c << 16 | valid << 24
+  constexpr int NPX = 16 * XWP * 8 / 64, XPW = (NPX + 3) / 4, NPD = 9, DPW = (NPD + 3) / 4;   // + 8 gradient pieces + 1 of zeros
+  int xdesc[XPW], ddesc[DPW];
+#pragma unroll
+  for (int j = 0; j < XPW; ++j) {
+    const int k = wave + 4 * j, i = k * 64 + lane, sl = i & 7, p = i >> 3;
+    const int iy = p / XWP, ix = p - iy * XWP, c = sl ^ swz(ix);
+    xdesc[j] = iy | (ix << 8) | (c << 16) | ((k < NPX && ix < XW && c * 8 < a.Cin) ? 1 << 24 : 0);
+  }
+#pragma unroll
+  for (int j = 0; j < DPW; ++j) {
+    const int k = wave + 4 * j, i = k * 64 + lane, c = i & 1, pp = i >> 1;          // 2 chunks per pixel, pixels row-major 16 x 16
+    ddesc[j] = (pp >> 4) | ((pp & 15) << 8) | (c << 16) | ((k < 8 && c * 8 < a.Cout) ? 1 << 24 : 0);
+  }
   auto dma_tile = [&](int tile, int b) {
     int pt = tile;
     const int tX = pt % tilesX;
@@ -173,29 +190,29 @@ __global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, i
     const int tY = pt % tilesY;
     const int n = pt / tilesY;
     const int y0 = tY * 16, x0 = tX * 16;
-    const int npx = 16 * XWP * 8 / 64;                           // pieces of the x rows (8 pixels each)
-    for (int k = wave; k < npx + 32; k += 4) {
-      const int i = (k < npx ? k : k - npx) * 64 + lane;
-      const int sl = i & 7, p = i >> 3;
-      if (k < npx) {
-        const int iy = p / XWP, ix = p - iy * XWP;
-        const int c = sl ^ swz(ix);
-        const int gy = y0 + iy + kh - P, gx = x0 + ix - P;
-        const bool ok = ix < XW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c * 8 < a.Cin;
-        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * 8) * 2) : 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+      const int k = wave + 4 * j;
+      if (k < NPX) {
+        const int d = xdesc[j], gy = y0 + (d & 255) + kh - P, gx = x0 + ((d >> 8) & 255) - P;
+        const bool ok = (d >> 24) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + ((d >> 16) & 255) * 8) * 2) : 0x80000000u;
         dma16_hidden(xrs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * buf + (k << 10))));
-      } else {
-        const int iy = p >> 4, ix = p & 15;
-        const int c = sl ^ swz(ix);
-        const int gy = y0 + iy, gx = x0 + ix;
-        const bool ok = gy < H && gx < W && c * 8 < a.Cout;
-        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.dy_pitch + a.dy_coff + c * 8) * 2) : 0x80000000u;
-        dma16_hidden(drs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * buf + xbuf + ((k - npx) << 10))));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+      const int k = wave + 4 * j;
+      if (k < NPD) {
+        const int d = ddesc[j], gy = y0 + (d & 255), gx = x0 + ((d >> 8) & 255);
+        const bool ok = (d >> 24) && gy < H && gx < W;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.dy_pitch + a.dy_coff + ((d >> 16) & 255) * 8) * 2) : 0x80000000u;
+        dma16_hidden(drs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * buf + xbuf + (k << 10))));
       }
     }
   };
 
-  const int npairs = 2 * K;
+  constexpr int npairs = 2 * K;
   f32x16 acc[MAXP];
 #pragma unroll
   for (int j = 0; j < MAXP; ++j)
@@ -208,8 +225,14 @@ __global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, i
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) aoff[j][rd] = tr_lane_off(p >> 1, rd, p & 1, lane);
   }
-  boff[0] = tr_lane_off(0, 0, 0, lane);
-  boff[1] = tr_lane_off(0, 1, 0, lane);
+  // gradient fragment: lane l of 16-lane group G supplies pixel 8 (G >> 1) + 4 rd + q, channels 4 p .. + 3 of block G & 1; block 1
+  // (channels 16 .. 31) does not exist: those lanes read the zero piece behind the tile
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int G = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const int col = 8 * (G >> 1) + 4 * rd + q;
+    boff[rd] = (G & 1) ? (16 * 16 * 32 + pq * 8) : (col * 32 + pq * 8);
+  }
 
   const bool do_bias = a.dbp != nullptr && kh == 0 && wave == 0;     // db = sum of the gradient: from the fragments wave 0 fetches anyway
   float dbz = 0.f;
@@ -219,9 +242,23 @@ __global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, i
     const char* const D = X + xbuf;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (it + 1 < nt) dma_tile(t0 + it + 1, (it + 1) & 1);
+    // fragments of tile row y + 1 are requested before the MFMAs of row y
+    i32x4 bfn, afn[MAXP];
+    auto fetch = [&](int y) {
+      const int yd = (lane & 16) ? 0 : y * 512;                  // (the zero piece has no rows)
+      bfn = tr_read2(D + yd + boff[0], D + yd + boff[1]);
+#pragma unroll
+      for (int j = 0; j < MAXP; ++j)
+        if (wave + 4 * j < npairs) afn[j] = tr_read2(X + y * (XWP * 128) + aoff[j][0], X + y * (XWP * 128) + aoff[j][1]);
+    };
+    fetch(0);
 #pragma unroll 2
     for (int y = 0; y < 16; ++y) {
-      const i32x4 bf = tr_read2(D + y * 2048 + boff[0], D + y * 2048 + boff[1]);
+      const i32x4 bf = bfn;
+      i32x4 af[MAXP];
+#pragma unroll
+      for (int j = 0; j < MAXP; ++j) af[j] = afn[j];
+      if (y + 1 < 16) fetch(y + 1);
       if (do_bias) {                                             // lane = channel (lane & 31), 8 pixels of it per read
         const int qw[4] = {bf.x, bf.y, bf.z, bf.w};
 #pragma unroll
@@ -233,10 +270,7 @@ __global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, i
       }
 #pragma unroll
       for (int j = 0; j < MAXP; ++j)
-        if (wave + 4 * j < npairs) {
-          const i32x4 af = tr_read2(X + y * (XWP * 128) + aoff[j][0], X + y * (XWP * 128) + aoff[j][1]);
-          acc[j] = Tr::mma(af, bf, acc[j]);
-        }
+        if (wave + 4 * j < npairs) acc[j] = Tr::mma(af[j], bf, acc[j]);
     }
   }
 
@@ -288,21 +322,28 @@ bool srk_conv_lk_ok(const srk_conv_args& a) {
   return mx * 2 < 0x7fff0000LL;
 }
 
-template <int DT, int CPP, int NRB> static int lk_launch(const srk_conv_args& a, hipStream_t st) {
-  const int K = a.KH, XT = 16 + K - 1, XTP = (XT + 1) & ~1;
-  const int xs = (XT * XTP * CPP * 16 + 1023) & ~1023, slab = K * CPP * 32 * NRB * 16;
-  const int lds = xs + 2 * slab;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_conv_kernel<DT, CPP, NRB>),
+template <int DT, int CPP, int NRB, int K> static int lk_launch_k(const srk_conv_args& a, hipStream_t st) {
+  constexpr int XT = 16 + K - 1, XTP = (XT + 1) & ~1;
+  constexpr int xs = (XT * XTP * CPP * 16 + 1023) & ~1023, slab = K * CPP * 32 * NRB * 16;
+  constexpr int lds = xs + 2 * slab;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_conv_kernel<DT, CPP, NRB, K>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess) { srk_set_error("srk_conv2d: cannot reserve LDS for the large-kernel conv"); return (int)attr; }
   SRK_CHECK_ARG(lds <= 160 * 1024, "srk_conv2d: %dx%d kernel needs %d bytes of LDS", K, K, lds);
   const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
   const long long nb = (long long)a.N * tilesX * tilesY;
   SRK_CHECK_ARG(nb <= 0x7fffffffLL, "srk_conv2d: %lld workgroups", nb);
-  hipLaunchKernelGGL((lk_conv_kernel<DT, CPP, NRB>), dim3((unsigned)nb), dim3(256), lds, st, a, tilesX, tilesY,
-                     (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2), (unsigned)((long long)K * slab), K);
+  hipLaunchKernelGGL((lk_conv_kernel<DT, CPP, NRB, K>), dim3((unsigned)nb), dim3(256), lds, st, a, tilesX, tilesY,
+                     (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2), (unsigned)((long long)K * slab));
   SRK_LAUNCH_CHECK();
   return 0;
+}
+template <int DT, int CPP, int NRB> static int lk_launch(const srk_conv_args& a, hipStream_t st) {
+  switch (a.KH) {
+    case 5: return lk_launch_k<DT, CPP, NRB, 5>(a, st);
+    case 7: return lk_launch_k<DT, CPP, NRB, 7>(a, st);
+    default: return lk_launch_k<DT, CPP, NRB, 9>(a, st);
+  }
 }
 
 int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st) {
@@ -318,20 +359,26 @@ bool srk_wgrad_lk_ok(const srk_wgrad_args& a) {
 }
 int srk_wgrad_lk_slabs(const srk_wgrad_args& a) { return lk_wgrad_slabs_for(a); }
 
-int srk_wgrad_lk_launch(const srk_wgrad_args& a, hipStream_t st) {
-  const int K = a.KH, XWP = (16 + K - 1 + 1) & ~1;
-  const int lds = 2 * (16 * XWP * 128 + 16 * 16 * 128);
-  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_wgrad_kernel<SRK_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_wgrad_kernel<SRK_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (attr0 != hipSuccess || attr1 != hipSuccess) { srk_set_error("srk_conv2d_wgrad: cannot reserve LDS"); return (int)(attr0 != hipSuccess ? attr0 : attr1); }
+template <int DT, int K> static int lk_wgrad_launch_k(const srk_wgrad_args& a, hipStream_t st) {
+  constexpr int XWP = (16 + K - 1 + 1) & ~1;
+  constexpr int lds = 2 * (16 * XWP * 128 + 16 * 16 * 32 + 1024);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_wgrad_kernel<DT, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) { srk_set_error("srk_conv2d_wgrad: cannot reserve LDS"); return (int)attr; }
   const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
   const long long ntiles = (long long)a.N * tilesX * tilesY;
   const int slabs = a.nslabs;
   const unsigned xb = (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2), db = (unsigned)((long long)a.N * a.H * a.W * a.dy_pitch * 2);
-  if (a.dtype == SRK_BF16)
-    hipLaunchKernelGGL(lk_wgrad_kernel<SRK_BF16>, dim3(slabs, K), dim3(256), lds, st, a, tilesX, tilesY, (int)ntiles, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db, K);
-  else
-    hipLaunchKernelGGL(lk_wgrad_kernel<SRK_F16>, dim3(slabs, K), dim3(256), lds, st, a, tilesX, tilesY, (int)ntiles, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db, K);
+  hipLaunchKernelGGL((lk_wgrad_kernel<DT, K>), dim3(slabs, K), dim3(256), lds, st, a, tilesX, tilesY, (int)ntiles, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db);
   SRK_LAUNCH_CHECK();
   return 0;
+}
+template <int DT> static int lk_wgrad_launch_dt(const srk_wgrad_args& a, hipStream_t st) {
+  switch (a.KH) {
+    case 5: return lk_wgrad_launch_k<DT, 5>(a, st);
+    case 7: return lk_wgrad_launch_k<DT, 7>(a, st);
+    default: return lk_wgrad_launch_k<DT, 9>(a, st);
+  }
+}
+int srk_wgrad_lk_launch(const srk_wgrad_args& a, hipStream_t st) {
+  return a.dtype == SRK_BF16 ? lk_wgrad_launch_dt<SRK_BF16>(a, st) : lk_wgrad_launch_dt<SRK_F16>(a, st);
 }
