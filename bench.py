@@ -180,10 +180,9 @@ def csrc_sha():
     """Fingerprint of the kernel sources a PMC measurement belongs to (profiles/r3_pmc_traffic.json carries the same)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sr-pytorch-lightning_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith(".hip") or f == "srk_common.h":
-            with open(os.path.join(d, f), "rb") as fh:
-                h.update(fh.read())
+    for f in ("conv_igemm.hip", "srk_common.h"):          # the sources of the kernel the committed traffic figure belongs to
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
     return h.hexdigest()[:16]
 
 
