@@ -453,7 +453,32 @@ def main():
     step = infer_step if a.inference else train_step
     last = {}
     graphs = None
-    if mode != "eager":
+    ogs = None
+    nseg = T.auto_segments(model) if (ddp and not use_torch_ddp and mode == "segmented") else 1
+    if nseg > 1:
+        # large models on several ranks: the backward pass as `nseg` graph segments with the bucket all-reduces between them
+        # (trainer.OverlappedGraphStep); SRK_DDP_SEGMENTS=1 keeps the single backward graph
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    step()
+                gsync.detach()
+                ogs = T.OverlappedGraphStep(model, opt, nseg)
+                ogs.prepare(batch)
+                for _ in range(2):
+                    ogs.eager_step(batch)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            ogs.capture(batch)
+            last["out"] = ogs.loss
+            graphs, mode = tuple(ogs.graphs), f"segmented_overlap{ogs.nseg}"
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] segmented-overlap capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graphs, mode = None, "eager"
+            step = (lambda: ogs.eager_step(batch)) if (ogs is not None and ogs.gsync is not None) else step
+            torch.cuda.synchronize()
+    elif mode != "eager":
         try:
             with torch.cuda.stream(side):
                 for _ in range(11 if ddp else 3):
@@ -481,6 +506,8 @@ def main():
     def run_one():
         if graphs is None:
             last["out"] = step()
+        elif ogs is not None:
+            ogs.step()
         elif len(graphs) == 1:
             graphs[0].replay()
         else:

@@ -30,9 +30,10 @@ class EDSR(SRModel):
             rgb = self._channels == 3
             f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, self.sub_mean.neg_shift() if rgb else None,
                               self.compute_dtype)
+            f = ops.cut(f, keep=True)                            # (segment boundaries: identity unless ops.record_segments is active)
             r = f
             for blk in list(self.body)[:-1]:
-                r = blk.nhwc(r)
+                r = ops.cut(blk.nhwc(r))
             r = self.body[-1].nhwc(r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
             r = self.tail[0].nhwc(r)                              # upsampler, PixelShuffle fused into the conv store
             t = self.tail[1]

@@ -94,9 +94,10 @@ class RCAN(SRModel):
             rgb = self._channels == 3
             f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, self.sub_mean.neg_shift() if rgb else None,
                               self.compute_dtype)
+            f = ops.cut(f, keep=True)
             r = f
             for grp in list(self.body)[:-1]:
-                r = grp.nhwc(r)
+                r = ops.cut(grp.nhwc(r))
             r = self.body[-1].nhwc(r, res=f)
             r = self.tail[0].nhwc(r)
             t = self.tail[1]

@@ -63,13 +63,13 @@ class RDN(SRModel):
     def forward(self, x):
         """rdn.py:99-111.  No MeanShift in this model."""
         with ops.forward_scope(self._pack_group()):
-            f1 = ops.head_conv(x, self.SFENet1.weight, self.SFENet1.bias, None, self.compute_dtype)
+            f1 = ops.cut(ops.head_conv(x, self.SFENet1.weight, self.SFENet1.bias, None, self.compute_dtype), keep=True)
             x = ops.conv(f1, self.SFENet2.weight, self.SFENet2.bias)
             # `torch.cat(RDBs_out, 1)` (rdn.py:108) without the copy: every block writes its output into its channel slice of ONE
             # buffer, which the 1x1 global feature fusion then reads whole
             outs, cat = [], ops.SliceBuffer(len(self._RDBs))
             for i, blk in enumerate(self._RDBs):
-                x = blk.nhwc(x, dest=(cat, i))
+                x = ops.cut(blk.nhwc(x, dest=(cat, i)), keep=True)     # every block output also feeds the global fusion
                 outs.append(x)
             x = ops.conv(ops.concat_slices(cat, outs), self.GFF[0].weight, self.GFF[0].bias)    # 1x1 over D*G0 channels
             x = ops.conv(x, self.GFF[1].weight, self.GFF[1].bias, res=f1)                  # `x += f__1`

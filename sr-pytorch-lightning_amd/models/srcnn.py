@@ -9,6 +9,7 @@ from typing import Any
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from .srmodel import SRModel
 
 
@@ -21,4 +22,8 @@ class SRCNN(SRModel):
 
     def forward(self, x):
         x = F.interpolate(x, scale_factor=self._scale_factor, mode='bicubic')
-        return self._net(x)
+        for m in self._net:
+            x = m(x)
+            if isinstance(m, nn.ReLU):
+                x = ops.cut(x)              # segment boundary (identity unless ops.record_segments is active)
+        return x

@@ -101,9 +101,10 @@ class WDSR(SRModel):
             r = self._scale_factor
             s = ops.skip_conv(x, ws[0], self.skip[0].bias, mean, r, self.compute_dtype)
             f = ops.head_conv(x, ws[1], self.head[0].bias, mean, self.compute_dtype)
+            s, f = ops.cut(s, f, keep=True)
             k = 2
             for blk in self.body:
                 nb = len(blk.wn_convs())
-                f = blk.nhwc(f, ws[k:k + nb])
+                f = ops.cut(blk.nhwc(f, ws[k:k + nb]))
                 k += nb
             return ops.tail_conv(f, ws[k], self.tail[0].bias, res=s, post_add=mean, ps_r=r)

@@ -1035,6 +1035,66 @@ def conv_chain(x, convs, relus, scale=1.0):
 
 
 # --------------------------------------------------------------------------------------------
+# backward in SEGMENTS (multi-GPU: a bucket's all-reduce can start while the rest of backward still runs, also when the
+# step is replayed from hipGraphs -- a capture cannot be switched from inside `backward()`, so the cut has to be in the graph)
+# --------------------------------------------------------------------------------------------
+class record_segments:
+    """`with record_segments(every=k) as rec: loss = forward(...)`: while active, every k-th `ops.cut(...)` the model's forward
+    passes DETACHES its tensors (the rest of the forward continues on leaf copies that share the memory), which splits the
+    autograd graph into independent pieces; `rec.cuts` lists, in forward order, the (original, leaf) pairs of every kept cut.
+    `backward_segments(loss, rec.cuts, after)` then runs the backward pass piece by piece, last layers first."""
+
+    def __init__(self, every=1, limit=None):
+        self.every, self.count, self.cuts, self.limit, self.taken, self.keeps = max(1, int(every)), 0, [], limit, 0, 0
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "seg", None)
+        _TLS.seg = self
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.seg = self.prev
+
+
+def cut(*ts, keep=False):
+    """Segment boundary in a model's forward: identity, unless a `record_segments` block is active (then every k-th call
+    detaches).  `keep=True` marks tensors that are consumed again FAR downstream (the head's output that is added back after
+    the body, RDN's block outputs that all feed the global fusion, WDSR's skip branch): they are always detached while
+    recording -- a long skip that is not a leaf would drag its producer into the top segment's pass and a second time into
+    its own -- and their leaves collect the gradient contributions of every later consumer."""
+    rec = getattr(_TLS, "seg", None)
+    out = ts
+    if rec is not None:
+        if not keep:
+            rec.count += 1
+        else:
+            rec.keeps += 1
+        take = keep or (rec.count % rec.every == 0 and (rec.limit is None or rec.taken < rec.limit))
+        if take and any(t.requires_grad for t in ts):
+            if not keep:
+                rec.taken += 1
+            out = tuple(t.detach().requires_grad_(True) if t.requires_grad else t for t in ts)
+            rec.cuts.append([(o, l) for o, l in zip(ts, out) if l is not o])
+    return out[0] if len(out) == 1 else out
+
+
+def backward_segments(loss, cuts, after=None):
+    """`loss.backward()` as len(cuts) + 1 autograd passes: the part above the last cut first, then downwards cut by cut, each
+    pass started from the cut's original tensors with the gradients its leaves have collected.  `after(k)` is called behind
+    pass k (k = 0: the top of the network): the gradients of that piece's parameters are complete there."""
+    loss.backward()
+    if after is not None:
+        after(0)
+    for k, pairs in enumerate(reversed(cuts), 1):
+        roots = [o for o, l in pairs if l.grad is not None]
+        grads = [l.grad for o, l in pairs if l.grad is not None]
+        if roots:
+            torch.autograd.backward(roots, grads)
+        if after is not None:
+            after(k)
+
+
+# --------------------------------------------------------------------------------------------
 # weight normalisation of all weight-normed convs of a model in one launch per direction (csrc/wn.hip)
 # --------------------------------------------------------------------------------------------
 class _WnFn(torch.autograd.Function):

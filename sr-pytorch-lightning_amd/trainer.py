@@ -81,23 +81,33 @@ class GradSync:
     calls `reduce()` eagerly and then issues the optimizer step's three launches: no collective inside a capture).
     Replicas start identical: `broadcast()` sends rank 0's parameters and buffers."""
 
-    def __init__(self, module, overlap=True, bucket_bytes=32 << 20):
+    def __init__(self, module, overlap=True, bucket_bytes=32 << 20, groups=None):
+        """groups: optional list of parameter lists in the order their gradients become complete (the segments of a segmented
+        backward pass, `OverlappedGraphStep`): buckets then never straddle two groups and `group_buckets[k]` lists group k's."""
         self.module = module
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.overlap = bool(overlap)
-        order = list(reversed(self.params))              # backward reaches the last layers' parameters first
+        if groups is None:
+            order = list(reversed(self.params))          # backward reaches the last layers' parameters first
+            group_of = {p: 0 for p in order}
+        else:
+            order = [p for g in groups for p in g]
+            assert sorted(map(id, order)) == sorted(map(id, self.params)), "groups must partition the trainable parameters"
+            group_of = {p: k for k, g in enumerate(groups) for p in g}
         self.flat = None
         self.views = {}
         self.buckets = []                                # [start, end, [params]]
+        self.group_buckets = [[] for _ in range(1 if groups is None else len(groups))]
         total = sum(p.numel() for p in order)
         if order:
             self.flat = torch.zeros(total, dtype=torch.float32, device=order[0].device)
-            off, cur = 0, None
+            off, cur, cur_g = 0, None, None
             for p in order:
                 n = p.numel()
-                if cur is None or (cur[1] - cur[0]) * 4 + n * 4 > bucket_bytes:
-                    cur = [off, off, []]
+                if cur is None or group_of[p] != cur_g or (cur[1] - cur[0]) * 4 + n * 4 > bucket_bytes:
+                    cur, cur_g = [off, off, []], group_of[p]
+                    self.group_buckets[cur_g].append(len(self.buckets))
                     self.buckets.append(cur)
                 self.views[p] = self.flat[off:off + n].view_as(p)
                 cur[1] = off + n
@@ -200,6 +210,17 @@ class GradSync:
             self.flat.mul_(1.0 / self.world)
 
 
+def auto_segments(model, bucket_bytes=32 << 20):
+    """How many backward segments the graph-replayed multi-rank step uses: SRK_DDP_SEGMENTS if set, else one per ~32 MB of
+    gradients (at most 8) once there are more than 48 MB of them -- below that one all-reduce is latency-bound and extra
+    graph launches (~15 us each) cost more than the overlap returns."""
+    env = os.environ.get("SRK_DDP_SEGMENTS", "auto")
+    if env != "auto":
+        return max(1, int(env))
+    nbytes = sum(p.numel() * 4 for p in model.parameters() if p.requires_grad)
+    return 1 if nbytes <= (48 << 20) else min(8, -(-nbytes // bucket_bytes))
+
+
 def synthetic_batch(n, channels, lr_size, scale, seed, device):
     """The BASELINE workload: uniform [0,1) LR patches and HR targets."""
     g = torch.Generator().manual_seed(seed)
@@ -249,6 +270,8 @@ class GraphedStep:
     def __init__(self, model, net, optimizer, gsync, warm_steps=3):
         self.model, self.net, self.opt, self.gsync = model, net, optimizer, gsync
         self.warm_steps = int(warm_steps)
+        self.segments = auto_segments(model) if gsync is not None else 1
+        self.ogs = None                      # OverlappedGraphStep (several ranks, large models): all-reduces beside backward
         self.seen = 0
         self.graphs = None
         self.static = None
@@ -298,9 +321,31 @@ class GraphedStep:
         self.seen += 1
         same = self.static is not None and batch["lr"].shape == self.static["lr"].shape and batch["hr"].shape == self.static["hr"].shape
         if self.failed or self.seen <= self.warm_steps or (self.graphs is not None and not same):
+            if self.ogs is not None and self.ogs.gsync is not None:
+                return self.ogs.eager_step(batch)          # (the buckets were re-cut along the segments: its own eager form)
             return _eager_step(self.model, self.net, self.opt, self.gsync, None, batch)
         if self.graphs is not None and self._hyper() != self.hyper:
             self.graphs = None                   # lr / betas / ... changed: capture again with the new values
+        if self.graphs is None and self.segments > 1 and self.gsync is not None:
+            if self.ogs is None:                 # (two ordinary eager steps: the segments' parameter groups, the re-cut buckets)
+                self.gsync.detach()
+                self.ogs = OverlappedGraphStep(self.model, self.opt, self.segments)
+                return self.ogs.prepare(batch)
+            try:
+                torch.cuda.synchronize()
+                self.ogs.capture(batch)
+                self.static, self.graphs, self.hyper = self.ogs.static, tuple(self.ogs.graphs), self._hyper()
+                return self.ogs.step()
+            except Exception as e:  # noqa: BLE001
+                import sys
+                from . import ops
+                ops.discard_wgrads()
+                print(f"[trainer] segmented hipGraph capture failed ({type(e).__name__}: {e}); training continues eagerly", file=sys.stderr)
+                self.failed, self.graphs, self.static = True, None, None
+                torch.cuda.synchronize()
+                return self.ogs.eager_step(batch)
+        if self.ogs is not None and self.graphs is not None:
+            return self.ogs.step(batch)
         if self.graphs is None:
             try:
                 torch.cuda.synchronize()
@@ -320,6 +365,148 @@ class GraphedStep:
         if len(self.graphs) == 2:
             self.gsync.reduce()
             self.opt.step()
+        return self.loss.detach()
+
+
+class OverlappedGraphStep:
+    """The multi-rank training step as hipGraph replays WITH the gradient all-reduces overlapping backward.
+
+    `GraphedStep`'s multi-rank form replays forward + backward as one graph and only then starts the bucket all-reduces: the
+    communication is exposed (for EDSR-large, 172 MB of gradients, ~1 ms of a 13 ms batch-16 step on 8 GPUs).  A capture cannot be
+    ended and another begun from inside `loss.backward()`, so the cut is made in the autograd graph instead: the models mark block
+    boundaries with `ops.cut`, `ops.record_segments(every)` detaches there, and `ops.backward_segments` runs the backward pass as
+    K + 1 independent autograd passes.  Captured: ONE graph for forward + loss, one graph per backward segment (a shared memory
+    pool; each also packs the few gradients that were not written into the flat buffer directly).  Replayed: forward graph, then
+    per segment its graph followed by the ASYNCHRONOUS all-reduces of that segment's buckets (RCCL orders itself behind the
+    segment on the launch stream and runs beside the next segment's graph), then one wait and the optimizer step's three
+    launches.  The buckets are re-cut along the segments (`GradSync(groups=...)`), every rank the same way.
+
+    prepare(batch) is ONE ordinary eager training step (it finds which parameters each segment completes and re-cuts the buckets)."""
+
+    def __init__(self, model, optimizer, segments, bucket_bytes=32 << 20):
+        self.model, self.opt, self.want = model, optimizer, max(2, int(segments))
+        self.bucket_bytes = bucket_bytes
+        self.gsync = self.graphs = self.static = self.loss = None
+        self.every, self.limit = 1, None
+
+    def _forward(self, batch, every):
+        from . import ops
+        with ops.record_segments(every, limit=self.limit) as rec:
+            loss = self.model._calculate_losses(img_sr=self.model(batch["lr"]), img_hr=batch["hr"])["loss"]
+        return loss, rec
+
+    def prepare(self, batch):
+        """Counts the model's cut points, picks the stride, finds the parameter groups with one eager training step on `batch`
+        and builds the GradSync along them."""
+        from . import ops
+        with torch.no_grad():
+            _, rec = self._forward(batch, 1)
+        ncut = rec.count
+        # the model's mandatory cuts (long skip connections, `ops.cut(..., keep=True)`) count towards the wanted segments; the
+        # optional ones (block boundaries) are thinned to spread the rest evenly
+        self.limit = max(0, self.want - 1 - rec.keeps)
+        self.every = max(1, ncut // (self.limit + 1)) if ncut else 1
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        seen, groups = set(), []
+
+        def collect(k):
+            ops.flush_wgrads()
+            g = [p for p in params if p.grad is not None and id(p) not in seen]
+            seen.update(id(p) for p in g)
+            groups.append(g)
+        self.opt.zero_grad(set_to_none=True)
+        loss, rec = self._forward(batch, self.every)
+        ops.backward_segments(loss, rec.cuts, after=collect)
+        rest = [p for p in params if id(p) not in seen]           # parameters without a gradient this step: one more group at the end
+        groups.append(rest)                                       # (empty groups stay: group k = segment k)
+        if dist.is_initialized() and dist.get_world_size() > 1:   # the first step's gradients still have to be averaged
+            for p in params:
+                if p.grad is not None:
+                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                    p.grad.div_(dist.get_world_size())
+        self.opt.step()
+        self.groups = groups
+        self.gsync = GradSync(self.model, overlap=False, bucket_bytes=self.bucket_bytes, groups=groups)
+        return loss.detach()
+
+    def _reduce_group(self, k, works):
+        for i in self.gsync.group_buckets[k] if k < len(self.gsync.group_buckets) else ():
+            works.append(self.gsync._reduce_bucket(i, True))
+
+    def _finish(self, works):
+        for w in works:
+            w.wait()
+        if not self.gsync._avg and self.gsync.world > 1:
+            self.gsync.flat.mul_(1.0 / self.gsync.world)
+        self.opt.step()
+
+    def eager_step(self, batch):
+        """The same step launch by launch (warm-up, batches of another shape)."""
+        from . import ops
+        self.opt.zero_grad(set_to_none=True)
+        loss, rec = self._forward(batch, self.every)
+        works = []
+
+        def after(k):
+            ops.flush_wgrads()
+            with torch.no_grad():
+                for i in (self.gsync.group_buckets[k] if k < len(self.gsync.group_buckets) else ()):
+                    self.gsync._pack_bucket(i)
+            self._reduce_group(k, works)
+        ops.backward_segments(loss, rec.cuts, after=after)
+        with torch.no_grad():
+            for k in range(len(rec.cuts) + 1, len(self.gsync.group_buckets)):      # the group of gradient-less parameters
+                for i in self.gsync.group_buckets[k]:
+                    self.gsync._pack_bucket(i)
+                self._reduce_group(k, works)
+        self._finish(works)
+        return loss.detach()
+
+    def capture(self, batch, capture_error_mode="thread_local"):
+        from . import ops
+        self.static = {"lr": batch["lr"].clone(), "hr": batch["hr"].clone()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        self.opt.zero_grad(set_to_none=True)
+        gf = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gf, stream=side, capture_error_mode=capture_error_mode):
+            loss, rec = self._forward(self.static, self.every)
+        pool = gf.pool()
+        graphs = [gf]
+        cuts = rec.cuts
+        nseg = len(cuts) + 1
+        for k in range(nseg):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, pool=pool, capture_error_mode=capture_error_mode):
+                if k == 0:
+                    loss.backward()
+                else:
+                    pairs = cuts[nseg - 1 - k]
+                    roots = [o for o, l in pairs if l.grad is not None]
+                    if roots:
+                        torch.autograd.backward(roots, [l.grad for o, l in pairs if l.grad is not None])
+                ops.flush_wgrads()
+                with torch.no_grad():
+                    ks = [k] if k < nseg - 1 else list(range(k, len(self.gsync.group_buckets)))
+                    for kk in ks:
+                        for i in self.gsync.group_buckets[kk]:
+                            self.gsync._pack_bucket(i)
+            graphs.append(g)
+        self.graphs, self.loss, self.nseg = graphs, loss, nseg
+        self._keep = (rec, cuts)                         # the cut tensors are the graphs' static memory
+
+    def step(self, batch=None):
+        if batch is not None:
+            self.static["lr"].copy_(batch["lr"], non_blocking=True)
+            self.static["hr"].copy_(batch["hr"], non_blocking=True)
+        self.graphs[0].replay()
+        works = []
+        for k in range(self.nseg):
+            self.graphs[1 + k].replay()
+            ks = [k] if k < self.nseg - 1 else range(k, len(self.gsync.group_buckets))
+            for kk in ks:
+                self._reduce_group(kk, works)
+        self._finish(works)
         return self.loss.detach()
 
 

@@ -94,3 +94,50 @@ def test_pack_reduce_form_matches_full_batch_gradient(tmp_path):
     for a, b, r in zip(g0, g1, ref):
         assert torch.equal(a, b)
         assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-12
+
+
+def _worker_segments(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import sr_amd
+    from sr_amd import trainer as T
+    T.init_distributed("cpu")
+    torch.manual_seed(0)
+    m = sr_amd.SRCNN(scale_factor=2, optimizer="SGD")
+    for t in list(m.parameters()):
+        torch.distributed.broadcast(t.data, src=0)
+    opt = m.configure_optimizers()[0]
+    ogs = T.OverlappedGraphStep(m, opt, segments=3, bucket_bytes=4096)
+    full = [T.synthetic_batch(4, 3, 16, 2, 100 + s, "cpu") for s in range(3)]
+    for i, b in enumerate(full):
+        sh = {"lr": b["lr"][rank * 2:(rank + 1) * 2], "hr": b["hr"][rank * 2:(rank + 1) * 2]}
+        if i == 0:
+            ogs.prepare(sh)                       # the step that finds the segments' parameter groups
+            assert len(ogs.groups) == 4 and [len(g) for g in ogs.groups] == [2, 2, 2, 0], [len(g) for g in ogs.groups]
+        else:
+            ogs.eager_step(sh)                    # segment by segment, the bucket all-reduces launched in between
+    torch.save({k: v.clone() for k, v in m.state_dict().items()}, os.path.join(out, f"seg_r{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_segmented_backward_two_ranks_equals_single_process(tmp_path):
+    """trainer.OverlappedGraphStep's launch-by-launch form on 2 gloo ranks (the backward pass of SRCNN cut into three autograd
+    passes at its `ops.cut` points, each followed by the asynchronous all-reduces of the buckets it completed): identical replicas,
+    equal to one process at twice the batch."""
+    port = _free_port()
+    mp.spawn(_worker_segments, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "seg_r0.pt"), torch.load(tmp_path / "seg_r1.pt")
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"replicas diverged at {k}"
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(v, None)
+    import sr_amd
+    from sr_amd import trainer as T
+    torch.manual_seed(0)
+    m = sr_amd.SRCNN(scale_factor=2, optimizer="SGD")
+    tr = T.Trainer(device="cpu", max_steps=3)
+    tr.fit(m, [T.synthetic_batch(4, 3, 16, 2, 100 + s, "cpu") for s in range(3)])
+    for k, v in m.state_dict().items():
+        assert torch.allclose(v, a[k], rtol=1e-5, atol=1e-7), k

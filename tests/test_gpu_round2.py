@@ -297,11 +297,11 @@ from sr_amd import trainer as T
 rank, world, local = T.init_distributed("cuda", force=True)
 dev = torch.device("cuda", local)
 torch.manual_seed(0)
-m = sr_amd.EDSR(n_feats=64, n_resblocks=2, res_scale=0.1, scale_factor=2, precision="bf16").to(dev)
+mode = {mode!r}
+m = sr_amd.EDSR(n_feats=64, n_resblocks=4 if mode == "segments" else 2, res_scale=0.1, scale_factor=2, precision="bf16").to(dev)
 g = torch.Generator().manual_seed(5)
 full = [{{"lr": torch.rand(4, 3, 24, 24, generator=g), "hr": torch.rand(4, 3, 48, 48, generator=g)}} for _ in range(6)]
 per = 4 // world
-mode = {mode!r}
 gs = T.GradSync(m, overlap=(mode != "pack_reduce"), bucket_bytes=64 << 10)
 gs.broadcast()
 opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, fused=True)
@@ -313,6 +313,16 @@ if mode == "graphed":
     for b in full:
         gstep({{k: v[rank * per:(rank + 1) * per].to(dev) for k, v in b.items()}})
     assert gstep.graphs is not None and len(gstep.graphs) == 2 and not gstep.failed
+    full = []
+if mode == "segments":
+    # large-model form: the backward pass as three graph segments with the bucket all-reduces issued between them
+    os.environ["SRK_DDP_SEGMENTS"] = "3"
+    opt = m.configure_optimizers()[0]
+    gstep = T.GraphedStep(m, m, opt, gs, warm_steps=2)
+    for b in full:
+        gstep({{k: v[rank * per:(rank + 1) * per].to(dev) for k, v in b.items()}})
+    assert gstep.ogs is not None and gstep.ogs.nseg == 3 and len(gstep.graphs) == 4 and not gstep.failed, (gstep.ogs and gstep.ogs.nseg, gstep.failed)
+    assert len(gstep.ogs.gsync.group_buckets) >= 3 and all(gstep.ogs.gsync.group_buckets[k] for k in range(3))
     full = []
 for b in full:
     sh = {{k: v[rank * per:(rank + 1) * per].to(dev) for k, v in b.items()}}
@@ -332,7 +342,7 @@ torch.distributed.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["hooks", "pack_reduce", "graphed"])
+@pytest.mark.parametrize("mode", ["hooks", "pack_reduce", "graphed", "segments"])
 def test_gradsync_over_rccl(A, tmp_path, mode):
     """A HIP EDSR trains 6 steps under trainer.GradSync on an `nccl` (= RCCL) process group: 1 rank always (the
     collective path itself), 2 ranks when the box has 2 GPUs (replica equality).  The result must equal the same
@@ -354,17 +364,17 @@ def test_gradsync_over_rccl(A, tmp_path, mode):
             assert torch.equal(sds[0][k], s[k]), f"replicas diverged at {k}"
     # the same three steps in this process, no process group
     torch.manual_seed(0)
-    m = A.EDSR(n_feats=64, n_resblocks=2, res_scale=0.1, scale_factor=2, precision="bf16").cuda()
+    m = A.EDSR(n_feats=64, n_resblocks=4 if mode == "segments" else 2, res_scale=0.1, scale_factor=2, precision="bf16").cuda()
     g = torch.Generator().manual_seed(5)
     full = [{"lr": torch.rand(4, 3, 24, 24, generator=g), "hr": torch.rand(4, 3, 48, 48, generator=g)} for _ in range(6)]
-    opt = m.configure_optimizers()[0] if mode == "graphed" else torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, fused=True)
+    opt = m.configure_optimizers()[0] if mode in ("graphed", "segments") else torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, fused=True)
     for b in full:
         opt.zero_grad(set_to_none=True)
         m._calculate_losses(img_sr=m(b["lr"].cuda()), img_hr=b["hr"].cuda())["loss"].backward()
         opt.step()
     for k, v in m.state_dict().items():
         dv = (v.float().cpu() - sds[0][k]).abs()
-        if mode == "graphed":
+        if mode in ("graphed", "segments"):
             # replayed steps vs launch-by-launch steps: the same kernels, but fp32 atomics of the small weight gradients and
             # Adam's lr-sized moves on near-zero gradients let single weights part by a few steps' worth
             assert float(dv.max()) <= 6.5e-3 and float(dv.mean()) <= 3e-4, (k, float(dv.max()), float(dv.mean()))
