@@ -444,36 +444,39 @@ __global__ __launch_bounds__(512) void pw_bwd_kernel(const srk_pw_bwd_args a, un
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// backward (weights): dW2[hid][z] = sum_p h[p][hid] gz[p][z],  dW1[hid][in] = sum_p gh[p][hid] x[p][in],  db1[hid] = sum_p gh[p][hid]
-// Neither h nor gh exists in HBM: a workgroup owns ONE slice of 64 hidden channels (its W1 / W2^T fragments stay in registers for
-// the whole launch) and a range of pixels, which it walks in tiles of 128.  Per tile: x and gz arrive by LDS-DMA as images in the
-// conv kernels' swizzled format (double-buffered); phase 1 re-computes the slice of h and gh for the tile (lane = pixel) and writes
-// both as 16-bit images; phase 2 reads the four images with the transposing LDS read (K = pixels) and accumulates the slice's
-// rows of dW2 and dW1 in registers.  At the end every workgroup stores its partial sums to its own slab (no atomics: fixed order,
-// reproducible); pw_wgrad_finalize_kernel adds the slabs of the pixel ranges.
-//   wave w, phase 1: pixel block w & 3, hidden 32-row block w >> 2                      16 MFMAs per tile
-//           phase 2: 64 x 64 tile w % NT64 of [dW2 | dW1], K part w / NT64               16 MFMAs per tile
+// backward (weights): dW2[hid][z] = sum_p h[p][hid] gz[p][z],  dW1[hid][in] = sum_p gh[p][hid] x[p][in],  db1[hid] = sum_p gh[p][hid],
+// db2[z] = sum_p gz[p][z].  Neither h nor gh exists in HBM: a workgroup owns TWO slices (128 hidden channels) and a range of pixels,
+// which it walks in tiles of 64; x and gz arrive by LDS-DMA as images in the conv kernels' swizzled format (three buffers).
+// The eight waves are PRODUCERS and CONSUMERS one tile apart (one of each per SIMD, so one's vector work runs beside the other's MFMAs):
+//   waves 0-3, tile t    : re-compute h and gh of the two slices for the tile (lane = pixel; the W1 / W2^T fragments of the wave's two
+//                          32-row blocks stay in registers for the whole launch), write both as 16-bit images        32 MFMAs per tile
+//   waves 4-7, tile t - 1: read the four images with the transposing LDS read (K = pixels) and accumulate the slices' rows of
+//                          dW2 and dW1 in registers (each wave the same 64-column tile of both slices)               32 MFMAs per tile
+// One workgroup barrier per tile; 32 KB of DMA per 2k MFMA cycles (the one-slice version needed 64 KB: at the ~31 B/clk a CU accepts).
+// At the end every workgroup stores its partial sums to its own slab (no atomics: fixed order, reproducible);
+// pw_wgrad_finalize_kernel adds the slabs of the pixel ranges.
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int DT, int KC1, int NRB>
 __global__ __launch_bounds__(512) void pw_wgrad_kernel(const srk_pw_wgrad_args a, unsigned x_bytes, unsigned gz_bytes, int NR, int tq, int trem) {
   typedef DTraits<DT> Tr;
   typedef PwCfg<KC1, NRB> C;
-  constexpr int TP = 128;                                        // pixels per tile
-  constexpr int PLANE = TP * 128;                                // one 64-channel block of a tile: 16 KB
+  constexpr int TP = 64;                                         // pixels per tile
+  constexpr int PLANE = TP * 128;                                // one 64-channel block of a tile: 8 KB
   constexpr int XPL = C::RI / 64, ZPL = C::R2 / 64;              // planes of x / gz
-  constexpr int BUF = (XPL + ZPL) * PLANE;
-  constexpr int NT64 = XPL + ZPL, KSPLIT = 8 / NT64, ROWS = 8 / KSPLIT;      // phase 2: tiles, K parts, 16-pixel rows per part
+  constexpr int BUF = (XPL + ZPL) * PLANE, NXB = 3;
+  constexpr int HB = 4 * PLANE;                                  // h (2 slices) | gh (2 slices) of one tile
+  constexpr int NTS = XPL + ZPL;                                 // 64 x 64 tiles of [dW2 | dW1] per slice
+  constexpr int TPW = 2 * NTS / 4;                               // ... per consumer wave
   constexpr int KCZ = NRB * 2;
-  constexpr int PPW = (XPL + ZPL) * 16 / 8;                      // DMA pieces per wave and tile
+  constexpr int PPW = (XPL + ZPL) * 8 / 8;                       // DMA pieces per wave and tile (8 pieces per plane)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const hs = smem + 2 * BUF;                               // h image [128 px][64 hidden]
-  char* const gs = hs + PLANE;                                   // gh image
+  char* const hbase = smem + NXB * BUF;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int NS = a.Chid >> 6;
-  const int s = blockIdx.x % NS, rg = blockIdx.x / NS;
+  const int NSP = a.Chid >> 7;                                   // slice pairs
+  const int sp = blockIdx.x % NSP, rg = blockIdx.x / NSP;
   const long long P = a.P;
   const int t0 = rg * tq + min(rg, trem), nt = tq + (rg < trem ? 1 : 0);
 
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(const srk_pw_wgrad_args a
   auto dma_tile = [&](int tile, int b) {
 #pragma unroll
     for (int k = 0; k < PPW; ++k) {
-      const int q = wave * PPW + k, plane = q >> 4, pc = q & 15;
+      const int q = wave * PPW + k, plane = q >> 3, pc = q & 7;
       const int pl = 8 * pc + (lane >> 3), c8 = (lane & 7) ^ swz(pl & 15);
       const long long p = (long long)tile * TP + pl;
       const bool isx = plane < XPL;
@@ -493,170 +496,178 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(const srk_pw_wgrad_args a
     }
   };
 
-  // ---- this wave's weight fragments (phase 1: hidden rows 32 rb .. + 32 of the slice) and bias, for the whole launch ----------
-  const int pb = wave & 3, rb = wave >> 2;
+  const bool producer = wave < 4;
   const int cst_bytes = (a.Chid * 4 + 1023) / 1024 * 1024;
-  const char* const slice = reinterpret_cast<const char*>(a.wpk) + cst_bytes + (size_t)s * C::BWD_SLICE;
-  i32x4 w1r[KC1], w2r[KCZ];
+  // Both roles run the SAME sequence of nt + 1 steps, each opened by `step_sync` (wait for the own DMA pieces, workgroup barrier, issue
+  // the next tile's pieces); the role bodies are separate code paths so that the register allocation is the larger of the two, not
+  // their sum (producers: 128 registers of weight fragments; consumers: 128 accumulator registers).
+  auto step_sync = [&](int st) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // tile st landed; h / gh of tile st - 1 written; tile st - 2 read
+    if (st + 1 < nt) dma_tile(t0 + st + 1, (st + 1) % NXB);
+  };
+  if (producer) {
+    // ---- weight fragments and bias of the wave's two 32-row blocks (global row block 2 rq + u of the 4: slice rbg >> 1) -------------
+    const int pb = wave & 1, rq = (wave >> 1) & 1;
+    i32x4 w1r[2][KC1], w2r[2][KCZ];
+    float b1r[2][16];
 #pragma unroll
-  for (int j = 0; j < KC1; ++j) w1r[j] = gload16(slice + (((2 * j + h) * 64 + rb * 32 + r) << 4));
+    for (int u = 0; u < 2; ++u) {
+      const int rbg = 2 * rq + u, sl = rbg >> 1, rb = rbg & 1;
+      const char* const slice = reinterpret_cast<const char*>(a.wpk) + cst_bytes + (size_t)(2 * sp + sl) * C::BWD_SLICE;
 #pragma unroll
-  for (int j = 0; j < KCZ; ++j) w2r[j] = gload16(slice + C::W1_BYTES + (((2 * j + h) * 64 + rb * 32 + r) << 4));
-  float b1r[16], bsum[16];
-  {
-    const float* b1 = reinterpret_cast<const float*>(a.wpk) + s * 64 + (rb * 2 + h) * 16;
+      for (int j = 0; j < KC1; ++j) w1r[u][j] = gload16(slice + (((2 * j + h) * 64 + rb * 32 + r) << 4));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { b1r[q] = b1[q]; bsum[q] = 0.f; }
-  }
-  asm volatile("" : "+v"(w1r[0]), "+v"(w2r[0]), "+v"(b1r[0]));       // (the loads are waited for here, before any hidden DMA is queued)
+      for (int j = 0; j < KCZ; ++j) w2r[u][j] = gload16(slice + C::W1_BYTES + (((2 * j + h) * 64 + rb * 32 + r) << 4));
+      const float* b1 = reinterpret_cast<const float*>(a.wpk) + (2 * sp + sl) * 64 + (rb * 2 + h) * 16;
 #pragma unroll
-  for (int j = 1; j < KC1; ++j) asm volatile("" : "+v"(w1r[j]));
-#pragma unroll
-  for (int j = 1; j < KCZ; ++j) asm volatile("" : "+v"(w2r[j]));
-#pragma unroll
-  for (int q = 1; q < 16; ++q) asm volatile("" : "+v"(b1r[q]));
-
-  const int t2 = wave % NT64, kq = wave / NT64;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][o][e] = 0.f;
-  int aoff[2][2], boff[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) aoff[i][rd] = boff[i][rd] = tr_lane_off(0, rd, i, lane);
-  // db2 = sum_p gz: the slice-0 workgroups' dW2 waves add up the gz fragments they fetch anyway (lane = channel, 8 pixels per read)
-  const bool do_db2 = s == 0 && t2 < ZPL && a.db2p != nullptr;
-  float dbz[2] = {0.f, 0.f};
-  const char* const a_img = t2 < ZPL ? hs : gs;                  // dW2 tiles read h, dW1 tiles read gh
-  const int b_plane = t2 < ZPL ? XPL + t2 : t2 - ZPL;            // ... against gz plane t2 / x plane t2 - ZPL
-
-  const int pl = 32 * pb + r, g = swz(pl & 15);
-  if (nt > 0) dma_tile(t0, 0);
-#pragma unroll 1
-  for (int it = 0; it < nt; ++it) {
-    const char* const B0 = smem + (it & 1) * BUF;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // tile `it` has landed ...
-    __builtin_amdgcn_s_barrier();                                // ... for every wave; phase 2 of the previous tile is over
-    if (it + 1 < nt) dma_tile(t0 + it + 1, (it + 1) & 1);
-    // ---- phase 1 ------------------------------------------------------------------------------------------------------------
-    {
-      f32x16 pre, gh;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { pre[q] = b1r[q]; gh[q] = 0.f; }
-      const char* const xp = B0 + (pl << 7);
-#pragma unroll
-      for (int j = 0; j < KC1; ++j)
-        pre = Tr::mma(w1r[j], lds_read16(xp + (j >> 2) * PLANE + (((((2 * j) & 7) + h) ^ g) << 4)), pre);
-      const char* const zp = B0 + XPL * PLANE + (pl << 7);
-#pragma unroll
-      for (int j = 0; j < KCZ; ++j)
-        gh = Tr::mma(w2r[j], lds_read16(zp + (j >> 2) * PLANE + (((((2 * j) & 7) + h) ^ g) << 4)), gh);
-      const bool valid = (long long)(t0 + it) * TP + pl < P;     // pixels beyond P: x and gz are zeros, but h = relu(b1) is not
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float hv[8], gv[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const bool on = pre[8 * m + t] > 0.f;
-          hv[t] = (on && valid) ? pre[8 * m + t] : 0.f;
-          gv[t] = on ? gh[8 * m + t] : 0.f;
-          bsum[8 * m + t] += gv[t];
-        }
-        const int off = (pl << 7) + (((4 * rb + 2 * m + h) ^ g) << 4);
-        lds_write16(hs + off, i32x4{(int)pack2<DT>(hv[0], hv[1]), (int)pack2<DT>(hv[2], hv[3]), (int)pack2<DT>(hv[4], hv[5]), (int)pack2<DT>(hv[6], hv[7])});
-        lds_write16(gs + off, i32x4{(int)pack2<DT>(gv[0], gv[1]), (int)pack2<DT>(gv[2], gv[3]), (int)pack2<DT>(gv[4], gv[5]), (int)pack2<DT>(gv[6], gv[7])});
-      }
+      for (int q = 0; q < 16; ++q) b1r[u][q] = b1[q];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // ---- phase 2 ------------------------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int rr = 0; rr < ROWS; ++rr) {
-      const int row = kq * ROWS + rr;
-      i32x4 af[2], bf[2];
+    for (int u = 0; u < 2; ++u) {                                // (the loads are waited for here, before any hidden DMA is queued)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = tr_read2(a_img + row * 2048 + aoff[i][0], a_img + row * 2048 + aoff[i][1]);
-        bf[i] = tr_read2(B0 + b_plane * PLANE + row * 2048 + boff[i][0], B0 + b_plane * PLANE + row * 2048 + boff[i][1]);
-      }
+      for (int j = 0; j < KC1; ++j) asm volatile("" : "+v"(w1r[u][j]));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < KCZ; ++j) asm volatile("" : "+v"(w2r[u][j]));
 #pragma unroll
-        for (int o = 0; o < 2; ++o) acc[i][o] = Tr::mma(af[i], bf[o], acc[i][o]);
-      if (do_db2) {
+      for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(b1r[u][q]));
+    }
+    const int pl = 32 * pb + r, g = swz(pl & 15);
+    if (nt > 0) dma_tile(t0, 0);
+#pragma unroll 1
+    for (int st = 0; st <= nt; ++st) {
+      step_sync(st);
+      if (st < nt) {
+        const char* const B0 = smem + (st % NXB) * BUF;
+        char* const hb = hbase + (st & 1) * HB;
+        const char* const xp = B0 + (pl << 7);
+        const char* const zp = B0 + XPL * PLANE + (pl << 7);
+        const bool valid = (long long)(t0 + st) * TP + pl < P;   // pixels beyond P: x and gz are zeros, but h = relu(b1) is not
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-          const int qw[4] = {bf[o].x, bf[o].y, bf[o].z, bf[o].w};
+        for (int u = 0; u < 2; ++u) {
+          const int rbg = 2 * rq + u, sl = rbg >> 1, rb = rbg & 1;
+          f32x16 pre, gh;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float f0, f1;
-            unpack2<DT>((uint32_t)qw[e], f0, f1);
-            dbz[o] += f0 + f1;
+          for (int q = 0; q < 16; ++q) { pre[q] = b1r[u][q]; gh[q] = 0.f; }
+#pragma unroll
+          for (int j = 0; j < KC1; ++j)
+            pre = Tr::mma(w1r[u][j], lds_read16(xp + (j >> 2) * PLANE + (((((2 * j) & 7) + h) ^ g) << 4)), pre);
+#pragma unroll
+          for (int j = 0; j < KCZ; ++j)
+            gh = Tr::mma(w2r[u][j], lds_read16(zp + (j >> 2) * PLANE + (((((2 * j) & 7) + h) ^ g) << 4)), gh);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            float hv[8], gv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const bool on = pre[8 * m + t] > 0.f;
+              hv[t] = (on && valid) ? pre[8 * m + t] : 0.f;
+              gv[t] = on ? gh[8 * m + t] : 0.f;
+            }
+            const int off = sl * PLANE + (pl << 7) + (((4 * rb + 2 * m + h) ^ g) << 4);
+            lds_write16(hb + off, i32x4{(int)pack2<DT>(hv[0], hv[1]), (int)pack2<DT>(hv[2], hv[3]), (int)pack2<DT>(hv[4], hv[5]), (int)pack2<DT>(hv[6], hv[7])});
+            lds_write16(hb + 2 * PLANE + off, i32x4{(int)pack2<DT>(gv[0], gv[1]), (int)pack2<DT>(gv[2], gv[3]), (int)pack2<DT>(gv[4], gv[5]), (int)pack2<DT>(gv[6], gv[7])});
           }
         }
       }
     }
-  }
-
-  // ---- the K parts of a tile are added through LDS (fixed order), part 0 stores the workgroup's slab -----------------------------
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  float* const red = reinterpret_cast<float*>(smem);             // [KSPLIT - 1][NT64][64 regs][64 lanes]
-  if (kq > 0) {
+  } else {
+    // ---- consumers: accumulator tiles tt = cw + 4 u: slice tt / NTS, column tile tt % NTS of [gz planes | x planes] -------------------
+    const int cw = wave & 3;
+    f32x16 acc[TPW][2][2];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[u][i][o][e] = 0.f;
+    int toff[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int o = 0; o < 2; ++o)
+      for (int rd = 0; rd < 2; ++rd) toff[i][rd] = tr_lane_off(0, rd, i, lane);
+    float dbz[2] = {0.f, 0.f}, dbh[TPW][2];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[(((kq - 1) * NT64 + t2) * 64 + (i * 2 + o) * 16 + e) * 64 + lane] = acc[i][o][e];
-  }
-  // db1: the lanes of a half hold the same 16 hidden channels for 32 different pixels
+    for (int u = 0; u < TPW; ++u) dbh[u][0] = dbh[u][1] = 0.f;
+    if (nt > 0) dma_tile(t0, 0);
+#pragma unroll 1
+    for (int st = 0; st <= nt; ++st) {
+      step_sync(st);
+      if (st >= 1) {
+        const char* const B0 = smem + ((st - 1) % NXB) * BUF;
+        const char* const hb = hbase + ((st - 1) & 1) * HB;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    float v = bsum[q];
+        for (int rr = 0; rr < TP / 16; ++rr) {
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    bsum[q] = v;
-  }
-  float* const bred = red + (KSPLIT - 1) * NT64 * 64 * 64;       // [4 pixel blocks][64 hidden] | [KSPLIT][ZPL tiles][2 blocks][64 lanes]
-  if (do_db2) {
+          for (int u = 0; u < TPW; ++u) {
+            const int tt = cw + 4 * u, sl = tt / NTS, t2 = tt % NTS;
+            const bool is2 = t2 < ZPL;                            // dW2 tiles read h against gz plane t2, dW1 tiles gh against x plane t2 - ZPL
+            const char* const a_img = hb + (is2 ? 0 : 2 * PLANE) + sl * PLANE + rr * 2048;
+            const char* const b_img = B0 + (is2 ? XPL + t2 : t2 - ZPL) * PLANE + rr * 2048;
+            i32x4 af[2], bf[2];
 #pragma unroll
-    for (int o = 0; o < 2; ++o) bred[256 + ((kq * ZPL + t2) * 2 + o) * 64 + lane] = dbz[o];
-  }
-  if (r == 0) {
+            for (int i = 0; i < 2; ++i) {
+              af[i] = tr_read2(a_img + toff[i][0], a_img + toff[i][1]);
+              bf[i] = tr_read2(b_img + toff[i][0], b_img + toff[i][1]);
+            }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bred[pb * 64 + pw_hid_of_row(32 * rb + 8 * (q >> 2) + 4 * h + (q & 3))] = bsum[q];
-  }
-  __syncthreads();
-  if (kq == 0) {
-    const int hq = lane >> 5;
-    const bool is2 = t2 < ZPL;
-    const int ncol = is2 ? C::R2 : C::RI;
-    float* const slab = (is2 ? a.dw2p : a.dw1p) + (size_t)rg * a.Chid * ncol;
-    const int col0 = 64 * (is2 ? t2 : t2 - ZPL);
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+              for (int o = 0; o < 2; ++o) acc[u][i][o] = Tr::mma(af[i], bf[o], acc[u][i][o]);
+            if (is2 && sl == 0 && sp == 0 && a.db2p != nullptr) { // db2 = sum_p gz: lane = channel, 8 pixels per read
 #pragma unroll
-      for (int o = 0; o < 2; ++o)
+              for (int o = 0; o < 2; ++o) {
+                const int qw[4] = {bf[o].x, bf[o].y, bf[o].z, bf[o].w};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[i][o][e];
+                for (int e = 0; e < 4; ++e) { float f0, f1; unpack2<DT>((uint32_t)qw[e], f0, f1); dbz[o] += f0 + f1; }
+              }
+            }
+            if (t2 == ZPL) {                                      // db1 = sum_p gh: from the fragments of the first x column tile's waves
 #pragma unroll
-          for (int k = 1; k < KSPLIT; ++k) v += red[(((k - 1) * NT64 + t2) * 64 + (i * 2 + o) * 16 + e) * 64 + lane];
-          const int row = 64 * s + 32 * i + 4 * hq + (e & 3) + 8 * (e >> 2);
-          slab[(size_t)row * ncol + col0 + 32 * o + (lane & 31)] = v;
+              for (int i = 0; i < 2; ++i) {
+                const int qw[4] = {af[i].x, af[i].y, af[i].z, af[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float f0, f1; unpack2<DT>((uint32_t)qw[e], f0, f1); dbh[u][i] += f0 + f1; }
+              }
+            }
+          }
         }
-  }
-  if (tid < 64) a.db1p[(size_t)rg * a.Chid + 64 * s + tid] = bred[tid] + bred[64 + tid] + bred[128 + tid] + bred[192 + tid];
-  if (s == 0 && a.db2p != nullptr && tid < C::R2) {               // channel tid = 64 t + 32 o + c: lanes c and c + 32 hold the two K halves of a read
-    const int t = tid >> 6, o = (tid >> 5) & 1, c = tid & 31;
-    float v = 0.f;
+      }
+    }
+    // ---- the consumers store the workgroup's slab -----------------------------------------------------------------------------------
+    const int hq = lane >> 5;
 #pragma unroll
-    for (int k = 0; k < KSPLIT; ++k) v += bred[256 + ((k * ZPL + t) * 2 + o) * 64 + c] + bred[256 + ((k * ZPL + t) * 2 + o) * 64 + 32 + c];
-    a.db2p[(size_t)rg * C::R2 + tid] = v;
+    for (int u = 0; u < TPW; ++u) {
+      const int tt = cw + 4 * u, sl = tt / NTS, t2 = tt % NTS;
+      const bool is2 = t2 < ZPL;
+      const int ncol = is2 ? C::R2 : C::RI;
+      float* const slab = (is2 ? a.dw2p : a.dw1p) + (size_t)rg * a.Chid * ncol;
+      const int col0 = 64 * (is2 ? t2 : t2 - ZPL), row0 = 64 * (2 * sp + sl);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = row0 + 32 * i + 4 * hq + (e & 3) + 8 * (e >> 2);
+            slab[(size_t)row * ncol + col0 + 32 * o + (lane & 31)] = acc[u][i][o][e];
+          }
+      if (t2 == ZPL) {                                            // lanes l and l + 32 hold the two K halves of a read
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float v = dbh[u][i] + __shfl_xor(dbh[u][i], 32, 64);
+          if (lane < 32) a.db1p[(size_t)rg * a.Chid + row0 + 32 * i + lane] = v;
+        }
+      }
+      if (is2 && sl == 0 && sp == 0 && a.db2p != nullptr) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const float v = dbz[o] + __shfl_xor(dbz[o], 32, 64);
+          if (lane < 32) a.db2p[(size_t)rg * C::R2 + 64 * t2 + 32 * o + lane] = v;
+        }
+      }
+    }
   }
 }
 
@@ -772,7 +783,7 @@ __global__ void pw_pack_group_kernel(const srk_pw_pack_args* __restrict__ table)
 }
 
 bool pw_shape_ok(int Cin, int Chid, int CoutP) {
-  return ((Cin == 128 && CoutP == 128) || (Cin == 64 && CoutP == 64)) && Chid % 64 == 0 && Chid >= 256 && Chid <= 4096;
+  return ((Cin == 128 && CoutP == 128) || (Cin == 64 && CoutP == 64)) && Chid % 128 == 0 && Chid >= 256 && Chid <= 4096;
 }
 
 template <int DT, int KC1, int NRB> int pw_fwd_launch(const srk_pw_args& a, hipStream_t st) {
@@ -812,15 +823,13 @@ template <int DT, int KC1, int NRB> int pw_bwd_launch(const srk_pw_bwd_args& a, 
 
 template <int DT, int KC1, int NRB> int pw_wgrad_launch(const srk_pw_wgrad_args& a, hipStream_t st, int NR) {
   typedef PwCfg<KC1, NRB> C;
-  constexpr int PLANE = 128 * 128, NT64 = C::RI / 64 + C::R2 / 64, BUF = NT64 * PLANE, IMG = 2 * BUF + 2 * PLANE;
-  constexpr int RED = (8 / NT64 - 1) * NT64 * 64 * 64 * 4 + 1024 + 8 * 2 * 64 * 4;       // the end-of-launch reduction re-uses the image area
-  constexpr int LDS = IMG > RED ? IMG : RED;
+  constexpr int PLANE = 64 * 128, BUF = (C::RI / 64 + C::R2 / 64) * PLANE, LDS = 3 * BUF + 2 * 4 * PLANE;
   static_assert(LDS <= 160 * 1024, "LDS");
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<DT, KC1, NRB>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess) { srk_set_error("srk_pw_wgrad: cannot reserve LDS"); return (int)attr; }
-  const long long ntiles = (a.P + 127) / 128;
-  const int NS = a.Chid / 64;
+  const long long ntiles = (a.P + 63) / 64;
+  const int NS = a.Chid / 128;                                   // slice pairs
   hipLaunchKernelGGL((pw_wgrad_kernel<DT, KC1, NRB>), dim3((unsigned)(NS * NR)), dim3(512), LDS, st, a,
                      (unsigned)(a.P * a.x_pitch * 2), (unsigned)(a.P * a.gz_pitch * 2), NR, (int)(ntiles / NR), (int)(ntiles % NR));
   const long long fin = (long long)a.Chid * (C::RI + C::R2) / 4 + a.Chid + C::R2;
@@ -831,8 +840,8 @@ template <int DT, int KC1, int NRB> int pw_wgrad_launch(const srk_pw_wgrad_args&
 
 int pw_wgrad_ranges(long long P, int Chid) {
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
-  const long long ntiles = (P + 127) / 128;
-  long long nr = cus / (Chid / 64);
+  const long long ntiles = (P + 63) / 64;
+  long long nr = cus / (Chid / 128);
   if (nr < 1) nr = 1;
   if (nr > ntiles) nr = ntiles;
   return (int)nr;
