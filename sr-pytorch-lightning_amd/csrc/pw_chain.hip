@@ -20,6 +20,15 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
+// diagnostics build only (make stamp: -DSRK_PW_STAMPS=1, tools/stamp_pw.py): s_memtime of workgroup 0's waves 0 and 4 at the stages
+// of pw_fwd_kernel, into a __device__ array nothing else reads
+#if SRK_PW_STAMPS
+__device__ unsigned long long pw_stamp_buf[2][64];
+#define PW_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (i) < 64) pw_stamp_buf[threadIdx.x >> 8][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PW_STAMP(i) do { } while (0)
+#endif
+
 // MFMA row rho (0..63) of a 64-row hidden slice -> hidden channel inside the slice.  After a 32x32 MFMA lane half hh holds rows
 // 8i + 4hh + e (i, e = 0..3) in accumulator register 4i + e; the next GEMM wants lane half hh to supply channels 16j + 8hh + t
 // (t = 0..7) of K-step j.  So: block b = rho >> 5 feeds K-steps 2b (registers i = 0, 1) and 2b + 1 (i = 2, 3).
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
   const i32x4 wrsrc = make_rsrc4(a.wpk, w_bytes);
   const unsigned ring_lds = lds_addr_of(ring), cst_lds = lds_addr_of(cst);
   const unsigned cst_bytes = (unsigned)cst_pieces * 1024u;
+  PW_STAMP(0);
 
   auto dma_slice = [&](int s) {
     const unsigned dst = ring_lds + (unsigned)((s % NSLOT) * SL);
@@ -115,8 +125,11 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
   pw_dma_pixels<2 * KC1>(xrsrc, p0, P, a.x_pitch, a.x_coff, a.Cin, xs_lds, lane);
   dma_slice(0);
   dma_slice(1);
+  PW_STAMP(1);
   if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  PW_STAMP(2);
   __builtin_amdgcn_s_barrier();
+  PW_STAMP(3);
 
   i32x4 xf[KC1];
   {
@@ -202,6 +215,7 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
 #pragma unroll
     for (int d = 0; d < 16; ++d) pack_piece(d, hfa);
   }
+  PW_STAMP(4);
   for (int s = 0; s < NS; s += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -211,8 +225,11 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
         if (ss == 0) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else if (ss + 2 < NS) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PW_STAMP(8 + 4 * ss);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        PW_STAMP(9 + 4 * ss);
         if (ss >= 1 && ss + 3 < NS) dma_slice(ss + 3);           // into the slot slice ss - 1 left
+        PW_STAMP(10 + 4 * ss);
         const char* const w1 = ring + ((ss + 1) % NSLOT) * SL + lane_a;
         const char* const w2 = ring + (ss % NSLOT) * SL + C::W1_BYTES + lane_a2;
         if (ss + 1 < NS) {
@@ -221,9 +238,11 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
         } else {
           if (u == 0) stream(G1, w1, w2, hfa, hfb); else stream(G1, w1, w2, hfb, hfa);
         }
+        PW_STAMP(11 + 4 * ss);
       }
     }
   }
+  PW_STAMP(5);
 
   // ---- store: lane (pixel r, half h) holds channels 64 B + 32 h .. + 32 of its pixel ---------------------------------------------
   const long long p = p0 + r;
@@ -246,6 +265,7 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
         }
       }
   }
+  PW_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -918,3 +938,9 @@ extern "C" int srk_pw_wgrad(const srk_pw_wgrad_args* a, srk_stream_t stream) {
   if (a->Cin == 128) return a->dtype == SRK_BF16 ? pw_wgrad_launch<SRK_BF16, 8, 4>(*a, st, NR) : pw_wgrad_launch<SRK_F16, 8, 4>(*a, st, NR);
   return a->dtype == SRK_BF16 ? pw_wgrad_launch<SRK_BF16, 4, 2>(*a, st, NR) : pw_wgrad_launch<SRK_F16, 4, 2>(*a, st, NR);
 }
+
+#if SRK_PW_STAMPS
+extern "C" int srk_pw_read_stamps(unsigned long long* host128) {
+  return (int)hipMemcpyFromSymbol(host128, HIP_SYMBOL(pw_stamp_buf), sizeof(unsigned long long) * 128);
+}
+#endif
