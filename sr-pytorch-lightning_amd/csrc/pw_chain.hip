@@ -25,8 +25,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #if SRK_PW_STAMPS
 __device__ unsigned long long pw_stamp_buf[2][64];
 #define PW_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (i) < 64) pw_stamp_buf[threadIdx.x >> 8][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PW_STAMP2(i) do { if (blockIdx.x == 0 && (threadIdx.x & 127) == 0 && (i) < 64) pw_stamp_buf[threadIdx.x >> 7][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PW_STAMP(i) do { } while (0)
+#define PW_STAMP2(i) do { } while (0)
 #endif
 
 // MFMA row rho (0..63) of a 64-row hidden slice -> hidden channel inside the slice.  After a 32x32 MFMA lane half hh holds rows
@@ -63,7 +65,7 @@ template <int KC1, int NRB> struct PwCfg {
 
 // swizzle of the staged pixel tiles: 16-byte slot of chunk c of pixel r = c ^ f(r), chosen so that the 16 lanes one
 // ds_read_b128 group serves ({0-3,12-15,20-27} and its shifts) hit 16 different 16-byte columns of the 256-byte bank row
-template <int CHUNKS> SRK_DEV int pw_swz(int r) {
+template <int CHUNKS> SRK_DEV constexpr int pw_swz(int r) {
   if constexpr (CHUNKS >= 16) return r & 15;
   else return (r >> 1) & 7;        // 8 chunks (128 B) per pixel: two pixels per bank row
 }
@@ -266,6 +268,352 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
       }
   }
   PW_STAMP(6);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// forward, persistent form: 4 waves x 64 pixels (two 32-pixel column blocks per wave: every weight fragment read from LDS feeds
+// TWO MFMAs, which halves the LDS read traffic that bounded the 8 x 32 form -- there each wave read the whole 32 KB slice for 32
+// MFMAs of 32 cycles: 128 B / clk / CU, the LDS's whole bandwidth), one wave per SIMD with the conv-2 accumulators in the
+// accumulation registers.  A workgroup walks tiles blockIdx.x, + gridDim.x, ... and the weight ring NEVER drains between them: ring
+// element i = [W2 of slice i | W1 of slice i + 1] (what ONE iteration uses: conv 2 of slice i, then conv 1 of slice i + 1, which
+// for the last slice is slice 0 of the NEXT tile), and the next tile's pixels travel through the ring too, as two elements
+// (column block 0 / 1 of every wave) placed before the tile's last element and read into the (by then dead) input registers during
+// that iteration's conv 2.  The tile's results leave during the conv 1 that follows.  One barrier per iteration; the LDS-DMA pieces
+// of the elements that barrier frees are issued one per MFMA step instead of in a burst.
+// ------------------------------------------------------------------------------------------------------------------------------
+// MFMAs with the accumulator's register file chosen by hand (the compiler's own choice put BOTH accumulator sets of the persistent
+// forward into the accumulation registers and copied conv 1's out again for every pack: 64 extra instructions per iteration of a
+// stream that has five issue slots per MFMA).  The compiler cannot see an MFMA inside the asm, so it inserts no wait states for
+// it: the streams below keep every VALU / store read of an accumulator two or more MFMAs behind its last write, and MFMA -> MFMA
+// on the same accumulator needs none.
+// GUARD: the wait states a read of the result needs ride inside the statement -- for the accumulators that stay live across code the
+// register allocator may spill around (it puts a spill right behind the defining instruction; tools/isa_mfma_hazards.py checks
+// the listing for such reads)
+template <int DT, bool GUARD = false> SRK_DEV void pw_mma_v(f32x16& acc, i32x4 a, i32x4 b) {
+  if constexpr (GUARD) {
+    if constexpr (DT == SRK_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 12" : "+v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 12" : "+v"(acc) : "v"(a), "v"(b));
+  } else {
+    if constexpr (DT == SRK_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  }
+}
+template <int DT> SRK_DEV void pw_mma_vc(f32x16& acc, i32x4 a, i32x4 b, const f32x16& c) {   // acc = a b + c, acc and c different registers
+  if constexpr (DT == SRK_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
+}
+template <int V> struct pw_int { static constexpr int value = V; };
+template <int I, int N, class F> SRK_DEV void pw_static_for(F&& f) {
+  if constexpr (I < N) { f(pw_int<I>{}); pw_static_for<I + 1, N>(f); }
+}
+// the hidden LDS-DMA with the wave-uniform part of the address in the scalar offset (NOT part of the range check: a lane is
+// masked by voff = 0x80000000)
+SRK_DEV void dma16_hidden_s(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory", "m0");
+}
+template <int DT, int KC1, int NRB>
+__global__ __launch_bounds__(256) void pw_fwd2_kernel(const srk_pw_args a, unsigned x_bytes, unsigned out_bytes, unsigned w_bytes, int cst_pieces, int ntiles) {
+  typedef DTraits<DT> Tr;
+  typedef PwCfg<KC1, NRB> C;
+  constexpr int SL = C::FWD_SLICE, PPW = SL / 4096;               // 1 KB pieces per wave and ring element
+  constexpr int PX = 256, CHUNKS = 2 * KC1;
+  static_assert(C::W1_BYTES == C::W2_BYTES && PPW == KC1, "waves 0, 1 carry the W2 half of an element, waves 2, 3 the W1 half; a column block is one wave share");
+  constexpr int NA = 4 * NRB, NB = 2 * KC1, PF = 3, NBF = 4;
+  constexpr int PER_A = 8 / NRB, PER_B = (16 + KC1 - 2) / (KC1 - 1);
+  constexpr int NSTORE = 4 * NRB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ring = smem;
+  char* const cst = smem + 4 * SL;                               // b1 (permuted, Chid floats) | b2 (permuted, R2 floats)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int NS = a.Chid >> 6;
+  const long long P = a.P;
+  const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+  const int m = (ntiles - bid + G - 1) / G;                      // tiles of this workgroup
+
+  const i32x4 xrsrc = make_rsrc4(a.x, x_bytes);
+  // results leave by buffer stores (a lane outside the tile or the stored channels gets an out-of-range offset: every store is
+  // issued, which the hand-counted vmcnt waits rely on); the builtin, not asm: the data registers of a 16-byte store must not be
+  // rewritten in the next cycles, and only the compiler can see to that
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)out_bytes, 0x00020000);
+  const i32x4 wrsrc = make_rsrc4(a.wpk, w_bytes);
+  const unsigned ring_lds = lds_addr_of(ring), cst_lds = lds_addr_of(cst);
+  const int cst_bytes = cst_pieces * 1024;
+
+  // ---- the loader: ring position q -> (tile k, place u in the tile's cycle  E(0) .. E(NS-2), X0, X1, E(NS-1)) ----------------------
+  int ld_q = 0, ld_k = -1, ld_u = NS - 1;                         // the stream opens with tile 0's pixels and E(NS-1) (for its W1 of slice 0)
+  // per-lane parts of the addresses (everything else is wave-uniform and rides in the scalar offset): a pixel piece covers PPL
+  // pixels, lane -> pixel q = lane / CHUNKS of the piece and 16-byte slot lane % CHUNKS, which holds chunk slot ^ swz(pixel); the
+  // swizzle of pixel pc * PPL + q splits into a lane part and a piece part (K below).  ONE branch-free piece sequence serves
+  // weight and pixel elements (a branch per piece would cut the pinned MFMA stream into basic blocks, and the compiler then
+  // sinks the riding VALU work out of its steps): the element descriptor carries the differences.
+  constexpr int PPL = 64 / CHUNKS;
+  const int xq = lane / CHUNKS;
+  const unsigned x_row = (unsigned)((xq * a.x_pitch + a.x_coff) * 2);
+  const unsigned x_c0 = (unsigned)(((lane % CHUNKS) ^ pw_swz<CHUNKS>(xq)) << 4);
+  const unsigned w_lane = (unsigned)(lane * 16);
+  struct El {
+    i32x4 rsrc;                                                   // the pixels' or the weights' buffer
+    bool isx;                                                     // pixels (per-lane offset x_row + swizzled chunk) or weights (lane * 16)
+    int lim;                                                      // pixels that exist from the element's first one on (weights: all)
+    unsigned km, soff, sstep, dst;                                // swizzle mask (weights: 0), scalar offset of piece 0, its step per piece, LDS address
+  };
+  El cur, cur1, cur2;                                             // the elements whose pieces ride in the current iteration's stream
+  auto describe = [&](El& e) __attribute__((always_inline)) {
+    e.dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring_lds + (unsigned)((ld_q & 3) * SL + wave * (PPW * 1024))));
+    const bool isx = ld_u == NS - 1 || ld_u == NS || ld_k >= m;   // pixels of tile k + 1: this wave's column block ld_u - (NS - 1); past the
+    int src;                                                      // last tile every element is a masked transfer (zeros into a free slot)
+    if (isx) {
+      src = ld_k + 1 < m && ld_k < m ? (bid + (ld_k + 1) * G) * PX + wave * 64 + (ld_u - (NS - 1)) * 32 : -1;
+      const long long left = src < 0 ? 0 : P - src;
+      e.lim = __builtin_amdgcn_readfirstlane((int)(left > 64 ? 64 : left));
+      e.soff = (unsigned)__builtin_amdgcn_readfirstlane(src < 0 ? 0 : src * a.x_pitch * 2);
+      e.sstep = (unsigned)__builtin_amdgcn_readfirstlane(PPL * a.x_pitch * 2);
+      e.km = ~0u;
+    } else {
+      const int s = ld_u == NS + 1 ? NS - 1 : ld_u;
+      src = wave < 2 ? cst_bytes + s * SL + C::W1_BYTES + wave * (PPW * 1024)
+                     : cst_bytes + (s + 1 == NS ? 0 : s + 1) * SL + (wave - 2) * (PPW * 1024);
+      e.lim = 0x7fffffff;
+      e.soff = (unsigned)__builtin_amdgcn_readfirstlane(src);
+      e.sstep = 1024u;
+      e.km = 0u;
+    }
+    e.rsrc = isx ? xrsrc : wrsrc;
+    e.isx = isx;
+    ++ld_q;
+    if (++ld_u == NS + 2) { ld_u = 0; ++ld_k; }
+  };
+  auto issue_piece = [&](const El& e, auto pcc) __attribute__((always_inline)) {
+    constexpr int pc = decltype(pcc)::value;
+    constexpr unsigned K = (unsigned)(pw_swz<CHUNKS>(pc * PPL) << 4);
+    static_assert(pw_swz<CHUNKS>(pc * PPL + PPL - 1) == (pw_swz<CHUNKS>(pc * PPL) | pw_swz<CHUNKS>(PPL - 1)), "swizzle splits");
+    const unsigned voff = xq < e.lim - pc * PPL ? (e.isx ? x_row + (x_c0 ^ K) : w_lane) : 0x80000000u;
+    dma16_hidden_s(e.rsrc, voff, e.soff + pc * e.sstep, e.dst + pc * 1024);
+  };
+  auto burst = [&]() __attribute__((always_inline)) {          // one whole element now
+    El e;
+    describe(e);
+    pw_static_for<0, PPW>([&](auto pcc) __attribute__((always_inline)) { issue_piece(e, pcc); });
+  };
+
+  // ---- state of the tile in flight ------------------------------------------------------------------------------------------------
+  i32x4 xf[KC1][2];
+  i32x4 hf[4][2];
+  f32x16 acc1[2][2], acc2[NRB][2];
+  const int lane_a = (h * 64 + r) << 4;                          // A fragments of the 64-row W1 part
+  const int lane_a2 = (h * C::R2 + r) << 4;                      // ... of the R2-row W2 part
+  const float* const b1c = reinterpret_cast<const float*>(cst);
+  const float* const b2c = b1c + a.Chid;
+
+  auto pack1 = [&](auto bc, auto dc) __attribute__((always_inline)) {                          // dword d (0..15) of row block b: K-step 2b + (d >> 3), column block (d >> 2) & 1
+    constexpr int b = decltype(bc)::value, d = decltype(dc)::value;
+    constexpr int mm = d >> 3, c = (d >> 2) & 1, w = d & 3;
+    const int v = (int)relu_pk16(pack2<DT>(acc1[b][c][8 * mm + 2 * w], acc1[b][c][8 * mm + 2 * w + 1]));
+    i32x4& t = hf[2 * b + mm][c];
+    if constexpr (w == 0) t.x = v; else if constexpr (w == 1) t.y = v; else if constexpr (w == 2) t.z = v; else t.w = v;
+  };
+  auto bias_vec = [&](const float* bp) __attribute__((always_inline)) {
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    return v;
+  };
+  // Results leave through LDS: a lane holds 8 channels of ITS pixel, and stored from there every lane of a 16-byte store hits a
+  // different pixel row -- 64 partial lines per instruction, the address path takes them one per cycle (measured: ~4,000 cycles
+  // per tile for the whole CU, 10 % of the tile).  The wave instead writes its 32 x R2 block (+ b2) into its share of a pixel
+  // element's ring slot (free once the next tile's fragments are in registers; 16-byte chunks swizzled like the input tile) and
+  // reads it back row-major: a store then covers 64 / CH2 whole pixel rows.
+  constexpr int CH2 = C::R2 / 8, ROWB = C::R2 * 2, RPI = 64 / CH2;
+  static_assert(32 * ROWB == PPW * 1024, "a column block's results fit its pixel-element share");
+  auto out_write = [&](auto rbc, auto cc, char* region) __attribute__((always_inline)) {
+    constexpr int rb = decltype(rbc)::value, c = decltype(cc)::value;
+    pw_static_for<0, 2>([&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
+      const int qch = 8 * (rb >> 1) + 2 * (rb & 1) + e + 4 * h;    // the 8-channel chunk these registers are
+      const f32x16& v = acc2[rb][c];
+      i32x4 q;
+      q.x = (int)pack2<DT>(v[8 * e + 0], v[8 * e + 1]);
+      q.y = (int)pack2<DT>(v[8 * e + 2], v[8 * e + 3]);
+      q.z = (int)pack2<DT>(v[8 * e + 4], v[8 * e + 5]);
+      q.w = (int)pack2<DT>(v[8 * e + 6], v[8 * e + 7]);
+      lds_write16(region + r * ROWB + ((qch ^ pw_swz<CH2>(r)) << 4), q);
+    });
+  };
+  // read-back / store i of a column block covers rows RPI i .. + RPI: lane -> row o_row of those, 16-byte position o_pos, which holds
+  // chunk o_pos ^ swz(row) = (o_pos ^ swz(o_row)) ^ swz(RPI i) (the swizzle splits as for the input pieces)
+  const int o_row = lane / CH2, o_pos = lane % CH2;
+  const unsigned o_lds = (unsigned)(o_row * ROWB + (o_pos << 4));
+  const unsigned o_c0 = (unsigned)((o_pos ^ pw_swz<CH2>(o_row)) << 4);
+  const unsigned o_base = (unsigned)((o_row * a.out_pitch + a.out_coff) * 2);
+  const unsigned o_cbytes = (unsigned)(a.Cout * 2);
+  auto out_read = [&](auto ic, const char* region) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    return lds_read16(region + RPI * i * ROWB + o_lds);
+  };
+  auto out_send = [&](auto ic, int pxc, i32x4 q) __attribute__((always_inline)) {                  // pxc: the column block's first pixel
+    constexpr int i = decltype(ic)::value;
+    constexpr unsigned K = (unsigned)(pw_swz<CH2>(RPI * i) << 4);
+    static_assert(pw_swz<CH2>(RPI * i + RPI - 1) == (pw_swz<CH2>(RPI * i) | pw_swz<CH2>(RPI - 1)), "swizzle splits");
+    const unsigned cb = o_c0 ^ K;                                 // byte offset of the lane's chunk in its pixel row
+    const int left = (int)(P - pxc) - RPI * i;                    // rows of this store that exist
+    const bool ok = o_row < left && cb < o_cbytes;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, q), orsrc, (int)(ok ? o_base + cb : 0x80000000u),
+                                           __builtin_amdgcn_readfirstlane((pxc + RPI * i) * a.out_pitch * 2), 0);
+  };
+
+  // One iteration = ONE pinned stream of steps (a weight fragment read PF steps ahead, two MFMAs, a share of the side work):
+  //   part A (HAS_A): conv 2 of slice s, K-step outer; rides: the second half of slice s's hidden values (acc1[1] -> hf[2], hf[3], wanted
+  //                   from K-step 2 on), with WRAP the next tile's input fragments, with BIAS_A (s = 0) the accumulators start from b2
+  //   part B (HAS_B): conv 1 of slice sn (bias in the first MFMA's C operand), row block outer; rides: acc1[0] -> hf[0], hf[1] during
+  //                   row block 1, with WRAP the tile's results (one accumulator block per step of row block 0)
+  constexpr int HAS_A = 1, HAS_B = 2, WRAP = 4;
+  auto iteration = [&](auto modec, const char* w2, const char* w1, int sn, bool s0, char* xs0, char* xs1, int px0) __attribute__((always_inline)) {
+    constexpr int mode = decltype(modec)::value;
+    constexpr int first = (mode & HAS_A) ? 0 : NA, last = (mode & HAS_B) ? NA + NB : NA;
+    auto rd = [&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      if constexpr (t < NA) return lds_read16(w2 + (t / NRB) * (2 * C::R2 * 16) + (t % NRB) * 512);
+      else return lds_read16(w1 + ((t - NA) % KC1) * 2048 + ((t - NA) / KC1) * 512);
+    };
+    i32x4 fa[NBF];
+    f32x16 bv0, bv1;                                              // conv 1's biases, the C operands of the row blocks' first MFMAs
+    pw_static_for<0, PF>([&](auto tc) __attribute__((always_inline)) { fa[decltype(tc)::value] = rd(pw_int<first + decltype(tc)::value>{}); });
+    if constexpr (!(mode & HAS_A)) bv0 = bias_vec(b1c + sn * 64 + h * 16);
+    pw_static_for<first, last>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      if constexpr (t + PF < last) fa[(t - first + PF) % NBF] = rd(pw_int<t + PF>{});
+      const i32x4 f = fa[(t - first) % NBF];
+      if constexpr (t < PPW) issue_piece(cur, pw_int<t>{});
+      if constexpr (t < NA) {
+        constexpr int j2 = t / NRB, rb = t % NRB;
+        acc2[rb][0] = Tr::mma(f, hf[j2][0], acc2[rb][0]);
+        acc2[rb][1] = Tr::mma(f, hf[j2][1], acc2[rb][1]);
+        if constexpr (t >= 1 && (t - 1) * PER_A < 16)
+          pw_static_for<(t - 1) * PER_A, (t * PER_A < 16 ? t * PER_A : 16)>([&](auto dc) __attribute__((always_inline)) { pack1(pw_int<1>{}, dc); });
+        if constexpr ((mode & WRAP) != 0 && (t >> 1) < KC1)
+          xf[t >> 1][t & 1] = lds_read16(((t & 1) ? xs1 : xs0) + r * (C::RI * 2) + (((2 * (t >> 1) + h) ^ pw_swz<CHUNKS>(r)) << 4));
+        if constexpr ((mode & HAS_B) != 0 && t == NA - 4) bv0 = bias_vec(b1c + sn * 64 + h * 16);
+      } else {
+        constexpr int u = t - NA, b = u / KC1, j = u % KC1;
+        if constexpr (j == 0) {
+          pw_mma_vc<DT>(acc1[b][0], f, xf[0][0], b == 0 ? bv0 : bv1);
+          pw_mma_vc<DT>(acc1[b][1], f, xf[0][1], b == 0 ? bv0 : bv1);
+        } else {
+          // outside the steady loop the last results stay live across the tile's output code or the loop's entry
+          constexpr bool guard = mode != (HAS_A | HAS_B) && b == 1 && j == KC1 - 1;
+          pw_mma_v<DT>(acc1[b][0], f, xf[j][0]);
+          pw_mma_v<DT, guard>(acc1[b][1], f, xf[j][1]);
+        }
+        // an MFMA reads its C operand LATE: the registers must not be handed to anything else (the compiler does not know the asm
+        // is an MFMA) until two more steps have gone by
+        if constexpr (j == 2 && b == 0) asm volatile("" :: "v"(bv0));
+        if constexpr (j == 2 && b == 1) asm volatile("" :: "v"(bv1));
+        if constexpr (b == 0 && j == (KC1 >= 8 ? 3 : 2)) bv1 = bias_vec(b1c + sn * 64 + (2 + h) * 16);
+        if constexpr (b == 1 && j >= 1 && (j - 1) * PER_B < 16)
+          pw_static_for<(j - 1) * PER_B, (j * PER_B < 16 ? j * PER_B : 16)>([&](auto dc) __attribute__((always_inline)) { pack1(pw_int<0>{}, dc); });
+        // s = 0: the two more elements the tile switch made room for, in the steps that carry no other side work (a branch cuts the
+        // stream into basic blocks, and side work whose results are used beyond the cut is sunk there by the compiler)
+        if constexpr (mode == (HAS_A | HAS_B) && b == 0) {
+          if (s0) {
+            issue_piece(2 * j < PPW ? cur1 : cur2, pw_int<(2 * j) % PPW>{});
+            issue_piece(2 * j + 1 < PPW ? cur1 : cur2, pw_int<(2 * j + 1) % PPW>{});
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // the tile's results: + b2 -> LDS -> memory, the accumulators back to zero.  NOT inside the stream: with its temporaries there the
+  // kernel no longer fits the register file, and a spill is a vector-memory instruction the hand-counted vmcnt waits do not know
+  auto finish_tile = [&](char* xs0, char* xs1, int px0) __attribute__((always_inline)) {
+    pw_static_for<0, NRB>([&](auto rbc) __attribute__((always_inline)) {
+      constexpr int rb = decltype(rbc)::value;
+      out_write(rbc, pw_int<0>{}, xs0);
+      out_write(rbc, pw_int<1>{}, xs1);
+      acc2[rb][0] = acc2[rb][1] = bias_vec(b2c + (rb * 2 + h) * 16);      // the next tile's accumulators start from b2
+    });
+    pw_static_for<0, 2>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      i32x4 od[2 * NRB];
+      pw_static_for<0, 2 * NRB>([&](auto ic) __attribute__((always_inline)) { od[decltype(ic)::value] = out_read(ic, c ? xs1 : xs0); });
+      pw_static_for<0, 2 * NRB>([&](auto ic) __attribute__((always_inline)) { out_send(ic, px0 + 32 * c, od[decltype(ic)::value]); });
+    });
+  };
+
+  // ---- start: constants, tile 0's pixels, E(NS-1) (for W1 of slice 0), E(0) ----------------------------------------------------------
+  PW_STAMP2(0);
+  for (int pc = wave; pc < cst_pieces; pc += 4)
+    dma16_hidden(wrsrc, (unsigned)(pc * 1024 + lane * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(cst_lds + pc * 1024)));
+#pragma unroll 1
+  for (int e = 0; e < 4; ++e) burst();
+  if (PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    const char* const xs0 = ring + wave * (PPW * 1024) + r * (C::RI * 2);
+    const int g = pw_swz<CHUNKS>(r);
+#pragma unroll
+    for (int j = 0; j < KC1; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) xf[j][c] = lds_read16(xs0 + c * SL + (((2 * j + h) ^ g) << 4));
+  }
+  PW_STAMP2(1);
+  pw_static_for<0, NRB>([&](auto rbc) __attribute__((always_inline)) {
+    constexpr int rb = decltype(rbc)::value;
+    acc2[rb][0] = acc2[rb][1] = bias_vec(b2c + (rb * 2 + h) * 16);
+  });
+  iteration(pw_int<HAS_B>{}, ring, ring + 2 * SL + C::W2_BYTES + lane_a, 0, false, ring, ring, 0);
+  PW_STAMP2(2);
+
+  for (int k = 0; k < m; ++k) {
+    const int base = 3 + k * (NS + 2);
+    const int px0 = (bid + k * G) * PX + wave * 64;
+    if (k == 2) PW_STAMP2(52);
+    // Before each iteration: its element (ring position p) must have landed -- younger transfers: two elements (s = 1 .. NS - 2), the
+    // previous tile's stores (s = 0), nothing (s = NS - 1) -- and every wave must be done with the slot the new transfers go to.
+    // Ring positions up to p + 3 may be filled: one element per iteration rides in its stream, at s = 0 three (the tile switch
+    // freed the pixel elements' slots too).
+#pragma unroll 1
+    for (int s_ = 0; s_ < NS - 1; ++s_) {
+      const int p = base + s_;
+      if (s_ == 0) {
+        if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NSTORE == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (PPW == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (k == 1) PW_STAMP2(4 + 4 * s_);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (k == 1) PW_STAMP2(5 + 4 * s_);
+      describe(cur);
+      if (s_ == 0) { describe(cur1); describe(cur2); }
+      const char* const slot = ring + (p & 3) * SL;
+      if (k == 1) PW_STAMP2(6 + 4 * s_);
+      iteration(pw_int<(HAS_A | HAS_B)>{}, slot + lane_a2, slot + C::W2_BYTES + lane_a, s_ + 1, s_ == 0, ring, ring, px0);
+      if (k == 1) PW_STAMP2(7 + 4 * s_);
+    }
+    const int p = base + NS + 1;
+    if (k == 1) PW_STAMP2(4 + 4 * (NS - 1));
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (k == 1) PW_STAMP2(5 + 4 * (NS - 1));
+    describe(cur);                               // position p + 1: the next tile's E(0)
+    if (k == 1) PW_STAMP2(6 + 4 * (NS - 1));
+    const char* const slot = ring + (p & 3) * SL;
+    char* const xs0 = ring + ((p - 2) & 3) * SL + wave * (PPW * 1024);      // this wave's shares of the two pixel elements
+    char* const xs1 = ring + ((p - 1) & 3) * SL + wave * (PPW * 1024);
+    // (after the last tile the conv 1 of "the next tile's slice 0" runs on the zeros of the masked pixel elements: 32 MFMAs per
+    // workgroup, and one copy of the stream less -- every copy is one more place where the compiler moves the accumulators)
+    iteration(pw_int<(HAS_A | HAS_B | WRAP)>{}, slot + lane_a2, slot + C::W2_BYTES + lane_a, 0, false, xs0, xs1, px0);
+    if (k == 1) PW_STAMP2(7 + 4 * (NS - 1));
+    finish_tile(xs0, xs1, px0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the masked transfers of the last iterations still target this LDS
+  PW_STAMP2(3);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -822,6 +1170,23 @@ template <int DT, int KC1, int NRB> int pw_fwd_launch(const srk_pw_args& a, hipS
   return 0;
 }
 
+template <int DT, int KC1, int NRB> int pw_fwd2_launch(const srk_pw_args& a, hipStream_t st) {
+  typedef PwCfg<KC1, NRB> C;
+  const int cst_bytes = ((a.Chid + C::R2) * 4 + 1023) / 1024 * 1024;
+  const int lds = 4 * C::FWD_SLICE + cst_bytes;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_fwd2_kernel<DT, KC1, NRB>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) { srk_set_error("srk_pw_forward: cannot reserve LDS"); return (int)attr; }
+  SRK_CHECK_ARG(lds <= 160 * 1024 && cst_bytes <= 8 * 1024, "srk_pw_forward: %d bytes of LDS", lds);
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  const long long nt = (a.P + 255) / 256;
+  const unsigned xb = (unsigned)(a.P * a.x_pitch * 2), ob = (unsigned)(a.P * a.out_pitch * 2);
+  const unsigned wb = (unsigned)(cst_bytes + (long long)(a.Chid / 64) * C::FWD_SLICE);
+  hipLaunchKernelGGL((pw_fwd2_kernel<DT, KC1, NRB>), dim3((unsigned)(nt < cus ? nt : cus)), dim3(256), lds, st, a, xb, ob, wb, cst_bytes / 1024, (int)nt);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int DT, int KC1, int NRB> int pw_bwd_launch(const srk_pw_bwd_args& a, hipStream_t st) {
   typedef PwCfg<KC1, NRB> C;
   const int cst_bytes = (a.Chid * 4 + 1023) / 1024 * 1024;
@@ -905,8 +1270,17 @@ extern "C" int srk_pw_forward(const srk_pw_args* a, srk_stream_t stream) {
                 a->out_pitch % 8 == 0 && a->out_coff % 8 == 0 && a->Cout % 8 == 0 && a->Cout <= a->CoutP,
                 "srk_pw_forward: addressing (P=%lld pitch %d)", a->P, a->x_pitch);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->Cin == 128) return a->dtype == SRK_BF16 ? pw_fwd_launch<SRK_BF16, 8, 4>(*a, st) : pw_fwd_launch<SRK_F16, 8, 4>(*a, st);
-  return a->dtype == SRK_BF16 ? pw_fwd_launch<SRK_BF16, 4, 2>(*a, st) : pw_fwd_launch<SRK_F16, 4, 2>(*a, st);
+  // up to one 256-pixel tile per CU: the one-tile-per-workgroup kernel (8 waves x 32 pixels: two waves per SIMD hide each other's
+  // waits, which is worth more than the persistent kernel's streamlined tile switch when there is no second tile); beyond: the
+  // persistent kernel (4 waves x 64 pixels, the weight ring kept running across a workgroup's tiles)
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  if ((a->P + 255) / 256 <= cus) {
+    if (a->Cin == 128) return a->dtype == SRK_BF16 ? pw_fwd_launch<SRK_BF16, 8, 4>(*a, st) : pw_fwd_launch<SRK_F16, 8, 4>(*a, st);
+    return a->dtype == SRK_BF16 ? pw_fwd_launch<SRK_BF16, 4, 2>(*a, st) : pw_fwd_launch<SRK_F16, 4, 2>(*a, st);
+  }
+  SRK_CHECK_ARG(a->P * (long long)a->out_pitch * 2 < 0x7fff0000LL, "srk_pw_forward: output addressing (P=%lld pitch %d)", a->P, a->out_pitch);
+  if (a->Cin == 128) return a->dtype == SRK_BF16 ? pw_fwd2_launch<SRK_BF16, 8, 4>(*a, st) : pw_fwd2_launch<SRK_F16, 8, 4>(*a, st);
+  return a->dtype == SRK_BF16 ? pw_fwd2_launch<SRK_BF16, 4, 2>(*a, st) : pw_fwd2_launch<SRK_F16, 4, 2>(*a, st);
 }
 
 extern "C" int srk_pw_backward(const srk_pw_bwd_args* a, srk_stream_t stream) {

@@ -42,6 +42,37 @@ def l2err(got, ref):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("f,tiles_per_cu,extra", [(128, 1, 37), (128, 2, 300), (64, 2, 5)])
+def test_pw_forward_persistent_tiles(A, dt, f, tiles_per_cu, extra):
+    """srk_pw_forward beyond one 256-pixel tile per CU takes the persistent kernel (csrc/pw_chain.hip, pw_fwd2_kernel): workgroups
+    with 2 and 3 tiles (the weight ring runs across the tile switch, the next tile's pixels arrive under the current tile's last
+    slices, results leave through LDS) and a ragged last tile, against float64 (models/wdsr.py:30-51: the block's two 1x1 convs)."""
+    ops = A.ops
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    npix = 256 * cus * tiles_per_cu + extra
+    chid, cmid = 6 * f, int(0.8 * f)
+    cz = ops.pad16(cmid)
+    x = rnd(1, 1, npix, f, seed=11)
+    w1, b1 = rnd(chid, f, 1, 1, seed=12, scale=1.0 / np.sqrt(f)), rnd(chid, seed=13, scale=0.1)
+    w2, b2 = rnd(cmid, chid, 1, 1, seed=14, scale=1.0 / np.sqrt(chid)), rnd(cmid, seed=15, scale=0.1)
+    xr = q(x, dt).view(npix, f)
+    hr = torch.relu(xr @ q(w1, dt).view(chid, f).t() + b1.double()).to(dt).double()
+    zr = hr @ q(w2, dt).view(cmid, chid).t() + b2.double()
+    pk = ops.pw_pack(torch.nn.Parameter(w1.cuda()), b1.cuda(), torch.nn.Parameter(w2.cuda()), b2.cuda(), dt)
+    z = torch.full((1, 1, npix, cz), 7.0, dtype=dt, device="cuda")
+    ops.pw_forward_raw(x.to(dt).cuda(), pk, z)
+    torch.cuda.synchronize()
+    got = z.view(npix, cz).double().cpu()
+    worst = float((got[:, :cmid] - zr).abs().max())
+    assert relerr(got[:, :cmid], zr) < TOL[dt], f"max abs err {worst}"
+    for lo in range(0, npix, 256 * cus):                          # no tile of any round is off (a single bad tile hides in the norm)
+        hi = min(npix, lo + 256 * cus)
+        assert relerr(got[lo:hi, :cmid], zr[lo:hi]) < TOL[dt], f"pixels {lo}..{hi}"
+    assert relerr(got[-512:, :cmid], zr[-512:]) < TOL[dt], "the ragged tail"
+    assert float(got[:, cmid:].abs().max()) == 0.0, "padding channels are zeros"
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("f,npix", [(128, 256), (128, 1000), (128, 37), (64, 512), (64, 300)])
 def test_pw_forward_and_backward_raw(A, dt, f, npix):
     """srk_pw_forward / srk_pw_backward on a flat pixel list (ragged sizes: the last workgroup / wave is partial), incl. the

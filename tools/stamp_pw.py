@@ -25,10 +25,17 @@ print(f"pw_fwd n={n}: {e0.elapsed_time(e1) * 1e3 / 20:.2f} us per launch")
 buf = (C.c_ulonglong * 128)()
 lib = A._lib.load()
 assert lib.srk_pw_read_stamps(buf) == 0
+old = os.environ.get("SRK_PW_FWD_OLD")
 for w in (0, 1):
     t = list(buf[w * 64:(w + 1) * 64])
     t0 = t[0]
-    names = {1: "DMA issued", 2: "own pieces landed", 3: "barrier", 4: "slice-0 conv 1 done (loop starts)", 5: "loop done", 6: "stores issued"}
-    print(("wave 0: " if w == 0 else "wave 4: ") + "; ".join(f"{names[i]} {t[i] - t0}" for i in (1, 2, 3, 4, 5, 6)))
-    print("   per slice [vmcnt wait, barrier, DMA issue, MFMA stream]: " + " | ".join(
-        f"{s}: {t[9 + 4 * s] - t[8 + 4 * s]}" f",{t[10 + 4 * s] - t[9 + 4 * s]},{t[11 + 4 * s] - t[10 + 4 * s]}" f" (@{t[8 + 4 * s] - t0})" for s in range(12) if t[11 + 4 * s]))
+    if old:
+        names = {1: "DMA issued", 2: "own pieces landed", 3: "barrier", 4: "slice-0 conv 1 done (loop starts)", 5: "loop done", 6: "stores issued"}
+        print(("wave 0: " if w == 0 else "wave 4: ") + "; ".join(f"{names[i]} {t[i] - t0}" for i in (1, 2, 3, 4, 5, 6)))
+        print("   per slice [barrier wait, DMA issue, MFMA stream]: " + " | ".join(
+            f"{s}: {t[9 + 4 * s] - t[8 + 4 * s]}" f",{t[10 + 4 * s] - t[9 + 4 * s]},{t[11 + 4 * s] - t[10 + 4 * s]}" f" (@{t[8 + 4 * s] - t0})" for s in range(12) if t[11 + 4 * s]))
+    else:
+        print(("wave 0: " if w == 0 else "wave 2: ") + f"start -> first conv 1 begins {t[1] - t0}, ends {t[2] - t0}; kernel end {t[3] - t0}")
+        print("   second tile, per iteration [barrier wait, burst + descriptor, stream] (@ since kernel start): " + " | ".join(
+            f"{s}: {t[5 + 4 * s] - t[4 + 4 * s]},{t[6 + 4 * s] - t[5 + 4 * s]},{t[7 + 4 * s] - t[6 + 4 * s]} (@{t[4 + 4 * s] - t0})" for s in range(12) if t[7 + 4 * s]))
+        print(f"   third tile starts @{t[52] - t0}")
