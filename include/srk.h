@@ -515,6 +515,10 @@ typedef struct {
   float* out;                             /* [rows][C] fp32 */
 } srk_chan_finalize_args;
 int srk_chan_finalize(const srk_chan_finalize_args* a, srk_stream_t stream);
+/* srk_chan_stats and srk_chan_finalize as ONE launch: the block that finishes last does the finalize step.  `f->partial` and
+ * `f->nblocks` are taken from `a`; `counter`: one int in device memory, 0 before the first use (the kernel leaves it 0) and not shared
+ * by launches that may run at the same time.                                                                          */
+int srk_chan_stats_finalize(const srk_chan_stats_args* a, const srk_chan_finalize_args* f, int* counter, srk_stream_t stream);
 
 /* out[p][c] = post( (a[c]*x + b[c]*y + d[c]) * gate ),  gate = (z > 0 ? 1 : slope[c*slope_stride]) when z is given,
  * post = PReLU with the same slope when post_prelu.  a / b / d NULL = 1 / 1 / 0; y NULL = no second input.

@@ -227,7 +227,7 @@ LAUNCHERS = {
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
-                 "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges", "srk_l1_loss_mean")
+                 "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges", "srk_l1_loss_mean", "srk_chan_stats_finalize")
 
 _lib = None
 
@@ -268,6 +268,8 @@ def load():
     lib.srk_rowsum_group.restype = C.c_int
     lib.srk_upload_small.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
     lib.srk_upload_small.restype = C.c_int
+    lib.srk_chan_stats_finalize.argtypes = [C.POINTER(ChanStatsArgs), C.POINTER(ChanFinalizeArgs), C.c_void_p, C.c_void_p]
+    lib.srk_chan_stats_finalize.restype = C.c_int
     lib.srk_chan_stats_blocks.argtypes = [C.c_longlong]
     lib.srk_chan_stats_blocks.restype = C.c_int
     lib.srk_ca_splits.argtypes = [C.c_int, C.c_int]

@@ -106,7 +106,13 @@ template <int DT> __global__ __launch_bounds__(GEN_NT) void fold_nhwc_kernel(con
 
 // ---- per-channel partial sums ---------------------------------------------------------------------------------------
 // grid = blocks over pixels; thread = (16-byte channel chunk, pixel row); partial[block][2][C]
-template <int DT> __global__ __launch_bounds__(GEN_NT) void chan_stats_kernel(const srk_chan_stats_args a, long long pix_per_block) {
+SRK_DEV void chan_finalize_body(const srk_chan_finalize_args& a);
+
+// FUSED: the block that finishes LAST (an arrival counter in device memory, which it resets for the next launch) goes on to do
+// srk_chan_finalize's work on the partials of all blocks: one launch per BatchNorm / PReLU reduction instead of two (the second
+// was one workgroup of [C]-sized arithmetic behind a launch boundary: ~7 us each, 118 per SRResNet training step)
+template <int DT, bool FUSED> __global__ __launch_bounds__(GEN_NT) void chan_stats_kernel(const srk_chan_stats_args a, long long pix_per_block,
+                                                                                           const srk_chan_finalize_args f, int* counter) {
   typedef DTraits<DT> Tr;
   typedef typename Tr::elem elem;
   constexpr int CH = Tr::CH;
@@ -124,23 +130,40 @@ template <int DT> __global__ __launch_bounds__(GEN_NT) void chan_stats_kernel(co
   if (prow < rows) {
     const elem* x = reinterpret_cast<const elem*>(a.x) + a.x_coff + cc * CH;
     const elem* y = a.y ? reinterpret_cast<const elem*>(a.y) + a.y_coff + cc * CH : nullptr;
-    for (long long p = p0 + prow; p < p1; p += rows) {
-      float xv[CH];
-      chunk_to_f32<DT>(gload16(x + (size_t)p * a.x_pitch), xv);
+    // U loads in flight per thread (the blocks are few: see stats_blocks), consumed in pixel order: the sums' order is fixed
+    constexpr int U = 8;
+    for (long long pb = p0 + prow; pb < p1; pb += (long long)rows * U) {
+      i32x4 xq[U], yq[U];
 #pragma unroll
-      for (int e = 0; e < CH; ++e) xv[e] -= sh[e];
-      if (a.mode == 0) {
+      for (int u = 0; u < U; ++u) {
+        const long long p = pb + (long long)u * rows;
+        if (p < p1) {
+          xq[u] = gload16(x + (size_t)p * a.x_pitch);
+          if (a.mode != 0) yq[u] = gload16(y + (size_t)p * a.y_pitch);
+        }
+      }
 #pragma unroll
-        for (int e = 0; e < CH; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }
-      } else {
-        float yv[CH];
-        chunk_to_f32<DT>(gload16(y + (size_t)p * a.y_pitch), yv);
-        if (a.mode == 1) {
+      for (int u = 0; u < U; ++u) {
+        const long long p = pb + (long long)u * rows;
+        if (p < p1) {
+          float xv[CH];
+          chunk_to_f32<DT>(xq[u], xv);
 #pragma unroll
-          for (int e = 0; e < CH; ++e) { s0[e] += yv[e]; s1[e] += xv[e] * yv[e]; }
-        } else {
+          for (int e = 0; e < CH; ++e) xv[e] -= sh[e];
+          if (a.mode == 0) {
 #pragma unroll
-          for (int e = 0; e < CH; ++e) s0[e] += xv[e] <= 0.f ? xv[e] * yv[e] : 0.f;
+            for (int e = 0; e < CH; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }
+          } else {
+            float yv[CH];
+            chunk_to_f32<DT>(yq[u], yv);
+            if (a.mode == 1) {
+#pragma unroll
+              for (int e = 0; e < CH; ++e) { s0[e] += yv[e]; s1[e] += xv[e] * yv[e]; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < CH; ++e) s0[e] += xv[e] <= 0.f ? xv[e] * yv[e] : 0.f;
+            }
+          }
         }
       }
     }
@@ -158,8 +181,25 @@ template <int DT> __global__ __launch_bounds__(GEN_NT) void chan_stats_kernel(co
       t0 += red[0][(r * nch + c_cc) * CH + c_e];
       t1 += red[1][(r * nch + c_cc) * CH + c_e];
     }
-    a.partial[((size_t)blockIdx.x * 2 + 0) * a.C + tid] = t0;
-    a.partial[((size_t)blockIdx.x * 2 + 1) * a.C + tid] = t1;
+    float* const p0 = a.partial + ((size_t)blockIdx.x * 2 + 0) * a.C + tid;
+    float* const p1 = a.partial + ((size_t)blockIdx.x * 2 + 1) * a.C + tid;
+    if constexpr (FUSED) {       // device-scope stores (written through to where every XCD sees them): the count below then needs no
+      __hip_atomic_store(p0, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cache write-back -- a release per block cost more
+      __hip_atomic_store(p1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // than the launch it saves
+    } else {
+      *p0 = t0;
+      *p1 = t1;
+    }
+  }
+  if constexpr (FUSED) {
+    __shared__ int last;
+    __syncthreads();                                             // every wave's stores are acknowledged (the barrier waits for them)
+    if (tid == 0) last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // the last block sees every other block's
+    if (tid == 0) *counter = 0;
+    chan_finalize_body(f);
   }
 }
 
@@ -212,8 +252,9 @@ inline unsigned grid_for(long long total) {
 }
 
 inline int stats_blocks(long long P) {
-  // >= 64 pixels per block, at most 1024 blocks
-  long long b = (P + 63) / 64;
+  // >= 512 pixels per block (a thread has 8 loads in flight: few blocks still pull the bandwidth, and the fused form's arrival
+  // count -- same-address atomics, one after the other -- stays short), at most 1024 blocks
+  long long b = (P + 511) / 512;
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;
@@ -223,7 +264,7 @@ inline int stats_blocks(long long P) {
 // The [C]-sized step between srk_chan_stats and srk_chan_apply of a BatchNorm2d / PReLU, as ONE small launch: the ordered sum of
 // the per-block partials and the vector arithmetic that was ~15 tiny elementwise launches per layer and direction (970 per
 // SRResNet training step at batch 16: 4.5 ms of 14.6).  One workgroup, one thread per channel.
-__global__ __launch_bounds__(GEN_NT) void chan_finalize_kernel(const srk_chan_finalize_args a) {
+SRK_DEV void chan_finalize_body(const srk_chan_finalize_args& a) {
   const int c = threadIdx.x, C = a.C;
   __shared__ float red[GEN_NT];
   __shared__ __attribute__((aligned(16))) float part0[4 * GEN_NT], part1[4 * GEN_NT];
@@ -299,6 +340,7 @@ __global__ __launch_bounds__(GEN_NT) void chan_finalize_kernel(const srk_chan_fi
     }
   }
 }
+__global__ __launch_bounds__(GEN_NT) void chan_finalize_kernel(const srk_chan_finalize_args a) { chan_finalize_body(a); }
 
 }  // namespace
 
@@ -338,18 +380,58 @@ extern "C" int srk_fold_nhwc(const srk_fold_nhwc_args* a, srk_stream_t stream) {
 
 extern "C" int srk_chan_stats_blocks(long long P) { return stats_blocks(P); }
 
-extern "C" int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream) {
+static int chan_stats_check(const srk_chan_stats_args* a) {
   SRK_CHECK_ARG(a && a->x && a->partial && (a->mode == 0 || a->y), "srk_chan_stats: null pointer");
   const int ch = a->dtype == SRK_F32 ? 4 : 8;
   SRK_CHECK_ARG(a->mode >= 0 && a->mode <= 2, "srk_chan_stats: mode %d", a->mode);
   SRK_CHECK_ARG(a->C > 0 && a->C <= GEN_NT && a->C % ch == 0 && a->x_pitch % ch == 0 && a->x_coff % ch == 0 &&
                     (!a->y || (a->y_pitch % ch == 0 && a->y_coff % ch == 0)), "srk_chan_stats: C=%d (multiple of %d, <= %d) / alignment", a->C, ch, GEN_NT);
-  if (a->P <= 0) return 0;
+  return 0;
+}
+static int chan_finalize_check(const srk_chan_finalize_args* a) {
+  SRK_CHECK_ARG(a && a->partial && a->out && a->nblocks > 0, "srk_chan_finalize: null pointer");
+  SRK_CHECK_ARG(a->C > 0 && a->C <= GEN_NT && a->Creal >= 0 && a->Creal <= a->C, "srk_chan_finalize: C=%d Creal=%d", a->C, a->Creal);
+  SRK_CHECK_ARG(a->mode >= 0 && a->mode <= 4, "srk_chan_finalize: mode %d", a->mode);
+  SRK_CHECK_ARG(a->mode != 1 || (a->mean && a->weight && a->bias && (!a->running_mean == !a->running_var)), "srk_chan_finalize: mode 1 needs mean, weight, bias");
+  SRK_CHECK_ARG((a->mode != 2 && a->mode != 3) || (a->invstd && a->gamma && (a->mode == 3 || a->mean)), "srk_chan_finalize: backward needs mean, invstd, gamma");
+  return 0;
+}
+template <bool FUSED> static int chan_stats_launch(const srk_chan_stats_args* a, const srk_chan_finalize_args& f, int* counter, srk_stream_t stream) {
   const int nb = stats_blocks(a->P);
   const long long ppb = (a->P + nb - 1) / nb;
-  GEN_DISPATCH(chan_stats_kernel, a->dtype, nb, reinterpret_cast<hipStream_t>(stream), *a, ppb);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (a->dtype) {
+    case SRK_BF16: hipLaunchKernelGGL((chan_stats_kernel<SRK_BF16, FUSED>), dim3(nb), dim3(GEN_NT), 0, st, *a, ppb, f, counter); break;
+    case SRK_F16: hipLaunchKernelGGL((chan_stats_kernel<SRK_F16, FUSED>), dim3(nb), dim3(GEN_NT), 0, st, *a, ppb, f, counter); break;
+    case SRK_F32: hipLaunchKernelGGL((chan_stats_kernel<SRK_F32, FUSED>), dim3(nb), dim3(GEN_NT), 0, st, *a, ppb, f, counter); break;
+    default: srk_set_error("dtype %d", (int)a->dtype); return SRK_E_BADARG;
+  }
   SRK_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream) {
+  if (const int rc = chan_stats_check(a)) return rc;
+  if (a->P <= 0) return 0;
+  return chan_stats_launch<false>(a, srk_chan_finalize_args{}, nullptr, stream);
+}
+
+extern "C" int srk_chan_finalize(const srk_chan_finalize_args* a, srk_stream_t stream) {
+  if (const int rc = chan_finalize_check(a)) return rc;
+  hipLaunchKernelGGL(chan_finalize_kernel, dim3(1), dim3(GEN_NT), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_chan_stats_finalize(const srk_chan_stats_args* a, const srk_chan_finalize_args* f, int* counter, srk_stream_t stream) {
+  if (const int rc = chan_stats_check(a)) return rc;
+  SRK_CHECK_ARG(f && counter && a->P > 0, "srk_chan_stats_finalize: null pointer / no pixels");
+  srk_chan_finalize_args g = *f;
+  g.partial = a->partial;
+  g.nblocks = stats_blocks(a->P);
+  SRK_CHECK_ARG(g.C == a->C, "srk_chan_stats_finalize: C %d vs %d", g.C, a->C);
+  if (const int rc = chan_finalize_check(&g)) return rc;
+  return chan_stats_launch<true>(a, g, counter, stream);
 }
 
 extern "C" int srk_chan_apply(const srk_chan_apply_args* a, srk_stream_t stream) {
@@ -365,13 +447,3 @@ extern "C" int srk_chan_apply(const srk_chan_apply_args* a, srk_stream_t stream)
   return 0;
 }
 
-extern "C" int srk_chan_finalize(const srk_chan_finalize_args* a, srk_stream_t stream) {
-  SRK_CHECK_ARG(a && a->partial && a->out && a->nblocks > 0, "srk_chan_finalize: null pointer");
-  SRK_CHECK_ARG(a->C > 0 && a->C <= GEN_NT && a->Creal >= 0 && a->Creal <= a->C, "srk_chan_finalize: C=%d Creal=%d", a->C, a->Creal);
-  SRK_CHECK_ARG(a->mode >= 0 && a->mode <= 4, "srk_chan_finalize: mode %d", a->mode);
-  SRK_CHECK_ARG(a->mode != 1 || (a->mean && a->weight && a->bias && (!a->running_mean == !a->running_var)), "srk_chan_finalize: mode 1 needs mean, weight, bias");
-  SRK_CHECK_ARG((a->mode != 2 && a->mode != 3) || (a->invstd && a->gamma && (a->mode == 3 || a->mean)), "srk_chan_finalize: backward needs mean, invstd, gamma");
-  hipLaunchKernelGGL(chan_finalize_kernel, dim3(1), dim3(GEN_NT), 0, reinterpret_cast<hipStream_t>(stream), *a);
-  SRK_LAUNCH_CHECK();
-  return 0;
-}

@@ -1769,6 +1769,45 @@ def chan_partials(x, y=None, mode=0, shift=None):
     return part
 
 
+_COUNTERS = {}
+_FUSE_MAX_BLOCKS = int(os.environ.get("SRK_CHAN_FUSE_MAX_BLOCKS", "128"))
+
+
+def _arrival_counter(device):
+    """One int32 of device memory per call, handed out round-robin from a zeroed pool: srk_chan_stats_finalize's arrival counter (the
+    kernel leaves it 0).  Launches that could overlap (other streams, parallel branches of a replayed graph) are many calls apart."""
+    st = _COUNTERS.get(device)
+    if st is None:
+        st = _COUNTERS[device] = [torch.zeros(4096, dtype=torch.int32, device=device), 0]
+    st[1] = (st[1] + 1) % 4096
+    return st[0].data_ptr() + 4 * st[1]
+
+
+def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None,
+                bias=None, running_mean=None, running_var=None, total=False):
+    """chan_finalize(chan_partials(x, y, smode, shift), fmode, rows, ...) as ONE launch (srk_chan_stats_finalize: the block that
+    finishes last does the [C]-sized step)."""
+    _need_gpu(x)
+    c = x.shape[-1]
+    P = x.numel() // c
+    nb = L.load().srk_chan_stats_blocks(P)
+    if nb > _FUSE_MAX_BLOCKS:            # many blocks: their arrival counts (same-address atomics) would take longer than the launch they save
+        return chan_finalize(chan_partials(x, y, smode, shift), fmode, rows, M=M, creal=creal, eps=eps, momentum=momentum, mean=mean, invstd=invstd,
+                             gamma=gamma, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var, total=total)
+    part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
+    out = torch.empty((rows, c), dtype=torch.float32, device=x.device)
+    sa = L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
+                         P=P, C=c, mode=smode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift))
+    fa = L.ChanFinalizeArgs(
+        partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=fmode, total=int(total),
+        M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
+        weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr())
+    import ctypes as C
+    L.check(L.load().srk_chan_stats_finalize(C.byref(sa), C.byref(fa), C.c_void_p(_arrival_counter(x.device)), C.c_void_p(_stream())),
+            "srk_chan_stats_finalize")
+    return out
+
+
 def chan_finalize(part, mode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None, bias=None,
                   running_mean=None, running_var=None, total=False):
     """srk_chan_finalize on the partials of chan_partials: `rows` x [C] fp32 results (include/srk.h lists them per mode)."""
@@ -1828,7 +1867,7 @@ class PReLUFn(torch.autograd.Function):
                 gw = torch.zeros_like(weight)
             else:       # partial sums over x <= 0 of x * g, summed (over the channels too for a single slope) by one small launch
                 one = weight.numel() == 1
-                s = chan_finalize(chan_partials(x, g, mode=2), 4, 1, total=one)[0]
+                s = chan_reduce(x, g, 2, None, 4, 1, total=one)[0]
                 gw = s[:1] if one else s[:weight.numel()]
         return gx, gw
 
@@ -1853,11 +1892,11 @@ class BatchNormFn(torch.autograd.Function):
             # two-pass statistics: the mean, then the sums of the CENTRED values (E[x^2] - mean^2 cancels in fp32 when
             # |mean| >> std, which formula-filled / badly scaled nets do have).  The [C]-sized arithmetic between the passes
             # (mean; variance, running buffers, invstd, scale and shift of the apply pass) is one small launch each.
-            mean = chan_finalize(chan_partials(x), 0, 1, M=M)[0]
+            mean = chan_reduce(x, None, 0, None, 0, 1, M=M)[0]
             w32, b32 = _f32c(weight), _f32c(bias)
             upd = running_mean is not None and running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
-            r = chan_finalize(chan_partials(x, shift=mean), 1, 4, M=M, creal=c, eps=eps, momentum=momentum, mean=mean, weight=w32, bias=b32,
-                              running_mean=running_mean if upd else None, running_var=running_var if upd else None)
+            r = chan_reduce(x, None, 0, mean, 1, 4, M=M, creal=c, eps=eps, momentum=momentum, mean=mean, weight=w32, bias=b32,
+                            running_mean=running_mean if upd else None, running_var=running_var if upd else None)
             invstd, gamma, a, d = r[0], r[1], r[2], r[3]
             if running_mean is not None and not upd:        # buffers in another dtype: torch arithmetic
                 var = 1.0 / (invstd * invstd) - eps
@@ -1888,14 +1927,14 @@ class BatchNormFn(torch.autograd.Function):
         if M == 0:
             z = torch.zeros(c, dtype=torch.float32, device=x.device)
             return torch.empty_like(g), z, z.clone(), None, None, None, None, None, (g if has_res else None)
-        part = chan_partials(x, g, mode=1, shift=mean.contiguous())      # sum dy, sum (x - mean)*dy
+        mean = mean.contiguous()                                         # the sums: sum dy, sum (x - mean)*dy
         if training:
             # dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M),  xhat = (x - mean)*invstd
-            r = chan_finalize(part, 2, 5, M=M, mean=mean, invstd=invstd.contiguous(), gamma=gamma.contiguous())
+            r = chan_reduce(x, g, 1, mean, 2, 5, M=M, mean=mean, invstd=invstd.contiguous(), gamma=gamma.contiguous())
             dgamma, dbeta = r[0], r[1]
             gx = chan_apply(g, y=x, a=r[2], b=r[3], d=r[4])
         else:
-            r = chan_finalize(part, 3, 3, M=M, invstd=invstd.contiguous(), gamma=gamma.contiguous())
+            r = chan_reduce(x, g, 1, mean, 3, 3, M=M, invstd=invstd.contiguous(), gamma=gamma.contiguous())
             dgamma, dbeta = r[0], r[1]
             gx = chan_apply(g, a=r[2])
         return gx, dgamma[:c], dbeta[:c], None, None, None, None, None, (g if has_res else None)
