@@ -504,7 +504,8 @@ int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream);
  *   mode 2 (sum0 = sum dy, sum1 = sum (x - mean) dy; batch statistics): out rows: dgamma = invstd sum1, dbeta = sum0,
  *           a = gamma invstd, b = -a invstd dgamma / M, d = -a dbeta / M - b mean     (dx = a dy + b x + d)
  *   mode 3 (running statistics): out rows: dgamma, dbeta, a = gamma invstd
- *   mode 4: out[0][c] = sum0 (PReLU slope gradients); total = 1: one number, summed over the channels too          */
+ *   mode 4: out[0][c] = sum0 (PReLU slope gradients); total = 1: one number, summed over the channels too; `dgamma_acc`
+ *           (nullable, [Creal] or [1]): the slope's existing .grad buffer, += the result                               */
 typedef struct {
   const float* partial; int nblocks; int C; int Creal;
   int mode; int total;
@@ -513,6 +514,8 @@ typedef struct {
   const float* weight; const float* bias;
   float* running_mean; float* running_var;
   float* out;                             /* [rows][C] fp32 */
+  long long* nbt;                         /* mode 1, nullable: nn.BatchNorm2d.num_batches_tracked, += 1                          */
+  float* dgamma_acc; float* dbeta_acc;    /* modes 2 / 3, nullable, [Creal]: the parameters' existing .grad buffers, += dgamma / dbeta */
 } srk_chan_finalize_args;
 int srk_chan_finalize(const srk_chan_finalize_args* a, srk_stream_t stream);
 /* srk_chan_stats and srk_chan_finalize as ONE launch: the block that finishes last does the finalize step.  `f->partial` and

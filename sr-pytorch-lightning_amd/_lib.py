@@ -82,7 +82,8 @@ class PwWgradArgs(C.Structure):
 class ChanFinalizeArgs(C.Structure):
     _fields_ = [("partial", _p), ("nblocks", _i), ("C", _i), ("Creal", _i), ("mode", _i), ("total", _i),
                 ("M", _f), ("eps", _f), ("momentum", _f), ("mean", _p), ("invstd", _p), ("gamma", _p),
-                ("weight", _p), ("bias", _p), ("running_mean", _p), ("running_var", _p), ("out", _p)]
+                ("weight", _p), ("bias", _p), ("running_mean", _p), ("running_var", _p), ("out", _p),
+                ("nbt", _p), ("dgamma_acc", _p), ("dbeta_acc", _p)]
 
 
 class RowsumJob(C.Structure):

@@ -302,9 +302,11 @@ SRK_DEV void chan_finalize_body(const srk_chan_finalize_args& a) {
         float t = 0.f;
         for (int k = 0; k < C; ++k) t += red[k];
         o[0] = t;
+        if (a.dgamma_acc) a.dgamma_acc[0] += t;
       }
     } else if (c < C) {
       o[c] = s0;
+      if (a.dgamma_acc && real) a.dgamma_acc[c] += s0;
     }
     return;
   }
@@ -315,6 +317,7 @@ SRK_DEV void chan_finalize_body(const srk_chan_finalize_args& a) {
     const float m1 = s0 / M;
     const float var = fmaxf(s1 / M - m1 * m1, 0.f);
     const float mean = a.mean[c];
+    if (a.nbt && c == 0) *a.nbt += 1;
     if (a.running_mean && real) {
       a.running_mean[c] = a.running_mean[c] * (1.f - a.momentum) + mean * a.momentum;
       a.running_var[c] = a.running_var[c] * (1.f - a.momentum) + var * (M / fmaxf(M - 1.f, 1.f)) * a.momentum;
@@ -332,6 +335,8 @@ SRK_DEV void chan_finalize_body(const srk_chan_finalize_args& a) {
     const float k = gamma * invstd;
     o[c] = dgamma;
     o[C + c] = dbeta;
+    if (a.dgamma_acc && real) a.dgamma_acc[c] += dgamma;
+    if (a.dbeta_acc && real) a.dbeta_acc[c] += dbeta;
     o[2 * C + c] = k;
     if (a.mode == 2) {                     // batch statistics: dx = k (dy - dbeta/M - xhat dgamma/M), xhat = (x - mean) invstd
       const float bx = -k * invstd * dgamma / M;

@@ -1784,7 +1784,7 @@ def _arrival_counter(device):
 
 
 def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None,
-                bias=None, running_mean=None, running_var=None, total=False):
+                bias=None, running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None):
     """chan_finalize(chan_partials(x, y, smode, shift), fmode, rows, ...) as ONE launch (srk_chan_stats_finalize: the block that
     finishes last does the [C]-sized step)."""
     _need_gpu(x)
@@ -1793,7 +1793,8 @@ def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, 
     nb = L.load().srk_chan_stats_blocks(P)
     if nb > _FUSE_MAX_BLOCKS:            # many blocks: their arrival counts (same-address atomics) would take longer than the launch they save
         return chan_finalize(chan_partials(x, y, smode, shift), fmode, rows, M=M, creal=creal, eps=eps, momentum=momentum, mean=mean, invstd=invstd,
-                             gamma=gamma, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var, total=total)
+                             gamma=gamma, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var, total=total,
+                             nbt=nbt, dgamma_acc=dgamma_acc, dbeta_acc=dbeta_acc)
     part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
     out = torch.empty((rows, c), dtype=torch.float32, device=x.device)
     sa = L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
@@ -1801,7 +1802,8 @@ def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, 
     fa = L.ChanFinalizeArgs(
         partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=fmode, total=int(total),
         M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
-        weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr())
+        weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr(),
+        nbt=_ptr(nbt), dgamma_acc=_ptr(dgamma_acc), dbeta_acc=_ptr(dbeta_acc))
     import ctypes as C
     L.check(L.load().srk_chan_stats_finalize(C.byref(sa), C.byref(fa), C.c_void_p(_arrival_counter(x.device)), C.c_void_p(_stream())),
             "srk_chan_stats_finalize")
@@ -1809,14 +1811,15 @@ def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, 
 
 
 def chan_finalize(part, mode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None, bias=None,
-                  running_mean=None, running_var=None, total=False):
+                  running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None):
     """srk_chan_finalize on the partials of chan_partials: `rows` x [C] fp32 results (include/srk.h lists them per mode)."""
     nb, _, c = part.shape
     out = torch.empty((rows, c), dtype=torch.float32, device=part.device)
     L.call("srk_chan_finalize", L.ChanFinalizeArgs(
         partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=mode, total=int(total),
         M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
-        weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr()), _stream())
+        weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr(),
+        nbt=_ptr(nbt), dgamma_acc=_ptr(dgamma_acc), dbeta_acc=_ptr(dbeta_acc)), _stream())
     return out
 
 
@@ -1854,6 +1857,7 @@ class PReLUFn(torch.autograd.Function):
     def forward(ctx, x, weight):
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
+        ctx.wparam = weight
         return chan_apply(x, slope=weight, post_prelu=True)
 
     @staticmethod
@@ -1867,8 +1871,10 @@ class PReLUFn(torch.autograd.Function):
                 gw = torch.zeros_like(weight)
             else:       # partial sums over x <= 0 of x * g, summed (over the channels too for a single slope) by one small launch
                 one = weight.numel() == 1
-                s = chan_reduce(x, g, 2, None, 4, 1, total=one)[0]
-                gw = s[:1] if one else s[:weight.numel()]
+                slot = _grad_slot(ctx.wparam, tuple(weight.shape))      # an existing fp32 .grad: the finalize step adds into it
+                acc = slot[1] if (slot is not None and slot[0] == "acc") else None
+                s = chan_reduce(x, g, 2, None, 4, 1, total=one, creal=None if one else weight.numel(), dgamma_acc=acc)[0]
+                gw = None if acc is not None else (s[:1] if one else s[:weight.numel()])
         return gx, gw
 
 
@@ -1883,8 +1889,9 @@ class BatchNormFn(torch.autograd.Function):
     Statistics: srk_chan_stats (fp32 sums); apply and backward: srk_chan_apply; [C]-sized vector math stays in torch."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, res):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, res, nbt=None):
         x = x.contiguous()
+        ctx.params = (weight, bias)
         c = weight.numel()
         cp = x.shape[-1]
         M = x.numel() // cp
@@ -1896,7 +1903,8 @@ class BatchNormFn(torch.autograd.Function):
             w32, b32 = _f32c(weight), _f32c(bias)
             upd = running_mean is not None and running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
             r = chan_reduce(x, None, 0, mean, 1, 4, M=M, creal=c, eps=eps, momentum=momentum, mean=mean, weight=w32, bias=b32,
-                            running_mean=running_mean if upd else None, running_var=running_var if upd else None)
+                            running_mean=running_mean if upd else None, running_var=running_var if upd else None, nbt=nbt)
+            nbt = None
             invstd, gamma, a, d = r[0], r[1], r[2], r[3]
             if running_mean is not None and not upd:        # buffers in another dtype: torch arithmetic
                 var = 1.0 / (invstd * invstd) - eps
@@ -1914,6 +1922,8 @@ class BatchNormFn(torch.autograd.Function):
             beta = torch.nn.functional.pad(bias.detach().float(), (0, cp - c))
             a = gamma * invstd
             d = beta - mean * a
+        if nbt is not None:                 # (no batch statistics pass ran: empty batch)
+            nbt.add_(1)
         out = chan_apply(x, y=res, a=a, d=d)
         ctx.save_for_backward(x, mean, invstd, gamma)
         ctx.cfg = (training, c, M, res is not None)
@@ -1926,32 +1936,42 @@ class BatchNormFn(torch.autograd.Function):
         g = g.contiguous()
         if M == 0:
             z = torch.zeros(c, dtype=torch.float32, device=x.device)
-            return torch.empty_like(g), z, z.clone(), None, None, None, None, None, (g if has_res else None)
+            return torch.empty_like(g), z, z.clone(), None, None, None, None, None, (g if has_res else None), None
         mean = mean.contiguous()                                         # the sums: sum dy, sum (x - mean)*dy
+        # gamma's / beta's gradients go straight into the parameters' existing fp32 .grad buffers when they have them (the finalize
+        # step adds them there: what autograd's AccumulateGrad would do with one more launch each), else to autograd as tensors
+        wslot = _grad_slot(ctx.params[0], (c,)) if ctx.needs_input_grad[1] else None
+        bslot = _grad_slot(ctx.params[1], (c,)) if ctx.needs_input_grad[2] else None
+        wacc = wslot[1] if (wslot is not None and wslot[0] == "acc") else None
+        bacc = bslot[1] if (bslot is not None and bslot[0] == "acc") else None
         if training:
             # dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M),  xhat = (x - mean)*invstd
-            r = chan_reduce(x, g, 1, mean, 2, 5, M=M, mean=mean, invstd=invstd.contiguous(), gamma=gamma.contiguous())
+            r = chan_reduce(x, g, 1, mean, 2, 5, M=M, creal=c, mean=mean, invstd=invstd.contiguous(), gamma=gamma.contiguous(), dgamma_acc=wacc, dbeta_acc=bacc)
             dgamma, dbeta = r[0], r[1]
             gx = chan_apply(g, y=x, a=r[2], b=r[3], d=r[4])
         else:
-            r = chan_reduce(x, g, 1, mean, 3, 3, M=M, invstd=invstd.contiguous(), gamma=gamma.contiguous())
+            r = chan_reduce(x, g, 1, mean, 3, 3, M=M, creal=c, invstd=invstd.contiguous(), gamma=gamma.contiguous(), dgamma_acc=wacc, dbeta_acc=bacc)
             dgamma, dbeta = r[0], r[1]
             gx = chan_apply(g, a=r[2])
-        return gx, dgamma[:c], dbeta[:c], None, None, None, None, None, (g if has_res else None)
+        return gx, (None if wacc is not None else dgamma[:c]), (None if bacc is not None else dbeta[:c]), None, None, None, None, None, (g if has_res else None), None
 
 
 def batch_norm(x, bn, res=None):
     """`bn`: an nn.BatchNorm2d (parameters, running buffers, training flag, momentum, eps) applied to NHWC `x`."""
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats and bn.num_batches_tracked is not None) else None
     if bn.momentum is not None:
-        mom = bn.momentum
-    elif bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        mom = 1.0 / float(bn.num_batches_tracked)           # torch: cumulative moving average (a host read, as in torch)
+        mom = bn.momentum                                   # num_batches_tracked += 1 rides in the statistics launch
+    elif nbt is not None:
+        nbt.add_(1)
+        mom = 1.0 / float(nbt)                              # torch: cumulative moving average (a host read, as in torch)
+        nbt = None
     else:
         mom = 0.0
     use_batch = bn.training or bn.running_mean is None
-    return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, res)
+    if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
+        nbt.add_(1)
+        nbt = None
+    return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, res, nbt)
 
 
 _LK_OFF = os.environ.get("SRK_NO_LK", "0") == "1"        # A/B knob: large kernels through im2col as in round 2

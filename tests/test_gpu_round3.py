@@ -190,3 +190,39 @@ def test_direct_large_kernel_conv_vs_float64(A, dt, k, cout, n, h, w):
     assert l2e(xd.grad.permute(0, 3, 1, 2), xr.grad) < l2
     assert l2e(wd.grad, wr.grad) < l2
     assert l2e(bd.grad, br.grad) < l2
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_batchnorm_prelu_gradients_accumulate_into_existing_grads(A, dt):
+    """ops.batch_norm / ops.prelu (nn.BatchNorm2d + nn.PReLU of SRResNet's blocks, models/srresnet.py:16-21): the statistics launch
+    also finalizes (srk_chan_stats_finalize), counts num_batches_tracked and, when the parameters already HAVE fp32 gradients, adds
+    dgamma / dbeta / dslope into them in place.  Two backward passes (None -> tensors from autograd, then in-place accumulation)
+    against torch in float64 on the same NCHW data."""
+    from sr_amd import ops
+    torch.manual_seed(3)
+    n, c, h, w = 4, 64, 12, 10
+    bn = torch.nn.BatchNorm2d(c).cuda()
+    pr = torch.nn.PReLU(c, init=0.2).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    bn_r = torch.nn.BatchNorm2d(c).double()
+    pr_r = torch.nn.PReLU(c, init=0.2).double()
+    bn_r.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu() for k, v in bn.state_dict().items()})
+    tol = 3e-2 if dt == torch.bfloat16 else 2e-4
+    for it in range(2):
+        x = torch.randn(n, c, h, w) * 2 + 1
+        gy = torch.randn(n, c, h, w)
+        xq = x.to(dt)
+        xd = xq.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+        y = ops.prelu(ops.batch_norm(xd, bn), pr.weight)
+        y.backward(gy.to(dt).permute(0, 2, 3, 1).contiguous().cuda())
+        xr = xq.double().requires_grad_(True)
+        yr = pr_r(bn_r(xr))
+        yr.backward(gy.to(dt).double())
+        torch.cuda.synchronize()
+        assert int(bn.num_batches_tracked) == it + 1 == int(bn_r.num_batches_tracked)
+        for got, ref, name in [(bn.weight.grad, bn_r.weight.grad, "dgamma"), (bn.bias.grad, bn_r.bias.grad, "dbeta"), (pr.weight.grad, pr_r.weight.grad, "dslope"),
+                               (xd.grad.permute(0, 3, 1, 2), xr.grad, "dx")]:
+            err = float((got.double().cpu() - ref).norm() / ref.norm())
+            assert err < tol, f"pass {it}: {name} off by {err:.2e}"
+        assert float((bn.running_var.double().cpu() - bn_r.running_var).abs().max()) < tol

@@ -19,7 +19,7 @@ tools/pmc_kernel.sh ${TAG}_conv_ks_256_n16 conv_ks_kernel tools/microbench_conv.
 tools/pmc_kernel.sh ${TAG}_conv1x1_576_n16 conv1x1_kernel tools/microbench_conv.py --n 16 --cin 576 --cout 64 --k 1 --iters 5 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_wgrad_group_n256 conv_wgrad_ws_group_kernel tools/microbench_variants.py --n 256 --variant wgrad --iters 4 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_conv_ws_n256 conv_ws_kernel tools/microbench_variants.py --n 256 --variant residual --iters 5 > /dev/null 2>&1
-for k in fwd bwd wgrad; do tools/pmc_kernel.sh ${TAG}_pw_${k}_n256 pw_${k}_kernel tools/microbench_pw.py --n 256 --only $k --iters 5 > /dev/null 2>&1; done
+for k in fwd2 bwd wgrad; do tools/pmc_kernel.sh ${TAG}_pw_${k%2}_n256 pw_${k}_kernel tools/microbench_pw.py --n 256 --only ${k%2} --iters 5 > /dev/null 2>&1; done
 for f in $O/${TAG}_*_pmc.txt; do echo "== $f"; grep -E "^void|MFMA pipe|HBM-side|BANK_CONFLICT" $f | cut -c1-140; done
 tools/ab_ddp.sh > $O/${TAG}_ab_ddp.txt 2>&1; cat $O/${TAG}_ab_ddp.txt
 tools/sweep.sh "16 64 256" > /dev/null 2>&1; cp $O/sweep.txt $O/${TAG}_sweep.txt; cat $O/${TAG}_sweep.txt
