@@ -479,8 +479,9 @@ int srk_fold_nhwc(const srk_fold_nhwc_args* a, srk_stream_t stream);
 
 /* Per-channel partial sums over P pixels of an NHWC tensor (fp32 accumulate), one plain store per block and channel:
  * partial[b][0][c], partial[b][1][c] for b < srk_chan_stats_blocks(P); the caller adds the blocks in order.
- *   mode 0: sum x, sum x^2          nn.BatchNorm2d batch statistics (srresnet.py:16-21 via common.py:97-98): one pass for
- *                                   the mean, a second pass with shift = mean for the variance
+ *   mode 0: sum x, sum x^2          nn.BatchNorm2d batch statistics (srresnet.py:16-21 via common.py:97-98) in ONE pass over
+ *                                   values shifted by the tensor's first pixel (shift_out != NULL), or one pass for the mean
+ *                                   and a second pass with shift = mean for the variance
  *   mode 1: sum y, sum x*y          BatchNorm backward (y = upstream gradient)
  *   mode 2: sum over x <= 0 of x*y  nn.PReLU slope gradient (partial[b][1] = 0)                                   */
 typedef struct {
@@ -492,15 +493,19 @@ typedef struct {
   int dtype;
   const float* shift;                     /* [C] or NULL: x is replaced by x - shift[c] in every sum (second pass of a  */
                                           /* two-pass variance, centred BatchNorm backward: no cancellation in fp32)   */
+  float* shift_out;                       /* [C] or NULL (then `shift` must be NULL): shift[c] = x[pixel 0][c], also    */
+                                          /* stored here -- the shifted-data variance: E[(x-K)^2] - (E[x-K])^2 with K a */
+                                          /* value of the data loses no digits to |mean| >> std                         */
 } srk_chan_stats_args;
 int srk_chan_stats_blocks(long long P);
 int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream);
 /* The per-channel step between srk_chan_stats and srk_chan_apply of nn.BatchNorm2d (models/common.py:97-98 in srresnet.py:16-21)
  * and nn.PReLU, as one launch: the ordered sum over the blocks of `partial` [nblocks][2][C] and the vector arithmetic.
  *   mode 0: out[0] = mean = sum0 / M
- *   mode 1 (sums of x - mean): var = max(sum1/M - (sum0/M)^2, 0); running_mean / running_var (nullable, [Creal]) updated with
+ *   mode 1 (sums of x - K, K = `mean`: the mean of a first pass, or srk_chan_stats' shift_out): the batch mean = K + sum0/M
+ *           (out row 4), var = max(sum1/M - (sum0/M)^2, 0); running_mean / running_var (nullable, [Creal]) updated with
  *           `momentum` (unbiased variance, like torch); out rows: invstd = rsqrt(var + eps), gamma (weight padded with 0),
- *           a = gamma * invstd, d = beta - mean * a            (srk_chan_apply: out = a x + d)
+ *           a = gamma * invstd, d = beta - mean * a, mean  (srk_chan_apply: out = a x + d)
  *   mode 2 (sum0 = sum dy, sum1 = sum (x - mean) dy; batch statistics): out rows: dgamma = invstd sum1, dbeta = sum0,
  *           a = gamma invstd, b = -a invstd dgamma / M, d = -a dbeta / M - b mean     (dx = a dy + b x + d)
  *   mode 3 (running statistics): out rows: dgamma, dbeta, a = gamma invstd

@@ -127,6 +127,13 @@ template <int DT, bool FUSED> __global__ __launch_bounds__(GEN_NT) void chan_sta
     s0[e] = s1[e] = 0.f;
     sh[e] = (a.shift && prow < rows) ? a.shift[cc * CH + e] : 0.f;      // x is centred first: sums of (x - shift[c])
   }
+  if (a.shift_out && prow < rows) {                                     // ... by the tensor's first pixel (every block reads it)
+    chunk_to_f32<DT>(gload16(reinterpret_cast<const elem*>(a.x) + a.x_coff + cc * CH), sh);
+    if (blockIdx.x == 0 && prow == 0) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) __hip_atomic_store(a.shift_out + cc * CH + e, sh[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   if (prow < rows) {
     const elem* x = reinterpret_cast<const elem*>(a.x) + a.x_coff + cc * CH;
     const elem* y = a.y ? reinterpret_cast<const elem*>(a.y) + a.y_coff + cc * CH : nullptr;
@@ -316,7 +323,7 @@ SRK_DEV void chan_finalize_body(const srk_chan_finalize_args& a) {
   } else if (a.mode == 1) {                // variance from the centred sums, running buffers, scale / shift of the apply pass
     const float m1 = s0 / M;
     const float var = fmaxf(s1 / M - m1 * m1, 0.f);
-    const float mean = a.mean[c];
+    const float mean = a.mean[c] + m1;                     // K + E[x - K]  (K = the first pass's mean: m1 is its rounding residue)
     if (a.nbt && c == 0) *a.nbt += 1;
     if (a.running_mean && real) {
       a.running_mean[c] = a.running_mean[c] * (1.f - a.momentum) + mean * a.momentum;
@@ -329,6 +336,7 @@ SRK_DEV void chan_finalize_body(const srk_chan_finalize_args& a) {
     o[C + c] = gamma;
     o[2 * C + c] = sc;
     o[3 * C + c] = beta - mean * sc;
+    o[4 * C + c] = mean;
   } else {                                 // backward: s0 = sum dy, s1 = sum (x - mean) dy
     const float invstd = a.invstd[c], gamma = a.gamma[c];
     const float dbeta = s0, dgamma = invstd * s1;
@@ -389,6 +397,7 @@ static int chan_stats_check(const srk_chan_stats_args* a) {
   SRK_CHECK_ARG(a && a->x && a->partial && (a->mode == 0 || a->y), "srk_chan_stats: null pointer");
   const int ch = a->dtype == SRK_F32 ? 4 : 8;
   SRK_CHECK_ARG(a->mode >= 0 && a->mode <= 2, "srk_chan_stats: mode %d", a->mode);
+  SRK_CHECK_ARG(!a->shift_out || !a->shift, "srk_chan_stats: shift and shift_out exclude each other");
   SRK_CHECK_ARG(a->C > 0 && a->C <= GEN_NT && a->C % ch == 0 && a->x_pitch % ch == 0 && a->x_coff % ch == 0 &&
                     (!a->y || (a->y_pitch % ch == 0 && a->y_coff % ch == 0)), "srk_chan_stats: C=%d (multiple of %d, <= %d) / alignment", a->C, ch, GEN_NT);
   return 0;

@@ -1748,7 +1748,7 @@ def chan_sums(x, y=None, mode=None, shift=None):
     nb = L.load().srk_chan_stats_blocks(P)
     part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
     L.call("srk_chan_stats", L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift)), _stream())
+                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=0), _stream())
     tot = part.sum(0)
     return tot[0], tot[1]
 
@@ -1757,7 +1757,7 @@ def _pitch4(t):
     return _pitch(t) if t.dim() == 4 else t.shape[-1]
 
 
-def chan_partials(x, y=None, mode=0, shift=None):
+def chan_partials(x, y=None, mode=0, shift=None, shift_out=None):
     """The per-block partial sums of srk_chan_stats [blocks][2][C] (see chan_sums), left unsummed for srk_chan_finalize."""
     _need_gpu(x)
     c = x.shape[-1]
@@ -1765,7 +1765,7 @@ def chan_partials(x, y=None, mode=0, shift=None):
     nb = L.load().srk_chan_stats_blocks(P)
     part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
     L.call("srk_chan_stats", L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift)), _stream())
+                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=_ptr(shift_out)), _stream())
     return part
 
 
@@ -1784,7 +1784,7 @@ def _arrival_counter(device):
 
 
 def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None,
-                bias=None, running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None):
+                bias=None, running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None, shift_out=None):
     """chan_finalize(chan_partials(x, y, smode, shift), fmode, rows, ...) as ONE launch (srk_chan_stats_finalize: the block that
     finishes last does the [C]-sized step)."""
     _need_gpu(x)
@@ -1792,13 +1792,13 @@ def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, 
     P = x.numel() // c
     nb = L.load().srk_chan_stats_blocks(P)
     if nb > _FUSE_MAX_BLOCKS:            # many blocks: their arrival counts (same-address atomics) would take longer than the launch they save
-        return chan_finalize(chan_partials(x, y, smode, shift), fmode, rows, M=M, creal=creal, eps=eps, momentum=momentum, mean=mean, invstd=invstd,
+        return chan_finalize(chan_partials(x, y, smode, shift, shift_out), fmode, rows, M=M, creal=creal, eps=eps, momentum=momentum, mean=mean, invstd=invstd,
                              gamma=gamma, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var, total=total,
                              nbt=nbt, dgamma_acc=dgamma_acc, dbeta_acc=dbeta_acc)
     part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
     out = torch.empty((rows, c), dtype=torch.float32, device=x.device)
     sa = L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-                         P=P, C=c, mode=smode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift))
+                         P=P, C=c, mode=smode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=_ptr(shift_out))
     fa = L.ChanFinalizeArgs(
         partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=fmode, total=int(total),
         M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
@@ -1896,14 +1896,15 @@ class BatchNormFn(torch.autograd.Function):
         cp = x.shape[-1]
         M = x.numel() // cp
         if training and M > 0:
-            # two-pass statistics: the mean, then the sums of the CENTRED values (E[x^2] - mean^2 cancels in fp32 when
-            # |mean| >> std, which formula-filled / badly scaled nets do have).  The [C]-sized arithmetic between the passes
-            # (mean; variance, running buffers, invstd, scale and shift of the apply pass) is one small launch each.
-            mean = chan_reduce(x, None, 0, None, 0, 1, M=M)[0]
+            # ONE pass: sums of the values shifted by the tensor's first pixel K (E[x^2] - mean^2 cancels in fp32 when |mean| >> std,
+            # which formula-filled / badly scaled nets do have; E[(x-K)^2] - (E[x-K])^2 with K from the data does not), and the
+            # [C]-sized arithmetic (mean; variance, running buffers, invstd, scale and shift of the apply pass) in the same launch.
             w32, b32 = _f32c(weight), _f32c(bias)
             upd = running_mean is not None and running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
-            r = chan_reduce(x, None, 0, mean, 1, 4, M=M, creal=c, eps=eps, momentum=momentum, mean=mean, weight=w32, bias=b32,
-                            running_mean=running_mean if upd else None, running_var=running_var if upd else None, nbt=nbt)
+            k0 = torch.empty(cp, dtype=torch.float32, device=x.device)
+            r = chan_reduce(x, None, 0, None, 1, 5, M=M, creal=c, eps=eps, momentum=momentum, mean=k0, weight=w32, bias=b32,
+                            running_mean=running_mean if upd else None, running_var=running_var if upd else None, nbt=nbt, shift_out=k0)
+            mean = r[4]
             nbt = None
             invstd, gamma, a, d = r[0], r[1], r[2], r[3]
             if running_mean is not None and not upd:        # buffers in another dtype: torch arithmetic

@@ -226,3 +226,26 @@ def test_batchnorm_prelu_gradients_accumulate_into_existing_grads(A, dt):
             err = float((got.double().cpu() - ref).norm() / ref.norm())
             assert err < tol, f"pass {it}: {name} off by {err:.2e}"
         assert float((bn.running_var.double().cpu() - bn_r.running_var).abs().max()) < tol
+
+
+@pytest.mark.parametrize("first_pixel", ["typical", "outlier"])
+def test_batchnorm_one_pass_statistics_are_well_conditioned(A, first_pixel):
+    """|mean| >> std in fp32 (300 +- 0.05: E[x^2] - mean^2 would lose every digit of the variance): the one-pass statistics of
+    ops.batch_norm shift the data by the tensor's first pixel before summing (srk_chan_stats shift_out), so the variance keeps
+    ~4 digits -- also when that pixel is 20 standard deviations out.  Against float64."""
+    from sr_amd import ops
+    torch.manual_seed(5)
+    n, c, h, w = 8, 64, 24, 24
+    x = 300.0 + 0.05 * torch.randn(n, h, w, c)
+    if first_pixel == "outlier":
+        x[0, 0, 0, :] = 301.0
+    bn = torch.nn.BatchNorm2d(c).cuda()
+    y = ops.batch_norm(x.cuda().requires_grad_(True), bn)
+    xr = x.double().view(-1, c)
+    mean, var = xr.mean(0), xr.var(0, unbiased=False)
+    yr = ((xr - mean) / torch.sqrt(var + bn.eps)).view(n, h, w, c)
+    torch.cuda.synchronize()
+    assert float((bn.running_mean.double().cpu() - 0.1 * mean).abs().max()) < 1e-4
+    assert float((bn.running_var.double().cpu() - (0.9 + 0.1 * xr.var(0, unbiased=True))).abs().max() / 0.9) < 1e-5
+    err = float((y.detach().double().cpu() - yr).abs().max())
+    assert err < 2e-2, f"normalised output off by {err} (values are ~N(0, 1); the fp32 input has 24 bits for 300 +- 0.05: ~6e-4 of a sigma)"
