@@ -30,17 +30,40 @@ struct KsCfg {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
+// diagnostics build only (make stamp: -DSRK_KS_STAMPS=1, tools/stamp_ks.py): s_memtime of workgroup 0's waves 0 (compute) and 4 (DMA)
+#if SRK_KS_STAMPS
+__device__ unsigned long long ks_stamp_buf[2][32];
+#define KS_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (i) < 32) ks_stamp_buf[threadIdx.x >> 8][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KS_STAMP(i) do { } while (0)
+#endif
+
 SRK_DEV __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int DT>
-__global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int tilesX, int tilesY, int ncob, unsigned x_bytes, unsigned w_bytes) {
+// compile-time loop: the K-block's 36 steps must be straight-line code (the fragment buffers are indexed by the step; a `#pragma unroll`
+// gives up silently once the body has grown enough, and then nothing below holds)
+template <int V> struct ks_int { static constexpr int value = V; };
+template <int I, int N, class F> SRK_DEV void ks_static_for(F&& f) {
+  if constexpr (I < N) { f(ks_int<I>{}); ks_static_for<I + 1, N>(f); }
+}
+
+// hidden 16-byte load into registers (the residual / mask values of a lane's pixel): the compiler does not see a vector-memory
+// instruction, so it neither counts it nor waits for it -- the kernel does, by hand (see the site table below)
+SRK_DEV void load16_hidden(i32x4& d, i32x4 rsrc, unsigned voff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(voff), "s"(rsrc) : "memory");
+}
+
+// PSIN: pixel-shuffled input (the dgrad of an upsampler conv): the halo pieces' addresses depend on the channel block
+template <int DT, bool PSIN>
+__global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int tilesX, int tilesY, int ncob, unsigned x_bytes, unsigned w_bytes, int ntiles) {
   typedef DTraits<DT> Tr;
   typedef KsCfg C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const X0 = smem;
   char* const Wr = smem + 2 * C::XS_BYTES;
+  float* const bias_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);     // this block's 64 biases (zeros without a bias)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -49,28 +72,71 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
   const int nkb = (a.Cin + 63) >> 6, nch = a.Cin >> 3;  // K-blocks of 64 input channels (the last one may be partial: Cin % 16 == 0);
                                                         // 16-byte chunks per pixel / tap
 
-  // output-channel block fastest: the workgroups that share a halo tile run together
-  int pt = blockIdx.x;
-  const int cob = pt % ncob;
-  pt /= ncob;
-  const int tX = pt % tilesX;
-  pt /= tilesX;
-  const int tY = pt % tilesY;
-  const int n = pt / tilesY;
-  const int y0 = tY * C::T, x0 = tX * C::T;
+  // PERSISTENT: the workgroup keeps its output-channel block and walks tiles q, q + stride, ... (the workgroups that share a halo
+  // tile -- the ncob blocks of one tile -- have neighbouring indices and run together).  The K-blocks of all its tiles form ONE
+  // stream Gk = 0 .. total - 1 (tile Gk / nkb, channel block Gk % nkb): halo tiles alternate between the two buffers by Gk's
+  // parity, weight slabs keep cycling through the ring -- the next tile's first halo tile and slabs arrive during the current
+  // tile's last K-block.  (One tile per workgroup, as before round 3's last change: 6k cycles of prologue, a first K-block twice as
+  // long as the later ones -- the ring not yet ahead -- and 3.5k of epilogue around 9.2k cycles of MFMA for 112 -> 128 channels.)
+  const int cob = (int)blockIdx.x % ncob;
+  const int q0 = (int)blockIdx.x / ncob, qstride = (int)gridDim.x / ncob;
+  const int mytiles = (ntiles - q0 + qstride - 1) / qstride;
+  const int total = mytiles * nkb;
+  auto tile_origin = [&](int ti, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+    int pt = q0 + ti * qstride;
+    const int tX = pt % tilesX;
+    pt /= tilesX;
+    const int tY = pt % tilesY;
+    n = pt / tilesY;
+    y0 = tY * C::T;
+    x0 = tX * C::T;
+  };
 
   const i32x4 xrsrc = make_rsrc4(a.x, x_bytes);
   const i32x4 wrsrc = make_rsrc4(a.wpk, w_bytes);
   const unsigned x_lds = lds_addr_of(X0), wr_lds = lds_addr_of(Wr);
 
-  // halo tile of K-block kb -> X[kb & 1]: pieces in the tile's LDS order (pixel-major, chunk slot XOR-swizzled by column)
-  const int rin = a.x_ps > 1 ? a.x_ps : 1, Cs = a.Cin / (rin * rin);
-  auto dma_xtile = [&](int kb) {
-    const unsigned dst = x_lds + (unsigned)((kb & 1) * C::XS_BYTES);
-    const int xij = (kb * 64) / Cs, xc0 = kb * 64 - xij * Cs, xsi = xij / rin, xsj = xij - xsi * rin;
+  // halo tile of stream K-block Gk -> X[Gk & 1]: pieces in the tile's LDS order (pixel-major, chunk slot XOR-swizzled by column)
+  const int rin = PSIN ? a.x_ps : 1, Cs = a.Cin / (rin * rin);
+  // Per lane and piece of a halo tile: xo[k] = byte offset of the piece's 16 bytes for channel block 0, | its chunk index c in the
+  // low bits (0x80000000 | c outside the image): the part of the address arithmetic that changes only with the TILE, kept in
+  // registers from one tile switch to the next (re-derived at every site it was 150 vector instructions per K-block and wave;
+  // the one-tile-per-workgroup kernel had the compiler hoist all of it).  Plain NHWC input only (rin == 1).
+  constexpr bool USE_XO = !PSIN;
+  int xo[USE_XO ? C::XK : 1];
+  auto xo_set = [&](int n, int y0, int x0) __attribute__((always_inline)) {
+    if constexpr (USE_XO) {
 #pragma unroll
     for (int k = 0; k < C::XK; ++k) {
       const int i = tid + k * C::NT;
+      const int sl = i & 7, p = i >> 3;
+      const int iy = p / C::XT, ix = p - iy * C::XT;
+      const int c = sl ^ swz(ix);
+      const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      xo[k] = (int)((ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * Tr::CH) * 2) : 0x80000000u) | (unsigned)c);
+    }
+    }
+  };
+  auto dma_xtile = [&](int par, int kb, int n, int y0, int x0) __attribute__((always_inline)) {      // par: the stream K-block's parity
+    const unsigned dst = x_lds + (unsigned)(par * C::XS_BYTES);
+    if constexpr (USE_XO) {
+#pragma unroll
+      for (int k = 0; k < C::XK; ++k) {
+        if (k * C::NT + wave * 64 < C::XPIECES) {         // wave-uniform
+          const int c = xo[k] & 7;
+          const unsigned voff = kb * 8 + c < nch ? ((unsigned)xo[k] & ~15u) + (unsigned)(kb * 128) : 0x80000000u;     // chunks beyond Cin: zeros
+          if (tid + k * C::NT < C::XPIECES)                // the last piece is half tile: its upper lanes are switched off
+            dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + ((k * C::NT + wave * 64) << 4))));
+        }
+      }
+    } else {
+    const int xij = (kb * 64) / Cs, xc0 = kb * 64 - xij * Cs, xsi = xij / rin, xsj = xij - xsi * rin;
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
+#pragma unroll
+    for (int k = 0; k < C::XK; ++k) {
+      const int i = tid_ + k * C::NT;
       if (k * C::NT + wave * 64 < C::XPIECES) {           // wave-uniform
         const int sl = i & 7, p = i >> 3;
         const int iy = p / C::XT, ix = p - iy * C::XT;
@@ -79,18 +145,18 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
         const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && kb * 8 + c < nch;      // chunks beyond Cin: zeros
         // (pixel-shuffled input, the dgrad of a conv -> PixelShuffle(r): logical channel k = (i*r+j)*Cs + c lives in pixel
         //  (gy*r+i, gx*r+j), channel c; a 64-channel K-block lies inside one (i, j) plane)
-        const int pix = rin == 1 ? (n * H + gy) * W + gx : (n * H * rin + gy * rin + xsi) * (W * rin) + gx * rin + xsj;
+        const int pix = !PSIN ? (n * H + gy) * W + gx : (n * H * rin + gy * rin + xsi) * (W * rin) + gx * rin + xsj;
         const unsigned voff = ok ? (unsigned)((pix * a.x_pitch + a.x_coff + xc0 + c * Tr::CH) * 2) : 0x80000000u;
         if (i < C::XPIECES)                                // the last piece is half tile: its upper lanes are switched off
           dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + ((k * C::NT + wave * 64) << 4))));
       }
     }
+    }
   };
-  // slab g = (K-block g / 3, kernel row g % 3): 3 taps x 8 chunks = 24 pieces of 64 rows x 16 B (contiguous in the packed
+  // slab g = (stream K-block g / 3, kernel row g % 3): 3 taps x 8 chunks = 24 pieces of 64 rows x 16 B (contiguous in the packed
   // layout wpk[tap][chunk][CoutP][CH]), 3 per wave, into ring slot g % 3 as [tap][chunk][row]
-  auto dma_slab = [&](int g) {
-    const int kb = g / 3, kh = g - 3 * kb;
-    const unsigned dst = wr_lds + (unsigned)((g % 3) * C::WG_BYTES);
+  auto dma_slab = [&](int kb, int kh) __attribute__((always_inline)) {
+    const unsigned dst = wr_lds + (unsigned)(kh * C::WG_BYTES);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int piece = wave * 3 + k;                      // tap kh*3 + piece / 8, chunk kb*8 + piece % 8
@@ -99,42 +165,37 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
                    (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));      // chunks beyond Cin: zeros
     }
   };
-  // residual / mask tile (16x16 pixels x this block's 64 channels) -> a halo buffer, image format with row pitch 16
-  auto dma_tile16 = [&](const void* src, int pitch, int coff, char* buf) {
-    const i32x4 rs = make_rsrc4(src, 0x7fffffffu);
-    const unsigned dst = lds_addr_of(buf);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int blk = wave + 8 * k;                        // 32 pieces of 8 pixels: row blk >> 1, columns (blk & 1) * 8 ..
-      const int iy = blk >> 1, ix = (blk & 1) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ swz(ix);
-      const int gy = y0 + iy, gx = x0 + ix;
-      const bool ok = gy < H && gx < W && cob * 64 + c * Tr::CH < a.Cout;      // Cout may end inside the last 64-row block
-      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * pitch + coff + cob * 64 + c * Tr::CH) * 2) : 0x80000000u;
-      dma16_hidden(rs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (blk << 10))));
-    }
-  };
 
-  // bias = initial accumulators; loaded BEFORE the first DMA (the vector-memory counter retires in order: a wait for these
-  // loads placed behind 115 KB of transfers would wait for all of them)
+  // bias: the accumulators' initial value at every tile start, from LDS (a global load per tile would enter the hand-counted
+  // vector-memory sequence; 32 registers per lane would not fit)
+  if (tid < 64) bias_lds[tid] = a.bias ? a.bias[cob * 64 + tid] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   f32x16 acc[2][2];                                       // [channel block][pixel block]
+  auto acc_init = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cob * 64 + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_lds + 4 * h + cb * 32 + 8 * i);
 #pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
-        acc[cb][pb][4 * i + 0] = b.x; acc[cb][pb][4 * i + 1] = b.y; acc[cb][pb][4 * i + 2] = b.z; acc[cb][pb][4 * i + 3] = b.w;
+        for (int pb = 0; pb < 2; ++pb) {
+          acc[cb][pb][4 * i + 0] = b.x; acc[cb][pb][4 * i + 1] = b.y; acc[cb][pb][4 * i + 2] = b.z; acc[cb][pb][4 * i + 3] = b.w;
+        }
       }
-    }
+  };
+  acc_init();
 
-  asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-
-  dma_xtile(0);
-  dma_slab(0);
-  dma_slab(1);
-  dma_slab(2);
+  // the stream's position, kept incrementally (no division inside the stream): K-block Gk = (tile ti, channel block kb), the
+  // tile's origin and the next tile's
+  int kb = 0, ti = 0, n0, y0c, x0c, n1 = 0, y1c = 0, x1c = 0;
+  tile_origin(0, n0, y0c, x0c);
+  if (mytiles > 1) tile_origin(1, n1, y1c, x1c);
+  KS_STAMP(0);
+  xo_set(n0, y0c, x0c);
+  dma_xtile(0, 0, n0, y0c, x0c);
+  dma_slab(0, 0);
+  dma_slab(0, 1);
+  dma_slab(0, 2);
 
   // ---- per-lane constants (as conv_pair's first conv: output pixel (row, col) reads halo pixels (row + kh, col + kw)) -----
   const bool cw = wave < 4;
@@ -150,163 +211,256 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     prow[pb] = 4 * (wave & 3) + 2 * pb + (r >> 4);
     xoff[pb] = (prow[pb] * C::XT + px) << 7;
   }
-  // Hand-overs inside K-block kb (slab g = 3 kb + kh), at K-steps 10 / 22 / 34 of its 36: fragments are read two steps
+  // LDS has no room for a residual / mask tile any more (the buffer it used to wait in now receives the next tile's first halo
+  // tile): both come into REGISTERS by hidden loads issued behind site B of a tile's last K-block.
+  //   residual: needed where the fp32 accumulators are -- the compute waves load their lanes' two pixels x 32 channels (8 loads of
+  //             16 B, each instruction touching 32 pixel rows);
+  //   mask    : applied to the finished 16-bit values, which is exact -- so it is applied during the copy-out, where a thread holds
+  //             16 B of a whole pixel row.  The copy-out is the DMA waves' job (8 pieces of the 16 x 16 x 64 tile per thread; the
+  //             compute waves are in the next K-block by then): they load their pieces' mask values (coalesced: 8 rows per instruction).
+  const bool has_res = a.res != nullptr, has_mask = a.mask != nullptr;
+  const int NLr = cw && has_res ? 8 : 0, NLm = !cw && has_mask ? 8 : 0, NST = cw ? 0 : 8;
+  const i32x4 rrsrc = make_rsrc4(has_res ? a.res : a.x, 0x7fffffffu), mrsrc = make_rsrc4(has_mask ? a.mask : a.x, 0x7fffffffu);
+  i32x4 tq[2][4], mq[8];                                   // (not initialised: a value from the kernel's start would occupy the registers all along)
+  auto load_res = [&](int n, int y0, int x0) __attribute__((always_inline)) {
+    int h_ = h;
+    asm volatile("" : "+v"(h_));                           // (as in dma_xtile: nothing of this is to be kept across the stream)
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+      const int gy = y0 + prow[pb], gx = x0 + px;
+      const int pix = (n * H + gy) * W + gx;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = cob * 64 + (4 * h_ + j) * Tr::CH;
+        const bool ok = gy < H && gx < W && ch < a.Cout;       // Cout may end inside the last 64-row block
+        load16_hidden(tq[pb][j], rrsrc, ok ? (unsigned)((pix * a.res_pitch + a.res_coff + ch) * 2) : 0x80000000u);
+      }
+    }
+  };
+  auto load_mask = [&](int n, int y0, int x0) __attribute__((always_inline)) {
+    int tid_ = tid - 256;                                  // DMA waves: threads 256 .. 511
+    asm volatile("" : "+v"(tid_));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid_ + 256 * k;                        // the copy-out's pieces: pixel i >> 3 (row-major 16 x 16), chunk i & 7
+      const int p = i >> 3, c = i & 7;
+      const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
+      const bool ok = gy < H && gx < W && cob * 64 + c * Tr::CH < a.Cout;
+      load16_hidden(mq[k], mrsrc, ok ? (unsigned)((((n * H + gy) * W + gx) * a.mask_pitch + a.mask_coff + cob * 64 + c * Tr::CH) * 2) : 0x80000000u);
+    }
+  };
+
+  // Hand-overs inside stream K-block Gk (slab g = 3 Gk + kh), at K-steps 10 / 22 / 34 of its 36: fragments are read two steps
   // ahead, so the reads of the slab that ends at step 12 / 24 / 36 have all been issued and, after the drain, returned --
   // its ring slot is free -- and the next slab must have landed (own pieces by the counted wait: the vector-memory counter
-  // retires in order and the counts are what each site leaves in flight; the others' by the barrier).
-  //   site A (step 10): needs slab 3kb+1; in flight: slab 3kb+2 (3).  Then issues slab 3kb+3 and the NEXT halo tile (<= 6) --
-  //                     in the last K-block the residual / mask tile (4) instead, into the idle halo buffer.
-  //   site B (step 22): needs slab 3kb+2; in flight: slab 3kb+3 + halo tile (>= 8 with 5 halo pieces; last K-block: waits for
-  //                     everything).  Then issues slab 3kb+4.
-  //   site C (step 34): needs slab 3kb+3 and the tile; in flight: slab 3kb+4 (3).  Then issues slab 3kb+5.
-  const int nslab = 3 * nkb;
-  const void* const tile_src = a.res ? a.res : a.mask;     // the tile fetched during the last K-block (the mask comes later if both)
-  char* const stage = X0 + (nkb & 1) * C::XS_BYTES;        // idle during the last K-block (which reads X[(nkb-1) & 1])
-  auto siteA = [&](int kb) {
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (3 * kb + 3 < nslab) dma_slab(3 * kb + 3);
-    if (kb + 1 < nkb) dma_xtile(kb + 1);
-    else if (tile_src) dma_tile16(tile_src, a.res ? a.res_pitch : a.mask_pitch, a.res ? a.res_coff : a.mask_coff, stage);
+  // retires in order and the counts are what each site leaves in flight; the others' by the barrier).  Per wave, in issue order:
+  //   site A (step 10): needs slab 3Gk+1; younger: slab 3Gk+2 (3) and, in a tile's FIRST K-block, the previous tile's stores (NST = 8,
+  //                     DMA waves).
+  //                     Then issues slab 3Gk+3 (3) and the next halo tile (5, wave 0: 6).
+  //   site B (step 22): needs slab 3Gk+2; younger: slab 3Gk+3 + halo tile (>= 8).  Then issues slab 3Gk+4 and, in a tile's LAST
+  //                     K-block, the residual loads (NLr = 8, compute waves) or the mask loads (NLm = 8, DMA waves) -- not at
+  //                     site A: its address arithmetic for the halo pieces is where the register file is fullest.  (In a tile's
+  //                     first K-block the stores are older than these transfers and by now long done: not counted = a stricter wait.)
+  //   site C (step 34): needs slab 3Gk+3 and the halo tile; younger: slab 3Gk+4 (3) + NLr + NLm.  Then issues slab 3Gk+5.
+  //   tile end        : compute waves need their residual, DMA waves their mask values: younger: slab 3Gk+5 (3).  The DMA waves then
+  //                     issue 8 stores each.
+  //   Nothing is issued for K-blocks beyond the stream's end (the last K-block's waits: everything).
+  auto wait_barrier = [&](int n) __attribute__((always_inline)) {                          // s_waitcnt vmcnt(n) lgkmcnt(0); s_barrier   (n: a few wave-uniform values)
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
   };
-  auto siteB = [&](int kb) {
-    // (last K-block: nothing but the residual / mask tile is younger than the slab that is needed)
-    if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (3 * kb + 4 < nslab) dma_slab(3 * kb + 4);
+  auto siteA = [&](int Gk) __attribute__((always_inline)) {
+    const bool more = Gk + 1 < total, lastkb = kb == nkb - 1;
+    wait_barrier(Gk > 0 && kb == 0 ? 3 + NST : 3);
+    if (more) {
+      dma_slab(lastkb ? 0 : kb + 1, 0);
+      if (lastkb) xo_set(n1, y1c, x1c);                    // from here on the halo tiles are the next tile's
+      dma_xtile((Gk + 1) & 1, lastkb ? 0 : kb + 1, lastkb ? n1 : n0, lastkb ? y1c : y0c, lastkb ? x1c : x0c);
+    }
   };
-  auto siteC = [&](int kb) {
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (3 * kb + 5 < nslab) dma_slab(3 * kb + 5);
+  auto siteB = [&](int Gk, auto computec) __attribute__((always_inline)) {
+    const bool more = Gk + 1 < total, lastkb = kb == nkb - 1;
+    wait_barrier(more ? 8 : 0);
+    if (more) dma_slab(lastkb ? 0 : kb + 1, 1);
+    if constexpr (decltype(computec)::value != 0) {
+      if (NLr && lastkb) load_res(n0, y0c, x0c);
+    } else {
+      if (NLm && lastkb) load_mask(n0, y0c, x0c);
+    }
+  };
+  auto siteC = [&](int Gk) __attribute__((always_inline)) {
+    const bool more = Gk + 1 < total, lastkb = kb == nkb - 1;
+    wait_barrier(more ? 3 + (lastkb ? NLr + NLm : 0) : 0);
+    if (more) dma_slab(lastkb ? 0 : kb + 1, 2);
+  };
+  auto advance = [&]() __attribute__((always_inline)) {     // to the next stream K-block (after tile_end where a tile ends)
+    if (++kb == nkb) {
+      kb = 0;
+      ++ti;
+      n0 = n1; y0c = y1c; x0c = x1c;
+      if (ti + 1 < mytiles) tile_origin(ti + 1, n1, y1c, x1c);
+    }
+  };
+
+  // ---- tile end: relu, * scale, + res, mask (channels >= mask_from) -> the halo buffer the tile's last K-block has just left, as
+  // a 16 x 16-pixel image; all eight waves copy it out in whole 128-byte pixels (no per-lane 16-byte global access) ------------------
+  const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.out);
+  const int orr = (a.out_mode == SRK_OUT_NHWC_PS && a.ps_r > 1) ? a.ps_r : 1, Cc = a.Cout / (orr * orr);
+  const int oij = (cob * 64) / Cc, ocb = cob * 64 - oij * Cc, osi = oij / orr, osj = oij - osi * orr;
+  auto tile_end = [&](int Gk, auto computec) __attribute__((always_inline)) {
+    char* const stage = X0 + (Gk & 1) * C::XS_BYTES;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every compute wave is done reading that buffer
+    if constexpr (decltype(computec)::value != 0) {
+      if (NLr) {                                                               // the residual registers are in
+        if (Gk + 1 < total) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(tq[pb][j]));
+      }
+      const float sc = a.scale;
+      const f32x2 sc2 = {sc, sc};
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const int po = ((prow[pb] * C::T + px) << 7);
+        const int g = swz(px);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {                   // 16 of the lane's 32 channels at a time (registers)
+          f32x2 v[8];
+#pragma unroll
+          for (int d = 0; d < 8; ++d) v[d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]};
+          if (a.relu) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) v[d] = f32x2{fmaxf(v[d].x, 0.f), fmaxf(v[d].y, 0.f)};
+          }
+#pragma unroll
+          for (int d = 0; d < 8; ++d) v[d] = v[d] * sc2;
+          if (has_res) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const i32x4 tv = tq[pb][2 * cb + jj];
+              const int qw[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float f0, f1;
+                unpack2<DT>((uint32_t)qw[e], f0, f1);
+                v[4 * jj + e] = v[4 * jj + e] + f32x2{f0, f1};
+              }
+            }
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+            lds_write16(stage + po + (((4 * h + 2 * cb + jj) ^ g) << 4),
+                        i32x4{(int)pack2<DT>(v[4 * jj].x, v[4 * jj].y), (int)pack2<DT>(v[4 * jj + 1].x, v[4 * jj + 1].y),
+                              (int)pack2<DT>(v[4 * jj + 2].x, v[4 * jj + 2].y), (int)pack2<DT>(v[4 * jj + 3].x, v[4 * jj + 3].y)});
+        }
+      }
+      acc_init();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the tile's results are in LDS: the compute waves go on
+    if constexpr (decltype(computec)::value == 0) {
+      const int n = n0, y0 = y0c, x0 = x0c;
+      if (NLm) {                                                               // the mask registers are in
+        if (Gk + 1 < total) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(mq[k]));
+      }
+      int tid_ = tid - 256;
+      asm volatile("" : "+v"(tid_));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = tid_ + 256 * k;                      // 2,048 pieces: pixel i >> 3 (row-major 16 x 16), chunk i & 7
+        const int p = i >> 3, c = i & 7;
+        const int row = p >> 4, col = p & 15;
+        const int gy = y0 + row, gx = x0 + col;
+        const bool ok = gy < H && gx < W && cob * 64 + c * Tr::CH < a.Cout;
+        i32x4 q = lds_read16(stage + (p << 7) + ((c ^ swz(col)) << 4));
+        if (has_mask && cob * 64 + c * Tr::CH >= a.mask_from) {            // ReLU mask: keep where the mask value is > 0 (mask_from: a multiple of 16)
+          int qw[4] = {q.x, q.y, q.z, q.w};
+          const int mw[4] = {mq[k].x, mq[k].y, mq[k].z, mq[k].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float m0, m1;
+            unpack2<DT>((uint32_t)mw[e], m0, m1);
+            qw[e] = (m0 > 0.f ? qw[e] & 0xffff : 0) | (m1 > 0.f ? qw[e] & (int)0xffff0000 : 0);
+          }
+          q = i32x4{qw[0], qw[1], qw[2], qw[3]};
+        }
+        // (fused PixelShuffle(r) store: packed channel co' = (i*r+j)*Cc + c goes to pixel (gy*r+i, gx*r+j), channel c)
+        const int opix = orr == 1 ? (n * H + gy) * W + gx : (n * H * orr + gy * orr + osi) * (W * orr) + gx * orr + osj;
+        const unsigned vo = ok ? (unsigned)((opix * a.out_pitch + a.out_coff + ocb + c * Tr::CH) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
+      }
+    }
   };
 
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // halo tile 0 and slab 0 (slabs 1, 2 are the 6 youngest transfers)
   __builtin_amdgcn_s_barrier();
+  KS_STAMP(1);
 
   if (cw) {
-    // fragments of K-step s of the current K-block (s >= 36: step s - 36 of the next one, other halo buffer)
+    // fragments of K-step s of stream K-block Gk (s >= 36: step s - 36 of the next one, other halo buffer)
     i32x4 fa[3][2], fb[3][2];
-    auto frag1 = [&](int kb, int s, int q, i32x4 (&af)[2], i32x4 (&bf)[2]) {
-      const int kbb = s >= 36 ? kb + 1 : kb, ss = s >= 36 ? s - 36 : s;
-      const int kh = ss / 12, kw = (ss % 12) / 4, ks = ss % 4;
-      if (q < 2) af[q] = lds_read16(wlane + kh * C::WG_BYTES + (((kw * 8 + 2 * ks) * 64 + q * 32) << 4));     // ring slot = kernel row
+    auto frag1 = [&](int Gk, auto sc, auto qc, i32x4 (&af)[2], i32x4 (&bf)[2]) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value, q = decltype(qc)::value;
+      constexpr int ss = s >= 36 ? s - 36 : s;
+      constexpr int kh = ss / 12, kw = (ss % 12) / 4, ks = ss % 4;
+      const int kbb = s >= 36 ? Gk + 1 : Gk;
+      if constexpr (q < 2) af[q] = lds_read16(wlane + kh * C::WG_BYTES + (((kw * 8 + 2 * ks) * 64 + q * 32) << 4));     // ring slot = kernel row
       else bf[q - 2] = lds_read16(X0 + (kbb & 1) * C::XS_BYTES + xoff[q - 2] + ((kh * C::XT + kw) << 7) + (((2 * ks + h) ^ gsw[kw]) << 4));
     };
-#pragma unroll
-    for (int q = 0; q < 4; ++q) frag1(0, 0, q, fa[0], fb[0]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) frag1(0, 1, q, fa[1], fb[1]);
+    ks_static_for<0, 4>([&](auto qc) __attribute__((always_inline)) { frag1(0, ks_int<0>{}, qc, fa[0], fb[0]); });
+    ks_static_for<0, 4>([&](auto qc) __attribute__((always_inline)) { frag1(0, ks_int<1>{}, qc, fa[1], fb[1]); });
     __builtin_amdgcn_s_setprio(1);
-    for (int kb = 0; kb < nkb; ++kb) {
-      const bool more = kb + 1 < nkb;
-#pragma unroll
-      for (int s = 0; s < 36; ++s) {
-        if (s == 10) siteA(kb);
-        if (s == 22) siteB(kb);
-        if (s == 34) siteC(kb);
-        const int c0 = s % 3, c2 = (s + 2) % 3;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          if (s + 2 < 36 || more) frag1(kb, s + 2, m, fa[c2], fb[c2]);
-          const int cb = m >> 1, pb = m & 1;
+    for (int Gk = 0; Gk < total; ++Gk) {
+      const bool more = Gk + 1 < total;
+      ks_static_for<0, 36>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s == 10) siteA(Gk);
+        if constexpr (s == 22) siteB(Gk, ks_int<1>{});
+        if constexpr (s == 34) siteC(Gk);
+        constexpr int c0 = s % 3, c2 = (s + 2) % 3;
+        ks_static_for<0, 4>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int m = decltype(mc)::value;
+          if (s + 2 < 36 || more) frag1(Gk, ks_int<s + 2>{}, mc, fa[c2], fb[c2]);
+          constexpr int cb = m >> 1, pb = m & 1;
           acc[cb][pb] = Tr::mma(fa[c0][cb], fb[c0][pb], acc[cb][pb]);
           __builtin_amdgcn_sched_barrier(0);
-        }
+        });
+      });
+      if (Gk < 8) KS_STAMP(2 + Gk);
+      if (kb == nkb - 1) {
+        __builtin_amdgcn_s_setprio(0);
+        tile_end(Gk, ks_int<1>{});
+        __builtin_amdgcn_s_setprio(1);
       }
+      advance();
     }
     __builtin_amdgcn_s_setprio(0);
   } else {
-    for (int kb = 0; kb < nkb; ++kb) {
-      siteA(kb);
-      siteB(kb);
-      siteC(kb);
+    for (int Gk = 0; Gk < total; ++Gk) {
+      siteA(Gk);
+      siteB(Gk, ks_int<0>{});
+      siteC(Gk);
+      if (kb == nkb - 1) tile_end(Gk, ks_int<0>{});
+      advance();
     }
   }
-  // everything has landed (the residual / mask tile included); the last K-block's halo buffer is free
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  char* const other = X0 + ((nkb - 1) & 1) * C::XS_BYTES;
-  const bool both = a.res && a.mask;
-  if (both) {                                              // residual AND mask (RDN's dense-block dgrad): the mask tile now
-    dma_tile16(a.mask, a.mask_pitch, a.mask_coff, other);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  }
-
-  // ---- epilogue: relu, * scale, + res, mask (channels >= mask_from), written over the residual tile in `stage` ------------
-  if (cw) {
-    const float sc = a.scale;
-    const f32x2 sc2 = {sc, sc};
-    const char* const mbuf = both ? other : stage;
-    const bool mask_on = a.mask && cob * 64 + 32 * h + 32 > a.mask_from;      // some of this lane's 32 channels are masked
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-      f32x2 v[16];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int d = 0; d < 8; ++d) v[8 * cb + d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]};
-      if (a.relu) {
-#pragma unroll
-        for (int d = 0; d < 16; ++d) v[d] = f32x2{fmaxf(v[d].x, 0.f), fmaxf(v[d].y, 0.f)};
-      }
-#pragma unroll
-      for (int d = 0; d < 16; ++d) v[d] = v[d] * sc2;
-      const int po = ((prow[pb] * C::T + px) << 7);
-      const int g = swz(px);
-      if (a.res) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const i32x4 q = lds_read16(stage + po + (((4 * h + j) ^ g) << 4));
-          const int qw[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float f0, f1;
-            unpack2<DT>((uint32_t)qw[e], f0, f1);
-            v[4 * j + e] = v[4 * j + e] + f32x2{f0, f1};
-          }
-        }
-      }
-      if (mask_on) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const i32x4 q = lds_read16(mbuf + po + (((4 * h + j) ^ g) << 4));
-          const int qw[4] = {q.x, q.y, q.z, q.w};
-          const bool on = cob * 64 + 32 * h + 8 * j >= a.mask_from;            // mask_from is a multiple of 16
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float m0, m1;
-            unpack2<DT>((uint32_t)qw[e], m0, m1);
-            if (on) v[4 * j + e] = f32x2{m0 > 0.f ? v[4 * j + e].x : 0.f, m1 > 0.f ? v[4 * j + e].y : 0.f};
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        lds_write16(stage + po + (((4 * h + j) ^ g) << 4),
-                    i32x4{(int)pack2<DT>(v[4 * j].x, v[4 * j].y), (int)pack2<DT>(v[4 * j + 1].x, v[4 * j + 1].y),
-                          (int)pack2<DT>(v[4 * j + 2].x, v[4 * j + 2].y), (int)pack2<DT>(v[4 * j + 3].x, v[4 * j + 3].y)});
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  {
-    const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.out);
-    const int orr = (a.out_mode == SRK_OUT_NHWC_PS && a.ps_r > 1) ? a.ps_r : 1, Cc = a.Cout / (orr * orr);
-    const int oij = (cob * 64) / Cc, ocb = cob * 64 - oij * Cc, osi = oij / orr, osj = oij - osi * orr;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + C::NT * k;                       // 2,048 pieces: pixel i >> 3 (row-major 16 x 16), chunk i & 7
-      const int p = i >> 3, c = i & 7;
-      const int row = p >> 4, col = p & 15;
-      const int gy = y0 + row, gx = x0 + col;
-      const bool ok = gy < H && gx < W && cob * 64 + c * Tr::CH < a.Cout;
-      const i32x4 q = lds_read16(stage + (p << 7) + ((c ^ swz(col)) << 4));
-      // (fused PixelShuffle(r) store: packed channel co' = (i*r+j)*Cc + c goes to pixel (gy*r+i, gx*r+j), channel c)
-      const int opix = orr == 1 ? (n * H + gy) * W + gx : (n * H * orr + gy * orr + osi) * (W * orr) + gx * orr + osj;
-      const unsigned vo = ok ? (unsigned)((opix * a.out_pitch + a.out_coff + ocb + c * Tr::CH) * 2) : 0x80000000u;
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
-    }
-  }
+  KS_STAMP(13);
 }
 
 }  // namespace
+
+#if SRK_KS_STAMPS
+extern "C" int srk_ks_read_stamps(unsigned long long* host64) {
+  return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(ks_stamp_buf), sizeof(unsigned long long) * 64);
+}
+#endif
+
 
 // Whether srk_conv2d takes this kernel for `a` (16-bit, 3x3, more than one 64-channel input block -- Cin >= 96, a multiple of 16 --,
 // the stored channels ending inside the last 64-row block of the packed weights,
@@ -335,22 +489,32 @@ bool srk_conv_ks_ok(const srk_conv_args& a) {
 
 int srk_conv_ks_launch(const srk_conv_args& a, hipStream_t st) {
   typedef KsCfg C;
-  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ks_kernel<SRK_BF16>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ks_kernel<SRK_F16>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-  if (attr0 != hipSuccess || attr1 != hipSuccess) {
-    srk_set_error("srk_conv2d: cannot reserve %d bytes of LDS", C::LDS_BYTES);
-    return (int)(attr0 != hipSuccess ? attr0 : attr1);
+  constexpr int LDS = C::LDS_BYTES + 256;                  // + the block's biases
+  typedef void (*ks_fn)(const srk_conv_args, int, int, int, unsigned, unsigned, int);
+  static const ks_fn fns[2][2] = {{conv_ks_kernel<SRK_BF16, false>, conv_ks_kernel<SRK_BF16, true>}, {conv_ks_kernel<SRK_F16, false>, conv_ks_kernel<SRK_F16, true>}};
+  static const hipError_t attr = [] {
+    for (int d = 0; d < 2; ++d)
+      for (int v = 0; v < 2; ++v) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[d][v]), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+      }
+    return hipSuccess;
+  }();
+  if (attr != hipSuccess) {
+    srk_set_error("srk_conv2d: cannot reserve %d bytes of LDS", LDS);
+    return (int)attr;
   }
   const int tilesX = (a.W + C::T - 1) / C::T, tilesY = (a.H + C::T - 1) / C::T, ncob = a.CoutP / 64;
-  const long long nb = (long long)a.N * tilesX * tilesY * ncob;
-  SRK_CHECK_ARG(nb <= 0x7fffffffLL, "srk_conv2d: %lld workgroups", nb);
+  const long long ntiles = (long long)a.N * tilesX * tilesY;
+  SRK_CHECK_ARG(ntiles * ncob <= 0x7fffffffLL, "srk_conv2d: %lld tiles", ntiles * ncob);
+  // one workgroup per CU (156 KB of LDS each), every one with the same number of output-channel blocks' worth of neighbours
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  long long nb = ntiles * ncob;
+  if (nb > cus) nb = cus >= ncob ? (long long)(cus / ncob) * ncob : ncob;
   const int rin = a.x_ps > 1 ? a.x_ps : 1;
   const unsigned xb = (unsigned)((long long)a.N * a.H * a.W * rin * rin * a.x_pitch * 2);
   const unsigned wb = (unsigned)(9LL * (a.Cin / 8) * a.CoutP * 16);
-  if (a.dtype == SRK_BF16) hipLaunchKernelGGL((conv_ks_kernel<SRK_BF16>), dim3((unsigned)nb), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY, ncob, xb, wb);
-  else hipLaunchKernelGGL((conv_ks_kernel<SRK_F16>), dim3((unsigned)nb), dim3(C::NT), C::LDS_BYTES, st, a, tilesX, tilesY, ncob, xb, wb);
+  hipLaunchKernelGGL(fns[a.dtype == SRK_BF16 ? 0 : 1][rin > 1 ? 1 : 0], dim3((unsigned)nb), dim3(C::NT), LDS, st, a, tilesX, tilesY, ncob, xb, wb, (int)ntiles);
   SRK_LAUNCH_CHECK();
   return 0;
 }

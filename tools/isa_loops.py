@@ -5,7 +5,7 @@ import re, sys
 text = open(sys.argv[1]).read().split('\n')
 key = sys.argv[2]
 start = next(i for i, l in enumerate(text) if l.startswith('_Z') and key in l.split(':')[0] and ':' in l)
-end = next(i for i in range(start, len(text)) if 's_endpgm' in text[i])
+end = next(i for i in range(start, len(text)) if text[i].startswith('.Lfunc_end'))
 lines = text[start:end + 1]
 lab = {}
 for i, l in enumerate(lines):
