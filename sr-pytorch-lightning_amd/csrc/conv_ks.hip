@@ -25,7 +25,8 @@ struct KsCfg {
   static constexpr int WG_BYTES = 3 * 8 * 64 * 16;      // one slab = 3 taps x 64 input channels x 64 rows: 24,576
   static constexpr int LDS_BYTES = 2 * XS_BYTES + 3 * WG_BYTES;
   static constexpr int XPIECES = XT * XT * 8;           // 2,592
-  static constexpr int XK = (XPIECES + NT - 1) / NT;    // 6 pieces per lane
+  static constexpr int DT_ = 256;                       // threads that issue the transfers: waves 4-7
+  static constexpr int XK = (XPIECES + DT_ - 1) / DT_;  // 11 halo pieces per DMA-wave lane (the last one: 32 lanes of wave 4)
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -103,12 +104,14 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
   // registers from one tile switch to the next (re-derived at every site it was 150 vector instructions per K-block and wave;
   // the one-tile-per-workgroup kernel had the compiler hoist all of it).  Plain NHWC input only (rin == 1).
   constexpr bool USE_XO = !PSIN;
+  const int dtid = tid - C::DT_, dwave = wave - 4;        // the transfers are the DMA waves' (4 - 7) alone: an LDS-DMA piece costs the
+                                                          // issuing wave ~60 cycles -- cycles a compute wave's MFMA stream does not have
   int xo[USE_XO ? C::XK : 1];
   auto xo_set = [&](int n, int y0, int x0) __attribute__((always_inline)) {
     if constexpr (USE_XO) {
 #pragma unroll
     for (int k = 0; k < C::XK; ++k) {
-      const int i = tid + k * C::NT;
+      const int i = dtid + k * C::DT_;
       const int sl = i & 7, p = i >> 3;
       const int iy = p / C::XT, ix = p - iy * C::XT;
       const int c = sl ^ swz(ix);
@@ -123,21 +126,21 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     if constexpr (USE_XO) {
 #pragma unroll
       for (int k = 0; k < C::XK; ++k) {
-        if (k * C::NT + wave * 64 < C::XPIECES) {         // wave-uniform
+        if (k * C::DT_ + dwave * 64 < C::XPIECES) {       // wave-uniform
           const int c = xo[k] & 7;
           const unsigned voff = kb * 8 + c < nch ? ((unsigned)xo[k] & ~15u) + (unsigned)(kb * 128) : 0x80000000u;     // chunks beyond Cin: zeros
-          if (tid + k * C::NT < C::XPIECES)                // the last piece is half tile: its upper lanes are switched off
-            dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + ((k * C::NT + wave * 64) << 4))));
+          if (dtid + k * C::DT_ < C::XPIECES)              // the last piece is half a wave: its upper lanes are switched off
+            dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + ((k * C::DT_ + dwave * 64) << 4))));
         }
       }
     } else {
     const int xij = (kb * 64) / Cs, xc0 = kb * 64 - xij * Cs, xsi = xij / rin, xsj = xij - xsi * rin;
-    int tid_ = tid;
+    int tid_ = dtid;
     asm volatile("" : "+v"(tid_));
 #pragma unroll
     for (int k = 0; k < C::XK; ++k) {
-      const int i = tid_ + k * C::NT;
-      if (k * C::NT + wave * 64 < C::XPIECES) {           // wave-uniform
+      const int i = tid_ + k * C::DT_;
+      if (k * C::DT_ + dwave * 64 < C::XPIECES) {         // wave-uniform
         const int sl = i & 7, p = i >> 3;
         const int iy = p / C::XT, ix = p - iy * C::XT;
         const int c = sl ^ swz(ix);
@@ -148,18 +151,18 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
         const int pix = !PSIN ? (n * H + gy) * W + gx : (n * H * rin + gy * rin + xsi) * (W * rin) + gx * rin + xsj;
         const unsigned voff = ok ? (unsigned)((pix * a.x_pitch + a.x_coff + xc0 + c * Tr::CH) * 2) : 0x80000000u;
         if (i < C::XPIECES)                                // the last piece is half tile: its upper lanes are switched off
-          dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + ((k * C::NT + wave * 64) << 4))));
+          dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + ((k * C::DT_ + dwave * 64) << 4))));
       }
     }
     }
   };
   // slab g = (stream K-block g / 3, kernel row g % 3): 3 taps x 8 chunks = 24 pieces of 64 rows x 16 B (contiguous in the packed
-  // layout wpk[tap][chunk][CoutP][CH]), 3 per wave, into ring slot g % 3 as [tap][chunk][row]
+  // layout wpk[tap][chunk][CoutP][CH]), 6 per DMA wave, into ring slot g % 3 as [tap][chunk][row]
   auto dma_slab = [&](int kb, int kh) __attribute__((always_inline)) {
     const unsigned dst = wr_lds + (unsigned)(kh * C::WG_BYTES);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int piece = wave * 3 + k;                      // tap kh*3 + piece / 8, chunk kb*8 + piece % 8
+    for (int k = 0; k < 6; ++k) {
+      const int piece = dwave * 6 + k;                     // tap kh*3 + piece / 8, chunk kb*8 + piece % 8
       const int tap = kh * 3 + (piece >> 3), cc = kb * 8 + (piece & 7);
       dma16_hidden(wrsrc, cc < nch ? (unsigned)((((tap * nch + cc) * a.CoutP + cob * 64) << 4) + lane * 16) : 0x80000000u,
                    (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));      // chunks beyond Cin: zeros
@@ -191,14 +194,16 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
   tile_origin(0, n0, y0c, x0c);
   if (mytiles > 1) tile_origin(1, n1, y1c, x1c);
   KS_STAMP(0);
-  xo_set(n0, y0c, x0c);
-  dma_xtile(0, 0, n0, y0c, x0c);
-  dma_slab(0, 0);
-  dma_slab(0, 1);
-  dma_slab(0, 2);
+  const bool cw = wave < 4;
+  if (!cw) {
+    xo_set(n0, y0c, x0c);
+    dma_xtile(0, 0, n0, y0c, x0c);
+    dma_slab(0, 0);
+    dma_slab(0, 1);
+    dma_slab(0, 2);
+  }
 
   // ---- per-lane constants (as conv_pair's first conv: output pixel (row, col) reads halo pixels (row + kh, col + kw)) -----
-  const bool cw = wave < 4;
   const int px = r & 15;
   int gsw[3];
 #pragma unroll
@@ -252,50 +257,60 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
 
   // Hand-overs inside stream K-block Gk (slab g = 3 Gk + kh), at K-steps 10 / 22 / 34 of its 36: fragments are read two steps
   // ahead, so the reads of the slab that ends at step 12 / 24 / 36 have all been issued and, after the drain, returned --
-  // its ring slot is free -- and the next slab must have landed (own pieces by the counted wait: the vector-memory counter
-  // retires in order and the counts are what each site leaves in flight; the others' by the barrier).  Per wave, in issue order:
-  //   site A (step 10): needs slab 3Gk+1; younger: slab 3Gk+2 (3) and, in a tile's FIRST K-block, the previous tile's stores (NST = 8,
-  //                     DMA waves).
-  //                     Then issues slab 3Gk+3 (3) and the next halo tile (5, wave 0: 6).
-  //   site B (step 22): needs slab 3Gk+2; younger: slab 3Gk+3 + halo tile (>= 8).  Then issues slab 3Gk+4 and, in a tile's LAST
-  //                     K-block, the residual loads (NLr = 8, compute waves) or the mask loads (NLm = 8, DMA waves) -- not at
-  //                     site A: its address arithmetic for the halo pieces is where the register file is fullest.  (In a tile's
-  //                     first K-block the stores are older than these transfers and by now long done: not counted = a stricter wait.)
-  //   site C (step 34): needs slab 3Gk+3 and the halo tile; younger: slab 3Gk+4 (3) + NLr + NLm.  Then issues slab 3Gk+5.
-  //   tile end        : compute waves need their residual, DMA waves their mask values: younger: slab 3Gk+5 (3).  The DMA waves then
-  //                     issue 8 stores each.
+  // its ring slot is free -- and the next slab must have landed.  The DMA waves own the transfers: each waits for its own
+  // pieces by a counted wait (the vector-memory counter retires in order; the counts are what each site leaves in flight), the
+  // barrier makes that collective; a compute wave only drains its LDS reads and joins the barrier.  Per DMA wave, in issue order:
+  //   site A (step 10): needs slab 3Gk+1; younger: slab 3Gk+2 (6) and, in a tile's FIRST K-block, the previous tile's 8 stores.
+  //                     Then issues slab 3Gk+3 (6) and the next halo tile (10, wave 4: 11).
+  //   site B (step 22): needs slab 3Gk+2; younger: slab 3Gk+3 + halo tile (>= 16).  Then issues slab 3Gk+4 and, in a tile's LAST
+  //                     K-block, its 8 mask loads (NLm).  (In a tile's first K-block the stores are older than these transfers
+  //                     and by now long done: not counted = a stricter wait.)
+  //   site C (step 34): needs slab 3Gk+3 and the halo tile; younger: slab 3Gk+4 (6) + NLm.  Then issues slab 3Gk+5.
+  //   tile end        : needs the mask values: younger: slab 3Gk+5 (6).  Then 8 stores.
   //   Nothing is issued for K-blocks beyond the stream's end (the last K-block's waits: everything).
+  // The compute waves' only vector-memory instructions are their 8 residual loads (behind site B of a tile's last K-block, awaited
+  // at the tile's end).
   auto wait_barrier = [&](int n) __attribute__((always_inline)) {                          // s_waitcnt vmcnt(n) lgkmcnt(0); s_barrier   (n: a few wave-uniform values)
     switch (n) {
       case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 14: asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;      // 16
     }
   };
-  auto siteA = [&](int Gk) __attribute__((always_inline)) {
-    const bool more = Gk + 1 < total, lastkb = kb == nkb - 1;
-    wait_barrier(Gk > 0 && kb == 0 ? 3 + NST : 3);
-    if (more) {
-      dma_slab(lastkb ? 0 : kb + 1, 0);
-      if (lastkb) xo_set(n1, y1c, x1c);                    // from here on the halo tiles are the next tile's
-      dma_xtile((Gk + 1) & 1, lastkb ? 0 : kb + 1, lastkb ? n1 : n0, lastkb ? y1c : y0c, lastkb ? x1c : x0c);
+  auto siteA = [&](int Gk, auto computec) __attribute__((always_inline)) {
+    if constexpr (decltype(computec)::value != 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      const bool more = Gk + 1 < total, lastkb = kb == nkb - 1;
+      wait_barrier(Gk > 0 && kb == 0 ? 14 : 6);
+      if (more) {
+        dma_slab(lastkb ? 0 : kb + 1, 0);
+        if (lastkb) xo_set(n1, y1c, x1c);                  // from here on the halo tiles are the next tile's
+        dma_xtile((Gk + 1) & 1, lastkb ? 0 : kb + 1, lastkb ? n1 : n0, lastkb ? y1c : y0c, lastkb ? x1c : x0c);
+      }
     }
   };
   auto siteB = [&](int Gk, auto computec) __attribute__((always_inline)) {
-    const bool more = Gk + 1 < total, lastkb = kb == nkb - 1;
-    wait_barrier(more ? 8 : 0);
-    if (more) dma_slab(lastkb ? 0 : kb + 1, 1);
+    const bool lastkb = kb == nkb - 1;
     if constexpr (decltype(computec)::value != 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (NLr && lastkb) load_res(n0, y0c, x0c);
     } else {
+      const bool more = Gk + 1 < total;
+      wait_barrier(more ? 16 : 0);
+      if (more) dma_slab(lastkb ? 0 : kb + 1, 1);
       if (NLm && lastkb) load_mask(n0, y0c, x0c);
     }
   };
-  auto siteC = [&](int Gk) __attribute__((always_inline)) {
-    const bool more = Gk + 1 < total, lastkb = kb == nkb - 1;
-    wait_barrier(more ? 3 + (lastkb ? NLr + NLm : 0) : 0);
-    if (more) dma_slab(lastkb ? 0 : kb + 1, 2);
+  auto siteC = [&](int Gk, auto computec) __attribute__((always_inline)) {
+    if constexpr (decltype(computec)::value != 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      const bool more = Gk + 1 < total, lastkb = kb == nkb - 1;
+      wait_barrier(more ? 6 + (lastkb ? NLm : 0) : 0);
+      if (more) dma_slab(lastkb ? 0 : kb + 1, 2);
+    }
   };
   auto advance = [&]() __attribute__((always_inline)) {     // to the next stream K-block (after tile_end where a tile ends)
     if (++kb == nkb) {
@@ -315,8 +330,8 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     char* const stage = X0 + (Gk & 1) * C::XS_BYTES;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every compute wave is done reading that buffer
     if constexpr (decltype(computec)::value != 0) {
-      if (NLr) {                                                               // the residual registers are in
-        if (Gk + 1 < total) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (NLr) {                                                               // the residual registers are in (this wave's only loads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
@@ -365,7 +380,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     if constexpr (decltype(computec)::value == 0) {
       const int n = n0, y0 = y0c, x0 = x0c;
       if (NLm) {                                                               // the mask registers are in
-        if (Gk + 1 < total) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (Gk + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(mq[k]));
       }
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     }
   };
 
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // halo tile 0 and slab 0 (slabs 1, 2 are the 6 youngest transfers)
+  if (!cw) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // halo tile 0 and slab 0 (slabs 1, 2 are a DMA wave's 12 youngest transfers)
   __builtin_amdgcn_s_barrier();
   KS_STAMP(1);
 
@@ -420,9 +435,9 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
       const bool more = Gk + 1 < total;
       ks_static_for<0, 36>([&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
-        if constexpr (s == 10) siteA(Gk);
+        if constexpr (s == 10) siteA(Gk, ks_int<1>{});
         if constexpr (s == 22) siteB(Gk, ks_int<1>{});
-        if constexpr (s == 34) siteC(Gk);
+        if constexpr (s == 34) siteC(Gk, ks_int<1>{});
         constexpr int c0 = s % 3, c2 = (s + 2) % 3;
         ks_static_for<0, 4>([&](auto mc) __attribute__((always_inline)) {
           constexpr int m = decltype(mc)::value;
@@ -443,9 +458,9 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     __builtin_amdgcn_s_setprio(0);
   } else {
     for (int Gk = 0; Gk < total; ++Gk) {
-      siteA(Gk);
+      siteA(Gk, ks_int<0>{});
       siteB(Gk, ks_int<0>{});
-      siteC(Gk);
+      siteC(Gk, ks_int<0>{});
       if (kb == nkb - 1) tile_end(Gk, ks_int<0>{});
       advance();
     }
