@@ -110,11 +110,17 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
   const unsigned cst_bytes = (unsigned)cst_pieces * 1024u;
   PW_STAMP(0);
 
+  // The weight slices are fetched by waves 4-7 alone, 2 PPW pieces each: an LDS-DMA piece costs its issuer ~60 cycles, and with all
+  // eight waves issuing right behind the barrier nobody computed meanwhile (stamps: 350-470 cycles per slice).  Now each SIMD's
+  // other wave (0-3) has the MFMA pipe to itself while its partner issues.  (Waves 0-3 have no transfers of their own in the
+  // loop: its counted waits pass at once for them.)
+  const bool issuer = wave >= 4;
   auto dma_slice = [&](int s) {
+    if (!issuer) return;
     const unsigned dst = ring_lds + (unsigned)((s % NSLOT) * SL);
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) {
-      const int piece = wave * PPW + k;
+    for (int k = 0; k < 2 * PPW; ++k) {
+      const int piece = (wave - 4) * 2 * PPW + k;
       dma16_hidden(wrsrc, cst_bytes + (unsigned)s * SL + piece * 1024 + lane * 16,
                    (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));
     }
@@ -128,7 +134,8 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
   dma_slice(0);
   dma_slice(1);
   PW_STAMP(1);
-  if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if (!issuer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // constants and pixels; an issuer: everything but slice 1
+  else if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   PW_STAMP(2);
   __builtin_amdgcn_s_barrier();
   PW_STAMP(3);
@@ -224,8 +231,8 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
       const int ss = s + u;
       if (ss < NS) {
         // slice ss + 1 must have landed; younger transfers: slices ss + 2 (and, in the first iteration, 3)
-        if (ss == 0) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else if (ss + 2 < NS) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        if (ss == 0) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else if (ss + 2 < NS) { if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PW_STAMP(8 + 4 * ss);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -646,11 +653,13 @@ __global__ __launch_bounds__(512) void pw_bwd_kernel(const srk_pw_bwd_args a, un
   const unsigned ring_lds = lds_addr_of(ring), cst_lds = lds_addr_of(cst);
   const unsigned cst_bytes = (unsigned)cst_pieces * 1024u;
 
+  const bool issuer = wave >= 4;                                  // the weight slices: waves 4-7 alone, 2 PPW pieces each (see pw_fwd_kernel)
   auto dma_slice = [&](int s) {
+    if (!issuer) return;
     const unsigned dst = ring_lds + (unsigned)((s % NSLOT) * SL);
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) {
-      const int piece = wave * PPW + k;
+    for (int k = 0; k < 2 * PPW; ++k) {
+      const int piece = (wave - 4) * 2 * PPW + k;
       dma16_hidden(wrsrc, cst_bytes + (unsigned)s * SL + piece * 1024 + lane * 16,
                    (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));
     }
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(512) void pw_bwd_kernel(const srk_pw_bwd_args a, un
         for (int ib = 0; ib < NIB; ++ib) gx[ib] = Tr::mma(lds_read16(w + j * (2 * C::RI * 16) + ib * 512), gf[j], gx[ib]);
     }
     // hand-over: slice s + 1 has landed (younger: slice s + 2 and this iteration's stores), slot s % 3 is free for slice s + 3
-    if (s + 2 < NS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + NST) : "memory");
+    if (s + 2 < NS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPW + NST) : "memory");      // (waves 0-3: only their NST stores can be out)
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (s + 3 < NS) dma_slice(s + 3);
