@@ -74,6 +74,11 @@ int srk_pack_conv_weights(const srk_pack_args* a, srk_stream_t stream);
 /* Same, for `n` convolutions in ONE launch: `table` is a DEVICE array of srk_pack_args (a training step re-packs
  * the forward and dgrad layouts of every conv of the model from the updated fp32 parameters).              */
 int srk_pack_conv_weights_group(const srk_pack_args* table, int n, srk_stream_t stream);
+/* The same launch with blocks that own one 16 x 64-channel tile of one entry each (coalesced reads through LDS).
+ * srk_pack_group_tiles (host) fills tile_begin[0 .. n] -- the prefix sums of the entries' tile counts, tile_begin[n] the total --
+ * from a HOST copy of the table; the launch takes device copies of both.                                              */
+int srk_pack_group_tiles(const srk_pack_args* host_table, int n, int* tile_begin);
+int srk_pack_conv_weights_group_tiled(const srk_pack_args* table, const int* tile_begin, int n, int total_tiles, srk_stream_t stream);
 
 /* ---- implicit-GEMM convolution (forward and dgrad) --------------------------------------------
  * Replaces nn.Conv2d(stride 1, padding k//2) + the elementwise ops the reference issues after it:

@@ -158,6 +158,120 @@ __global__ void pack_group_kernel(const srk_pack_args* __restrict__ table) {
   }
 }
 
+// ---- the grouped launch, tiled ---------------------------------------------------------------------------------------------------
+// pack_body's threads each walk their own strided source runs: per step a model's parameters are read as millions of 4-byte loads
+// (RCAN's 829 layouts: 0.38 ms per step, ~12x the time of moving the bytes).  Here a block owns one TILE of one table entry -- 16
+// output channels x 64 input channels x all taps of the OIHW parameter: 16 contiguous runs -- reads it with coalesced loads into
+// LDS and writes the 16-byte chunks of the packed layout (forward: the tile's 16 rows x 8 chunks per tap; dgrad: its 64 rows x 2
+// chunks per tap) from there.  Blocks are assigned through a prefix table of tiles per entry (no block without work; the first
+// attempt at LDS staging gave every block of a (tiles x entries) grid a whole CU's LDS and lost).  Entries the tile form does not
+// cover (more than 9 taps, fp32, a pixel-shuffle permutation on a dgrad layout) get 16 blocks of pack_body.
+constexpr int PT_CO = 16, PT_CI = 64, PT_PITCH = PT_CI * 9 + 1;
+
+// (layers beyond 128 x 128 channels keep pack_body too: its 4,096 threads per entry are busy there, and measured the tile form
+// LOSES on them -- EDSR-large 1,376 -> 1,353 patches/s with every layer tiled; RCAN's 829 small layouts gain: 1,647 -> 1,689)
+__host__ __device__ inline bool pack_tiled_ok(const srk_pack_args& a) {
+  return a.KH * a.KW <= 9 && a.dtype != SRK_F32 && !(a.dgrad && a.ps_r > 1) && (long long)a.Cout * a.Cin <= 128LL * 128;
+}
+__host__ __device__ inline int pack_tiles_of(const srk_pack_args& a) {
+  return pack_tiled_ok(a) ? ((a.Cout + PT_CO - 1) / PT_CO) * ((a.Cin + PT_CI - 1) / PT_CI) : 16;
+}
+// MFMA row of stored channel `chan` inside its blk-row block: the inverse of row_to_chan (srk_common.h)
+__device__ __forceinline__ int chan_to_row(int chan, int blk) {
+  if (blk == 64) return ((chan >> 4) & 1) * 32 + ((chan >> 2) & 3) * 8 + ((chan >> 5) & 1) * 4 + (chan & 3);
+  return ((chan >> 2) & 3) * 8 + ((chan >> 4) & 1) * 4 + (chan & 3);
+}
+
+template <int DT> __device__ void pack_tile(const srk_pack_args& a, int t, float* tile) {
+  typedef DTraits<DT> Tr;
+  typename Tr::elem* out = reinterpret_cast<typename Tr::elem*>(a.wpk);
+  const int taps = a.KH * a.KW;
+  const int ncog = (a.Cout + PT_CO - 1) / PT_CO;
+  const int cog = t % ncog, cig = t / ncog;
+  const int co0 = cog * PT_CO, ci0 = cig * PT_CI;
+  const int nco = min(PT_CO, a.Cout - co0), nci = min(PT_CI, a.Cin - ci0);
+  const int run = nci * taps;                                    // contiguous floats per output channel
+  for (int i = threadIdx.x; i < nco * run; i += blockDim.x) {
+    const int r16 = i / run, j = i - r16 * run;
+    tile[r16 * PT_PITCH + j] = a.w[((size_t)(co0 + r16) * a.Cin + ci0) * taps + j];
+  }
+  __syncthreads();
+  const int nch = a.KinP / 8;
+  const int blk = (a.CoutP % 64 == 0) ? 64 : 32;
+  if (!a.dgrad) {
+    // item (r16, cc): source channel co0 + r16 -> packed row; 8 input channels ci0 + 8 cc ..
+    for (int idx = threadIdx.x; idx < 128 * taps; idx += blockDim.x) {
+      const int item = idx & 127, tap = idx >> 7;
+      const int r16 = item & 15, cc = item >> 4;
+      if (r16 >= nco || ci0 + cc * 8 >= a.KinP) continue;
+      const int co = co0 + r16;
+      int chan = co;
+      if (a.ps_r > 1) {                                          // torch co = c*r*r + ij  ->  packed channel ij*Cc + c
+        const int r2 = a.ps_r * a.ps_r;
+        chan = (co % r2) * (a.Cout / r2) + co / r2;
+      }
+      const int row = (chan / blk) * blk + chan_to_row(chan % blk, blk);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = cc * 8 + e < nci ? tile[r16 * PT_PITCH + (cc * 8 + e) * taps + tap] : 0.f;
+      i32x4 q;
+      q.x = (int)((uint32_t)Tr::from_f32(v[0]) | ((uint32_t)Tr::from_f32(v[1]) << 16));
+      q.y = (int)((uint32_t)Tr::from_f32(v[2]) | ((uint32_t)Tr::from_f32(v[3]) << 16));
+      q.z = (int)((uint32_t)Tr::from_f32(v[4]) | ((uint32_t)Tr::from_f32(v[5]) << 16));
+      q.w = (int)((uint32_t)Tr::from_f32(v[6]) | ((uint32_t)Tr::from_f32(v[7]) << 16));
+      *reinterpret_cast<i32x4*>(out + (((size_t)tap * nch + (ci0 >> 3) + cc) * a.CoutP + row) * 8) = q;
+    }
+  } else {
+    // item (ci_l, ccl): input channel ci0 + ci_l -> packed row; 8 output channels co0 + 8 ccl .. (dy's storage order), taps flipped
+    for (int idx = threadIdx.x; idx < 128 * taps; idx += blockDim.x) {
+      const int item = idx & 127, tap = idx >> 7;
+      const int ci_l = item & 63, ccl = item >> 6;
+      if (ci_l >= nci || co0 + ccl * 8 >= a.KinP) continue;
+      const int chan = ci0 + ci_l;
+      const int row = (chan / blk) * blk + chan_to_row(chan % blk, blk);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ccl * 8 + e < nco ? tile[(ccl * 8 + e) * PT_PITCH + ci_l * taps + (taps - 1 - tap)] : 0.f;
+      i32x4 q;
+      q.x = (int)((uint32_t)Tr::from_f32(v[0]) | ((uint32_t)Tr::from_f32(v[1]) << 16));
+      q.y = (int)((uint32_t)Tr::from_f32(v[2]) | ((uint32_t)Tr::from_f32(v[3]) << 16));
+      q.z = (int)((uint32_t)Tr::from_f32(v[4]) | ((uint32_t)Tr::from_f32(v[5]) << 16));
+      q.w = (int)((uint32_t)Tr::from_f32(v[6]) | ((uint32_t)Tr::from_f32(v[7]) << 16));
+      *reinterpret_cast<i32x4*>(out + (((size_t)tap * nch + (co0 >> 3) + ccl) * a.CoutP + row) * 8) = q;
+    }
+  }
+  if (t == 0 && a.bias_pk && !a.dgrad) {
+    for (int i = threadIdx.x; i < a.CoutP; i += blockDim.x) {
+      const int chan = (i / blk) * blk + row_to_chan(i % blk, blk);       // bias_pk is indexed by MFMA row
+      float b = 0.f;
+      if (a.bias && chan < a.Cout) b = a.bias[ps_unperm(chan, a.Cout, a.ps_r)];
+      a.bias_pk[i] = b;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_group_tiled_kernel(const srk_pack_args* __restrict__ table, const int* __restrict__ tile_begin, int n) {
+  extern __shared__ float pack_tile_lds[];
+  int lo = 0, hi = n;                                            // the entry whose tile range holds this block
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_begin[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const srk_pack_args a = table[lo];
+  const int t = (int)blockIdx.x - tile_begin[lo];
+  if (pack_tiled_ok(a)) {
+    if (a.dtype == SRK_BF16) pack_tile<SRK_BF16>(a, t, pack_tile_lds); else pack_tile<SRK_F16>(a, t, pack_tile_lds);
+    return;
+  }
+  const long long total = (long long)a.KH * a.KW * a.KinP * a.CoutP;
+  const long long first = (long long)t * blockDim.x + threadIdx.x, stride = 16LL * blockDim.x;
+  switch (a.dtype) {
+    case SRK_BF16: pack_body<SRK_BF16>(a, total, first, stride); break;
+    case SRK_F16: pack_body<SRK_F16>(a, total, first, stride); break;
+    default: pack_body<SRK_F32>(a, total, first, stride); break;
+  }
+}
+
 // Sums the per-workgroup slabs and converts [tap][ci][co'] -> OIHW.  Block = 128 consecutive slab elements x 8 waves;
 // wave w sums slabs w, w+8, ... with float2 loads (512 contiguous bytes per wave instruction, 8 loads in flight),
 // the 8 partial sums meet in LDS in a fixed order (bitwise reproducible).
@@ -460,6 +574,26 @@ extern "C" int srk_pack_conv_weights(const srk_pack_args* a, srk_stream_t stream
     case SRK_F32: hipLaunchKernelGGL(pack_kernel<SRK_F32>, dim3(grid), dim3(256), 0, st, *a, total); break;
     default: SRK_CHECK_ARG(false, "srk_pack_conv_weights: dtype %d", a->dtype);
   }
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_pack_group_tiles(const srk_pack_args* host_table, int n, int* tile_begin) {
+  SRK_CHECK_ARG(host_table && tile_begin && n > 0, "srk_pack_group_tiles: bad table / n=%d", n);
+  long long tot = 0;
+  for (int i = 0; i < n; ++i) {
+    tile_begin[i] = (int)tot;
+    tot += pack_tiles_of(host_table[i]);
+    SRK_CHECK_ARG(tot < 0x7fffffffLL, "srk_pack_group_tiles: %lld tiles", tot);
+  }
+  tile_begin[n] = (int)tot;
+  return 0;
+}
+
+extern "C" int srk_pack_conv_weights_group_tiled(const srk_pack_args* table, const int* tile_begin, int n, int total_tiles, srk_stream_t stream) {
+  SRK_CHECK_ARG(table && tile_begin && n > 0 && total_tiles > 0, "srk_pack_conv_weights_group_tiled: bad table / n=%d tiles=%d", n, total_tiles);
+  hipLaunchKernelGGL(pack_group_tiled_kernel, dim3((unsigned)total_tiles), dim3(256), PT_CO * PT_PITCH * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), table, tile_begin, n);
   SRK_LAUNCH_CHECK();
   return 0;
 }

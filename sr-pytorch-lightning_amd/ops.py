@@ -84,6 +84,9 @@ class pack_cache:
         _PACK_CACHE_ENABLED = self.prev
 
 
+_PACK_TILED = os.environ.get("SRK_NO_PACK_TILED", "0") != "1"      # A/B knob: the strided-read grouped pack launch
+
+
 class PackGroup:
     """The packed shadow weights of ONE model, re-packed by a single kernel launch per step.
 
@@ -102,6 +105,7 @@ class PackGroup:
         self.entries = {}       # key -> [PackArgs, Packed, w, b]
         self.pw_entries = {}    # key -> [PwPackArgs, PwPacked, (w1, b1, w2, b2)]  (fused pointwise pairs, csrc/pw_chain.hip)
         self.pw_table = None
+        self.tiles, self.total_tiles = None, 0
         self.pw_dirty = False
         self.table = None
         self.dirty = False
@@ -154,17 +158,28 @@ class PackGroup:
                 a.w, a.bias = w.data_ptr(), bp
                 self.dirty = True
         if self.dirty:
-            arr = (L.PackArgs * len(self.entries))(*[e[0] for e in self.entries.values()])
+            import ctypes as C
+            n = len(self.entries)
+            arr = (L.PackArgs * n)(*[e[0] for e in self.entries.values()])
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             dev = next(iter(self.entries.values()))[2].device
             # the table keeps its ADDRESS while it fits (a captured step points at it): grown in place, with head room
             if self.table is None or self.table.device != dev or self.table.numel() < raw.numel():
                 self.table = torch.empty(max(2 * raw.numel(), 4096), dtype=torch.uint8, device=dev)
             self.table[:raw.numel()].copy_(raw)
+            # blocks of the launch -> (entry, tile): prefix sums of the entries' tile counts, next to the table
+            tb = (C.c_int * (n + 1))()
+            L.check(L.load().srk_pack_group_tiles(C.addressof(arr), n, C.addressof(tb)), "srk_pack_group_tiles")
+            if self.tiles is None or self.tiles.device != dev or self.tiles.numel() < n + 1:
+                self.tiles = torch.empty(max(2 * (n + 1), 1024), dtype=torch.int32, device=dev)
+            self.tiles[:n + 1].copy_(torch.tensor(list(tb), dtype=torch.int32))
+            self.total_tiles = int(tb[n])
             self.dirty = False
-        rc = L.load().srk_pack_conv_weights_group(self.table.data_ptr(), len(self.entries), _stream())
-        if rc != 0:
-            raise RuntimeError(f"srk_pack_conv_weights_group failed (rc={rc}): {L.load().srk_last_error().decode()}")
+        if _PACK_TILED:
+            L.check(L.load().srk_pack_conv_weights_group_tiled(self.table.data_ptr(), self.tiles.data_ptr(), len(self.entries), self.total_tiles, _stream()),
+                    "srk_pack_conv_weights_group_tiled")
+        else:
+            L.check(L.load().srk_pack_conv_weights_group(self.table.data_ptr(), len(self.entries), _stream()), "srk_pack_conv_weights_group")
 
 
 import threading
