@@ -216,42 +216,31 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     prow[pb] = 4 * (wave & 3) + 2 * pb + (r >> 4);
     xoff[pb] = (prow[pb] * C::XT + px) << 7;
   }
-  // LDS has no room for a residual / mask tile any more (the buffer it used to wait in now receives the next tile's first halo
-  // tile): both come into REGISTERS by hidden loads issued behind site B of a tile's last K-block.
-  //   residual: needed where the fp32 accumulators are -- the compute waves load their lanes' two pixels x 32 channels (8 loads of
-  //             16 B, each instruction touching 32 pixel rows);
-  //   mask    : applied to the finished 16-bit values, which is exact -- so it is applied during the copy-out, where a thread holds
-  //             16 B of a whole pixel row.  The copy-out is the DMA waves' job (8 pieces of the 16 x 16 x 64 tile per thread; the
-  //             compute waves are in the next K-block by then): they load their pieces' mask values (coalesced: 8 rows per instruction).
+  // LDS has no room for a residual / mask tile during the K-blocks any more (the buffer it used to wait in now receives the next
+  // tile's first halo tile).  The DMA waves fetch both into REGISTERS -- their 8 copy-out pieces' worth each, coalesced (a thread
+  // holds 16 B of a whole pixel row: 8 rows per instruction), hidden loads behind site B of a tile's last K-block:
+  //   residual: needed where the fp32 accumulators are, so at the tile's end the DMA waves write it into the halo buffer that has
+  //             just become free, as the image the epilogue reads (one more barrier);
+  //   mask    : applied to the finished 16-bit values, which is exact, during the copy-out.
+  // (First form: the compute waves loaded their own lanes' residual values -- 8 instructions that each touch 64 places.  Stamps:
+  // +2.7k cycles on the K-block that carried them; a vector-memory instruction holds its wave until the address path has taken
+  // all its lanes' requests.)
   const bool has_res = a.res != nullptr, has_mask = a.mask != nullptr;
-  const int NLr = cw && has_res ? 8 : 0, NLm = !cw && has_mask ? 8 : 0, NST = cw ? 0 : 8;
+  const int NL = cw ? 0 : (has_res ? 8 : 0) + (has_mask ? 8 : 0);
   const i32x4 rrsrc = make_rsrc4(has_res ? a.res : a.x, 0x7fffffffu), mrsrc = make_rsrc4(has_mask ? a.mask : a.x, 0x7fffffffu);
-  i32x4 tq[2][4], mq[8];                                   // (not initialised: a value from the kernel's start would occupy the registers all along)
-  auto load_res = [&](int n, int y0, int x0) __attribute__((always_inline)) {
-    int h_ = h;
-    asm volatile("" : "+v"(h_));                           // (as in dma_xtile: nothing of this is to be kept across the stream)
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-      const int gy = y0 + prow[pb], gx = x0 + px;
-      const int pix = (n * H + gy) * W + gx;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ch = cob * 64 + (4 * h_ + j) * Tr::CH;
-        const bool ok = gy < H && gx < W && ch < a.Cout;       // Cout may end inside the last 64-row block
-        load16_hidden(tq[pb][j], rrsrc, ok ? (unsigned)((pix * a.res_pitch + a.res_coff + ch) * 2) : 0x80000000u);
-      }
-    }
-  };
-  auto load_mask = [&](int n, int y0, int x0) __attribute__((always_inline)) {
-    int tid_ = tid - 256;                                  // DMA waves: threads 256 .. 511
+  i32x4 rq[8], mq[8];                                      // (not initialised: a value from the kernel's start would occupy the registers all along)
+  auto load_tiles = [&](int n, int y0, int x0) __attribute__((always_inline)) {
+    int tid_ = dtid;
     asm volatile("" : "+v"(tid_));
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = tid_ + 256 * k;                        // the copy-out's pieces: pixel i >> 3 (row-major 16 x 16), chunk i & 7
       const int p = i >> 3, c = i & 7;
       const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
-      const bool ok = gy < H && gx < W && cob * 64 + c * Tr::CH < a.Cout;
-      load16_hidden(mq[k], mrsrc, ok ? (unsigned)((((n * H + gy) * W + gx) * a.mask_pitch + a.mask_coff + cob * 64 + c * Tr::CH) * 2) : 0x80000000u);
+      const bool ok = gy < H && gx < W && cob * 64 + c * Tr::CH < a.Cout;       // Cout may end inside the last 64-row block
+      const int pix = (n * H + gy) * W + gx;
+      if (has_res) load16_hidden(rq[k], rrsrc, ok ? (unsigned)((pix * a.res_pitch + a.res_coff + cob * 64 + c * Tr::CH) * 2) : 0x80000000u);
+      if (has_mask) load16_hidden(mq[k], mrsrc, ok ? (unsigned)((pix * a.mask_pitch + a.mask_coff + cob * 64 + c * Tr::CH) * 2) : 0x80000000u);
     }
   };
 
@@ -263,18 +252,18 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
   //   site A (step 10): needs slab 3Gk+1; younger: slab 3Gk+2 (6) and, in a tile's FIRST K-block, the previous tile's 8 stores.
   //                     Then issues slab 3Gk+3 (6) and the next halo tile (10, wave 4: 11).
   //   site B (step 22): needs slab 3Gk+2; younger: slab 3Gk+3 + halo tile (>= 16).  Then issues slab 3Gk+4 and, in a tile's LAST
-  //                     K-block, its 8 mask loads (NLm).  (In a tile's first K-block the stores are older than these transfers
-  //                     and by now long done: not counted = a stricter wait.)
-  //   site C (step 34): needs slab 3Gk+3 and the halo tile; younger: slab 3Gk+4 (6) + NLm.  Then issues slab 3Gk+5.
-  //   tile end        : needs the mask values: younger: slab 3Gk+5 (6).  Then 8 stores.
+  //                     K-block, its NL = 8 residual and / or 8 mask loads.  (In a tile's first K-block the stores are older than
+  //                     these transfers and by now long done: not counted = a stricter wait.)
+  //   site C (step 34): needs slab 3Gk+3 and the halo tile; younger: slab 3Gk+4 (6) + NL.  Then issues slab 3Gk+5.
+  //   tile end        : needs the residual / mask values: younger: slab 3Gk+5 (6).  Then 8 stores.
   //   Nothing is issued for K-blocks beyond the stream's end (the last K-block's waits: everything).
-  // The compute waves' only vector-memory instructions are their 8 residual loads (behind site B of a tile's last K-block, awaited
-  // at the tile's end).
+  // The compute waves issue no vector-memory instruction at all.
   auto wait_barrier = [&](int n) __attribute__((always_inline)) {                          // s_waitcnt vmcnt(n) lgkmcnt(0); s_barrier   (n: a few wave-uniform values)
     switch (n) {
       case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
       case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
       case 14: asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 22: asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;      // 16
     }
   };
@@ -295,12 +284,11 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     const bool lastkb = kb == nkb - 1;
     if constexpr (decltype(computec)::value != 0) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (NLr && lastkb) load_res(n0, y0c, x0c);
     } else {
       const bool more = Gk + 1 < total;
       wait_barrier(more ? 16 : 0);
       if (more) dma_slab(lastkb ? 0 : kb + 1, 1);
-      if (NLm && lastkb) load_mask(n0, y0c, x0c);
+      if (NL && lastkb) load_tiles(n0, y0c, x0c);
     }
   };
   auto siteC = [&](int Gk, auto computec) __attribute__((always_inline)) {
@@ -308,7 +296,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
       const bool more = Gk + 1 < total, lastkb = kb == nkb - 1;
-      wait_barrier(more ? 6 + (lastkb ? NLm : 0) : 0);
+      wait_barrier(more ? 6 + (lastkb ? NL : 0) : 0);
       if (more) dma_slab(lastkb ? 0 : kb + 1, 2);
     }
   };
@@ -329,14 +317,21 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
   auto tile_end = [&](int Gk, auto computec) __attribute__((always_inline)) {
     char* const stage = X0 + (Gk & 1) * C::XS_BYTES;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every compute wave is done reading that buffer
-    if constexpr (decltype(computec)::value != 0) {
-      if (NLr) {                                                               // the residual registers are in (this wave's only loads)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (has_res) {                                                             // the residual tile: DMA waves' registers -> the image the epilogue reads
+      if constexpr (decltype(computec)::value == 0) {
+        if (Gk + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int tid_ = dtid;
+        asm volatile("" : "+v"(tid_));
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(tq[pb][j]));
+        for (int k = 0; k < 8; ++k) {
+          asm volatile("" : "+v"(rq[k]));
+          const int i = tid_ + 256 * k, p = i >> 3, c = i & 7;
+          lds_write16(stage + (p << 7) + ((c ^ swz(p & 15)) << 4), rq[k]);
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if constexpr (decltype(computec)::value != 0) {
       const float sc = a.scale;
       const f32x2 sc2 = {sc, sc};
 #pragma unroll
@@ -357,7 +352,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
           if (has_res) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-              const i32x4 tv = tq[pb][2 * cb + jj];
+              const i32x4 tv = lds_read16(stage + po + (((4 * h + 2 * cb + jj) ^ g) << 4));
               const int qw[4] = {tv.x, tv.y, tv.z, tv.w};
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -379,7 +374,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the tile's results are in LDS: the compute waves go on
     if constexpr (decltype(computec)::value == 0) {
       const int n = n0, y0 = y0c, x0 = x0c;
-      if (NLm) {                                                               // the mask registers are in
+      if (has_mask) {                                                          // the mask registers are in
         if (Gk + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(mq[k]));

@@ -30,8 +30,8 @@ wgs = a.n * 9 * ((a.cout + 63) // 64)
 print(f"conv_ks {a.cin} -> {a.cout} x{a.n}: {us:.1f} us per launch, {wgs} workgroups of {nkb} K-blocks ({nkb * 4608} MFMA cycles per compute wave)")
 buf = (C.c_ulonglong * 64)()
 assert A._lib.load().srk_ks_read_stamps(buf) == 0
-for wv, name in ((0, "compute wave 0"), (1, "DMA wave 4   ")):
-    t = list(buf[wv * 32:(wv + 1) * 32]); t0 = t[0]
-    kb = " ".join(str(t[2 + k] - t0) for k in range(nkb)) if wv == 0 else "-"
-    print(f"{name}: first data landed + barrier @{t[1] - t0}; K-blocks end @[{kb}]; loop left @{t[10] - t0}; all landed + barrier @{t[11] - t0}; "
-          f"epilogue in LDS @{t[12] - t0}; stores issued @{t[13] - t0}")
+t = list(buf[0:32]); t0 = t[0]
+ntile = (a.n * 9 * ((a.cout + 63) // 64) + 255) // 256 if wgs > 256 else 1
+kbs = [t[2 + k] - t0 for k in range(min(8, nkb * ntile)) if t[2 + k] > t0]
+print(f"compute wave 0 of workgroup 0 ({ntile} tiles): first data landed + barrier @{t[1] - t0}; its first stream K-blocks end @{kbs} "
+      f"(a tile's last one is followed by the tile end: epilogue to LDS, two barriers); kernel end @{t[13] - t0}")
