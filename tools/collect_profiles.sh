@@ -13,7 +13,7 @@ for m in edsr_baseline rcan edsr_large wdsr_b rdn_b; do
   python3 -c "import json,sys; d=json.load(open('$O/${TAG}_bench_b16_$m.json')); print('$m b16', d['value'], d['roofline']['variants_us'], d['roofline'].get('step_weighted_frac'))"
 done
 tools/profile_bench.sh ${TAG}final --no-roofline --sustain-seconds 0 > /dev/null 2>&1; cp $O/prof_${TAG}final/kernel_stats_summary.txt $O/${TAG}_kernel_stats_default.txt; head -12 $O/${TAG}_kernel_stats_default.txt | cut -c1-150
-for m in edsr_baseline rcan wdsr_b srresnet ddbpn; do tools/profile_model.sh $m 16 $TAG > /dev/null 2>&1; done
+for m in edsr_baseline rcan edsr_large wdsr_b rdn_b srresnet ddbpn; do tools/profile_model.sh $m 16 $TAG > /dev/null 2>&1; done
 tools/pmc_kernel.sh ${TAG}_conv_pair_n16 conv_pair_kernel tools/microbench_pair.py 16 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_conv_ks_256_n16 conv_ks_kernel tools/microbench_conv.py --n 16 --cin 256 --cout 256 --iters 5 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_conv1x1_576_n16 conv1x1_kernel tools/microbench_conv.py --n 16 --cin 576 --cout 64 --k 1 --iters 5 > /dev/null 2>&1
