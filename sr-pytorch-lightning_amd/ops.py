@@ -116,8 +116,17 @@ class PackGroup:
         e = self.entries.get(key)
         return e[1] if e is not None else None
 
+    @staticmethod
+    def _held(t):
+        """What an entry keeps of a source tensor: the tensor itself for a leaf (its address is re-read every refresh), a
+        DETACHED alias for anything else.  A weight-normed conv's effective weight carries the grad_fn of the step that made
+        it; held here, that node would keep the AccumulateGrad nodes of an eager step (created on the eager stream) alive
+        into a later hipGraph capture, whose backward then ties the eager stream into the capture and hipStreamEndCapture
+        crashes."""
+        return t if (t is None or t.grad_fn is None) else t.detach()
+
     def add(self, key, args, packed, w, b):
-        self.entries[key] = [args, packed, w, b]
+        self.entries[key] = [args, packed, self._held(w), self._held(b)]
         self.dirty = True
 
     def lookup_pw(self, key):
@@ -125,7 +134,7 @@ class PackGroup:
         return e[1] if e is not None else None
 
     def add_pw(self, key, args, packed, tensors):
-        self.pw_entries[key] = [args, packed, tensors]
+        self.pw_entries[key] = [args, packed, tuple(self._held(t) for t in tensors)]
         self.pw_dirty = True
 
     def _refresh_pw(self):
@@ -380,7 +389,7 @@ def _grad_target(p, shape, dev):
     one flat fp32 buffer (what the bucket all-reduces run on) and names each parameter's slice here: the weight-gradient
     kernels then write the slice directly and autograd adopts a view of it as `.grad` -- no per-step pack copy.  Only while the
     parameter has no gradient yet (an existing one is accumulated into, as before)."""
-    if p is None or not isinstance(p, torch.Tensor) or p.grad is not None:
+    if p is None or not isinstance(p, torch.Tensor) or not p.is_leaf or p.grad is not None:
         return None
     t = p.__dict__.get("_srk_grad_target")
     if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:

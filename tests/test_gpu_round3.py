@@ -76,7 +76,11 @@ def test_rcan_64_feature_chain_16bit_vs_oracle(A, dt, min_psnr, min_cos):
 
 
 @pytest.mark.parametrize("cls,kw", [("RCAN", dict(n_feats=64, n_resgroups=2, n_resblocks=3, reduction=16, scale_factor=2)),
-                                    ("EDSR", dict(n_feats=64, n_resblocks=4, res_scale=0.1, scale_factor=2))])
+                                    ("EDSR", dict(n_feats=64, n_resblocks=4, res_scale=0.1, scale_factor=2)),
+                                    # weight-normed convs: the effective weights are non-leaf tensors (ops.WeightNormGroup); a
+                                    # reference to one that outlives its eager step used to crash the capture of a later step
+                                    ("WDSR", dict(type="B", n_feats=64, n_resblocks=3, scale_factor=2)),
+                                    ("WDSR", dict(type="A", n_feats=32, n_resblocks=2, scale_factor=2))])
 def test_graph_replayed_steps_follow_the_oracle_trajectory(A, cls, kw):
     """Trainer.fit (3 eager steps, then hipGraph replays of the pair-kernel step) against the ORACLE's Adam trajectory on the
     same batches (srmodel.py:145-171): the loss of every step, computed from weights that all earlier steps produced."""
