@@ -482,6 +482,41 @@ typedef struct {
 } srk_fold_nhwc_args;
 int srk_fold_nhwc(const srk_fold_nhwc_args* a, srk_stream_t stream);
 
+/* D-DBPN's projection convolutions at scale 4, directly (csrc/proj.hip): nn.Conv2d / nn.ConvTranspose2d(32, 32, kernel 8, stride 4,
+ * padding 2) -- /root/reference models/ddbpn.py:10-24 `projection_conv` as `DenseProjection` uses it (ddbpn.py:42-53) -- on NHWC
+ * 16-bit tensors, no column tensor.  Replaces the cuDNN strided / transposed convolutions behind those modules and their autograd.
+ * One weight convention for both module kinds: w4[cl][ch][ky][kx], cl = channel on the LOW-resolution side, ch = channel on the
+ * HIGH-resolution side (Conv2d's [out][in][ky][kx], ConvTranspose2d's [in][out][ky][kx]).  (N, H, W) are the LOW-resolution dims;
+ * the other tensor is [N][4H][4W].
+ *   srk_proj_down : HR -> LR   out[q][cl] = bias[cl] + sum xh[4q - 2 + k][ch] w4[cl][ch][k]     (Conv2d forward; ConvTranspose2d dgrad)
+ *   srk_proj_up   : LR -> HR   out[4q - 2 + k][ch] += x[q][cl] w4[cl][ch][k], + bias[ch]         (ConvTranspose2d forward; Conv2d dgrad)
+ *   srk_proj_wgrad: dw4[cl][ch][k] (=, +=) sum_q g[q][cl] xh[4q - 2 + k][ch]                     ((xh, g) = (x, dy) resp. (dy, x))
+ * srk_proj_pack turns fp32 w4 into the MFMA fragment order of both directions: wpk (srk_proj_pack_bytes() bytes, 16-byte aligned)
+ * holds the `down` fragments first, the `up` fragments at byte srk_proj_pack_bytes() / 2.                                     */
+typedef struct {
+  const void* x; int x_pitch;             /* input NHWC, 32 channels used, pitch in elements                                */
+  void* out; int out_pitch;
+  const void* wpk;                        /* the direction's half of srk_proj_pack's output                                 */
+  const float* bias;                      /* [32] or NULL                                                                   */
+  int N, H, W;                            /* low-resolution dims                                                            */
+  int dtype;                              /* SRK_BF16 / SRK_F16                                                             */
+} srk_proj_args;
+long long srk_proj_pack_bytes(void);
+int srk_proj_pack(const float* w4, void* wpk, int dtype, srk_stream_t stream);
+int srk_proj_down(const srk_proj_args* a, srk_stream_t stream);
+int srk_proj_up(const srk_proj_args* a, srk_stream_t stream);
+typedef struct {
+  const void* xh; int xh_pitch;           /* high-resolution operand [N][4H][4W][>= 32]                                     */
+  const void* g; int g_pitch;             /* low-resolution operand [N][H][W][>= 32]                                        */
+  float* scratch;                         /* srk_proj_wgrad_scratch_floats(N, H, W) floats                                  */
+  float* dw;                              /* [32][32][8][8] fp32                                                            */
+  int accumulate;                         /* 1: dw += (an existing gradient)                                                */
+  int N, H, W;
+  int dtype;
+} srk_proj_wgrad_args;
+long long srk_proj_wgrad_scratch_floats(int N, int H, int W);
+int srk_proj_wgrad(const srk_proj_wgrad_args* a, srk_stream_t stream);
+
 /* Per-channel partial sums over P pixels of an NHWC tensor (fp32 accumulate), one plain store per block and channel:
  * partial[b][0][c], partial[b][1][c] for b < srk_chan_stats_blocks(P); the caller adds the blocks in order.
  *   mode 0: sum x, sum x^2          nn.BatchNorm2d batch statistics (srresnet.py:16-21 via common.py:97-98) in ONE pass over

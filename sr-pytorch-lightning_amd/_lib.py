@@ -117,6 +117,16 @@ class WgradFinArgs(C.Structure):
                 ("ps_r", _i), ("scale", _f), ("accumulate", _i)]
 
 
+class ProjArgs(C.Structure):
+    _fields_ = [("x", _p), ("x_pitch", _i), ("out", _p), ("out_pitch", _i), ("wpk", _p), ("bias", _p),
+                ("N", _i), ("H", _i), ("W", _i), ("dtype", _i)]
+
+
+class ProjWgradArgs(C.Structure):
+    _fields_ = [("xh", _p), ("xh_pitch", _i), ("g", _p), ("g_pitch", _i), ("scratch", _p), ("dw", _p), ("accumulate", _i),
+                ("N", _i), ("H", _i), ("W", _i), ("dtype", _i)]
+
+
 class UnfoldArgs(C.Structure):
     _fields_ = [("x", _p), ("sub", _p), ("dst", _p), ("dst_pitch", _i), ("dst_coff", _i),
                 ("N", _i), ("Cin", _i), ("H", _i), ("W", _i), ("KH", _i), ("KW", _i), ("Kstore", _i), ("dtype", _i)]
@@ -224,11 +234,15 @@ LAUNCHERS = {
     "srk_fold_nhwc": FoldNhwcArgs,
     "srk_chan_stats": ChanStatsArgs,
     "srk_chan_apply": ChanApplyArgs,
+    "srk_proj_down": ProjArgs,
+    "srk_proj_up": ProjArgs,
+    "srk_proj_wgrad": ProjWgradArgs,
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
-                 "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges", "srk_l1_loss_mean", "srk_chan_stats_finalize", "srk_pack_group_tiles", "srk_pack_conv_weights_group_tiled")
+                 "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges", "srk_l1_loss_mean", "srk_chan_stats_finalize", "srk_pack_group_tiles", "srk_pack_conv_weights_group_tiled",
+                 "srk_proj_pack", "srk_proj_pack_bytes", "srk_proj_wgrad_scratch_floats")
 
 _lib = None
 
@@ -293,6 +307,11 @@ def load():
     lib.srk_pw_pack_group.restype = C.c_int
     lib.srk_weight_norm_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.srk_weight_norm_group.restype = C.c_int
+    lib.srk_proj_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.srk_proj_pack.restype = C.c_int
+    lib.srk_proj_pack_bytes.restype = C.c_longlong
+    lib.srk_proj_wgrad_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.srk_proj_wgrad_scratch_floats.restype = C.c_longlong
     lib.srk_last_error.restype = C.c_char_p
     lib.srk_version.restype = C.c_int
     lib.srk_device_cus.restype = C.c_int

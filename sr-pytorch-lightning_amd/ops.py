@@ -2002,12 +2002,83 @@ def batch_norm(x, bn, res=None):
 _LK_OFF = os.environ.get("SRK_NO_LK", "0") == "1"        # A/B knob: large kernels through im2col as in round 2
 
 
+_PROJ_OFF = os.environ.get("SRK_NO_PROJ", "0") == "1"    # A/B knob: D-DBPN's projections through im2col / col2im as in round 2
+
+
+def proj_ok(x, w, stride, pad, up):
+    """Whether a D-DBPN projection conv (ddbpn.py:10-24) on NHWC `x` runs on the direct kernels (csrc/proj.hip): scale 4
+    (kernel 8, stride 4, padding 2), 32 channels on both sides, 16-bit storage."""
+    if _PROJ_OFF or x.dtype not in (torch.bfloat16, torch.float16) or x.numel() == 0:
+        return False
+    if tuple(w.shape) != (32, 32, 8, 8) or stride != 4 or pad != 2 or x.shape[3] != 32:
+        return False
+    if not up and (x.shape[1] % 4 or x.shape[2] % 4):
+        return False
+    return x.numel() * (16 if up else 1) * 2 < _ADDR_LIMIT
+
+
+def _proj_launch(x, wpk_half, bias, up):
+    n, h, wd, _ = x.shape
+    lh, lw = (h, wd) if up else (h // 4, wd // 4)
+    out = torch.empty((n, 4 * lh, 4 * lw, 32) if up else (n, lh, lw, 32), dtype=x.dtype, device=x.device)
+    L.call("srk_proj_up" if up else "srk_proj_down",
+           L.ProjArgs(x=x.data_ptr(), x_pitch=_pitch(x), out=out.data_ptr(), out_pitch=32, wpk=wpk_half.data_ptr(), bias=_ptr(bias),
+                      N=n, H=lh, W=lw, dtype=_DT[x.dtype]), _stream())
+    return out
+
+
+class ProjFn(torch.autograd.Function):
+    """nn.Conv2d / nn.ConvTranspose2d(32, 32, 8, stride=4, padding=2) on an NHWC 16-bit tensor (ddbpn.py:10-24): forward, data
+    gradient and weight gradient on the direct kernels of csrc/proj.hip.  Both weight layouts read as [c_low][c_high][ky][kx]
+    (Conv2d: [out][in], ConvTranspose2d: [in][out]), so `up` alone tells the directions apart."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, up):
+        _need_gpu(x)
+        x = x.contiguous()
+        half = L.load().srk_proj_pack_bytes() // 2
+        wpk = torch.empty(2 * half, dtype=torch.uint8, device=x.device)
+        L.check(L.load().srk_proj_pack(_f32c(w).data_ptr(), wpk.data_ptr(), _DT[x.dtype], _stream()), "srk_proj_pack")
+        ctx.save_for_backward(x, wpk)
+        ctx.up, ctx.half = bool(up), half
+        ctx.wparam, ctx.bparam = w, b
+        return _proj_launch(x, wpk[half:] if up else wpk[:half], None if b is None else _f32c(b), up)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wpk = ctx.saved_tensors
+        up, half = ctx.up, ctx.half
+        g = g.contiguous()
+        gx = _proj_launch(g, wpk[:half] if up else wpk[half:], None, not up) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            xh, gl = (g, x) if up else (x, g)
+            n, lh, lw, _ = gl.shape
+            slot = _grad_slot(ctx.wparam, (32, 32, 8, 8))
+            acc = slot[1] if (slot is not None and slot[0] == "acc") else None
+            dw = acc
+            if dw is None:      # (trainer.GradSync's flat buffer names the parameter's slice: written there, no pack copy)
+                dw = _grad_target(ctx.wparam, (32, 32, 8, 8), x.device)
+            if dw is None:
+                dw = torch.empty((32, 32, 8, 8), dtype=torch.float32, device=x.device)
+            scratch = torch.empty(L.load().srk_proj_wgrad_scratch_floats(n, lh, lw), dtype=torch.float32, device=x.device)
+            L.call("srk_proj_wgrad", L.ProjWgradArgs(xh=xh.data_ptr(), xh_pitch=_pitch(xh), g=gl.data_ptr(), g_pitch=_pitch(gl),
+                                                     scratch=scratch.data_ptr(), dw=dw.data_ptr(), accumulate=int(acc is not None),
+                                                     N=n, H=lh, W=lw, dtype=_DT[x.dtype]), _stream())
+            gw = None if acc is not None else dw
+        if ctx.bparam is not None and ctx.needs_input_grad[2]:
+            gb = chan_sums(g)[0][:32]
+        return gx, gw, gb, None
+
+
 def conv_general(x, w, b, *, stride=1, pad=0):
     """nn.Conv2d with any square kernel / stride / zero padding on NHWC `x`: im2col (srk_unfold_nhwc) + the 1x1 MFMA conv
     with the OIHW weight presented as a [Cout][K*K*Cin] matrix in (kh, kw, ci) order.  The permute / reshape of the
     parameter is a view-level torch op, so its gradient flows back to the OIHW parameter through autograd."""
     cout, cin, k, _ = w.shape
     cp = x.shape[-1]
+    if proj_ok(x, w, stride, pad, False):             # D-DBPN's down-projection at scale 4: direct kernels (csrc/proj.hip)
+        return ProjFn.apply(x, w, b, False)
     if (stride == 1 and pad == k // 2 and k in (5, 7, 9) and cin == cp == 64 and cout <= 16 and x.dtype in (torch.bfloat16, torch.float16)
             and x.numel() * 2 < _ADDR_LIMIT and not _LK_OFF):
         # SRResNet's 9x9 tail conv (srresnet.py:29): the direct large-kernel kernels (csrc/conv_lk.hip), no column tensor
@@ -2024,6 +2095,8 @@ def conv_transpose_general(x, w, b, *, stride=1, pad=0):
     (srk_fold_nhwc) with the bias added once per output element."""
     cin, cout, k, _ = w.shape
     n, h, wd, cp = x.shape
+    if proj_ok(x, w, stride, pad, True):              # D-DBPN's up-projection at scale 4: direct kernels (csrc/proj.hip)
+        return ProjFn.apply(x, w, b, True)
     coutp = pad16(cout)
     if cp != cin:
         w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cp - cin))

@@ -1,0 +1,113 @@
+"""GPU parity of D-DBPN's direct projection kernels (csrc/proj.hip: srk_proj_pack / srk_proj_down / srk_proj_up / srk_proj_wgrad,
+through ops.ProjFn) against torch's float64 conv2d / conv_transpose2d on the SAME 16-bit-rounded operands.
+Reference: models/ddbpn.py:10-24 (`projection_conv`: kernel 8, stride 4, padding 2) and :42-62 (how DenseProjection chains them)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import sr_amd
+    return sr_amd
+
+
+def _ref(x_nhwc, w, b, up):
+    x = x_nhwc.permute(0, 3, 1, 2).double()
+    f = torch.nn.functional.conv_transpose2d if up else torch.nn.functional.conv2d
+    return f(x, w.double(), None if b is None else b.double(), stride=4, padding=2)
+
+
+# LR-side dims: tile multiples, ragged in both directions, smaller than one tile, several images, the reference's batch shape
+@pytest.mark.parametrize("n,lh,lw", [(1, 4, 8), (2, 5, 11), (1, 1, 1), (3, 12, 7), (2, 48, 48)])
+@pytest.mark.parametrize("up", [True, False])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("bias", [True, False])
+def test_projection_forward_and_gradients(A, n, lh, lw, up, dt, bias):
+    from sr_amd import ops
+    g = torch.Generator().manual_seed(1000 * n + 10 * lh + lw + int(up))
+    h, wd = (lh, lw) if up else (4 * lh, 4 * lw)
+    x = torch.randn(n, h, wd, 32, generator=g).to(dt)
+    # the kernels round the fp32 weights to the storage type: the reference takes the rounded values
+    w = (torch.randn(32, 32, 8, 8, generator=g) * 0.05).to(dt).float()
+    b = torch.randn(32, generator=g) if bias else None
+    xd = x.cuda().requires_grad_(True)
+    wdv = w.cuda().requires_grad_(True)
+    bd = b.cuda().requires_grad_(True) if bias else None
+    assert ops.proj_ok(xd, wdv, 4, 2, up)
+    y = (ops.conv_transpose_general if up else ops.conv_general)(xd, wdv, bd, stride=4, pad=2)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = _ref(xr, wr, br, up).permute(0, 2, 3, 1)
+    assert tuple(y.shape) == tuple(yr.shape)
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    err = (y.detach().cpu().double() - yr.detach()).abs().max().item()
+    scale = yr.detach().abs().max().item()
+    assert err <= 1.5 * eps * scale + 1e-6, f"forward: {err} vs scale {scale}"
+    # gradients: a 16-bit upstream gradient, the same one on both sides
+    gy = torch.randn(yr.shape, generator=g).to(dt)
+    y.backward(gy.cuda())
+    yr.backward(gy.double())
+    gx = xd.grad.cpu().double()
+    assert (gx - xr.grad).abs().max().item() <= 1.5 * eps * xr.grad.abs().max().item() + 1e-6
+    # fp32 sums over all pixels of products of 16-bit values: fp32 accumulation error only
+    gw = wdv.grad.cpu().double()
+    assert (gw - wr.grad).abs().max().item() <= 2e-4 * wr.grad.abs().max().item() + 1e-5
+    if bias:
+        assert (bd.grad.cpu().double() - br.grad).abs().max().item() <= 2e-4 * br.grad.abs().max().item() + 1e-4
+
+
+def test_weight_gradient_accumulates_into_an_existing_grad(A):
+    from sr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 6, 9, 32, generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
+    w = (torch.randn(32, 32, 8, 8, generator=g) * 0.05).cuda().requires_grad_(True)
+    y = ops.conv_transpose_general(x, w, None, stride=4, pad=2)
+    gy = torch.randn(y.shape, generator=g).to(torch.bfloat16).cuda()
+    y.backward(gy)
+    first = w.grad.clone()
+    ptr = w.grad.data_ptr()
+    y2 = ops.conv_transpose_general(x, w, None, stride=4, pad=2)
+    y2.backward(gy)
+    assert w.grad.data_ptr() == ptr
+    torch.testing.assert_close(w.grad, 2 * first, rtol=1e-6, atol=1e-6)
+
+
+def test_shapes_outside_the_direct_kernels_keep_the_column_path(A):
+    """Scale 2 / 8 projections, fp32 storage, other channel counts: proj_ok says no and the im2col / col2im path answers."""
+    from sr_amd import ops
+    x = torch.randn(1, 8, 8, 32).cuda()
+    w = torch.randn(32, 32, 8, 8).cuda()
+    assert not ops.proj_ok(x, w, 4, 2, True)                                    # fp32
+    xb = x.to(torch.bfloat16)
+    assert not ops.proj_ok(xb, torch.randn(32, 32, 6, 6).cuda(), 2, 2, True)    # scale 2
+    assert not ops.proj_ok(xb[:, :7], w, 4, 2, False)                           # HR height not a multiple of 4
+    assert ops.proj_ok(xb, w, 4, 2, False)
+
+
+def test_ddbpn_training_step_uses_the_direct_projections(A, monkeypatch):
+    """A D-DBPN x4 training step in bf16 issues 33 forward projections and none of the im2col launches."""
+    from sr_amd import ops, _lib as L
+    calls = {}
+    real = L.call
+
+    def spy(name, args, stream):
+        calls[name] = calls.get(name, 0) + 1
+        return real(name, args, stream)
+    monkeypatch.setattr(L, "call", spy)
+    torch.manual_seed(0)
+    m = A.DDBPN(scale_factor=4, precision="bf16").cuda()
+    lr = torch.rand(2, 3, 16, 16).cuda()
+    hr = torch.rand(2, 3, 64, 64).cuda()
+    loss = (m(lr) - hr).abs().mean()
+    loss.backward()
+    ops.flush_wgrads()
+    assert calls.get("srk_proj_up", 0) + calls.get("srk_proj_down", 0) == 66, calls      # 33 forward + 33 data gradients
+    assert calls.get("srk_proj_wgrad", 0) == 33
+    assert calls.get("srk_unfold_nhwc", 0) == 0 and calls.get("srk_fold_nhwc", 0) == 0
+    for p in m.parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all()
