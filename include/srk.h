@@ -513,6 +513,9 @@ typedef struct {
   int accumulate;                         /* 1: dw += (an existing gradient)                                                */
   int N, H, W;
   int dtype;
+  float* db;                              /* bias gradient [32] (sum of the upstream gradient over its pixels), or NULL     */
+  int bias_side;                          /* which operand is the upstream gradient: 1 = g (Conv2d), 2 = xh (ConvTranspose2d) */
+  int db_accumulate;
 } srk_proj_wgrad_args;
 long long srk_proj_wgrad_scratch_floats(int N, int H, int W);
 int srk_proj_wgrad(const srk_proj_wgrad_args* a, srk_stream_t stream);

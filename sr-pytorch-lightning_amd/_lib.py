@@ -124,7 +124,7 @@ class ProjArgs(C.Structure):
 
 class ProjWgradArgs(C.Structure):
     _fields_ = [("xh", _p), ("xh_pitch", _i), ("g", _p), ("g_pitch", _i), ("scratch", _p), ("dw", _p), ("accumulate", _i),
-                ("N", _i), ("H", _i), ("W", _i), ("dtype", _i)]
+                ("N", _i), ("H", _i), ("W", _i), ("dtype", _i), ("db", _p), ("bias_side", _i), ("db_accumulate", _i)]
 
 
 class UnfoldArgs(C.Structure):

@@ -42,8 +42,10 @@ constexpr int U_HALO = (PJ_TY + 2) * U_RP;                             // 5,376
 constexpr int U_LDS = U_HALO + 4 * 8192;
 // ---- wgrad ----
 constexpr int G_QP = 320, G_RP = (D_COLS / 4) * G_QP;                  // 2,880
-constexpr int G_X = PJ_TY * G_RP, G_G = 32 * 64;
+constexpr int G_TY = 8;                                                // wgrad tiles: 8 x 8 LR pixels
+constexpr int G_X = G_TY * G_RP, G_G = G_TY * 8 * 64;
 constexpr int G_LDS = G_X + G_G;
+constexpr int G_CHUNKS = G_TY * D_COLS * 4, G_NST = (G_CHUNKS + 255) / 256;
 
 template <int DT> SRK_DEV uint16_t cvt16(float f) { return DTraits<DT>::from_f32(f); }
 
@@ -273,8 +275,16 @@ __global__ __launch_bounds__(256, 2) void proj_up_kernel(const srk_proj_args a, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// wgrad: scratch[slice][ky][kx][ch][cl]
+// wgrad: scratch[slice][ky][kx][ch][cl], then bpart[slice][ky][32].  Tiles of 8 x 8 LR pixels (four 16-pixel K-steps).
 // ------------------------------------------------------------------------------------------------------------------
+SRK_DEV void gtile_coords(int tile, int tilesX, int tilesY, int& n, int& ty0, int& tx0) {
+  const int per = tilesX * tilesY;
+  n = tile / per;
+  const int r = tile - n * per, ty = r / tilesX;
+  ty0 = ty * G_TY;
+  tx0 = (r - ty * tilesX) * PJ_TX;
+}
+
 template <int DT>
 __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad_args a, int tilesX, int tilesY, int ntiles, int nslices) {
   typedef DTraits<DT> Tr;
@@ -296,22 +306,22 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
   const char* abase = xs + (G >> 1) * G_RP + q * G_QP + choff;
   const char* bbase = gs + ((G >> 1) * 8 + q) * 64 + choff;
 
-  i32x4 sx[3], sg = i32x4{0, 0, 0, 0};
+  i32x4 sx[G_NST], sg = i32x4{0, 0, 0, 0};
   auto fetch = [&](int tile) {
     int n, ty0, tx0;
-    tile_coords(tile, tilesX, tilesY, n, ty0, tx0);
+    gtile_coords(tile, tilesX, tilesY, n, ty0, tx0);
     const int hx0 = 4 * tx0 - 2;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int u = tid + 256 * i;                       // 4 rows x 36 pixels x 4 chunks = 576
+    for (int i = 0; i < G_NST; ++i) {
+      const int u = tid + 256 * i;                       // 8 rows x 36 pixels x 4 chunks
       const int row = u / 144, rem = u - row * 144, pp = rem >> 2, c = rem & 3;
       const int y = 4 * (ty0 + row) - 2 + ky, x = hx0 + pp;
       sx[i] = i32x4{0, 0, 0, 0};
-      if (u < 576 && ty0 + row < a.H && y >= 0 && y < HH && x >= 0 && x < WH) sx[i] = gload16(xb + ((size_t)(n * HH + y) * WH + x) * xpb + c * 16);
+      if (u < G_CHUNKS && ty0 + row < a.H && y >= 0 && y < HH && x >= 0 && x < WH) sx[i] = gload16(xb + ((size_t)(n * HH + y) * WH + x) * xpb + c * 16);
     }
     sg = i32x4{0, 0, 0, 0};
-    if (tid < 128) {
-      const int pp = tid >> 2, c = tid & 3;
+    {
+      const int pp = tid >> 2, c = tid & 3;              // 64 pixels x 4 chunks
       const int y = ty0 + (pp >> 3), x = tx0 + (pp & 7);
       if (y < a.H && x < a.W) sg = gload16(gb + ((size_t)(n * a.H + y) * a.W + x) * gpb + c * 16);
     }
@@ -321,21 +331,26 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // bias gradient = per-channel sum of the upstream gradient over all its pixels, taken from the tiles in LDS: the LR operand by
+  // the ky = 0 workgroups; the HR operand by ky = 2..5 (rows 4q .. 4q + 3: every HR row once), columns 2..33 of the 36 (the tile's own)
+  const bool bsum = a.db != nullptr && (a.bias_side == 1 ? ky == 0 : (ky >= 2 && ky <= 5));
+  const int bc4 = tid & 7, bpg = tid >> 3;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
   int tile = t0;
   if (tile < t1) fetch(tile);
   for (; tile < t1; ++tile) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < G_NST; ++i) {
       const int u = tid + 256 * i;
       const int row = u / 144, rem = u - row * 144, pp = rem >> 2, c = rem & 3;
-      if (u < 576) lds_write16(xs + row * G_RP + (pp >> 2) * G_QP + (pp & 3) * 64 + c * 16, sx[i]);
+      if (u < G_CHUNKS) lds_write16(xs + row * G_RP + (pp >> 2) * G_QP + (pp & 3) * 64 + c * 16, sx[i]);
     }
-    if (tid < 128) lds_write16(gs + tid * 16, sg);
+    lds_write16(gs + tid * 16, sg);
     __syncthreads();
     if (tile + 1 < t1) fetch(tile + 1);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < G_TY / 2; ++s) {
       const i32x4 b = tr_read2(bbase + s * 16 * 64, bbase + s * 16 * 64 + 4 * 64);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -343,6 +358,26 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
         const char* ap = abase + s * 2 * G_RP + (kx >> 2) * G_QP + (kx & 3) * 64;
         const i32x4 av = tr_read2(ap, ap + 4 * G_QP);
         acc[j] = Tr::mma(av, b, acc[j]);
+      }
+    }
+    if (bsum) {
+      if (a.bias_side == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v[4];
+          load4<DT>(reinterpret_cast<const typename Tr::elem*>(gs + (bpg + 32 * h) * 64 + bc4 * 8), v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bs[e] += v[e];
+        }
+      } else {
+        const int pp = 2 + bpg;
+#pragma unroll
+        for (int row = 0; row < G_TY; ++row) {
+          float v[4];
+          load4<DT>(reinterpret_cast<const typename Tr::elem*>(xs + row * G_RP + (pp >> 2) * G_QP + (pp & 3) * 64 + bc4 * 8), v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bs[e] += v[e];
+        }
       }
     }
     __syncthreads();
@@ -355,16 +390,51 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[(8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 32] = acc[j][r];
   }
+  if (a.db) {           // every workgroup writes its (maybe zero) partial: bpart[slice][ky][32]
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[bpg * 32 + bc4 * 4 + e] = bs[e];
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+      for (int g2 = 0; g2 < 32; ++g2) t += red[g2 * 32 + tid];
+      a.scratch[(size_t)nslices * 65536 + (size_t)(slice * 8 + ky) * 32 + tid] = t;
+    }
+  }
 }
 
-// dW4[cl][ch][ky][kx] (=, +=) sum over the slices, in slice order
-__global__ void proj_wgrad_finalize_kernel(const float* __restrict__ scratch, float* __restrict__ dw, int nslices, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;     // ((ky * 8 + kx) * 32 + ch) * 32 + cl
-  const int cl = i & 31, ch = (i >> 5) & 31, kx = (i >> 10) & 7, ky = i >> 13;
+// dW4[cl][ch][ky][kx] (=, +=) sum over the slices: a block of 1,024 threads owns 256 outputs, thread (part, i) adds slices part, part + 4, ..
+// and the four parts meet in LDS (one fixed order: bitwise reproducible).  Block 256: the bias gradient from bpart, likewise.
+__global__ __launch_bounds__(1024) void proj_wgrad_finalize_kernel(const float* __restrict__ scratch, float* __restrict__ dw, int nslices, int accumulate,
+                                                                  float* __restrict__ db, int db_accumulate) {
+  __shared__ float red[1024];
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 256) {
+    const int c = tid & 31, part = tid >> 5;             // 32 parts
+    const float* bp = scratch + (size_t)nslices * 65536 + c;
+    float s = 0.f;
+    for (int j = part; j < nslices * 8; j += 32) s += bp[j * 32];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+      for (int k = 0; k < 32; ++k) t += red[k * 32 + tid];
+      db[tid] = db_accumulate ? db[tid] + t : t;
+    }
+    return;
+  }
+  const int part = tid >> 8, i = blockIdx.x * 256 + (tid & 255);     // ((ky * 8 + kx) * 32 + ch) * 32 + cl
   float s = 0.f;
-  for (int sl = 0; sl < nslices; ++sl) s += scratch[(size_t)sl * 65536 + i];
-  float* o = dw + ((cl * 32 + ch) * 8 + ky) * 8 + kx;
-  *o = accumulate ? *o + s : s;
+#pragma unroll 4
+  for (int sl = part; sl < nslices; sl += 4) s += scratch[(size_t)sl * 65536 + i];
+  red[tid] = s;
+  __syncthreads();
+  if (tid < 256) {
+    const float t = (red[tid] + red[tid + 256]) + (red[tid + 512] + red[tid + 768]);
+    const int cl = i & 31, ch = (i >> 5) & 31, kx = (i >> 10) & 7, ky = i >> 13;
+    float* o = dw + ((cl * 32 + ch) * 8 + ky) * 8 + kx;
+    *o = accumulate ? *o + t : t;
+  }
 }
 
 int grid_for(int ntiles) {
@@ -452,25 +522,26 @@ static int wgrad_slices(long long ntiles) {
 }
 
 extern "C" long long srk_proj_wgrad_scratch_floats(int N, int H, int W) {
-  const long long nt = (long long)N * ((W + PJ_TX - 1) / PJ_TX) * ((H + PJ_TY - 1) / PJ_TY);
-  return (long long)wgrad_slices(nt) * 65536;
+  const long long nt = (long long)N * ((W + PJ_TX - 1) / PJ_TX) * ((H + G_TY - 1) / G_TY);
+  return (long long)wgrad_slices(nt) * (65536 + 8 * 32);
 }
 
 extern "C" int srk_proj_wgrad(const srk_proj_wgrad_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a && a->xh && a->g && a->scratch && a->dw, "srk_proj_wgrad: null pointer");
   SRK_CHECK_ARG(a->dtype == SRK_BF16 || a->dtype == SRK_F16, "srk_proj_wgrad: 16-bit storage only (dtype %d)", a->dtype);
+  SRK_CHECK_ARG(a->db == nullptr || a->bias_side == 1 || a->bias_side == 2, "srk_proj_wgrad: bias_side %d (1: low-resolution operand, 2: high-resolution)", a->bias_side);
   SRK_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0, "srk_proj_wgrad: bad dims N=%d H=%d W=%d", a->N, a->H, a->W);
   SRK_CHECK_ARG(a->xh_pitch >= 32 && a->xh_pitch % 8 == 0 && a->g_pitch >= 32 && a->g_pitch % 8 == 0, "srk_proj_wgrad: pitches %d / %d", a->xh_pitch, a->g_pitch);
   SRK_CHECK_ARG((((uintptr_t)a->xh | (uintptr_t)a->g) & 15) == 0, "srk_proj_wgrad: 16-byte alignment");
   SRK_CHECK_ARG(16LL * a->N * a->H * a->W < 0x7fffffffLL, "srk_proj_wgrad: too many pixels");
-  const int tilesX = (a->W + PJ_TX - 1) / PJ_TX, tilesY = (a->H + PJ_TY - 1) / PJ_TY;
+  const int tilesX = (a->W + PJ_TX - 1) / PJ_TX, tilesY = (a->H + G_TY - 1) / G_TY;
   const long long nt = (long long)a->N * tilesX * tilesY;
   const int ns = wgrad_slices(nt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == SRK_BF16) hipLaunchKernelGGL(proj_wgrad_kernel<SRK_BF16>, dim3(8 * ns), dim3(256), G_LDS, st, *a, tilesX, tilesY, (int)nt, ns);
   else hipLaunchKernelGGL(proj_wgrad_kernel<SRK_F16>, dim3(8 * ns), dim3(256), G_LDS, st, *a, tilesX, tilesY, (int)nt, ns);
   SRK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(proj_wgrad_finalize_kernel, dim3(256), dim3(256), 0, st, a->scratch, a->dw, ns, a->accumulate);
+  hipLaunchKernelGGL(proj_wgrad_finalize_kernel, dim3(a->db ? 257 : 256), dim3(1024), 0, st, a->scratch, a->dw, ns, a->accumulate, a->db, a->db_accumulate);
   SRK_LAUNCH_CHECK();
   return 0;
 }

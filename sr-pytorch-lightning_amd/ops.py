@@ -2051,22 +2051,26 @@ class ProjFn(torch.autograd.Function):
         g = g.contiguous()
         gx = _proj_launch(g, wpk[:half] if up else wpk[half:], None, not up) if ctx.needs_input_grad[0] else None
         gw = gb = None
+        want_b = ctx.bparam is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             xh, gl = (g, x) if up else (x, g)
             n, lh, lw, _ = gl.shape
-            slot = _grad_slot(ctx.wparam, (32, 32, 8, 8))
-            acc = slot[1] if (slot is not None and slot[0] == "acc") else None
-            dw = acc
-            if dw is None:      # (trainer.GradSync's flat buffer names the parameter's slice: written there, no pack copy)
-                dw = _grad_target(ctx.wparam, (32, 32, 8, 8), x.device)
-            if dw is None:
-                dw = torch.empty((32, 32, 8, 8), dtype=torch.float32, device=x.device)
+
+            def slot_of(p, shape):          # existing fp32 .grad: added into; GradSync's flat-buffer slice: written there; else fresh
+                sl = _grad_slot(p, shape)
+                acc = sl[1] if (sl is not None and sl[0] == "acc") else None
+                t = acc if acc is not None else _grad_target(p, shape, x.device)
+                return (t if t is not None else torch.empty(shape, dtype=torch.float32, device=x.device)), acc is not None
+            dw, wacc = slot_of(ctx.wparam, (32, 32, 8, 8))
+            db, bacc = slot_of(ctx.bparam, (32,)) if want_b else (None, False)
             scratch = torch.empty(L.load().srk_proj_wgrad_scratch_floats(n, lh, lw), dtype=torch.float32, device=x.device)
             L.call("srk_proj_wgrad", L.ProjWgradArgs(xh=xh.data_ptr(), xh_pitch=_pitch(xh), g=gl.data_ptr(), g_pitch=_pitch(gl),
-                                                     scratch=scratch.data_ptr(), dw=dw.data_ptr(), accumulate=int(acc is not None),
-                                                     N=n, H=lh, W=lw, dtype=_DT[x.dtype]), _stream())
-            gw = None if acc is not None else dw
-        if ctx.bparam is not None and ctx.needs_input_grad[2]:
+                                                     scratch=scratch.data_ptr(), dw=dw.data_ptr(), accumulate=int(wacc),
+                                                     N=n, H=lh, W=lw, dtype=_DT[x.dtype], db=_ptr(db), bias_side=2 if up else 1,
+                                                     db_accumulate=int(bacc)), _stream())
+            gw = None if wacc else dw
+            gb = None if (bacc or not want_b) else db
+        elif want_b:
             gb = chan_sums(g)[0][:32]
         return gx, gw, gb, None
 

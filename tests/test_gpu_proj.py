@@ -65,15 +65,17 @@ def test_weight_gradient_accumulates_into_an_existing_grad(A):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 6, 9, 32, generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
     w = (torch.randn(32, 32, 8, 8, generator=g) * 0.05).cuda().requires_grad_(True)
-    y = ops.conv_transpose_general(x, w, None, stride=4, pad=2)
+    b = torch.randn(32, generator=g).cuda().requires_grad_(True)
+    y = ops.conv_transpose_general(x, w, b, stride=4, pad=2)
     gy = torch.randn(y.shape, generator=g).to(torch.bfloat16).cuda()
     y.backward(gy)
-    first = w.grad.clone()
-    ptr = w.grad.data_ptr()
-    y2 = ops.conv_transpose_general(x, w, None, stride=4, pad=2)
+    first, firstb = w.grad.clone(), b.grad.clone()
+    ptr, ptrb = w.grad.data_ptr(), b.grad.data_ptr()
+    y2 = ops.conv_transpose_general(x, w, b, stride=4, pad=2)
     y2.backward(gy)
-    assert w.grad.data_ptr() == ptr
+    assert w.grad.data_ptr() == ptr and b.grad.data_ptr() == ptrb
     torch.testing.assert_close(w.grad, 2 * first, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(b.grad, 2 * firstb, rtol=1e-6, atol=1e-5)
 
 
 def test_shapes_outside_the_direct_kernels_keep_the_column_path(A):
