@@ -539,6 +539,8 @@ typedef struct {
   float* shift_out;                       /* [C] or NULL (then `shift` must be NULL): shift[c] = x[pixel 0][c], also    */
                                           /* stored here -- the shifted-data variance: E[(x-K)^2] - (E[x-K])^2 with K a */
                                           /* value of the data loses no digits to |mean| >> std                         */
+  void* gate_out; int gate_pitch;         /* mode 2 only, or NULL: gate_out[p][c] = y * (x > 0 ? 1 : slope[c]) -- nn.PReLU's */
+  const float* slope; int slope_stride;   /* input gradient written by the pass that sums its slope gradient (one read of x, y) */
 } srk_chan_stats_args;
 int srk_chan_stats_blocks(long long P);
 int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream);

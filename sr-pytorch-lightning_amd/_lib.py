@@ -196,7 +196,8 @@ class FoldNhwcArgs(C.Structure):
 
 class ChanStatsArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("y", _p), ("y_pitch", _i), ("y_coff", _i),
-                ("P", C.c_longlong), ("C", _i), ("mode", _i), ("partial", _p), ("dtype", _i), ("shift", _p), ("shift_out", _p)]
+                ("P", C.c_longlong), ("C", _i), ("mode", _i), ("partial", _p), ("dtype", _i), ("shift", _p), ("shift_out", _p),
+                ("gate_out", _p), ("gate_pitch", _i), ("slope", _p), ("slope_stride", _i)]
 
 
 class ChanApplyArgs(C.Structure):

@@ -169,6 +169,12 @@ template <int DT, bool FUSED> __global__ __launch_bounds__(GEN_NT) void chan_sta
             } else {
 #pragma unroll
               for (int e = 0; e < CH; ++e) s0[e] += xv[e] <= 0.f ? xv[e] * yv[e] : 0.f;
+              if (a.gate_out) {      // nn.PReLU's input gradient from the same read: y * (x > 0 ? 1 : slope)
+                float gv[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) gv[e] = yv[e] * (xv[e] > 0.f ? 1.f : a.slope[(cc * CH + e) * a.slope_stride]);
+                *reinterpret_cast<i32x4*>(reinterpret_cast<elem*>(a.gate_out) + (size_t)p * a.gate_pitch + cc * CH) = f32_to_chunk<DT>(gv);
+              }
             }
           }
         }
@@ -400,6 +406,8 @@ static int chan_stats_check(const srk_chan_stats_args* a) {
   SRK_CHECK_ARG(!a->shift_out || !a->shift, "srk_chan_stats: shift and shift_out exclude each other");
   SRK_CHECK_ARG(a->C > 0 && a->C <= GEN_NT && a->C % ch == 0 && a->x_pitch % ch == 0 && a->x_coff % ch == 0 &&
                     (!a->y || (a->y_pitch % ch == 0 && a->y_coff % ch == 0)), "srk_chan_stats: C=%d (multiple of %d, <= %d) / alignment", a->C, ch, GEN_NT);
+  SRK_CHECK_ARG(!a->gate_out || (a->mode == 2 && a->slope && !a->shift && !a->shift_out && a->gate_pitch % ch == 0 && a->gate_pitch >= a->C),
+                "srk_chan_stats: gate_out needs mode 2, the slope and an aligned pitch");
   return 0;
 }
 static int chan_finalize_check(const srk_chan_finalize_args* a) {

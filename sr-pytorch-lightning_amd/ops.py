@@ -1664,21 +1664,29 @@ class SliceBuffer:
     def __init__(self, count):
         self.count, self.buf = int(count), None
 
-    def slice(self, i, like):
-        n, h, w, c = like.shape
+    def alloc(self, n, h, w, c, dtype, device):
+        self.buf = torch.empty((n, h, w, self.count * c), dtype=dtype, device=device)
+        self.c = c
+        return self
+
+    def slice(self, i, like=None):
         if self.buf is None:
-            self.buf = torch.empty((n, h, w, self.count * c), dtype=like.dtype, device=like.device)
+            n, h, w, c = like.shape
+            self.alloc(n, h, w, c, like.dtype, like.device)
+        c = self.c if like is None else like.shape[3]
         return self.buf[..., i * c:(i + 1) * c]
 
 
 class ConcatSlicesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, *parts):
-        ctx.c = parts[0].shape[3]
+        ctx.c = c = parts[0].shape[3]
         for i, p_ in enumerate(parts):
             assert p_.numel() == 0 or p_.data_ptr() == holder.buf.data_ptr() + i * ctx.c * p_.element_size(), \
                 "part %d is not slice %d of the buffer" % (i, i)
-        return holder.buf.view(holder.buf.shape)
+        if len(parts) == holder.count:
+            return holder.buf.view(holder.buf.shape)
+        return holder.buf[..., :len(parts) * c]             # a prefix: a channel-slice view the convs read with the buffer's pitch
 
     @staticmethod
     def backward(ctx, g):
@@ -1687,8 +1695,28 @@ class ConcatSlicesFn(torch.autograd.Function):
 
 
 def concat_slices(holder, parts):
-    """torch.cat(parts, dim=3) for parts that already ARE the consecutive channel slices of `holder` (no copy)."""
+    """torch.cat(parts, dim=3) for parts that already ARE the first consecutive channel slices of `holder` (no copy): all of them
+    (RDN's global fusion input, rdn.py:108) or a prefix (D-DBPN's growing concatenations, ddbpn.py:116-131)."""
     return ConcatSlicesFn.apply(holder, *parts)
+
+
+class AddIntoFn(torch.autograd.Function):
+    """slice `index` of a SliceBuffer = a + b (the `a_0.add(a_1)` that ends a D-DBPN projection unit, ddbpn.py:62-64, lands in
+    its slot of the later concatenations).  Written by srk_chan_apply through the raw address, like every slice write: autograd
+    sees a fresh output tensor, and the tensors other units saved of the same buffer keep their version."""
+
+    @staticmethod
+    def forward(ctx, a, b, holder, index):
+        return chan_apply(a.contiguous(), y=b.contiguous(), out=holder.slice(index, a))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, None, None
+
+
+def add_into(a, b, dest):
+    """dest: None (a plain sum) or (SliceBuffer, index)."""
+    return AddIntoFn.apply(a, b, dest[0], dest[1]) if dest is not None else a.add(b)
 
 
 def rdb(x, convs, lff, dest=None):
@@ -1781,7 +1809,15 @@ def _pitch4(t):
     return _pitch(t) if t.dim() == 4 else t.shape[-1]
 
 
-def chan_partials(x, y=None, mode=0, shift=None, shift_out=None):
+def _gate_fields(gate):
+    """ChanStatsArgs fields of the optional PReLU input-gradient output: gate = (out tensor, fp32 slope [1] or [C])."""
+    if gate is None:
+        return dict(gate_out=0, gate_pitch=0, slope=0, slope_stride=0)
+    out, sl = gate
+    return dict(gate_out=out.data_ptr(), gate_pitch=_pitch4(out), slope=sl.data_ptr(), slope_stride=0 if sl.numel() == 1 else 1)
+
+
+def chan_partials(x, y=None, mode=0, shift=None, shift_out=None, gate=None):
     """The per-block partial sums of srk_chan_stats [blocks][2][C] (see chan_sums), left unsummed for srk_chan_finalize."""
     _need_gpu(x)
     c = x.shape[-1]
@@ -1789,7 +1825,8 @@ def chan_partials(x, y=None, mode=0, shift=None, shift_out=None):
     nb = L.load().srk_chan_stats_blocks(P)
     part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
     L.call("srk_chan_stats", L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=_ptr(shift_out)), _stream())
+                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=_ptr(shift_out),
+                                             **_gate_fields(gate)), _stream())
     return part
 
 
@@ -1808,7 +1845,7 @@ def _arrival_counter(device):
 
 
 def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None,
-                bias=None, running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None, shift_out=None):
+                bias=None, running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None, shift_out=None, gate=None):
     """chan_finalize(chan_partials(x, y, smode, shift), fmode, rows, ...) as ONE launch (srk_chan_stats_finalize: the block that
     finishes last does the [C]-sized step)."""
     _need_gpu(x)
@@ -1816,13 +1853,14 @@ def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, 
     P = x.numel() // c
     nb = L.load().srk_chan_stats_blocks(P)
     if nb > _FUSE_MAX_BLOCKS:            # many blocks: their arrival counts (same-address atomics) would take longer than the launch they save
-        return chan_finalize(chan_partials(x, y, smode, shift, shift_out), fmode, rows, M=M, creal=creal, eps=eps, momentum=momentum, mean=mean, invstd=invstd,
+        return chan_finalize(chan_partials(x, y, smode, shift, shift_out, gate), fmode, rows, M=M, creal=creal, eps=eps, momentum=momentum, mean=mean, invstd=invstd,
                              gamma=gamma, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var, total=total,
                              nbt=nbt, dgamma_acc=dgamma_acc, dbeta_acc=dbeta_acc)
     part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
     out = torch.empty((rows, c), dtype=torch.float32, device=x.device)
     sa = L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-                         P=P, C=c, mode=smode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=_ptr(shift_out))
+                         P=P, C=c, mode=smode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=_ptr(shift_out),
+                         **_gate_fields(gate))
     fa = L.ChanFinalizeArgs(
         partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=fmode, total=int(total),
         M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
@@ -1847,12 +1885,16 @@ def chan_finalize(part, mode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0,
     return out
 
 
-def chan_apply(x, *, y=None, z=None, a=None, b=None, d=None, slope=None, post_prelu=False):
-    """out = post((a*x + b*y + d) * gate(z)) per channel (srk_chan_apply).  a/b/d/slope: fp32 [C] (slope may have 1 element)."""
+def chan_apply(x, *, y=None, z=None, a=None, b=None, d=None, slope=None, post_prelu=False, out=None):
+    """out = post((a*x + b*y + d) * gate(z)) per channel (srk_chan_apply).  a/b/d/slope: fp32 [C] (slope may have 1 element).
+    out: a tensor of x's shape to write (a channel-slice view of a wider NHWC buffer is fine), else a fresh one."""
     _need_gpu(x)
     c = x.shape[-1]
     P = x.numel() // c
-    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    else:
+        assert tuple(out.shape) == tuple(x.shape) and out.dtype == x.dtype
     if P == 0:
         return out
     sl = None if slope is None else _f32c(slope)
@@ -1869,7 +1911,7 @@ def chan_apply(x, *, y=None, z=None, a=None, b=None, d=None, slope=None, post_pr
         x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
         z=_ptr(z), z_pitch=0 if z is None else _pitch4(z), z_coff=0, a=_ptr(a), b=_ptr(b), d=_ptr(d),
         slope=_ptr(sl), slope_stride=0 if (sl is None or sl.numel() == 1) else 1, post_prelu=int(post_prelu),
-        out=out.data_ptr(), out_pitch=c, out_coff=0, P=P, C=c, dtype=_DT[x.dtype]), _stream())
+        out=out.data_ptr(), out_pitch=_pitch4(out), out_coff=0, P=P, C=c, dtype=_DT[x.dtype]), _stream())
     return out
 
 
@@ -1888,17 +1930,26 @@ class PReLUFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
-        gx = chan_apply(g, z=x, slope=weight) if ctx.needs_input_grad[0] else None
-        gw = None
-        if ctx.needs_input_grad[1]:
-            if x.numel() == 0:
-                gw = torch.zeros_like(weight)
-            else:       # partial sums over x <= 0 of x * g, summed (over the channels too for a single slope) by one small launch
-                one = weight.numel() == 1
-                slot = _grad_slot(ctx.wparam, tuple(weight.shape))      # an existing fp32 .grad: the finalize step adds into it
-                acc = slot[1] if (slot is not None and slot[0] == "acc") else None
-                s = chan_reduce(x, g, 2, None, 4, 1, total=one, creal=None if one else weight.numel(), dgamma_acc=acc)[0]
-                gw = None if acc is not None else (s[:1] if one else s[:weight.numel()])
+        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if x.numel() == 0:
+            return (torch.empty_like(g) if want_x else None), (torch.zeros_like(weight) if want_w else None)
+        if not want_w:
+            return chan_apply(g, z=x, slope=weight), None
+        # partial sums over x <= 0 of x * g, summed (over the channels too for a single slope) by one small launch; the pass that
+        # takes them writes the input gradient g * (x > 0 ? 1 : slope) from the same read of x and g
+        c = x.shape[-1]
+        gate = gx = None
+        if want_x:
+            sl = _f32c(weight)
+            if sl.numel() not in (1, c):
+                sl = torch.nn.functional.pad(sl, (0, c - sl.numel()))
+            gx = torch.empty_like(g)
+            gate = (gx, sl)
+        one = weight.numel() == 1
+        slot = _grad_slot(ctx.wparam, tuple(weight.shape))      # an existing fp32 .grad: the finalize step adds into it
+        acc = slot[1] if (slot is not None and slot[0] == "acc") else None
+        s = chan_reduce(x, g, 2, None, 4, 1, total=one, creal=None if one else weight.numel(), dgamma_acc=acc, gate=gate)[0]
+        gw = None if acc is not None else (s[:1] if one else s[:weight.numel()])
         return gx, gw
 
 
@@ -2002,6 +2053,16 @@ def batch_norm(x, bn, res=None):
 _LK_OFF = os.environ.get("SRK_NO_LK", "0") == "1"        # A/B knob: large kernels through im2col as in round 2
 
 
+def _nhwc_view(x):
+    """`x` itself when it is a dense NHWC tensor or a channel-slice view of one (the kernels take a pixel pitch), else a copy."""
+    try:
+        if x.data_ptr() % 16 == 0 and _pitch(x) % 8 == 0:
+            return x
+    except AssertionError:
+        pass
+    return x.contiguous()
+
+
 _PROJ_OFF = os.environ.get("SRK_NO_PROJ", "0") == "1"    # A/B knob: D-DBPN's projections through im2col / col2im as in round 2
 
 
@@ -2035,7 +2096,7 @@ class ProjFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, up):
         _need_gpu(x)
-        x = x.contiguous()
+        x = _nhwc_view(x)
         half = L.load().srk_proj_pack_bytes() // 2
         wpk = torch.empty(2 * half, dtype=torch.uint8, device=x.device)
         L.check(L.load().srk_proj_pack(_f32c(w).data_ptr(), wpk.data_ptr(), _DT[x.dtype], _stream()), "srk_proj_pack")
