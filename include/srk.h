@@ -500,6 +500,8 @@ typedef struct {
   const float* bias;                      /* [32] or NULL                                                                   */
   int N, H, W;                            /* low-resolution dims                                                            */
   int dtype;                              /* SRK_BF16 / SRK_F16                                                             */
+  const float* slope; int slope_stride;   /* fused nn.PReLU (ddbpn.py:42-53: every projection conv is followed by one), or NULL: */
+  void* pre; int pre_pitch;               /* out = prelu(stored conv output), pre (or NULL) = the stored conv output, for its backward */
 } srk_proj_args;
 long long srk_proj_pack_bytes(void);
 int srk_proj_pack(const float* w4, void* wpk, int dtype, srk_stream_t stream);

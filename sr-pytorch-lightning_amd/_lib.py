@@ -119,7 +119,7 @@ class WgradFinArgs(C.Structure):
 
 class ProjArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("out", _p), ("out_pitch", _i), ("wpk", _p), ("bias", _p),
-                ("N", _i), ("H", _i), ("W", _i), ("dtype", _i)]
+                ("N", _i), ("H", _i), ("W", _i), ("dtype", _i), ("slope", _p), ("slope_stride", _i), ("pre", _p), ("pre_pitch", _i)]
 
 
 class ProjWgradArgs(C.Structure):

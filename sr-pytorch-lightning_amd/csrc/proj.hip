@@ -38,8 +38,9 @@ constexpr int D_LDS = D_HALO + 4 * 32 * 32 * 4;                        // + the 
 constexpr int D_CHUNKS = D_ROWS * D_COLS * 4, D_NST = (D_CHUNKS + 255) / 256;     // 2,880 chunks, 12 per thread
 // ---- up ----
 constexpr int U_PP = 80, U_RP = 896;                                   // pixel pitch, row pitch of the (6 x 10)-pixel LR halo
-constexpr int U_HALO = (PJ_TY + 2) * U_RP;                             // 5,376
-constexpr int U_LDS = U_HALO + 4 * 8192;
+constexpr int U_CONST = 256;                                           // bias[32], slope[32] (fp32) in front of the halo
+constexpr int U_HALO = U_CONST + (PJ_TY + 2) * U_RP;                   // 5,632
+constexpr int U_LDS = U_HALO + 4 * 8192;                                   // + 4 x 8192 more with the fused PReLU (pre-activation stage)
 // ---- wgrad ----
 constexpr int G_QP = 320, G_RP = (D_COLS / 4) * G_QP;                  // 2,880
 constexpr int G_TY = 8;                                                // wgrad tiles: 8 x 8 LR pixels
@@ -73,6 +74,13 @@ template <int DT> __global__ void proj_pack_kernel(const float* __restrict__ w4,
     const int kx = tx == 0 ? rx + 2 : (rx < 2 ? rx + 6 : rx - 2);
     up[j] = cvt16<DT>(w4[((cl * 32 + ch) * 8 + ky) * 8 + kx]);
   }
+}
+
+// nn.PReLU on two stored (already rounded) 16-bit values: what a separate PReLU pass over the stored tensor computes
+template <int DT> SRK_DEV uint32_t prelu_pk(uint32_t w, float s0, float s1) {
+  float lo, hi;
+  unpack2<DT>(w, lo, hi);
+  return pack2<DT>(lo > 0.f ? lo : lo * s0, hi > 0.f ? hi : hi * s1);
 }
 
 SRK_DEV void tile_coords(int tile, int tilesX, int tilesY, int& n, int& ty0, int& tx0) {
@@ -171,7 +179,14 @@ __global__ __launch_bounds__(256, 2) void proj_down_kernel(const srk_proj_args a
         i32x2 o;
         o.x = (int)pack2<DT>(s.x, s.y);
         o.y = (int)pack2<DT>(s.z, s.w);
-        *reinterpret_cast<i32x2*>(reinterpret_cast<char*>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * (size_t)a.out_pitch * 2 + cg * 8) = o;
+        const size_t pix = (size_t)(n * a.H + y) * a.W + x;
+        if (a.slope) {         // fused nn.PReLU: the pre-activation is kept for its backward, the activation goes to `out`
+          if (a.pre) *reinterpret_cast<i32x2*>(reinterpret_cast<char*>(a.pre) + pix * (size_t)a.pre_pitch * 2 + cg * 8) = o;
+          const float* sl = a.slope + cg * 4 * a.slope_stride;
+          o.x = (int)prelu_pk<DT>((uint32_t)o.x, sl[0], sl[a.slope_stride]);
+          o.y = (int)prelu_pk<DT>((uint32_t)o.y, sl[2 * a.slope_stride], sl[3 * a.slope_stride]);
+        }
+        *reinterpret_cast<i32x2*>(reinterpret_cast<char*>(a.out) + pix * (size_t)a.out_pitch * 2 + cg * 8) = o;
       }
     }
   }
@@ -184,9 +199,14 @@ template <int DT>
 __global__ __launch_bounds__(256, 2) void proj_up_kernel(const srk_proj_args a, int tilesX, int tilesY, int ntiles) {
   typedef DTraits<DT> Tr;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* halo = smem;
+  char* halo = smem + U_CONST;
+  const float* cbias = reinterpret_cast<const float*>(smem);
+  const float* cslope = cbias + 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 32) reinterpret_cast<float*>(smem)[tid] = a.bias ? a.bias[tid] : 0.f;
+  else if (tid < 64) reinterpret_cast<float*>(smem)[tid] = a.slope ? a.slope[(tid - 32) * a.slope_stride] : 1.f;
   char* stage = smem + U_HALO + wave * 8192;
+  char* stage2 = smem + U_LDS + wave * 8192;             // fused PReLU only: the pre-activations
   i32x4 wf[32];
   {
     const i32x4* wp = reinterpret_cast<const i32x4*>(a.wpk) + (size_t)wave * 32 * 64 + lane;
@@ -196,12 +216,10 @@ __global__ __launch_bounds__(256, 2) void proj_up_kernel(const srk_proj_args a, 
   const int ry = wave, sy = ry < 2 ? -1 : 1;
   const int px = lane & 31, half = lane >> 5, mx = px & 7, my = px >> 3;
   const char* bbase = halo + (my + 1) * U_RP + (mx + 1) * U_PP + half * 16;
-  float bv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[16 * half + r] : 0.f;
+  const bool act = a.slope != nullptr;
   const int HH = 4 * a.H, WH = 4 * a.W;
   const char* xb = reinterpret_cast<const char*>(a.x);
-  const size_t xpb = (size_t)a.x_pitch * 2, opb = (size_t)a.out_pitch * 2;
+  const size_t xpb = (size_t)a.x_pitch * 2, opb = (size_t)a.out_pitch * 2, ppb = (size_t)a.pre_pitch * 2;
   // staging of the (6 x 10)-pixel halo: 240 chunks
   const int hrow = tid / 40, hrem = tid - hrow * 40, hp = hrem >> 2, hc = hrem & 3;
   const int skey = (mx << 1) | (my & 1);                 // XOR key of the stage's 16-byte slots (bank spread of the 32 pixel lanes)
@@ -237,7 +255,10 @@ __global__ __launch_bounds__(256, 2) void proj_up_kernel(const srk_proj_args a, 
       const int sx = rx < 2 ? -1 : 1;
       f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = bv[r];
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(cbias + 16 * half + 4 * j);
+        acc[4 * j] = b4.x; acc[4 * j + 1] = b4.y; acc[4 * j + 2] = b4.z; acc[4 * j + 3] = b4.w;
+      }
 #pragma unroll
       for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
@@ -251,8 +272,19 @@ __global__ __launch_bounds__(256, 2) void proj_up_kernel(const srk_proj_args a, 
       hi.x = (int)pack2<DT>(acc[8], acc[9]);   hi.y = (int)pack2<DT>(acc[10], acc[11]);
       hi.z = (int)pack2<DT>(acc[12], acc[13]); hi.w = (int)pack2<DT>(acc[14], acc[15]);
       const int slot = mx * 16 + rx * 4 + half * 2;
+      if (act) {             // fused nn.PReLU on the stored values; the pre-activations leave through the second stage
+        lds_write16(stage2 + my * 2048 + (((slot) ^ skey) << 4), lo);
+        lds_write16(stage2 + my * 2048 + (((slot + 1) ^ skey) << 4), hi);
+        const f32x4* sl = reinterpret_cast<const f32x4*>(cslope + 16 * half);
+        const f32x4 s0 = sl[0], s1 = sl[1], s2 = sl[2], s3 = sl[3];
+        lo.x = (int)prelu_pk<DT>((uint32_t)lo.x, s0.x, s0.y); lo.y = (int)prelu_pk<DT>((uint32_t)lo.y, s0.z, s0.w);
+        lo.z = (int)prelu_pk<DT>((uint32_t)lo.z, s1.x, s1.y); lo.w = (int)prelu_pk<DT>((uint32_t)lo.w, s1.z, s1.w);
+        hi.x = (int)prelu_pk<DT>((uint32_t)hi.x, s2.x, s2.y); hi.y = (int)prelu_pk<DT>((uint32_t)hi.y, s2.z, s2.w);
+        hi.z = (int)prelu_pk<DT>((uint32_t)hi.z, s3.x, s3.y); hi.w = (int)prelu_pk<DT>((uint32_t)hi.w, s3.z, s3.w);
+      }
       lds_write16(stage + my * 2048 + (((slot) ^ skey) << 4), lo);
       lds_write16(stage + my * 2048 + (((slot + 1) ^ skey) << 4), hi);
+      __builtin_amdgcn_sched_barrier(0);                 // one phase's accumulators at a time (the weights take 128 registers)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -263,10 +295,14 @@ __global__ __launch_bounds__(256, 2) void proj_up_kernel(const srk_proj_args a, 
       const int key = (((vpos >> 4) & 7) << 1) | (srow & 1);
       const int v = vpos ^ key;                          // which (pixel, chunk) of the row segment lives in slot vpos
       const i32x4 d = lds_read16(stage + u * 16);
+      i32x4 d2 = d;
+      if (act && a.pre) d2 = lds_read16(stage2 + u * 16);
       const int yl = ty0 + srow, xl = tx0 + (v >> 4);
       if (yl < a.H && xl < a.W) {
         const int y = 4 * yl + ry, x = 4 * tx0 + (v >> 2);
-        *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(a.out) + ((size_t)(n * HH + y) * WH + x) * opb + (v & 3) * 16) = d;
+        const size_t pix = (size_t)(n * HH + y) * WH + x;
+        *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(a.out) + pix * opb + (v & 3) * 16) = d;
+        if (act && a.pre) *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(a.pre) + pix * ppb + (v & 3) * 16) = d2;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -306,8 +342,9 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
   const char* abase = xs + (G >> 1) * G_RP + q * G_QP + choff;
   const char* bbase = gs + ((G >> 1) * 8 + q) * 64 + choff;
 
-  i32x4 sx[G_NST], sg = i32x4{0, 0, 0, 0};
-  auto fetch = [&](int tile) {
+  // three tiles in flight per workgroup (a tile's MFMAs take ~0.3 us, a load under this traffic ~2 us): register stages 0..2
+  i32x4 sx[3][G_NST], sg[3];
+  auto fetch = [&](int tile, i32x4 (&fx)[G_NST], i32x4& fg) {
     int n, ty0, tx0;
     gtile_coords(tile, tilesX, tilesY, n, ty0, tx0);
     const int hx0 = 4 * tx0 - 2;
@@ -316,14 +353,14 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
       const int u = tid + 256 * i;                       // 8 rows x 36 pixels x 4 chunks
       const int row = u / 144, rem = u - row * 144, pp = rem >> 2, c = rem & 3;
       const int y = 4 * (ty0 + row) - 2 + ky, x = hx0 + pp;
-      sx[i] = i32x4{0, 0, 0, 0};
-      if (u < G_CHUNKS && ty0 + row < a.H && y >= 0 && y < HH && x >= 0 && x < WH) sx[i] = gload16(xb + ((size_t)(n * HH + y) * WH + x) * xpb + c * 16);
+      fx[i] = i32x4{0, 0, 0, 0};
+      if (u < G_CHUNKS && ty0 + row < a.H && y >= 0 && y < HH && x >= 0 && x < WH) fx[i] = gload16(xb + ((size_t)(n * HH + y) * WH + x) * xpb + c * 16);
     }
-    sg = i32x4{0, 0, 0, 0};
+    fg = i32x4{0, 0, 0, 0};
     {
       const int pp = tid >> 2, c = tid & 3;              // 64 pixels x 4 chunks
       const int y = ty0 + (pp >> 3), x = tx0 + (pp & 7);
-      if (y < a.H && x < a.W) sg = gload16(gb + ((size_t)(n * a.H + y) * a.W + x) * gpb + c * 16);
+      if (y < a.H && x < a.W) fg = gload16(gb + ((size_t)(n * a.H + y) * a.W + x) * gpb + c * 16);
     }
   };
   f32x16 acc[2];
@@ -337,18 +374,17 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
   const int bc4 = tid & 7, bpg = tid >> 3;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
-  int tile = t0;
-  if (tile < t1) fetch(tile);
-  for (; tile < t1; ++tile) {
+  // one tile: its register stage -> LDS, the tile two ahead -> the stage that was consumed last, MFMAs
+  auto step = [&](int tile, i32x4 (&cx)[G_NST], i32x4& cg, i32x4 (&nx)[G_NST], i32x4& ng) {
 #pragma unroll
     for (int i = 0; i < G_NST; ++i) {
       const int u = tid + 256 * i;
       const int row = u / 144, rem = u - row * 144, pp = rem >> 2, c = rem & 3;
-      if (u < G_CHUNKS) lds_write16(xs + row * G_RP + (pp >> 2) * G_QP + (pp & 3) * 64 + c * 16, sx[i]);
+      if (u < G_CHUNKS) lds_write16(xs + row * G_RP + (pp >> 2) * G_QP + (pp & 3) * 64 + c * 16, cx[i]);
     }
-    lds_write16(gs + tid * 16, sg);
+    lds_write16(gs + tid * 16, cg);
     __syncthreads();
-    if (tile + 1 < t1) fetch(tile + 1);
+    if (tile + 2 < t1) fetch(tile + 2, nx, ng);
 #pragma unroll
     for (int s = 0; s < G_TY / 2; ++s) {
       const i32x4 b = tr_read2(bbase + s * 16 * 64, bbase + s * 16 * 64 + 4 * 64);
@@ -381,6 +417,14 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
       }
     }
     __syncthreads();
+  };
+
+  if (t0 < t1) fetch(t0, sx[0], sg[0]);
+  if (t0 + 1 < t1) fetch(t0 + 1, sx[1], sg[1]);
+  for (int tile = t0; tile < t1; tile += 3) {
+    step(tile, sx[0], sg[0], sx[2], sg[2]);
+    if (tile + 1 < t1) step(tile + 1, sx[1], sg[1], sx[0], sg[0]);
+    if (tile + 2 < t1) step(tile + 2, sx[2], sg[2], sx[1], sg[1]);
   }
   // rows = ch (8 (r / 4) + 4 (lane / 32) + r % 4), column = cl (lane % 32)
   float* out = a.scratch + ((size_t)(slice * 8 + ky) * 8) * 1024;
@@ -461,6 +505,8 @@ int check_proj(const srk_proj_args* a, const char* what, bool up) {
   SRK_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->out | (uintptr_t)a->wpk) & 15) == 0, "%s: 16-byte alignment", what);
   const long long hr = 16LL * a->N * a->H * a->W;
   SRK_CHECK_ARG(hr < 0x7fffffffLL, "%s: %lld HR pixels", what, hr);
+  SRK_CHECK_ARG(!a->pre || (a->slope && a->pre_pitch >= 32 && a->pre_pitch % 8 == 0 && ((uintptr_t)a->pre & 15) == 0), "%s: pre needs the slope and an aligned pitch", what);
+  SRK_CHECK_ARG(!a->slope || a->slope_stride == 0 || a->slope_stride == 1, "%s: slope_stride %d", what, a->slope_stride);
   (void)up;
   return 0;
 }
@@ -500,16 +546,17 @@ extern "C" int srk_proj_down(const srk_proj_args* a, srk_stream_t stream) {
 extern "C" int srk_proj_up(const srk_proj_args* a, srk_stream_t stream) {
   if (int rc = check_proj(a, "srk_proj_up", true)) return rc;
   static const int attr = [] {
-    int r = set_lds(proj_up_kernel<SRK_BF16>, U_LDS, "srk_proj_up");
-    return r ? r : set_lds(proj_up_kernel<SRK_F16>, U_LDS, "srk_proj_up");
+    int r = set_lds(proj_up_kernel<SRK_BF16>, U_LDS + 4 * 8192, "srk_proj_up");
+    return r ? r : set_lds(proj_up_kernel<SRK_F16>, U_LDS + 4 * 8192, "srk_proj_up");
   }();
   if (attr) return attr;
   const int tilesX = (a->W + PJ_TX - 1) / PJ_TX, tilesY = (a->H + PJ_TY - 1) / PJ_TY;
   const long long nt = (long long)a->N * tilesX * tilesY;
   SRK_CHECK_ARG(nt < 0x7fffffffLL, "srk_proj_up: %lld tiles", nt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(proj_up_kernel<SRK_BF16>, dim3(grid_for((int)nt)), dim3(256), U_LDS, st, *a, tilesX, tilesY, (int)nt);
-  else hipLaunchKernelGGL(proj_up_kernel<SRK_F16>, dim3(grid_for((int)nt)), dim3(256), U_LDS, st, *a, tilesX, tilesY, (int)nt);
+  const int lds = U_LDS + (a->slope ? 4 * 8192 : 0);
+  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(proj_up_kernel<SRK_BF16>, dim3(grid_for((int)nt)), dim3(256), lds, st, *a, tilesX, tilesY, (int)nt);
+  else hipLaunchKernelGGL(proj_up_kernel<SRK_F16>, dim3(grid_for((int)nt)), dim3(256), lds, st, *a, tilesX, tilesY, (int)nt);
   SRK_LAUNCH_CHECK();
   return 0;
 }

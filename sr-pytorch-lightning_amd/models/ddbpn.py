@@ -23,7 +23,10 @@ def projection_conv(in_channels, out_channels, scale, up=True):
 def _proj(seq, x):
     """[projection conv, PReLU] on NHWC x."""
     c, act = seq[0], seq[1]
-    if isinstance(c, nn.ConvTranspose2d):
+    up = isinstance(c, nn.ConvTranspose2d)
+    if act.weight.numel() in (1, 32) and ops.proj_ok(x, c.weight, c.stride[0], c.padding[0], up):
+        return ops.proj_prelu(x, c.weight, c.bias, act.weight, up=up)      # scale 4, 16-bit: conv + PReLU in one launch (csrc/proj.hip)
+    if up:
         y = ops.conv_transpose_general(x, c.weight, c.bias, stride=c.stride[0], pad=c.padding[0])
     else:
         y = ops.conv_general(x, c.weight, c.bias, stride=c.stride[0], pad=c.padding[0])

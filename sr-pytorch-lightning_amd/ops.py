@@ -2078,39 +2078,61 @@ def proj_ok(x, w, stride, pad, up):
     return x.numel() * (16 if up else 1) * 2 < _ADDR_LIMIT
 
 
-def _proj_launch(x, wpk_half, bias, up):
+def _proj_launch(x, wpk_half, bias, up, slope=None, want_pre=False):
+    """One srk_proj_up / srk_proj_down launch; with `slope` (fp32 [1] or [32]) the following nn.PReLU rides in the epilogue:
+    returns (activation, stored conv output or None)."""
     n, h, wd, _ = x.shape
     lh, lw = (h, wd) if up else (h // 4, wd // 4)
-    out = torch.empty((n, 4 * lh, 4 * lw, 32) if up else (n, lh, lw, 32), dtype=x.dtype, device=x.device)
+    shape = (n, 4 * lh, 4 * lw, 32) if up else (n, lh, lw, 32)
+    out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    pre = torch.empty(shape, dtype=x.dtype, device=x.device) if (slope is not None and want_pre) else None
     L.call("srk_proj_up" if up else "srk_proj_down",
            L.ProjArgs(x=x.data_ptr(), x_pitch=_pitch(x), out=out.data_ptr(), out_pitch=32, wpk=wpk_half.data_ptr(), bias=_ptr(bias),
-                      N=n, H=lh, W=lw, dtype=_DT[x.dtype]), _stream())
-    return out
+                      N=n, H=lh, W=lw, dtype=_DT[x.dtype], slope=_ptr(slope), slope_stride=0 if (slope is None or slope.numel() == 1) else 1,
+                      pre=_ptr(pre), pre_pitch=32), _stream())
+    return out, pre
 
 
 class ProjFn(torch.autograd.Function):
-    """nn.Conv2d / nn.ConvTranspose2d(32, 32, 8, stride=4, padding=2) on an NHWC 16-bit tensor (ddbpn.py:10-24): forward, data
-    gradient and weight gradient on the direct kernels of csrc/proj.hip.  Both weight layouts read as [c_low][c_high][ky][kx]
-    (Conv2d: [out][in], ConvTranspose2d: [in][out]), so `up` alone tells the directions apart."""
+    """nn.Conv2d / nn.ConvTranspose2d(32, 32, 8, stride=4, padding=2) [+ the nn.PReLU(32) behind it] on an NHWC 16-bit tensor
+    (ddbpn.py:10-24, 42-53): forward, data gradient and weight gradient on the direct kernels of csrc/proj.hip.  Both weight
+    layouts read as [c_low][c_high][ky][kx] (Conv2d: [out][in], ConvTranspose2d: [in][out]), so `up` alone tells the directions
+    apart.  With `slope` the activation is applied in the conv's epilogue (the stored conv output is kept for the backward:
+    PReLU's input gradient and slope gradient come from one pass over it, srk_chan_stats mode 2 with gate_out)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, up):
+    def forward(ctx, x, w, b, slope, up):
         _need_gpu(x)
         x = _nhwc_view(x)
         half = L.load().srk_proj_pack_bytes() // 2
         wpk = torch.empty(2 * half, dtype=torch.uint8, device=x.device)
         L.check(L.load().srk_proj_pack(_f32c(w).data_ptr(), wpk.data_ptr(), _DT[x.dtype], _stream()), "srk_proj_pack")
-        ctx.save_for_backward(x, wpk)
+        sl = None if slope is None else _f32c(slope)
+        need_pre = sl is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3])
+        out, pre = _proj_launch(x, wpk[half:] if up else wpk[:half], None if b is None else _f32c(b), up, sl, need_pre)
+        ctx.save_for_backward(x, wpk, pre, sl)
         ctx.up, ctx.half = bool(up), half
-        ctx.wparam, ctx.bparam = w, b
-        return _proj_launch(x, wpk[half:] if up else wpk[:half], None if b is None else _f32c(b), up)
+        ctx.wparam, ctx.bparam, ctx.sparam = w, b, slope
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        x, wpk = ctx.saved_tensors
+        x, wpk, pre, sl = ctx.saved_tensors
         up, half = ctx.up, ctx.half
         g = g.contiguous()
-        gx = _proj_launch(g, wpk[:half] if up else wpk[half:], None, not up) if ctx.needs_input_grad[0] else None
+        gs = None
+        if sl is not None:                       # through the PReLU first: g <- g * (pre > 0 ? 1 : slope), slope gradient on the side
+            if ctx.needs_input_grad[3]:
+                one = sl.numel() == 1
+                slot = _grad_slot(ctx.sparam, tuple(ctx.sparam.shape))
+                acc = slot[1] if (slot is not None and slot[0] == "acc") else None
+                gp = torch.empty_like(g)
+                s = chan_reduce(pre, g, 2, None, 4, 1, total=one, creal=None if one else sl.numel(), dgamma_acc=acc, gate=(gp, sl))[0]
+                gs = None if acc is not None else (s[:1] if one else s[:sl.numel()])
+                g = gp
+            else:
+                g = chan_apply(g, z=pre, slope=sl)
+        gx = _proj_launch(g, wpk[:half] if up else wpk[half:], None, not up)[0] if ctx.needs_input_grad[0] else None
         gw = gb = None
         want_b = ctx.bparam is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -2118,10 +2140,10 @@ class ProjFn(torch.autograd.Function):
             n, lh, lw, _ = gl.shape
 
             def slot_of(p, shape):          # existing fp32 .grad: added into; GradSync's flat-buffer slice: written there; else fresh
-                sl = _grad_slot(p, shape)
-                acc = sl[1] if (sl is not None and sl[0] == "acc") else None
-                t = acc if acc is not None else _grad_target(p, shape, x.device)
-                return (t if t is not None else torch.empty(shape, dtype=torch.float32, device=x.device)), acc is not None
+                sl_ = _grad_slot(p, shape)
+                acc_ = sl_[1] if (sl_ is not None and sl_[0] == "acc") else None
+                t = acc_ if acc_ is not None else _grad_target(p, shape, x.device)
+                return (t if t is not None else torch.empty(shape, dtype=torch.float32, device=x.device)), acc_ is not None
             dw, wacc = slot_of(ctx.wparam, (32, 32, 8, 8))
             db, bacc = slot_of(ctx.bparam, (32,)) if want_b else (None, False)
             scratch = torch.empty(L.load().srk_proj_wgrad_scratch_floats(n, lh, lw), dtype=torch.float32, device=x.device)
@@ -2133,7 +2155,12 @@ class ProjFn(torch.autograd.Function):
             gb = None if (bacc or not want_b) else db
         elif want_b:
             gb = chan_sums(g)[0][:32]
-        return gx, gw, gb, None
+        return gx, gw, gb, gs, None
+
+
+def proj_prelu(x, w, b, slope, *, up):
+    """D-DBPN's [projection conv, PReLU] pair (ddbpn.py:42-53) on NHWC `x` as ONE forward launch (shapes: see proj_ok)."""
+    return ProjFn.apply(x, w, b, slope, bool(up))
 
 
 def conv_general(x, w, b, *, stride=1, pad=0):
@@ -2143,7 +2170,7 @@ def conv_general(x, w, b, *, stride=1, pad=0):
     cout, cin, k, _ = w.shape
     cp = x.shape[-1]
     if proj_ok(x, w, stride, pad, False):             # D-DBPN's down-projection at scale 4: direct kernels (csrc/proj.hip)
-        return ProjFn.apply(x, w, b, False)
+        return ProjFn.apply(x, w, b, None, False)
     if (stride == 1 and pad == k // 2 and k in (5, 7, 9) and cin == cp == 64 and cout <= 16 and x.dtype in (torch.bfloat16, torch.float16)
             and x.numel() * 2 < _ADDR_LIMIT and not _LK_OFF):
         # SRResNet's 9x9 tail conv (srresnet.py:29): the direct large-kernel kernels (csrc/conv_lk.hip), no column tensor
@@ -2161,7 +2188,7 @@ def conv_transpose_general(x, w, b, *, stride=1, pad=0):
     cin, cout, k, _ = w.shape
     n, h, wd, cp = x.shape
     if proj_ok(x, w, stride, pad, True):              # D-DBPN's up-projection at scale 4: direct kernels (csrc/proj.hip)
-        return ProjFn.apply(x, w, b, True)
+        return ProjFn.apply(x, w, b, None, True)
     coutp = pad16(cout)
     if cp != cin:
         w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cp - cin))

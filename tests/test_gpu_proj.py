@@ -113,3 +113,34 @@ def test_ddbpn_training_step_uses_the_direct_projections(A, monkeypatch):
     for p in m.parameters():
         if p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all()
+
+
+@pytest.mark.parametrize("up", [True, False])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nslope", [1, 32])
+def test_fused_prelu_matches_the_two_launch_form(A, up, dt, nslope):
+    """ops.proj_prelu (the PReLU in the projection's epilogue, ddbpn.py:42-53) against ops.prelu behind the plain projection: the
+    activation is applied to the STORED conv output, so the forward is bit-identical; all four gradients follow."""
+    from sr_amd import ops
+    g = torch.Generator().manual_seed(77 + int(up) + nslope)
+    n, lh, lw = 2, 7, 10
+    h, wd = (lh, lw) if up else (4 * lh, 4 * lw)
+    x0 = torch.randn(n, h, wd, 32, generator=g).to(dt).cuda()
+    w0 = (torch.randn(32, 32, 8, 8, generator=g) * 0.05).cuda()
+    b0 = torch.randn(32, generator=g).cuda()
+    s0 = (torch.rand(nslope, generator=g) * 0.5 - 0.1).cuda()            # a few negative slopes too
+    outs = []
+    for fused in (True, False):
+        x, w, b, s = (t.clone().requires_grad_(True) for t in (x0, w0, b0, s0))
+        if fused:
+            y = ops.proj_prelu(x, w, b, s, up=up)
+        else:
+            y = ops.prelu((ops.conv_transpose_general if up else ops.conv_general)(x, w, b, stride=4, pad=2), s)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dt).cuda()
+        y.backward(gy)
+        outs.append((y.detach(), x.grad, w.grad, b.grad, s.grad))
+    f, u = outs
+    assert torch.equal(f[0], u[0])
+    assert torch.equal(f[1], u[1])
+    for i in (2, 3, 4):
+        torch.testing.assert_close(f[i], u[i], rtol=1e-5, atol=1e-5)
