@@ -242,6 +242,32 @@ def _flavours(A, model_name, batch, patch, feats, dtype):
               dict(name="dgrad3x3", fn=lambda: ops.conv_raw(g, pk3d, N=n, H=hw, W=hw, Cin=f, Cout=112, out=gz, use_bias=False), flops=f3, count=1),
               wg_flavour(z, g, cmid, f, 3, f3, 1)]
         return "pw_fwd_kernel + pw_bwd_kernel + pw_wgrad_kernel (WDSR-B pointwise pair 128->768->102, csrc/pw_chain.hip) and conv_ks_kernel 3x3 102->128", fl
+    if model_name == "ddbpn" and dtype != "f32" and patch % 4 == 0:
+        # D-DBPN's projection convs (ddbpn.py:10-24: kernel 8, stride 4, padding 2, 32 <-> 32 channels): 33 per step, each once as
+        # `up` or `down` forward, once as the other for its data gradient, once as weight gradient (csrc/proj.hip).  HBM-bound:
+        # 4.8 GFLOP per launch against the 32-channel HR tensor (algorithmic bytes = HR tensor + LR tensor, read or written once)
+        import ctypes as C
+        lib = A._lib.load()
+        xl = act(32)
+        xh = (torch.rand(n, 4 * hw, 4 * hw, 32, device=dev) - 0.5).to(dt)
+        w4 = (torch.rand(32, 32, 8, 8, device=dev) - 0.5) * 0.05
+        b32 = torch.zeros(32, device=dev)
+        half = lib.srk_proj_pack_bytes() // 2
+        wpk = torch.empty(2 * half, dtype=torch.uint8, device=dev)
+        A._lib.check(lib.srk_proj_pack(w4.data_ptr(), wpk.data_ptr(), ops._DT[dt], torch.cuda.current_stream().cuda_stream), "srk_proj_pack")
+        dw, db = torch.empty(32, 32, 8, 8, device=dev), torch.empty(32, device=dev)
+        scratch = torch.empty(lib.srk_proj_wgrad_scratch_floats(n, hw, hw), dtype=torch.float32, device=dev)
+
+        def wg():
+            A._lib.call("srk_proj_wgrad", A._lib.ProjWgradArgs(xh=xh.data_ptr(), xh_pitch=32, g=xl.data_ptr(), g_pitch=32, scratch=scratch.data_ptr(),
+                                                             dw=dw.data_ptr(), accumulate=0, N=n, H=hw, W=hw, dtype=ops._DT[dt], db=db.data_ptr(),
+                                                             bias_side=2, db_accumulate=0), torch.cuda.current_stream().cuda_stream)
+        fpr = 2.0 * px * 2048 * 32
+        by = float(17 * px * 32 * 2)
+        fl = [dict(name="proj_up", fn=lambda: ops._proj_launch(xl, wpk[half:], b32, True), flops=fpr, bytes=by, count=1),
+              dict(name="proj_down", fn=lambda: ops._proj_launch(xh, wpk[:half], b32, False), flops=fpr, bytes=by, count=1),
+              dict(name="proj_wgrad", fn=wg, flops=fpr, bytes=by, count=1)]
+        return "proj_up_kernel / proj_down_kernel / proj_wgrad_kernel (D-DBPN projection 8x8 stride 4, 32 <-> 32 channels, csrc/proj.hip)", fl
     if model_name == "rdn_b" and dtype != "f32":
         cin, g0 = 320, 64                  # the middle dense layer of an RDB (rdn.py:9-21: Cin = 64 + 64 c)
         x, y, gy = act(cin), act(g0), act(g0)
@@ -314,6 +340,20 @@ def dominant_kernel_roofline(A, model_name, batch, patch, feats, dtype, iters=10
         burst[f["name"]], sust[f["name"]] = b_ / per, (s_ if s_ is not None else b_) / per
     f0 = fl[0]
     us = sust[f0["name"]]
+    if "bytes" in f0:            # an HBM-bound path: algorithmic bytes per launch over the launch time, against ~8 TB/s
+        ach = f0["bytes"] / (us * 1e-6) / 1e9
+        r = {"bound": "hbm", "kernel": f"{kernel} @{patch}x{patch} x{batch} ({dtype}); quoted flavour: {f0['name']}",
+             "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+             "frac_burst": round(f0["bytes"] / (burst[f0["name"]] * 1e-6) / 1e9 / 8000.0, 4),
+             "us_per_launch": round(us, 2), "algorithmic_bytes_per_launch": f0["bytes"], "flops_per_launch": f0["flops"],
+             "mfma_frac": round(f0["flops"] / (us * 1e-6) / 1e12 / peak, 4), "traffic": None,
+             "variants_us": {k: round(v, 2) for k, v in sust.items()},
+             "variants_us_burst": {k: round(v, 2) for k, v in burst.items()},
+             "timing": f"HIP events around hipGraph replays; sustained = second half of {sustain_s:g} s of replays per flavour"}
+        tot = sum(f["count"] * f["bytes"] for f in fl)
+        r["step_weighted_frac"] = round(tot / (sum(f["count"] * sust[f["name"]] for f in fl) * 1e-6) / 1e9 / 8000.0, 4)
+        r["launches_per_block"] = {f["name"]: f["count"] for f in fl}
+        return r
     ach = f0["flops"] / (us * 1e-6) / 1e12
     px = batch * patch * patch
     alg_bytes = 2.0 * px * feats * esz                              # one read + one write of the block's activation
@@ -576,11 +616,11 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_other_configs and not a.inference and a.model == "edsr_baseline" and a.batch == 256:
-            # BASELINE.json configs 2-5 at the reference's batch (16 patches per GPU), a few seconds each, after the timed region
+            # BASELINE.json configs 2-5 (+ SURVEY 8(f)'s SRResNet / D-DBPN) at the reference's batch (16 patches per GPU), a few seconds each, after the timed region
             oc = []
             graphs = None                      # (frees the default line's graph and its private memory pool)
             torch.cuda.empty_cache()
-            for name in ("edsr_baseline", "rcan", "edsr_large", "wdsr_b", "rdn_b"):
+            for name in ("edsr_baseline", "rcan", "edsr_large", "wdsr_b", "rdn_b", "srresnet", "ddbpn"):
                 try:
                     oc.append(quick_train_rate(A, T, name, 16, a.patch, a.scale, a.dtype))
                 except Exception as e:  # noqa: BLE001

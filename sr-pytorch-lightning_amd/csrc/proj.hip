@@ -25,6 +25,7 @@
 //  * wgrad: K = pixels, so both operands are fetched with the transposing LDS read (ds_read_b64_tr_b16); a workgroup owns one
 //    kernel row ky and a slice of the tiles (it reads only the HR rows = ky - 2 mod 4 of them), its waves own two kx each; the
 //    partial sums of the slices are added by srk_proj_wgrad's second launch, in slice order (bitwise reproducible).
+#include <stdlib.h>
 #include "srk_common.h"
 
 namespace {
@@ -44,9 +45,10 @@ constexpr int U_LDS = U_HALO + 4 * 8192;                                   // + 
 // ---- wgrad ----
 constexpr int G_QP = 320, G_RP = (D_COLS / 4) * G_QP;                  // 2,880
 constexpr int G_TY = 8;                                                // wgrad tiles: 8 x 8 LR pixels
-constexpr int G_X = G_TY * G_RP, G_G = G_TY * 8 * 64;
+constexpr int G_ROWS = G_TY + 1;                                       // HR rows per tile: tap ky + 4 of LR row q = tap ky of row q + 1
+constexpr int G_X = G_ROWS * G_RP, G_G = G_TY * 8 * 64;
 constexpr int G_LDS = G_X + G_G;
-constexpr int G_CHUNKS = G_TY * D_COLS * 4, G_NST = (G_CHUNKS + 255) / 256;
+constexpr int G_CHUNKS = G_ROWS * D_COLS * 4, G_NST = (G_CHUNKS + 255) / 256;
 
 template <int DT> SRK_DEV uint16_t cvt16(float f) { return DTraits<DT>::from_f32(f); }
 
@@ -328,7 +330,9 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
   char* xs = smem;
   char* gs = smem + G_X;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ky = blockIdx.x & 7, slice = blockIdx.x >> 3;
+  // a workgroup owns the kernel rows ky and ky + 4: both read the HR rows = ky - 2 (mod 4), so every HR row is fetched by ONE of the
+  // four row groups (and 9 rows serve the 8 LR rows of a tile)
+  const int ky = blockIdx.x & 3, slice = blockIdx.x >> 2;
   const int per = (ntiles + nslices - 1) / nslices;
   const int t0 = slice * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
   const int HH = 4 * a.H, WH = 4 * a.W;
@@ -350,11 +354,11 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
     const int hx0 = 4 * tx0 - 2;
 #pragma unroll
     for (int i = 0; i < G_NST; ++i) {
-      const int u = tid + 256 * i;                       // 8 rows x 36 pixels x 4 chunks
+      const int u = tid + 256 * i;                       // 9 rows x 36 pixels x 4 chunks
       const int row = u / 144, rem = u - row * 144, pp = rem >> 2, c = rem & 3;
       const int y = 4 * (ty0 + row) - 2 + ky, x = hx0 + pp;
       fx[i] = i32x4{0, 0, 0, 0};
-      if (u < G_CHUNKS && ty0 + row < a.H && y >= 0 && y < HH && x >= 0 && x < WH) fx[i] = gload16(xb + ((size_t)(n * HH + y) * WH + x) * xpb + c * 16);
+      if (u < G_CHUNKS && y >= 0 && y < HH && x >= 0 && x < WH) fx[i] = gload16(xb + ((size_t)(n * HH + y) * WH + x) * xpb + c * 16);
     }
     fg = i32x4{0, 0, 0, 0};
     {
@@ -363,14 +367,18 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
       if (y < a.H && x < a.W) fg = gload16(gb + ((size_t)(n * a.H + y) * a.W + x) * gpb + c * 16);
     }
   };
-  f32x16 acc[2];
+  f32x16 acc[2][2];                                      // [ky, ky + 4][kx = 2 wave + j]
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int d = 0; d < 2; ++d)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  // bias gradient = per-channel sum of the upstream gradient over all its pixels, taken from the tiles in LDS: the LR operand by
-  // the ky = 0 workgroups; the HR operand by ky = 2..5 (rows 4q .. 4q + 3: every HR row once), columns 2..33 of the 36 (the tile's own)
-  const bool bsum = a.db != nullptr && (a.bias_side == 1 ? ky == 0 : (ky >= 2 && ky <= 5));
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[d][j][r] = 0.f;
+  // bias gradient = per-channel sum of the upstream gradient over all its pixels, taken from the tiles in LDS: the LR operand by the
+  // ky = 0 workgroups; the HR operand from the rows 4q .. 4q + 3 (kernel rows 2..5: LDS rows 0..7 of the groups ky = 2, 3, LDS rows
+  // 1..8 of the groups ky = 0, 1 -- their kernel rows 4, 5), columns 2..33 of the 36 (the tile's own): every HR pixel once
+  const bool bsum = a.db != nullptr && (a.bias_side == 1 ? ky == 0 : true);
+  const int brow0 = ky < 2 ? 1 : 0;
   const int bc4 = tid & 7, bpg = tid >> 3;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -389,12 +397,14 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
     for (int s = 0; s < G_TY / 2; ++s) {
       const i32x4 b = tr_read2(bbase + s * 16 * 64, bbase + s * 16 * 64 + 4 * 64);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int kx = 2 * wave + j;
-        const char* ap = abase + s * 2 * G_RP + (kx >> 2) * G_QP + (kx & 3) * 64;
-        const i32x4 av = tr_read2(ap, ap + 4 * G_QP);
-        acc[j] = Tr::mma(av, b, acc[j]);
-      }
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int kx = 2 * wave + j;
+          const char* ap = abase + (s * 2 + d) * G_RP + (kx >> 2) * G_QP + (kx & 3) * 64;
+          const i32x4 av = tr_read2(ap, ap + 4 * G_QP);
+          acc[d][j] = Tr::mma(av, b, acc[d][j]);
+        }
     }
     if (bsum) {
       if (a.bias_side == 1) {
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
 #pragma unroll
         for (int row = 0; row < G_TY; ++row) {
           float v[4];
-          load4<DT>(reinterpret_cast<const typename Tr::elem*>(xs + row * G_RP + (pp >> 2) * G_QP + (pp & 3) * 64 + bc4 * 8), v);
+          load4<DT>(reinterpret_cast<const typename Tr::elem*>(xs + (row + brow0) * G_RP + (pp >> 2) * G_QP + (pp & 3) * 64 + bc4 * 8), v);
 #pragma unroll
           for (int e = 0; e < 4; ++e) bs[e] += v[e];
         }
@@ -427,14 +437,17 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
     if (tile + 2 < t1) step(tile + 2, sx[2], sg[2], sx[1], sg[1]);
   }
   // rows = ch (8 (r / 4) + 4 (lane / 32) + r % 4), column = cl (lane % 32)
-  float* out = a.scratch + ((size_t)(slice * 8 + ky) * 8) * 1024;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    float* o = out + (2 * wave + j) * 1024 + (lane & 31);
+  for (int d = 0; d < 2; ++d) {
+    float* out = a.scratch + ((size_t)(slice * 8 + ky + 4 * d) * 8) * 1024;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[(8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 32] = acc[j][r];
+    for (int j = 0; j < 2; ++j) {
+      float* o = out + (2 * wave + j) * 1024 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 32] = acc[d][j][r];
+    }
   }
-  if (a.db) {           // every workgroup writes its (maybe zero) partial: bpart[slice][ky][32]
+  if (a.db) {           // every workgroup writes its (maybe zero) partial: bpart[slice][ky][32] (the ky + 4 rows of the table stay zero)
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[bpg * 32 + bc4 * 4 + e] = bs[e];
@@ -442,7 +455,9 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(const srk_proj_wgrad
     if (tid < 32) {
       float t = 0.f;
       for (int g2 = 0; g2 < 32; ++g2) t += red[g2 * 32 + tid];
-      a.scratch[(size_t)nslices * 65536 + (size_t)(slice * 8 + ky) * 32 + tid] = t;
+      float* bp = a.scratch + (size_t)nslices * 65536 + (size_t)(slice * 8 + ky) * 32 + tid;
+      bp[0] = t;
+      bp[4 * 32] = 0.f;
     }
   }
 }
@@ -563,7 +578,10 @@ extern "C" int srk_proj_up(const srk_proj_args* a, srk_stream_t stream) {
 
 static int wgrad_slices(long long ntiles) {
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
-  long long s = cus / 4;                       // 8 kernel rows x slices = 2 workgroups per CU
+  static const int env = [] { const char* e = getenv("SRK_PROJ_WG_SLICES"); return e ? atoi(e) : 0; }();     // A/B knob
+  // 4 kernel-row pairs x slices workgroups: 2 per CU when every slice still gets >= 16 tiles, else 1 per CU (the slices' partial sums
+  // are 256 KB each: measured at 16 x 48 x 48, 64 slices 26.3 us, 128 slices 30.3; at 256 x 48 x 48, 254 vs 218 us)
+  long long s = env > 0 ? env : (ntiles >= 16LL * (cus / 2) ? cus / 2 : cus / 4);
   if (s > ntiles) s = ntiles;
   return s < 1 ? 1 : (int)s;
 }
@@ -585,8 +603,8 @@ extern "C" int srk_proj_wgrad(const srk_proj_wgrad_args* a, srk_stream_t stream)
   const long long nt = (long long)a->N * tilesX * tilesY;
   const int ns = wgrad_slices(nt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(proj_wgrad_kernel<SRK_BF16>, dim3(8 * ns), dim3(256), G_LDS, st, *a, tilesX, tilesY, (int)nt, ns);
-  else hipLaunchKernelGGL(proj_wgrad_kernel<SRK_F16>, dim3(8 * ns), dim3(256), G_LDS, st, *a, tilesX, tilesY, (int)nt, ns);
+  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(proj_wgrad_kernel<SRK_BF16>, dim3(4 * ns), dim3(256), G_LDS, st, *a, tilesX, tilesY, (int)nt, ns);
+  else hipLaunchKernelGGL(proj_wgrad_kernel<SRK_F16>, dim3(4 * ns), dim3(256), G_LDS, st, *a, tilesX, tilesY, (int)nt, ns);
   SRK_LAUNCH_CHECK();
   hipLaunchKernelGGL(proj_wgrad_finalize_kernel, dim3(a->db ? 257 : 256), dim3(1024), 0, st, a->scratch, a->dw, ns, a->accumulate, a->db, a->db_accumulate);
   SRK_LAUNCH_CHECK();
