@@ -505,6 +505,9 @@ typedef struct {
 } srk_proj_args;
 long long srk_proj_pack_bytes(void);
 int srk_proj_pack(const float* w4, void* wpk, int dtype, srk_stream_t stream);
+/* the same for n (weights, packed buffer) pairs in ONE launch: `table_dev` is a device array (D-DBPN: its 33 projections per step) */
+typedef struct { const float* w4; void* wpk; } srk_proj_pack_job;
+int srk_proj_pack_group(const srk_proj_pack_job* table_dev, int n, int dtype, srk_stream_t stream);
 int srk_proj_down(const srk_proj_args* a, srk_stream_t stream);
 int srk_proj_up(const srk_proj_args* a, srk_stream_t stream);
 typedef struct {

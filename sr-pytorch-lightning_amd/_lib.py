@@ -122,6 +122,10 @@ class ProjArgs(C.Structure):
                 ("N", _i), ("H", _i), ("W", _i), ("dtype", _i), ("slope", _p), ("slope_stride", _i), ("pre", _p), ("pre_pitch", _i)]
 
 
+class ProjPackJob(C.Structure):
+    _fields_ = [("w4", _p), ("wpk", _p)]
+
+
 class ProjWgradArgs(C.Structure):
     _fields_ = [("xh", _p), ("xh_pitch", _i), ("g", _p), ("g_pitch", _i), ("scratch", _p), ("dw", _p), ("accumulate", _i),
                 ("N", _i), ("H", _i), ("W", _i), ("dtype", _i), ("db", _p), ("bias_side", _i), ("db_accumulate", _i)]
@@ -243,7 +247,7 @@ OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_c
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
                  "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges", "srk_l1_loss_mean", "srk_chan_stats_finalize", "srk_pack_group_tiles", "srk_pack_conv_weights_group_tiled",
-                 "srk_proj_pack", "srk_proj_pack_bytes", "srk_proj_wgrad_scratch_floats")
+                 "srk_proj_pack", "srk_proj_pack_bytes", "srk_proj_wgrad_scratch_floats", "srk_proj_pack_group")
 
 _lib = None
 
@@ -310,6 +314,8 @@ def load():
     lib.srk_weight_norm_group.restype = C.c_int
     lib.srk_proj_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.srk_proj_pack.restype = C.c_int
+    lib.srk_proj_pack_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.srk_proj_pack_group.restype = C.c_int
     lib.srk_proj_pack_bytes.restype = C.c_longlong
     lib.srk_proj_wgrad_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.srk_proj_wgrad_scratch_floats.restype = C.c_longlong

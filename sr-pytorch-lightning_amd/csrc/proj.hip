@@ -85,6 +85,27 @@ template <int DT> SRK_DEV uint32_t prelu_pk(uint32_t w, float s0, float s1) {
   return pack2<DT>(lo > 0.f ? lo : lo * s0, hi > 0.f ? hi : hi * s1);
 }
 
+// the same for a table of (fp32 weights, packed buffer) pairs: blockIdx.y = entry (all of D-DBPN's 33 projections in one launch)
+template <int DT> __global__ void proj_pack_group_kernel(const srk_proj_pack_job* __restrict__ jobs) {
+  const srk_proj_pack_job j = jobs[blockIdx.y];
+  const float* w4 = j.w4;
+  uint16_t* down = reinterpret_cast<uint16_t*>(j.wpk);
+  uint16_t* up = down + 65536;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int which = i >> 16, jj = i & 65535;
+  const int e = jj & 7, lane = (jj >> 3) & 63, f = (jj >> 9) & 31, w = jj >> 14;
+  const int c = row_to_chan(lane & 31, 32), kk = (lane >> 5) * 8 + e;
+  if (which == 0) {
+    const int kb = f & 1, kx = (f >> 1) & 7, kyl = f >> 4;
+    down[jj] = cvt16<DT>(w4[((c * 32 + kb * 16 + kk) * 8 + 2 * w + kyl) * 8 + kx]);
+  } else {
+    const int kb = f & 1, tx = (f >> 1) & 1, ty = (f >> 2) & 1, rx = f >> 3, ry = w;
+    const int ky = ty == 0 ? ry + 2 : (ry < 2 ? ry + 6 : ry - 2);
+    const int kx = tx == 0 ? rx + 2 : (rx < 2 ? rx + 6 : rx - 2);
+    up[jj] = cvt16<DT>(w4[(((kb * 16 + kk) * 32 + c) * 8 + ky) * 8 + kx]);
+  }
+}
+
 SRK_DEV void tile_coords(int tile, int tilesX, int tilesY, int& n, int& ty0, int& tx0) {
   const int per = tilesX * tilesY;
   n = tile / per;
@@ -498,7 +519,8 @@ __global__ __launch_bounds__(1024) void proj_wgrad_finalize_kernel(const float* 
 
 int grid_for(int ntiles) {
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
-  const int g = 2 * cus;
+  static const int env = [] { const char* e = getenv("SRK_PROJ_WGS_PER_CU"); return e ? atoi(e) : 0; }();     // A/B knob
+  const int g = (env > 0 ? env : 2) * cus;
   return ntiles < g ? ntiles : g;
 }
 
@@ -537,6 +559,16 @@ extern "C" int srk_proj_pack(const float* w4, void* wpk, int dtype, srk_stream_t
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SRK_BF16) hipLaunchKernelGGL(proj_pack_kernel<SRK_BF16>, dim3(512), dim3(256), 0, st, w4, d, d + 65536);
   else hipLaunchKernelGGL(proj_pack_kernel<SRK_F16>, dim3(512), dim3(256), 0, st, w4, d, d + 65536);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_proj_pack_group(const srk_proj_pack_job* table_dev, int n, int dtype, srk_stream_t stream) {
+  SRK_CHECK_ARG(table_dev && n > 0 && n <= 65535, "srk_proj_pack_group: bad table (%d entries)", n);
+  SRK_CHECK_ARG(dtype == SRK_BF16 || dtype == SRK_F16, "srk_proj_pack_group: 16-bit storage only (dtype %d)", dtype);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SRK_BF16) hipLaunchKernelGGL(proj_pack_group_kernel<SRK_BF16>, dim3(512, n), dim3(256), 0, st, table_dev);
+  else hipLaunchKernelGGL(proj_pack_group_kernel<SRK_F16>, dim3(512, n), dim3(256), 0, st, table_dev);
   SRK_LAUNCH_CHECK();
   return 0;
 }

@@ -105,6 +105,8 @@ class PackGroup:
         self.entries = {}       # key -> [PackArgs, Packed, w, b]
         self.pw_entries = {}    # key -> [PwPackArgs, PwPacked, (w1, b1, w2, b2)]  (fused pointwise pairs, csrc/pw_chain.hip)
         self.pw_table = None
+        self.proj_entries = {}  # (id(w), dtype) -> [w, packed buffer]  (D-DBPN's projection convs, csrc/proj.hip)
+        self.proj_tables = {}   # dtype -> [device table, addresses it was built from]
         self.tiles, self.total_tiles = None, 0
         self.pw_dirty = False
         self.table = None
@@ -137,6 +139,35 @@ class PackGroup:
         self.pw_entries[key] = [args, packed, tuple(self._held(t) for t in tensors)]
         self.pw_dirty = True
 
+    def lookup_proj(self, key):
+        e = self.proj_entries.get(key)
+        return e[1] if e is not None else None
+
+    def add_proj(self, key, w, wpk):
+        self.proj_entries[key] = [w, wpk]
+
+    def _refresh_proj(self):
+        """All projection weights of one storage dtype -> fragment order in ONE launch (was one 5 us launch per conv and step)."""
+        import ctypes as C
+        by_dt = {}
+        for (_, dt), (w, wpk) in self.proj_entries.items():
+            by_dt.setdefault(dt, []).append((w, wpk))
+        for dt, ents in by_dt.items():
+            addrs = tuple((w.data_ptr(), wpk.data_ptr()) for w, wpk in ents)
+            tb = self.proj_tables.get(dt)
+            if tb is None or tb[1] != addrs:
+                host = (L.ProjPackJob * len(ents))()
+                for i, (wa, pa) in enumerate(addrs):
+                    host[i].w4, host[i].wpk = wa, pa
+                raw = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8)
+                dev = ents[0][1].device
+                if tb is None or tb[0].numel() < raw.numel():       # the table keeps its address while it fits (a captured step names it)
+                    tb = [torch.empty(max(2 * raw.numel(), 1024), dtype=torch.uint8, device=dev), None]
+                tb[0][:raw.numel()].copy_(raw)
+                tb[1] = addrs
+                self.proj_tables[dt] = tb
+            L.check(L.load().srk_proj_pack_group(tb[0].data_ptr(), len(ents), _DT[dt], _stream()), "srk_proj_pack_group")
+
     def _refresh_pw(self):
         for e in self.pw_entries.values():
             a, _, (w1, b1, w2, b2) = e
@@ -158,6 +189,8 @@ class PackGroup:
         self.epoch += 1
         if self.pw_entries:
             self._refresh_pw()
+        if self.proj_entries:
+            self._refresh_proj()
         if not self.entries:
             return
         for e in self.entries.values():          # parameters moved / re-allocated since the table was built?
@@ -2105,8 +2138,18 @@ class ProjFn(torch.autograd.Function):
         _need_gpu(x)
         x = _nhwc_view(x)
         half = L.load().srk_proj_pack_bytes() // 2
-        wpk = torch.empty(2 * half, dtype=torch.uint8, device=x.device)
-        L.check(L.load().srk_proj_pack(_f32c(w).data_ptr(), wpk.data_ptr(), _DT[x.dtype], _stream()), "srk_proj_pack")
+        # a model's forward window (forward_scope) packs the projection weights it has seen before in ONE launch; a first use, a
+        # weight that is not a plain fp32 parameter, or a call outside any window packs here
+        group = _group_for(None) if (isinstance(w, torch.nn.Parameter) and w.dtype == torch.float32 and w.is_contiguous()) else None
+        key = (id(w), x.dtype)
+        wpk = group.lookup_proj(key) if group is not None else None
+        ctx.pg = _tok() if wpk is not None else None
+        if wpk is None or wpk.device != x.device:
+            wpk = torch.empty(2 * half, dtype=torch.uint8, device=x.device)
+            L.check(L.load().srk_proj_pack(_f32c(w).data_ptr(), wpk.data_ptr(), _DT[x.dtype], _stream()), "srk_proj_pack")
+            if group is not None:
+                group.add_proj(key, w, wpk)
+                ctx.pg = _tok()
         sl = None if slope is None else _f32c(slope)
         need_pre = sl is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3])
         out, pre = _proj_launch(x, wpk[half:] if up else wpk[:half], None if b is None else _f32c(b), up, sl, need_pre)
@@ -2119,6 +2162,10 @@ class ProjFn(torch.autograd.Function):
     def backward(ctx, g):
         x, wpk, pre, sl = ctx.saved_tensors
         up, half = ctx.up, ctx.half
+        if ctx.pg is not None and _group_for(ctx.pg) is None:
+            # the group's buffer was re-packed by a later forward window (from possibly updated weights): pack the weights again, here
+            wpk = torch.empty(2 * half, dtype=torch.uint8, device=x.device)
+            L.check(L.load().srk_proj_pack(_f32c(ctx.wparam).data_ptr(), wpk.data_ptr(), _DT[x.dtype], _stream()), "srk_proj_pack")
         g = g.contiguous()
         gs = None
         if sl is not None:                       # through the PReLU first: g <- g * (pre > 0 ? 1 : slope), slope gradient on the side

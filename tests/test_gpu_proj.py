@@ -144,3 +144,34 @@ def test_fused_prelu_matches_the_two_launch_form(A, up, dt, nslope):
     assert torch.equal(f[1], u[1])
     for i in (2, 3, 4):
         torch.testing.assert_close(f[i], u[i], rtol=1e-5, atol=1e-5)
+
+
+def test_grouped_projection_pack_follows_the_weights(A):
+    """From the second forward on, D-DBPN's 33 projection weights are packed by ONE launch at the top of the forward (PackGroup):
+    after an in-place parameter update the next forward must see the new weights -- bit-identical to a fresh model that packs per use --
+    and a backward that runs after a LATER forward window packs the weights again instead of trusting the group's buffer."""
+    import copy
+    from sr_amd import ops
+    torch.manual_seed(0)
+    m = A.DDBPN(scale_factor=4, precision="bf16").cuda()
+    lr = torch.rand(1, 3, 12, 12).cuda()
+    y1 = m(lr)
+    assert len(m._pack_group().proj_entries) == 33
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.requires_grad:
+                p.mul_(1.01)
+    y2 = m(lr)
+    m2 = A.DDBPN(scale_factor=4, precision="bf16").cuda()
+    m2.load_state_dict(copy.deepcopy(m.state_dict()))
+    y3 = m2(lr)
+    assert torch.equal(y2, y3) and not torch.equal(y1, y2)
+    # a backward that runs after a LATER forward window of the same model: its token is stale, the weights are packed again there
+    ga = torch.autograd.grad(y3.sum(), [p for p in m2.parameters() if p.requires_grad], allow_unused=True)
+    y4 = m(lr)
+    y5 = m(lr)
+    gb = torch.autograd.grad(y4.sum(), [p for p in m.parameters() if p.requires_grad], allow_unused=True)
+    assert torch.equal(y4, y5)
+    for a_, b_ in zip(ga, gb):
+        if a_ is not None:
+            torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-6)
