@@ -99,7 +99,7 @@ class DDBPN(SRModel):
             # read (ddbpn.py:116-134) are its prefixes -- no copy (they were 0.6 of 6.6 ms per step at the reference's batch)
             n, h, w, _ = x.shape
             r = self._scale_factor
-            hbuf = ops.SliceBuffer(self.depth).alloc(n, h * r, w * r, x.shape[3], x.dtype, x.device)
+            hbuf = ops.SliceBuffer(self.depth, accumulate_grads=True).alloc(n, h * r, w * r, x.shape[3], x.dtype, x.device)
             h_list, l_list = [], []
             for i in range(self.depth - 1):
                 l = x if i == 0 else torch.cat(l_list, dim=3)

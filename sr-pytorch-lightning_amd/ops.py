@@ -858,6 +858,7 @@ class ConvFn(torch.autograd.Function):
         ctx.cfg = (scale, ps_r, b is not None, res is not None)
         ctx.wb = (w, b)
         ctx.pg = _tok()
+        ctx.gacc = x.__dict__.get("_srk_gacc")          # x is a prefix of a SliceBuffer whose consumers' gradients meet in one buffer
         return out
 
     @staticmethod
@@ -871,8 +872,12 @@ class ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             pkd = pack_conv(w, None, x.dtype, dgrad=True, ps_r=ps_r, token=ctx.pg)
-            gx = torch.empty_like(x)
-            conv_raw(g, pkd, N=n, H=h, W=wd, Cin=coutp, Cout=cinp, out=gx, scale=scale, x_ps=ps_r, use_bias=False)
+            if ctx.gacc is not None and ps_r <= 1:
+                gx, add = ctx.gacc[0].grad_dest(ctx.gacc[1])       # the data gradient lands in (is added to) the shared gradient buffer
+                conv_raw(g, pkd, N=n, H=h, W=wd, Cin=coutp, Cout=cinp, out=gx, scale=scale, use_bias=False, res=gx if add else None)
+            else:
+                gx = torch.empty_like(x)
+                conv_raw(g, pkd, N=n, H=h, W=wd, Cin=coutp, Cout=cinp, out=gx, scale=scale, x_ps=ps_r, use_bias=False)
         if ctx.needs_input_grad[1]:
             gw, gb = wgrad(x, g, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cinp, Cout=coutp, k=k,
                            w_shape=tuple(w.shape), ps_r=ps_r, scale=scale, dy_ps=ps_r, want_bias=has_b)
@@ -1688,14 +1693,29 @@ class RDBFn(torch.autograd.Function):
         return (gx, None, *grads)
 
 
+_SLICE_GACC = os.environ.get("SRK_NO_SLICE_GACC", "0") != "1"      # A/B knob: autograd's own sums of the concatenations' gradient slices
+
+
 class SliceBuffer:
     """One [N, H, W, count * C] NHWC buffer whose channel slices are the outputs of `count` blocks (RDN: the D residual dense
-    blocks feeding the global feature fusion, models/rdn.py:99-108).  A plain Python object, so autograd sees neither the
-    buffer nor the in-place slice writes: every block returns its slice as a fresh output tensor, `ConcatSlicesFn` returns the
-    whole buffer as the concatenation and hands each block its slice of the gradient (views, no copy either way)."""
+    blocks feeding the global feature fusion, models/rdn.py:99-108; D-DBPN: the HR feature maps whose growing concatenations the
+    down units read, ddbpn.py:116-134).  A plain Python object, so autograd sees neither the buffer nor the in-place slice writes:
+    every block returns its slice as a fresh output tensor, `ConcatSlicesFn` returns the buffer (or a prefix of it) as the
+    concatenation and hands each block its slice of the gradient (views, no copy either way).
 
-    def __init__(self, count):
+    With `accumulate_grads` (several concatenations of growing prefixes: D-DBPN) the gradients of all consumers meet in ONE
+    buffer of the same shape: the consumer of the longest prefix runs first in backward and its gradient becomes the buffer, every
+    later consumer adds its gradient to its prefix -- a 1x1 conv does so in its own data-gradient launch (`res` = `out` = the
+    prefix: ConvFn) -- and a part's slice is handed to autograd by the LAST consumer that covers it.  Autograd itself would add
+    the (count - i) slices of part i one strided launch at a time (15 launches over 37.7 MB each per D-DBPN step at the
+    reference's batch).  The order (longest prefix first) is what the data flow forces -- part k - 1 is produced from the output of
+    the consumer of prefix k - 1 -- and is checked: a consumer arriving out of order raises."""
+
+    def __init__(self, count, accumulate_grads=False):
         self.count, self.buf = int(count), None
+        self.accumulate = bool(accumulate_grads) and _SLICE_GACC
+        self.ks = []            # prefix lengths of the concatenations taken in this forward
+        self.gbuf, self.last_k = None, None
 
     def alloc(self, n, h, w, c, dtype, device):
         self.buf = torch.empty((n, h, w, self.count * c), dtype=dtype, device=device)
@@ -1709,28 +1729,78 @@ class SliceBuffer:
         c = self.c if like is None else like.shape[3]
         return self.buf[..., i * c:(i + 1) * c]
 
+    # -- gradient side (accumulate_grads) --
+    def grad_dest(self, k):
+        """Where the consumer of prefix `k` writes its data gradient: (view of the gradient buffer, add to what is there?)."""
+        if self.gbuf is None:
+            if k != max(self.ks):
+                raise RuntimeError(f"SliceBuffer: the consumer of prefix {k} runs its backward before the one of prefix {max(self.ks)}")
+            self.gbuf = torch.empty_like(self.buf)
+            self.last_k = None
+            first = True
+        else:
+            first = False
+        return self.gbuf[..., :k * self.c], not first
+
+    def deliver(self, k, g):
+        """Called by the concatenation's backward with the consumer's gradient `g` of prefix `k`: makes sure it is in the buffer
+        and returns the per-part gradients this consumer hands to autograd (None for parts a later consumer covers)."""
+        c = self.c
+        if self.gbuf is not None and g.data_ptr() == self.gbuf.data_ptr():
+            pass                                                    # written / added in place by the consumer's own launch
+        elif self.gbuf is None:
+            if k != max(self.ks):
+                raise RuntimeError(f"SliceBuffer: the consumer of prefix {k} runs its backward before the one of prefix {max(self.ks)}")
+            if k == self.count and g.is_contiguous():
+                self.gbuf = g                                       # the full-width gradient IS the buffer from here on
+            else:
+                self.gbuf = torch.zeros_like(self.buf)
+                self.gbuf[..., :k * c].copy_(g)
+            self.last_k = None
+        else:
+            self.gbuf[..., :k * c].add_(g)
+        if self.last_k is not None and k >= self.last_k:
+            raise RuntimeError(f"SliceBuffer: consumers must run their backward longest prefix first (prefix {k} after {self.last_k})")
+        self.last_k = k
+        below = [q for q in self.ks if q < k]
+        lo = max(below) if below else 0
+        out = [self.gbuf[..., i * c:(i + 1) * c] if i >= lo else None for i in range(k)]
+        if not below:                                               # the last consumer: the next backward pass starts afresh
+            self.gbuf, self.last_k = None, None
+        return out
+
 
 class ConcatSlicesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, *parts):
         ctx.c = c = parts[0].shape[3]
+        ctx.holder, ctx.k = holder, len(parts)
         for i, p_ in enumerate(parts):
             assert p_.numel() == 0 or p_.data_ptr() == holder.buf.data_ptr() + i * ctx.c * p_.element_size(), \
                 "part %d is not slice %d of the buffer" % (i, i)
+        if holder.accumulate and len(parts) not in holder.ks:
+            holder.ks.append(len(parts))
         if len(parts) == holder.count:
-            return holder.buf.view(holder.buf.shape)
-        return holder.buf[..., :len(parts) * c]             # a prefix: a channel-slice view the convs read with the buffer's pitch
+            out = holder.buf.view(holder.buf.shape)
+        else:
+            out = holder.buf[..., :len(parts) * c]          # a prefix: a channel-slice view the convs read with the buffer's pitch
+        return out
 
     @staticmethod
     def backward(ctx, g):
         c = ctx.c
+        if ctx.holder.accumulate:
+            return (None, *ctx.holder.deliver(ctx.k, g))
         return (None, *[g[..., i * c:(i + 1) * c] for i in range(g.shape[3] // c)])
 
 
 def concat_slices(holder, parts):
     """torch.cat(parts, dim=3) for parts that already ARE the first consecutive channel slices of `holder` (no copy): all of them
     (RDN's global fusion input, rdn.py:108) or a prefix (D-DBPN's growing concatenations, ddbpn.py:116-131)."""
-    return ConcatSlicesFn.apply(holder, *parts)
+    out = ConcatSlicesFn.apply(holder, *parts)
+    if holder.accumulate:
+        out.__dict__["_srk_gacc"] = (holder, len(parts))    # a conv that consumes it adds its data gradient in place (ConvFn)
+    return out
 
 
 class AddIntoFn(torch.autograd.Function):
@@ -2166,7 +2236,7 @@ class ProjFn(torch.autograd.Function):
             # the group's buffer was re-packed by a later forward window (from possibly updated weights): pack the weights again, here
             wpk = torch.empty(2 * half, dtype=torch.uint8, device=x.device)
             L.check(L.load().srk_proj_pack(_f32c(ctx.wparam).data_ptr(), wpk.data_ptr(), _DT[x.dtype], _stream()), "srk_proj_pack")
-        g = g.contiguous()
+        g = _nhwc_view(g)               # (a slice of a SliceBuffer's gradient buffer is read with its pitch: no copy)
         gs = None
         if sl is not None:                       # through the PReLU first: g <- g * (pre > 0 ? 1 : slope), slope gradient on the side
             if ctx.needs_input_grad[3]:

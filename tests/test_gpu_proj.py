@@ -175,3 +175,37 @@ def test_grouped_projection_pack_follows_the_weights(A):
     for a_, b_ in zip(ga, gb):
         if a_ is not None:
             torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-6)
+
+
+def _ddbpn_grads(A, lr, hr):
+    torch.manual_seed(0)
+    m = A.DDBPN(scale_factor=4, precision="bf16").cuda()
+    loss = (m(lr) - hr).abs().mean()
+    loss.backward()
+    return float(loss.detach()), {k: p.grad.detach().float().cpu() for k, p in m.named_parameters() if p.grad is not None}
+
+
+def test_ddbpn_direct_path_agrees_with_the_column_path(A, monkeypatch):
+    """The whole D-DBPN x4 training step in bf16 on the direct projection kernels + the shared gradient buffer of the concatenations,
+    against (a) the im2col / col2im projections of round 2 (pinned by the `ddbpn_*` goldens) and (b) autograd's own sums of the
+    gradient slices: same loss, every parameter gradient in the same direction and size (16-bit storage: rounding differs)."""
+    from sr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    lr, hr = torch.rand(2, 3, 16, 16, generator=g).cuda(), torch.rand(2, 3, 64, 64, generator=g).cuda()
+    l0, g0 = _ddbpn_grads(A, lr, hr)
+    monkeypatch.setattr(ops, "_SLICE_GACC", False)
+    l1, g1 = _ddbpn_grads(A, lr, hr)
+    monkeypatch.setattr(ops, "_PROJ_OFF", True)
+    l2, g2 = _ddbpn_grads(A, lr, hr)
+    assert abs(l0 - l1) < 1e-6 and abs(l0 - l2) < 2e-3 * abs(l2)
+    assert set(g0) == set(g1) == set(g2)
+    for name, other, lim in (("autograd sums", g1, 0.9995), ("column path", g2, 0.995)):
+        worst = 1.0
+        for k in g0:
+            a_, b_ = g0[k].flatten().double(), other[k].flatten().double()
+            if b_.norm() < 1e-9:
+                continue
+            cos = float(a_ @ b_ / (a_.norm() * b_.norm() + 1e-30))
+            worst = min(worst, cos)
+            assert cos > lim and 0.97 < float(a_.norm() / b_.norm()) < 1.03, f"{name}: {k}: cos {cos:.5f}, norm ratio {float(a_.norm() / b_.norm()):.4f}"
+        print(f"D-DBPN bf16 gradients vs {name}: worst cosine {worst:.6f}")
