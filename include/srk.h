@@ -262,6 +262,8 @@ typedef struct {
                             /*      slab (no atomics, no zeroing, bitwise reproducible);          */
                             /*   0: atomic mode, ONE slab that the caller has zeroed              */
   int dtype;
+  int cout_real;            /* the conv's real output channels (<= Cout), or 0 = unknown: large kernels   */
+                            /* with few of them (cout_real * KW <= 32) put (kw, co) pairs on the MFMA columns */
 } srk_wgrad_args;
 int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream);
 /* number of slabs srk_conv2d_wgrad will write for these arguments (0 = atomic mode, see nslabs) */

@@ -108,7 +108,7 @@ class WgradArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("x_ps", _i),
                 ("dy", _p), ("dy_pitch", _i), ("dy_coff", _i), ("dy_ps", _i),
                 ("N", _i), ("H", _i), ("W", _i), ("Cin", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
-                ("dwp", _p), ("dbp", _p), ("nslabs", _i), ("dtype", _i)]
+                ("dwp", _p), ("dbp", _p), ("nslabs", _i), ("dtype", _i), ("cout_real", _i)]
 
 
 class WgradFinArgs(C.Structure):

@@ -11,6 +11,7 @@
 //                                 row, both operands by the transposing LDS read; partial sums to per-workgroup slabs
 //                                 (srk_wgrad_finalize's layout).
 // Packed weights, epilogue order and slab format are srk_conv2d's / srk_conv2d_wgrad's: those entry points dispatch here.
+#include <stdlib.h>
 #include "srk_common.h"
 
 namespace {
@@ -297,6 +298,161 @@ __global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient when the conv has FEW real output channels (SRResNet's 9x9 tail: 3; cr * K <= 32): the MFMA columns carry
+// (kw, co) pairs instead of 16 stored gradient channels of which 3 are real.  With u = x + kw - P (a column of the input halo):
+//     dW[co][ci][kh][kw] = sum_{y, u} X[y + kh - P][u][ci] * dY[y][u - kw + P][co]
+// so per tile row ONE operand of the input (K index = halo column u, no tap shift) meets ONE operand built from the gradient row,
+// B[u][(kw, co)] = dY[y][u - kw][co]: 2 column blocks x 2 channel blocks = 4 MFMAs per tile row and kernel row instead of 2 K,
+// one per wave.  The gradient tile is transposed once per tile into channel planes with K - 1 zero columns on both sides
+// (DT[co][y][col + K - 1], + one all-zero plane for the unused MFMA columns), so the 8 two-byte reads of a lane's operand need
+// no bounds logic.  Slab layout, bias partials and the finalize launch are lk_wgrad_kernel's.
+// ------------------------------------------------------------------------------------------------------------------
+template <int DT, int K>
+__global__ __launch_bounds__(256) void lk_wgrad_packed_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int ntiles, int tq, int trem,
+                                                              unsigned x_bytes, unsigned dy_bytes) {
+  typedef DTraits<DT> Tr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XW = 16 + K - 1, XWP = (XW + 1) & ~1;
+  constexpr int xbuf = 16 * XWP * 128, dbuf = 16 * 16 * 32, buf = xbuf + dbuf;
+  constexpr int DTW = 16 + 2 * (K - 1) + 16, DTP = DTW * 2;      // plane row: columns -(K-1) .. 16 + (K-1) + 15, two bytes each
+  constexpr int NPL = 8;                                          // planes: <= 6 real + the zero plane (index cr)
+  constexpr int dt_bytes = NPL * 16 * DTP;
+  char* const DTb = smem + 2 * buf;
+  float* const red = reinterpret_cast<float*>(DTb + dt_bytes);    // 2 x 16 x 64 floats: the s = 1 waves' sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = blockIdx.x, kh = blockIdx.y;
+  const int H = a.H, W = a.W, P = K / 2, cr = a.cout_real;
+  const int t0 = slot * tq + min(slot, trem), nt = tq + (slot < trem ? 1 : 0);
+  const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+
+  constexpr int NPX = 16 * XWP * 8 / 64, XPW = (NPX + 3) / 4, DPW = 2;          // + 8 gradient pieces (two per wave)
+  int xdesc[XPW], ddesc[DPW];
+#pragma unroll
+  for (int j = 0; j < XPW; ++j) {
+    const int k = wave + 4 * j, i = k * 64 + lane, sl = i & 7, p = i >> 3;
+    const int iy = p / XWP, ix = p - iy * XWP, c = sl ^ swz(ix);
+    xdesc[j] = iy | (ix << 8) | (c << 16) | ((k < NPX && ix < XW && c * 8 < a.Cin) ? 1 << 24 : 0);
+  }
+#pragma unroll
+  for (int j = 0; j < DPW; ++j) {
+    const int k = wave + 4 * j, i = k * 64 + lane, c = i & 1, pp = i >> 1;
+    ddesc[j] = (pp >> 4) | ((pp & 15) << 8) | (c << 16) | ((c * 8 < a.Cout) ? 1 << 24 : 0);
+  }
+  auto dma_tile = [&](int tile, int b) {
+    int pt = tile;
+    const int tX = pt % tilesX;
+    pt /= tilesX;
+    const int tY = pt % tilesY;
+    const int n = pt / tilesY;
+    const int y0 = tY * 16, x0 = tX * 16;
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+      const int k = wave + 4 * j;
+      if (k < NPX) {
+        const int d = xdesc[j], gy = y0 + (d & 255) + kh - P, gx = x0 + ((d >> 8) & 255) - P;
+        const bool ok = (d >> 24) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + ((d >> 16) & 255) * 8) * 2) : 0x80000000u;
+        dma16_hidden(xrs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * buf + (k << 10))));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+      const int k = wave + 4 * j;
+      const int d = ddesc[j], gy = y0 + (d & 255), gx = x0 + ((d >> 8) & 255);
+      const bool ok = (d >> 24) && gy < H && gx < W;
+      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.dy_pitch + a.dy_coff + ((d >> 16) & 255) * 8) * 2) : 0x80000000u;
+      dma16_hidden(drs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * buf + xbuf + (k << 10))));
+    }
+  };
+
+  // zero the planes once: the pad columns and the zero plane are never written again
+  for (int i = tid; i < dt_bytes / 16; i += 256) lds_write16(DTb + i * 16, i32x4{0, 0, 0, 0});
+
+  const int s = wave >> 1, rb = wave & 1;                         // column block (halo columns 16 s ..), channel block
+  int aoff[2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) aoff[rd] = tr_lane_off(16 * s, rd, rb, lane);
+  // B operand: lane (n = lane & 31 -> (kw, co), g = lane >> 5) reads gradient columns 16 s + 8 g - kw + j, j = 0..7, of plane co
+  const int nn = lane & 31, kwn = nn / cr, con = nn - kwn * cr;
+  const int plane = kwn < K ? con : cr;                           // columns beyond K * cr: the zero plane
+  const int boff = plane * 16 * DTP + (16 * s + 8 * (lane >> 5) - (kwn < K ? kwn : 0) + (K - 1)) * 2;
+  // transposition pass: thread = pixel (ty, tx) of the gradient tile
+  const int ty = tid >> 4, tx = tid & 15;
+  const bool do_bias = a.dbp != nullptr && kh == 0;
+  float dbs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  if (nt > 0) dma_tile(t0, 0);
+  for (int it = 0; it < nt; ++it) {
+    const char* const X = smem + (it & 1) * buf;
+    const char* const D = X + xbuf;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (it + 1 < nt) dma_tile(t0 + it + 1, (it + 1) & 1);
+    {
+      const i32x4 v = lds_read16(D + (ty * 16 + tx) * 32);        // channels 0..7 of the pixel (cr <= 6)
+      const uint32_t w4[4] = {(uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w};
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        if (c < cr) {
+          const uint16_t hv = (uint16_t)(w4[c >> 1] >> ((c & 1) * 16));
+          *reinterpret_cast<uint16_t*>(DTb + (c * 16 + ty) * DTP + (tx + K - 1) * 2) = hv;
+          if (do_bias) dbs[c] += Tr::to_f32(hv);
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int y = 0; y < 16; ++y) {
+      const i32x4 af = tr_read2(X + y * (XWP * 128) + aoff[0], X + y * (XWP * 128) + aoff[1]);
+      const uint16_t* bp = reinterpret_cast<const uint16_t*>(DTb + boff + y * DTP);
+      i32x4 bf;
+      bf.x = (int)((uint32_t)bp[0] | ((uint32_t)bp[1] << 16));
+      bf.y = (int)((uint32_t)bp[2] | ((uint32_t)bp[3] << 16));
+      bf.z = (int)((uint32_t)bp[4] | ((uint32_t)bp[5] << 16));
+      bf.w = (int)((uint32_t)bp[6] | ((uint32_t)bp[7] << 16));
+      acc = Tr::mma(af, bf, acc);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  if (do_bias) {                                                  // db partial of this slot: block sum of the per-thread sums
+    float* rs = reinterpret_cast<float*>(smem);                   // (the tile buffers are free now)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rs[c * 256 + tid] = dbs[c];
+    __syncthreads();
+    if (tid < a.Cout) {
+      float t = 0.f;
+      if (tid < cr)
+        for (int i = 0; i < 256; ++i) t += rs[tid * 256 + i];
+      a.dbp[(size_t)slot * a.Cout + tid] = t;
+    }
+    __syncthreads();
+  }
+  // the two column blocks' sums meet in LDS; rows = input channels rb * 32 + 8 (e >> 2) + 4 (lane >> 5) + (e & 3), column = (kw, co)
+  if (s == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(rb * 16 + e) * 64 + lane] = acc[e];
+  }
+  __syncthreads();
+  const size_t per = (size_t)K * K * a.Cin * a.Cout;
+  float* const sl = a.dwp + (size_t)slot * per + (size_t)kh * K * a.Cin * a.Cout;
+  if (s == 0 && kwn < K) {
+    const int hq = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ci = rb * 32 + 4 * hq + (e & 3) + 8 * (e >> 2);
+      if (ci < a.Cin) sl[((size_t)kwn * a.Cin + ci) * a.Cout + con] = acc[e] + red[(rb * 16 + e) * 64 + lane];
+    }
+  }
+  // the stored channels that are padding: zeros (the finalize step adds whole slabs)
+  for (int i = tid; i < K * a.Cin * a.Cout; i += 256)
+    if (i % a.Cout >= cr) sl[i] = 0.f;
+}
+
 int lk_wgrad_slabs_for(const srk_wgrad_args& a) {
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
   const long long ntiles = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
@@ -368,6 +524,17 @@ template <int DT, int K> static int lk_wgrad_launch_k(const srk_wgrad_args& a, h
   const long long ntiles = (long long)a.N * tilesX * tilesY;
   const int slabs = a.nslabs;
   const unsigned xb = (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2), db = (unsigned)((long long)a.N * a.H * a.W * a.dy_pitch * 2);
+  static const bool no_packed = [] { const char* e = getenv("SRK_NO_LK_PACKED"); return e && e[0] == '1'; }();      // A/B knob
+  if (a.cout_real > 0 && a.cout_real <= 6 && a.cout_real * K <= 32 && !no_packed) {
+    // few real output channels (SRResNet's tail: 3): MFMA columns = (kw, co) pairs
+    constexpr int plds = 2 * (16 * XWP * 128 + 16 * 16 * 32) + 8 * 16 * (16 + 2 * (K - 1) + 16) * 2 + 2 * 16 * 64 * 4;
+    static_assert(plds <= 160 * 1024, "LDS");
+    static const hipError_t pattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_wgrad_packed_kernel<DT, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (pattr != hipSuccess) { srk_set_error("srk_conv2d_wgrad: cannot reserve LDS"); return (int)pattr; }
+    hipLaunchKernelGGL((lk_wgrad_packed_kernel<DT, K>), dim3(slabs, K), dim3(256), plds, st, a, tilesX, tilesY, (int)ntiles, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db);
+    SRK_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL((lk_wgrad_kernel<DT, K>), dim3(slabs, K), dim3(256), lds, st, a, tilesX, tilesY, (int)ntiles, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db);
   SRK_LAUNCH_CHECK();
   return 0;

@@ -456,7 +456,8 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
         return dw, db
     a = L.WgradArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(x_ps),
                     dy=dy.data_ptr(), dy_pitch=_pitch(dy), dy_coff=0, dy_ps=int(dy_ps),
-                    N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, dwp=0, dbp=0, nslabs=0, dtype=_DT[x.dtype])
+                    N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, dwp=0, dbp=0, nslabs=0, dtype=_DT[x.dtype],
+                    cout_real=int(cout) if (ps_r <= 1 and not x_ps and not dy_ps) else 0)
     nslabs = L.load().srk_wgrad_slabs(a)
     per = k * k * Cin * Cout
     if nslabs > 0:      # slab mode: every workgroup writes its own slab, nothing to zero

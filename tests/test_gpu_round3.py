@@ -153,7 +153,9 @@ def test_gradsync_gradients_land_in_the_flat_buffer(A):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("k,cout,n,h,w", [(9, 3, 2, 40, 33), (9, 3, 1, 16, 16), (5, 8, 1, 21, 19), (7, 16, 2, 17, 30)])
+@pytest.mark.parametrize("k,cout,n,h,w", [(9, 3, 2, 40, 33), (9, 3, 1, 16, 16), (5, 8, 1, 21, 19), (7, 16, 2, 17, 30),
+                                         # few real output channels: the weight gradient with (kw, co) pairs on the MFMA columns (cout * k <= 32)
+                                         (9, 1, 1, 35, 20), (7, 4, 2, 16, 47), (5, 6, 1, 33, 33)])
 def test_direct_large_kernel_conv_vs_float64(A, dt, k, cout, n, h, w):
     """ops.conv_general on the direct 5x5 / 7x7 / 9x9 kernels (csrc/conv_lk.hip: SRResNet's 9x9 tail conv 64 -> 3, models/srresnet.py:29)
     against float64 F.conv2d: output, data gradient, weight and bias gradients (no column tensor: the forward must not call
