@@ -548,6 +548,11 @@ typedef struct {
                                           /* value of the data loses no digits to |mean| >> std                         */
   void* gate_out; int gate_pitch;         /* mode 2 only, or NULL: gate_out[p][c] = y * (x > 0 ? 1 : slope[c]) -- nn.PReLU's */
   const float* slope; int slope_stride;   /* input gradient written by the pass that sums its slope gradient (one read of x, y) */
+  /* mode 3: nn.BatchNorm2d's backward BEHIND an nn.PReLU (srresnet.py:16-21) in one pass: x = the BatchNorm's input, y = the gradient
+   * of the PReLU's output; with yb = gate_a x + gate_d (the BatchNorm's output, recomputed) and gp = y (yb > 0 ? 1 : slope):
+   * partial[b][0] = sum gp, partial[b][1] = sum (x - shift) gp, partial2[b] = sum over yb <= 0 of yb y (the slope's gradient)   */
+  const float* gate_a; const float* gate_d;   /* [C] fp32: the forward scale / shift (srk_chan_finalize mode 1, rows 2 and 3)   */
+  float* partial2;                        /* [blocks][C]                                                                    */
 } srk_chan_stats_args;
 int srk_chan_stats_blocks(long long P);
 int srk_chan_stats(const srk_chan_stats_args* a, srk_stream_t stream);
@@ -573,6 +578,8 @@ typedef struct {
   float* out;                             /* [rows][C] fp32 */
   long long* nbt;                         /* mode 1, nullable: nn.BatchNorm2d.num_batches_tracked, += 1                          */
   float* dgamma_acc; float* dbeta_acc;    /* modes 2 / 3, nullable, [Creal]: the parameters' existing .grad buffers, += dgamma / dbeta */
+  const float* partial2; int total2;      /* modes 2 / 3, nullable: srk_chan_stats mode 3's third sums [nblocks][C] -> out row 5 = the  */
+  float* dslope_acc;                      /* PReLU slope gradient (total2: ONE number, summed over the channels); += into dslope_acc    */
 } srk_chan_finalize_args;
 int srk_chan_finalize(const srk_chan_finalize_args* a, srk_stream_t stream);
 /* srk_chan_stats and srk_chan_finalize as ONE launch: the block that finishes last does the finalize step.  `f->partial` and
@@ -593,6 +600,9 @@ typedef struct {
   void* out; int out_pitch, out_coff;
   long long P; int C;
   int dtype;
+  const float* gate_a; const float* gate_d;   /* [C] or NULL.  Given (with z and slope): the gate's argument is gate_a z + gate_d and   */
+                                              /* only the first term passes it: out = a x gate + b y + d (BatchNorm backward behind a  */
+                                              /* PReLU: x = dy, y = z = the BatchNorm's input)                                          */
 } srk_chan_apply_args;
 int srk_chan_apply(const srk_chan_apply_args* a, srk_stream_t stream);
 

@@ -83,7 +83,7 @@ class ChanFinalizeArgs(C.Structure):
     _fields_ = [("partial", _p), ("nblocks", _i), ("C", _i), ("Creal", _i), ("mode", _i), ("total", _i),
                 ("M", _f), ("eps", _f), ("momentum", _f), ("mean", _p), ("invstd", _p), ("gamma", _p),
                 ("weight", _p), ("bias", _p), ("running_mean", _p), ("running_var", _p), ("out", _p),
-                ("nbt", _p), ("dgamma_acc", _p), ("dbeta_acc", _p)]
+                ("nbt", _p), ("dgamma_acc", _p), ("dbeta_acc", _p), ("partial2", _p), ("total2", _i), ("dslope_acc", _p)]
 
 
 class RowsumJob(C.Structure):
@@ -201,14 +201,15 @@ class FoldNhwcArgs(C.Structure):
 class ChanStatsArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("y", _p), ("y_pitch", _i), ("y_coff", _i),
                 ("P", C.c_longlong), ("C", _i), ("mode", _i), ("partial", _p), ("dtype", _i), ("shift", _p), ("shift_out", _p),
-                ("gate_out", _p), ("gate_pitch", _i), ("slope", _p), ("slope_stride", _i)]
+                ("gate_out", _p), ("gate_pitch", _i), ("slope", _p), ("slope_stride", _i),
+                ("gate_a", _p), ("gate_d", _p), ("partial2", _p)]
 
 
 class ChanApplyArgs(C.Structure):
     _fields_ = [("x", _p), ("x_pitch", _i), ("x_coff", _i), ("y", _p), ("y_pitch", _i), ("y_coff", _i),
                 ("z", _p), ("z_pitch", _i), ("z_coff", _i), ("a", _p), ("b", _p), ("d", _p),
                 ("slope", _p), ("slope_stride", _i), ("post_prelu", _i), ("out", _p), ("out_pitch", _i), ("out_coff", _i),
-                ("P", C.c_longlong), ("C", _i), ("dtype", _i)]
+                ("P", C.c_longlong), ("C", _i), ("dtype", _i), ("gate_a", _p), ("gate_d", _p)]
 
 
 # every launcher declared in include/srk.h: name -> argument struct

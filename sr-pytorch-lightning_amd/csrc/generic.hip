@@ -108,6 +108,21 @@ template <int DT> __global__ __launch_bounds__(GEN_NT) void fold_nhwc_kernel(con
 // grid = blocks over pixels; thread = (16-byte channel chunk, pixel row); partial[block][2][C]
 SRK_DEV void chan_finalize_body(const srk_chan_finalize_args& a);
 
+// CH consecutive per-channel fp32 constants as 16-byte loads (p + c0 is 16-byte aligned: c0 is a multiple of CH >= 4)
+template <int CH> SRK_DEV void load_consts(const float* p, int c0, int stride, float (&o)[CH]) {
+  if (stride == 0) {
+    const float v = p[0];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) o[e] = v;
+  } else {
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + c0 + 4 * q);
+      o[4 * q] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+    }
+  }
+}
+
 // FUSED: the block that finishes LAST (an arrival counter in device memory, which it resets for the next launch) goes on to do
 // srk_chan_finalize's work on the partials of all blocks: one launch per BatchNorm / PReLU reduction instead of two (the second
 // was one workgroup of [C]-sized arithmetic behind a launch boundary: ~7 us each, 118 per SRResNet training step)
@@ -116,15 +131,15 @@ template <int DT, bool FUSED> __global__ __launch_bounds__(GEN_NT) void chan_sta
   typedef DTraits<DT> Tr;
   typedef typename Tr::elem elem;
   constexpr int CH = Tr::CH;
-  __shared__ float red[2][GEN_NT * 8];
+  __shared__ float red[3][GEN_NT * 8];
   const int tid = threadIdx.x;
   const int nch = a.C / CH, rows = GEN_NT / nch;
   const int cc = tid % nch, prow = tid / nch;
   const long long p0 = (long long)blockIdx.x * pix_per_block, p1 = min(a.P, p0 + pix_per_block);
-  float s0[CH], s1[CH], sh[CH];
+  float s0[CH], s1[CH], s2[CH], sh[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) {
-    s0[e] = s1[e] = 0.f;
+    s0[e] = s1[e] = s2[e] = 0.f;
     sh[e] = (a.shift && prow < rows) ? a.shift[cc * CH + e] : 0.f;      // x is centred first: sums of (x - shift[c])
   }
   if (a.shift_out && prow < rows) {                                     // ... by the tensor's first pixel (every block reads it)
@@ -137,6 +152,14 @@ template <int DT, bool FUSED> __global__ __launch_bounds__(GEN_NT) void chan_sta
   if (prow < rows) {
     const elem* x = reinterpret_cast<const elem*>(a.x) + a.x_coff + cc * CH;
     const elem* y = a.y ? reinterpret_cast<const elem*>(a.y) + a.y_coff + cc * CH : nullptr;
+    float ga[CH], gd[CH], gs[CH];                                       // mode 3: the thread's channels' constants, loaded once
+    if (a.mode == 3) {
+      load_consts<CH>(a.gate_a, cc * CH, 1, ga);
+      load_consts<CH>(a.gate_d, cc * CH, 1, gd);
+      load_consts<CH>(a.slope, cc * CH, a.slope_stride, gs);
+    } else if (a.gate_out) {
+      load_consts<CH>(a.slope, cc * CH, a.slope_stride, gs);
+    }
     // U loads in flight per thread (the blocks are few: see stats_blocks), consumed in pixel order: the sums' order is fixed
     constexpr int U = 8;
     for (long long pb = p0 + prow; pb < p1; pb += (long long)rows * U) {
@@ -155,6 +178,22 @@ template <int DT, bool FUSED> __global__ __launch_bounds__(GEN_NT) void chan_sta
         if (p < p1) {
           float xv[CH];
           chunk_to_f32<DT>(xq[u], xv);
+          if (a.mode == 3) {
+            // BatchNorm backward BEHIND a PReLU, in one pass over (x = the BatchNorm's input, y = the gradient of the PReLU's
+            // output): the BatchNorm output yb = gate_a x + gate_d is recomputed, gp = y * (yb > 0 ? 1 : slope) is the gradient the
+            // BatchNorm sees: s0 = sum gp, s1 = sum (x - shift) gp, s2 = sum over yb <= 0 of yb * y (the slope's gradient)
+            float yv[CH];
+            chunk_to_f32<DT>(yq[u], yv);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+              const float yb = ga[e] * xv[e] + gd[e];
+              const float gp = yv[e] * (yb > 0.f ? 1.f : gs[e]);
+              s0[e] += gp;
+              s1[e] += (xv[e] - sh[e]) * gp;
+              s2[e] += yb <= 0.f ? yb * yv[e] : 0.f;
+            }
+            continue;
+          }
 #pragma unroll
           for (int e = 0; e < CH; ++e) xv[e] -= sh[e];
           if (a.mode == 0) {
@@ -172,7 +211,7 @@ template <int DT, bool FUSED> __global__ __launch_bounds__(GEN_NT) void chan_sta
               if (a.gate_out) {      // nn.PReLU's input gradient from the same read: y * (x > 0 ? 1 : slope)
                 float gv[CH];
 #pragma unroll
-                for (int e = 0; e < CH; ++e) gv[e] = yv[e] * (xv[e] > 0.f ? 1.f : a.slope[(cc * CH + e) * a.slope_stride]);
+                for (int e = 0; e < CH; ++e) gv[e] = yv[e] * (xv[e] > 0.f ? 1.f : gs[e]);
                 *reinterpret_cast<i32x4*>(reinterpret_cast<elem*>(a.gate_out) + (size_t)p * a.gate_pitch + cc * CH) = f32_to_chunk<DT>(gv);
               }
             }
@@ -185,23 +224,28 @@ template <int DT, bool FUSED> __global__ __launch_bounds__(GEN_NT) void chan_sta
   for (int e = 0; e < CH; ++e) {
     red[0][tid * CH + e] = (prow < rows) ? s0[e] : 0.f;
     red[1][tid * CH + e] = (prow < rows) ? s1[e] : 0.f;
+    if (a.mode == 3) red[2][tid * CH + e] = (prow < rows) ? s2[e] : 0.f;
   }
   __syncthreads();
   if (tid < a.C) {
     const int c_cc = tid / CH, c_e = tid % CH;
-    float t0 = 0.f, t1 = 0.f;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
     for (int r = 0; r < rows; ++r) {
       t0 += red[0][(r * nch + c_cc) * CH + c_e];
       t1 += red[1][(r * nch + c_cc) * CH + c_e];
+      if (a.mode == 3) t2 += red[2][(r * nch + c_cc) * CH + c_e];
     }
     float* const p0 = a.partial + ((size_t)blockIdx.x * 2 + 0) * a.C + tid;
     float* const p1 = a.partial + ((size_t)blockIdx.x * 2 + 1) * a.C + tid;
+    float* const p2 = a.mode == 3 ? a.partial2 + (size_t)blockIdx.x * a.C + tid : nullptr;
     if constexpr (FUSED) {       // device-scope stores (written through to where every XCD sees them): the count below then needs no
       __hip_atomic_store(p0, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cache write-back -- a release per block cost more
       __hip_atomic_store(p1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // than the launch it saves
+      if (p2) __hip_atomic_store(p2, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       *p0 = t0;
       *p1 = t1;
+      if (p2) *p2 = t2;
     }
   }
   if constexpr (FUSED) {
@@ -232,26 +276,41 @@ template <int DT> __global__ __launch_bounds__(GEN_NT) void chan_apply_kernel(co
     const long long p = i / nch;
     float xv[CH], v[CH];
     chunk_to_f32<DT>(gload16(x + (size_t)p * a.x_pitch + a.x_coff + cc * CH), xv);
+    // the chunk's per-channel constants as 16-byte loads (they were 8 dword loads each: a launch of this kernel is mostly latency)
+    float aa[CH], dd[CH], gs[CH];
+    if (a.a) load_consts<CH>(a.a, cc * CH, 1, aa);
+    if (a.d) load_consts<CH>(a.d, cc * CH, 1, dd);
+    if (a.slope) load_consts<CH>(a.slope, cc * CH, a.slope_stride, gs);
 #pragma unroll
-    for (int e = 0; e < CH; ++e) {
-      const int c = cc * CH + e;
-      v[e] = (a.a ? a.a[c] : 1.f) * xv[e] + (a.d ? a.d[c] : 0.f);
-    }
+    for (int e = 0; e < CH; ++e) v[e] = (a.a ? aa[e] : 1.f) * xv[e] + (a.d ? dd[e] : 0.f);
     if (y) {
-      float yv[CH];
+      float yv[CH], bb[CH];
       chunk_to_f32<DT>(gload16(y + (size_t)p * a.y_pitch + a.y_coff + cc * CH), yv);
+      if (a.b) load_consts<CH>(a.b, cc * CH, 1, bb);
 #pragma unroll
-      for (int e = 0; e < CH; ++e) v[e] += (a.b ? a.b[cc * CH + e] : 1.f) * yv[e];
+      for (int e = 0; e < CH; ++e) v[e] += (a.b ? bb[e] : 1.f) * yv[e];
     }
-    if (z) {          // gate: PReLU backward, d/dz prelu(z) = z > 0 ? 1 : slope
+    if (z && a.gate_a) {   // BatchNorm backward behind a PReLU (srk_chan_stats mode 3): only the a x term passes the gate, whose
+      float zv[CH];        // argument is the recomputed BatchNorm output gate_a z + gate_d:  out = a x gate + b y + d
+      chunk_to_f32<DT>(gload16(z + (size_t)p * a.z_pitch + a.z_coff + cc * CH), zv);
+      float ga[CH], gd[CH];
+      load_consts<CH>(a.gate_a, cc * CH, 1, ga);
+      load_consts<CH>(a.gate_d, cc * CH, 1, gd);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const float ax = (a.a ? aa[e] : 1.f) * xv[e];
+        const float gate = (ga[e] * zv[e] + gd[e]) > 0.f ? 1.f : gs[e];
+        v[e] += ax * (gate - 1.f);
+      }
+    } else if (z) {          // gate: PReLU backward, d/dz prelu(z) = z > 0 ? 1 : slope
       float zv[CH];
       chunk_to_f32<DT>(gload16(z + (size_t)p * a.z_pitch + a.z_coff + cc * CH), zv);
 #pragma unroll
-      for (int e = 0; e < CH; ++e) v[e] *= zv[e] > 0.f ? 1.f : a.slope[(cc * CH + e) * a.slope_stride];
+      for (int e = 0; e < CH; ++e) v[e] *= zv[e] > 0.f ? 1.f : gs[e];
     }
     if (a.post_prelu) {
 #pragma unroll
-      for (int e = 0; e < CH; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope[(cc * CH + e) * a.slope_stride];
+      for (int e = 0; e < CH; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * gs[e];
     }
     *reinterpret_cast<i32x4*>(out + (size_t)p * a.out_pitch + a.out_coff + cc * CH) = f32_to_chunk<DT>(v);
   }
@@ -344,6 +403,24 @@ SRK_DEV void chan_finalize_body(const srk_chan_finalize_args& a) {
     o[3 * C + c] = beta - mean * sc;
     o[4 * C + c] = mean;
   } else {                                 // backward: s0 = sum dy, s1 = sum (x - mean) dy
+    if (a.partial2) {                      // (+ the slope gradient of the PReLU behind the BatchNorm: srk_chan_stats mode 3; out row 5)
+      float t = 0.f;
+#pragma unroll 8
+      for (int b = 0; b < a.nblocks; ++b) t += a.partial2[(size_t)b * C + c];
+      if (a.total2) {                      // one shared slope: summed over the channels too (the threads c >= C left above)
+        red[c] = t;
+        __syncthreads();
+        if (c == 0) {
+          float tt = 0.f;
+          for (int k = 0; k < C; ++k) tt += red[k];
+          o[5 * C] = tt;
+          if (a.dslope_acc) a.dslope_acc[0] += tt;
+        }
+      } else {
+        o[5 * C + c] = t;
+        if (a.dslope_acc && real) a.dslope_acc[c] += t;
+      }
+    }
     const float invstd = a.invstd[c], gamma = a.gamma[c];
     const float dbeta = s0, dgamma = invstd * s1;
     const float k = gamma * invstd;
@@ -402,12 +479,16 @@ extern "C" int srk_chan_stats_blocks(long long P) { return stats_blocks(P); }
 static int chan_stats_check(const srk_chan_stats_args* a) {
   SRK_CHECK_ARG(a && a->x && a->partial && (a->mode == 0 || a->y), "srk_chan_stats: null pointer");
   const int ch = a->dtype == SRK_F32 ? 4 : 8;
-  SRK_CHECK_ARG(a->mode >= 0 && a->mode <= 2, "srk_chan_stats: mode %d", a->mode);
+  SRK_CHECK_ARG(a->mode >= 0 && a->mode <= 3, "srk_chan_stats: mode %d", a->mode);
+  SRK_CHECK_ARG(a->mode != 3 || (a->gate_a && a->gate_d && a->slope && a->partial2 && !a->shift_out && !a->gate_out &&
+                                 (((uintptr_t)a->gate_a | (uintptr_t)a->gate_d | (a->slope_stride ? (uintptr_t)a->slope : 0)) & 15) == 0),
+                "srk_chan_stats: mode 3 needs 16-byte aligned gate_a, gate_d, slope and partial2");
   SRK_CHECK_ARG(!a->shift_out || !a->shift, "srk_chan_stats: shift and shift_out exclude each other");
   SRK_CHECK_ARG(a->C > 0 && a->C <= GEN_NT && a->C % ch == 0 && a->x_pitch % ch == 0 && a->x_coff % ch == 0 &&
                     (!a->y || (a->y_pitch % ch == 0 && a->y_coff % ch == 0)), "srk_chan_stats: C=%d (multiple of %d, <= %d) / alignment", a->C, ch, GEN_NT);
-  SRK_CHECK_ARG(!a->gate_out || (a->mode == 2 && a->slope && !a->shift && !a->shift_out && a->gate_pitch % ch == 0 && a->gate_pitch >= a->C),
-                "srk_chan_stats: gate_out needs mode 2, the slope and an aligned pitch");
+  SRK_CHECK_ARG(!a->gate_out || (a->mode == 2 && a->slope && !a->shift && !a->shift_out && a->gate_pitch % ch == 0 && a->gate_pitch >= a->C &&
+                                 (a->slope_stride == 0 || ((uintptr_t)a->slope & 15) == 0)),
+                "srk_chan_stats: gate_out needs mode 2, the (16-byte aligned) slope and an aligned pitch");
   return 0;
 }
 static int chan_finalize_check(const srk_chan_finalize_args* a) {
@@ -450,6 +531,7 @@ extern "C" int srk_chan_stats_finalize(const srk_chan_stats_args* a, const srk_c
   SRK_CHECK_ARG(f && counter && a->P > 0, "srk_chan_stats_finalize: null pointer / no pixels");
   srk_chan_finalize_args g = *f;
   g.partial = a->partial;
+  g.partial2 = a->mode == 3 ? a->partial2 : nullptr;
   g.nblocks = stats_blocks(a->P);
   SRK_CHECK_ARG(g.C == a->C, "srk_chan_stats_finalize: C %d vs %d", g.C, a->C);
   if (const int rc = chan_finalize_check(&g)) return rc;
@@ -463,6 +545,9 @@ extern "C" int srk_chan_apply(const srk_chan_apply_args* a, srk_stream_t stream)
                     (!a->y || (a->y_pitch % ch == 0 && a->y_coff % ch == 0)) && (!a->z || (a->z_pitch % ch == 0 && a->z_coff % ch == 0)),
                 "srk_chan_apply: channels / pitches must be 16-byte multiples");
   SRK_CHECK_ARG((!a->z && !a->post_prelu) || a->slope, "srk_chan_apply: gate / PReLU needs the slope");
+  SRK_CHECK_ARG((((uintptr_t)a->a | (uintptr_t)a->b | (uintptr_t)a->d | (uintptr_t)a->gate_a | (uintptr_t)a->gate_d |
+                  (a->slope_stride ? (uintptr_t)a->slope : 0)) & 15) == 0, "srk_chan_apply: the per-channel vectors must be 16-byte aligned");
+  SRK_CHECK_ARG(!a->gate_a || (a->gate_d && a->z && a->slope), "srk_chan_apply: gate_a needs gate_d, z and the slope");
   if (a->P <= 0) return 0;
   GEN_DISPATCH(chan_apply_kernel, a->dtype, grid_for(a->P * (a->C / ch)), reinterpret_cast<hipStream_t>(stream), *a);
   SRK_LAUNCH_CHECK();

@@ -77,13 +77,16 @@ class BasicBlock(_NCHWContract, nn.Sequential):
         else:
             r = ops.conv_general(x, conv.weight, conv.bias, stride=1, pad=conv.kernel_size[0] // 2)
         done_res = norm is None and act is None and conv.kernel_size[0] in (1, 3)
-        if norm is not None:
-            r = ops.batch_norm(r, norm, res=res if act is None else None)
-            done_res = done_res or act is None
-        if isinstance(act, nn.PReLU):
-            r = ops.prelu(r, act.weight)
-        elif act is not None:
-            r = torch.relu(r)
+        if norm is not None and isinstance(act, nn.PReLU):
+            r = ops.batch_norm_prelu(r, norm, act.weight)         # one unit: the BatchNorm's output is never stored
+        else:
+            if norm is not None:
+                r = ops.batch_norm(r, norm, res=res if act is None else None)
+                done_res = done_res or act is None
+            if isinstance(act, nn.PReLU):
+                r = ops.prelu(r, act.weight)
+            elif act is not None:
+                r = torch.relu(r)
         if res is not None and not done_res:
             r = r + res
         return r
@@ -161,10 +164,17 @@ class ResBlock(_NCHWContract, nn.Module):
         # SRResNet: conv -> BatchNorm -> PReLU -> conv -> BatchNorm (+ x fused into the last BatchNorm apply)
         r = x
         fused_res = False
+        skip = False
         for i, m in enumerate(mods):
             last = i == len(mods) - 1
+            if skip:                                   # (the PReLU that rode in the BatchNorm before it)
+                skip = False
+                continue
             if isinstance(m, nn.Conv2d):
                 r = m.nhwc(r)
+            elif isinstance(m, nn.BatchNorm2d) and not last and isinstance(mods[i + 1], nn.PReLU):
+                r = ops.batch_norm_prelu(r, m, mods[i + 1].weight)
+                skip = True
             elif isinstance(m, nn.BatchNorm2d):
                 if last and self.res_scale == 1:
                     r = ops.batch_norm(r, m, res=x)

@@ -1914,9 +1914,14 @@ def _pitch4(t):
 
 
 def _gate_fields(gate):
-    """ChanStatsArgs fields of the optional PReLU input-gradient output: gate = (out tensor, fp32 slope [1] or [C])."""
+    """ChanStatsArgs fields of the optional PReLU input-gradient output: gate = (out tensor, fp32 slope [1] or [C]); or, for mode 3
+    (BatchNorm backward behind a PReLU), gate = ("bn", gate_a, gate_d, slope, partial2)."""
     if gate is None:
         return dict(gate_out=0, gate_pitch=0, slope=0, slope_stride=0)
+    if gate[0] == "bn":
+        _, ga, gd, sl, p2 = gate
+        return dict(gate_out=0, gate_pitch=0, slope=sl.data_ptr(), slope_stride=0 if sl.numel() == 1 else 1,
+                    gate_a=ga.data_ptr(), gate_d=gd.data_ptr(), partial2=p2.data_ptr())
     out, sl = gate
     return dict(gate_out=out.data_ptr(), gate_pitch=_pitch4(out), slope=sl.data_ptr(), slope_stride=0 if sl.numel() == 1 else 1)
 
@@ -1949,15 +1954,20 @@ def _arrival_counter(device):
 
 
 def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None,
-                bias=None, running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None, shift_out=None, gate=None):
+                bias=None, running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None, shift_out=None, gate=None,
+                bn_gate=None, total2=False, dslope_acc=None):
     """chan_finalize(chan_partials(x, y, smode, shift), fmode, rows, ...) as ONE launch (srk_chan_stats_finalize: the block that
     finishes last does the [C]-sized step)."""
     _need_gpu(x)
     c = x.shape[-1]
     P = x.numel() // c
     nb = L.load().srk_chan_stats_blocks(P)
+    p2 = None
+    if bn_gate is not None:              # smode 3: (gate_a, gate_d, slope) -> third partial sums (the PReLU slope gradient)
+        p2 = torch.empty((nb, c), dtype=torch.float32, device=x.device)
+        gate = ("bn", bn_gate[0], bn_gate[1], bn_gate[2], p2)
     if nb > _FUSE_MAX_BLOCKS:            # many blocks: their arrival counts (same-address atomics) would take longer than the launch they save
-        return chan_finalize(chan_partials(x, y, smode, shift, shift_out, gate), fmode, rows, M=M, creal=creal, eps=eps, momentum=momentum, mean=mean, invstd=invstd,
+        return chan_finalize(chan_partials(x, y, smode, shift, shift_out, gate), fmode, rows, partial2=p2, total2=total2, dslope_acc=dslope_acc, M=M, creal=creal, eps=eps, momentum=momentum, mean=mean, invstd=invstd,
                              gamma=gamma, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var, total=total,
                              nbt=nbt, dgamma_acc=dgamma_acc, dbeta_acc=dbeta_acc)
     part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
@@ -1969,7 +1979,7 @@ def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, 
         partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=fmode, total=int(total),
         M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
         weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr(),
-        nbt=_ptr(nbt), dgamma_acc=_ptr(dgamma_acc), dbeta_acc=_ptr(dbeta_acc))
+        nbt=_ptr(nbt), dgamma_acc=_ptr(dgamma_acc), dbeta_acc=_ptr(dbeta_acc), partial2=_ptr(p2), total2=int(total2), dslope_acc=_ptr(dslope_acc))
     import ctypes as C
     L.check(L.load().srk_chan_stats_finalize(C.byref(sa), C.byref(fa), C.c_void_p(_arrival_counter(x.device)), C.c_void_p(_stream())),
             "srk_chan_stats_finalize")
@@ -1977,7 +1987,8 @@ def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, 
 
 
 def chan_finalize(part, mode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None, bias=None,
-                  running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None):
+                  running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None, partial2=None, total2=False,
+                  dslope_acc=None):
     """srk_chan_finalize on the partials of chan_partials: `rows` x [C] fp32 results (include/srk.h lists them per mode)."""
     nb, _, c = part.shape
     out = torch.empty((rows, c), dtype=torch.float32, device=part.device)
@@ -1985,11 +1996,12 @@ def chan_finalize(part, mode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0,
         partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=mode, total=int(total),
         M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
         weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr(),
-        nbt=_ptr(nbt), dgamma_acc=_ptr(dgamma_acc), dbeta_acc=_ptr(dbeta_acc)), _stream())
+        nbt=_ptr(nbt), dgamma_acc=_ptr(dgamma_acc), dbeta_acc=_ptr(dbeta_acc), partial2=_ptr(partial2), total2=int(total2),
+        dslope_acc=_ptr(dslope_acc)), _stream())
     return out
 
 
-def chan_apply(x, *, y=None, z=None, a=None, b=None, d=None, slope=None, post_prelu=False, out=None):
+def chan_apply(x, *, y=None, z=None, a=None, b=None, d=None, slope=None, post_prelu=False, out=None, gate_a=None, gate_d=None):
     """out = post((a*x + b*y + d) * gate(z)) per channel (srk_chan_apply).  a/b/d/slope: fp32 [C] (slope may have 1 element).
     out: a tensor of x's shape to write (a channel-slice view of a wider NHWC buffer is fine), else a fresh one."""
     _need_gpu(x)
@@ -2015,7 +2027,7 @@ def chan_apply(x, *, y=None, z=None, a=None, b=None, d=None, slope=None, post_pr
         x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
         z=_ptr(z), z_pitch=0 if z is None else _pitch4(z), z_coff=0, a=_ptr(a), b=_ptr(b), d=_ptr(d),
         slope=_ptr(sl), slope_stride=0 if (sl is None or sl.numel() == 1) else 1, post_prelu=int(post_prelu),
-        out=out.data_ptr(), out_pitch=_pitch4(out), out_coff=0, P=P, C=c, dtype=_DT[x.dtype]), _stream())
+        out=out.data_ptr(), out_pitch=_pitch4(out), out_coff=0, P=P, C=c, dtype=_DT[x.dtype], gate_a=_ptr(gate_a), gate_d=_ptr(gate_d)), _stream())
     return out
 
 
@@ -2134,6 +2146,74 @@ class BatchNormFn(torch.autograd.Function):
             dgamma, dbeta = r[0], r[1]
             gx = chan_apply(g, a=r[2])
         return gx, (None if wacc is not None else dgamma[:c]), (None if bacc is not None else dbeta[:c]), None, None, None, None, None, (g if has_res else None), None
+
+
+class BNPReLUFn(torch.autograd.Function):
+    """nn.BatchNorm2d (batch statistics) followed by nn.PReLU -- SRResNet's conv -> norm -> act (srresnet.py:16-21 through
+    common.py:94-100) -- as ONE unit: forward = the statistics launch + one apply launch (the activation rides in it, the BatchNorm's
+    output is never stored); backward = ONE statistics launch over (x, dy) that recomputes the BatchNorm output a x + d for the
+    PReLU's gate and takes the BatchNorm's two sums AND the slope's gradient (srk_chan_stats mode 3), + one apply launch
+    (dx = A dy gate + B x + D).  Five launches per layer instead of seven."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, slope, nbt):
+        x = x.contiguous()
+        c, cp = weight.numel(), x.shape[-1]
+        M = x.numel() // cp
+        w32, b32 = _f32c(weight), _f32c(bias)
+        upd = running_mean is not None and running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
+        k0 = torch.empty(cp, dtype=torch.float32, device=x.device)
+        r = chan_reduce(x, None, 0, None, 1, 5, M=M, creal=c, eps=eps, momentum=momentum, mean=k0, weight=w32, bias=b32,
+                        running_mean=running_mean if upd else None, running_var=running_var if upd else None, nbt=nbt, shift_out=k0)
+        invstd, gamma, a, d, mean = r[0], r[1], r[2], r[3], r[4]
+        if running_mean is not None and not upd:            # buffers in another dtype: torch arithmetic
+            var = 1.0 / (invstd * invstd) - eps
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean[:c].to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1 - momentum).add_((var[:c] * (M / max(M - 1, 1))).to(running_var.dtype), alpha=momentum)
+        sl = _f32c(slope)
+        if sl.numel() not in (1, cp):
+            sl = torch.nn.functional.pad(sl, (0, cp - sl.numel()))
+        out = chan_apply(x, a=a, d=d, slope=sl, post_prelu=True)
+        ctx.save_for_backward(x, mean, invstd, gamma, a, d, sl)
+        ctx.cfg = (c, M, slope.numel())
+        ctx.params = (weight, bias, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, invstd, gamma, a, d, sl = ctx.saved_tensors
+        c, M, ns = ctx.cfg
+        g = g.contiguous()
+
+        def acc_of(p, shape, want):
+            slot = _grad_slot(p, shape) if want else None
+            return slot[1] if (slot is not None and slot[0] == "acc") else None
+        wacc = acc_of(ctx.params[0], (c,), ctx.needs_input_grad[1])
+        bacc = acc_of(ctx.params[1], (c,), ctx.needs_input_grad[2])
+        sacc = acc_of(ctx.params[2], tuple(ctx.params[2].shape), ctx.needs_input_grad[7])
+        r = chan_reduce(x, g, 3, mean.contiguous(), 2, 6, M=M, creal=c, mean=mean.contiguous(), invstd=invstd.contiguous(), gamma=gamma.contiguous(),
+                        dgamma_acc=wacc, dbeta_acc=bacc, bn_gate=(a.contiguous(), d.contiguous(), sl), total2=ns == 1, dslope_acc=sacc)
+        gx = chan_apply(g, y=x, z=x, a=r[2], b=r[3], d=r[4], slope=sl, gate_a=a.contiguous(), gate_d=d.contiguous())
+        gs = None
+        if ctx.needs_input_grad[7] and sacc is None:
+            gs = r[5][:1] if ns == 1 else r[5][:ns]
+        return (gx, (None if wacc is not None else r[0][:c]), (None if bacc is not None else r[1][:c]), None, None, None, None, gs, None)
+
+
+_BN_PRELU_FUSED = os.environ.get("SRK_NO_BN_PRELU", "0") != "1"      # A/B knob
+
+
+def batch_norm_prelu(x, bn, slope):
+    """`prelu(batch_norm(x, bn), slope)` -- fused (BNPReLUFn) in training mode with batch statistics and momentum set."""
+    if (_BN_PRELU_FUSED and (bn.training or bn.running_mean is None) and bn.momentum is not None and x.numel() > 0
+            and slope.numel() in (1, bn.weight.numel()) and bn.weight is not None):
+        nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats and bn.num_batches_tracked is not None) else None
+        if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
+            nbt.add_(1)
+            nbt = None
+        return BNPReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, slope, nbt)
+    return prelu(batch_norm(x, bn), slope)
 
 
 def batch_norm(x, bn, res=None):

@@ -288,3 +288,50 @@ def test_tiled_group_pack_is_bit_identical_to_the_standalone_pack(A):
             assert torch.equal(qf.wpk.view(torch.int16), rf.wpk.view(torch.int16)), ("forward", shp, dt)
             assert torch.equal(qf.bias, rf.bias), ("bias", shp, dt)
             assert torch.equal(qd.wpk.view(torch.int16), rd.wpk.view(torch.int16)), ("dgrad", shp, dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("npar", [1, 32])
+@pytest.mark.parametrize("shape", [(3, 32, 9, 7), (4, 32, 48, 48)])          # few blocks (fused finalize) / 18 blocks
+def test_fused_batchnorm_prelu_vs_float64(A, dt, npar, shape):
+    """ops.batch_norm_prelu (SRResNet's conv -> BatchNorm -> PReLU, srresnet.py:16-21 via common.py:94-100, as one unit: the BatchNorm
+    output is recomputed in the backward pass, its statistics and the slope's gradient come from ONE pass) against float64
+    F.batch_norm + F.prelu: values, input gradient, the gradients of gamma / beta / slope, running buffers, num_batches_tracked;
+    a second backward accumulates into the existing gradients."""
+    import torch.nn.functional as F
+    from sr_amd import ops
+    g = torch.Generator().manual_seed(13)
+    n, c, h, w = shape
+    tol = {torch.float32: 2e-4, torch.bfloat16: 3e-2, torch.float16: 4e-3}[dt]
+    x = torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3
+    t = torch.randn(n, c, h, w, generator=g)
+    q = lambda v: v.to(dt).double()
+    rel = lambda got, ref: float((got.double().cpu() - ref).abs().max() / max(1e-9, float(ref.abs().max())))
+    bn = torch.nn.BatchNorm2d(c).cuda()
+    ref = torch.nn.BatchNorm2d(c).double()
+    with torch.no_grad():
+        for m_ in (bn, ref):
+            m_.weight.copy_(torch.linspace(0.5, 1.5, c)); m_.bias.copy_(torch.linspace(-0.4, 0.2, c))
+    a = torch.nn.Parameter(torch.linspace(0.05, 0.4, npar).cuda())
+    ar = torch.linspace(0.05, 0.4, npar).double().requires_grad_(True)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dt).cuda().requires_grad_(True)
+    td = t.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    y = ops.batch_norm_prelu(xd, bn, a)
+    assert type(y.grad_fn).__name__ == "BNPReLUFnBackward"
+    xr = q(x).requires_grad_(True)
+    yr = F.prelu(ref(xr), ar)
+    y.backward(td)
+    yr.backward(q(t))
+    assert rel(y.detach().permute(0, 3, 1, 2), yr.detach()) < tol
+    assert rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < 6 * tol
+    assert rel(bn.weight.grad, ref.weight.grad) < 4 * tol and rel(bn.bias.grad, ref.bias.grad) < 4 * tol
+    assert rel(a.grad, ar.grad) < 4 * tol
+    assert rel(bn.running_mean, ref.running_mean) < tol and rel(bn.running_var, ref.running_var) < tol
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    first = [p.grad.clone() for p in (bn.weight, bn.bias, a)]
+    ptrs = [p.grad.data_ptr() for p in (bn.weight, bn.bias, a)]
+    y2 = ops.batch_norm_prelu(xd, bn, a)
+    y2.backward(td)
+    for p, f, ptr in zip((bn.weight, bn.bias, a), first, ptrs):
+        assert p.grad.data_ptr() == ptr
+        torch.testing.assert_close(p.grad, 2 * f, rtol=1e-5, atol=1e-5)
