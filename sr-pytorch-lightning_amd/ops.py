@@ -1940,7 +1940,7 @@ def chan_partials(x, y=None, mode=0, shift=None, shift_out=None, gate=None):
 
 
 _COUNTERS = {}
-_FUSE_MAX_BLOCKS = int(os.environ.get("SRK_CHAN_FUSE_MAX_BLOCKS", "128"))
+_FUSE_MAX_BLOCKS = int(os.environ.get("SRK_CHAN_FUSE_MAX_BLOCKS", "160"))
 
 
 def _arrival_counter(device):
