@@ -268,6 +268,9 @@ typedef struct {
 int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream);
 /* number of slabs srk_conv2d_wgrad will write for these arguments (0 = atomic mode, see nslabs) */
 int srk_wgrad_slabs(const srk_wgrad_args* a);
+/* channels per (tap, ci) row of a slab (and of a dbp row): Cout, or 4 for the compact slabs of large kernels with few real output
+ * channels (cout_real <= 4); the caller sizes dwp / dbp and sets srk_wgrad_finalize's CoutP with it */
+int srk_wgrad_slab_cout(const srk_wgrad_args* a);
 
 typedef struct {
   const float* dwp; const float* dbp;   /* from srk_conv2d_wgrad                                 */

@@ -248,7 +248,7 @@ OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_c
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
                  "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges", "srk_l1_loss_mean", "srk_chan_stats_finalize", "srk_pack_group_tiles", "srk_pack_conv_weights_group_tiled",
-                 "srk_proj_pack", "srk_proj_pack_bytes", "srk_proj_wgrad_scratch_floats", "srk_proj_pack_group")
+                 "srk_proj_pack", "srk_proj_pack_bytes", "srk_proj_wgrad_scratch_floats", "srk_proj_pack_group", "srk_wgrad_slab_cout")
 
 _lib = None
 
@@ -273,6 +273,8 @@ def load():
     lib.srk_conv_pair_tiles.restype = C.c_int
     lib.srk_wgrad_slabs.argtypes = [C.POINTER(WgradArgs)]
     lib.srk_wgrad_slabs.restype = C.c_int
+    lib.srk_wgrad_slab_cout.argtypes = [C.POINTER(WgradArgs)]
+    lib.srk_wgrad_slab_cout.restype = C.c_int
     lib.srk_pack_conv_weights_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.srk_pack_conv_weights_group.restype = C.c_int
     lib.srk_pack_group_tiles.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

@@ -453,8 +453,174 @@ __global__ __launch_bounds__(256) void lk_wgrad_packed_kernel(const srk_wgrad_ar
     if (i % a.Cout >= cr) sl[i] = 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same with ALL kernel rows in one workgroup: tiles of 8 x 16 output pixels, whose 16 x (16 + K - 1)-pixel input halo serves the
+// K kernel rows of the 8 output rows (the one-row-per-workgroup form reads the input K times: 1.2 GB into LDS per launch for
+// SRResNet's 9x9 tail at 16 x 192 x 192).  K accumulators per wave; slabs are COMPACT: [tap][ci][4] (cout_real <= 4), one per
+// workgroup (srk_wgrad_slab_cout tells the caller).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int LK_TR = 8, LK_CS = 4;
+template <int DT, int K>
+__global__ __launch_bounds__(256) void lk_wgrad_allrows_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int ntiles, int tq, int trem,
+                                                               unsigned x_bytes, unsigned dy_bytes) {
+  typedef DTraits<DT> Tr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TR = LK_TR, CS = LK_CS;
+  constexpr int XW = 16 + K - 1, XWP = (XW + 1) & ~1, XR = TR + K - 1;
+  constexpr int xbuf = (XR * XWP * 128 + 1023) & ~1023, dbuf = TR * 16 * 32, buf = xbuf + dbuf;     // whole 1 KB DMA pieces
+  constexpr int DTW = 16 + 2 * (K - 1) + 16, DTP = DTW * 2;
+  constexpr int NPL = 8;
+  constexpr int dt_bytes = NPL * TR * DTP;
+  static_assert(K * 2 * 16 * 64 * 4 <= 2 * buf, "the final reduction reuses the tile buffers");
+  char* const DTb = smem + 2 * buf;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = blockIdx.x;
+  const int H = a.H, W = a.W, P = K / 2, cr = a.cout_real;
+  const int t0 = slot * tq + min(slot, trem), nt = tq + (slot < trem ? 1 : 0);
+  const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+
+  constexpr int NPX = (XR * XWP * 8 + 63) / 64, XPW = (NPX + 3) / 4;      // + 4 gradient pieces (one per wave)
+  int xdesc[XPW], ddesc;
+#pragma unroll
+  for (int j = 0; j < XPW; ++j) {
+    const int k = wave + 4 * j, i = k * 64 + lane, sl = i & 7, p = i >> 3;
+    const int iy = p / XWP, ix = p - iy * XWP, c = sl ^ swz(ix);
+    xdesc[j] = iy | (ix << 8) | (c << 16) | ((k < NPX && iy < XR && ix < XW && c * 8 < a.Cin) ? 1 << 24 : 0);
+  }
+  {
+    const int i = wave * 64 + lane, c = i & 1, pp = i >> 1;        // 2 chunks per pixel, pixels row-major 8 x 16
+    ddesc = (pp >> 4) | ((pp & 15) << 8) | (c << 16) | ((c * 8 < a.Cout) ? 1 << 24 : 0);
+  }
+  auto dma_tile = [&](int tile, int b) {
+    int pt = tile;
+    const int tX = pt % tilesX;
+    pt /= tilesX;
+    const int tY = pt % tilesY;
+    const int n = pt / tilesY;
+    const int y0 = tY * TR, x0 = tX * 16;
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+      const int k = wave + 4 * j;
+      if (k < NPX) {
+        const int d = xdesc[j], gy = y0 + (d & 255) - P, gx = x0 + ((d >> 8) & 255) - P;
+        const bool ok = (d >> 24) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + ((d >> 16) & 255) * 8) * 2) : 0x80000000u;
+        dma16_hidden(xrs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * buf + (k << 10))));
+      }
+    }
+    {
+      const int d = ddesc, gy = y0 + (d & 255), gx = x0 + ((d >> 8) & 255);
+      const bool ok = (d >> 24) && gy < H && gx < W;
+      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.dy_pitch + a.dy_coff + ((d >> 16) & 255) * 8) * 2) : 0x80000000u;
+      dma16_hidden(drs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * buf + xbuf + (wave << 10))));
+    }
+  };
+
+  for (int i = tid; i < dt_bytes / 16; i += 256) lds_write16(DTb + i * 16, i32x4{0, 0, 0, 0});
+
+  const int s = wave >> 1, rb = wave & 1;
+  int aoff[2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) aoff[rd] = tr_lane_off(16 * s, rd, rb, lane);
+  const int nn = lane & 31, kwn = nn / cr, con = nn - kwn * cr;
+  const int plane = kwn < K ? con : cr;
+  const int boff = plane * TR * DTP + (16 * s + 8 * (lane >> 5) - (kwn < K ? kwn : 0) + (K - 1)) * 2;
+  const int ty = tid >> 4, tx = tid & 15;                          // transposition pass: threads 0 .. 127 = the tile's pixels
+  const bool do_bias = a.dbp != nullptr;
+  float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  f32x16 acc[K];
+#pragma unroll
+  for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[kh][e] = 0.f;
+  if (nt > 0) dma_tile(t0, 0);
+  for (int it = 0; it < nt; ++it) {
+    const char* const X = smem + (it & 1) * buf;
+    const char* const D = X + xbuf;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (it + 1 < nt) dma_tile(t0 + it + 1, (it + 1) & 1);
+    if (tid < TR * 16) {
+      const i32x4 v = lds_read16(D + (ty * 16 + tx) * 32);
+      const uint32_t w4[4] = {(uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w};
+#pragma unroll
+      for (int c = 0; c < CS; ++c)
+        if (c < cr) {
+          const uint16_t hv = (uint16_t)(w4[c >> 1] >> ((c & 1) * 16));
+          *reinterpret_cast<uint16_t*>(DTb + (c * TR + ty) * DTP + (tx + K - 1) * 2) = hv;
+          if (do_bias) dbs[c] += Tr::to_f32(hv);
+        }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int y = 0; y < TR; ++y) {
+      const uint16_t* bp = reinterpret_cast<const uint16_t*>(DTb + boff + y * DTP);
+      i32x4 bf;
+      bf.x = (int)((uint32_t)bp[0] | ((uint32_t)bp[1] << 16));
+      bf.y = (int)((uint32_t)bp[2] | ((uint32_t)bp[3] << 16));
+      bf.z = (int)((uint32_t)bp[4] | ((uint32_t)bp[5] << 16));
+      bf.w = (int)((uint32_t)bp[6] | ((uint32_t)bp[7] << 16));
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const char* xr = X + (y + kh) * (XWP * 128);
+        const i32x4 af = tr_read2(xr + aoff[0], xr + aoff[1]);
+        acc[kh] = Tr::mma(af, bf, acc[kh]);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  if (do_bias) {
+    float* rs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int c = 0; c < CS; ++c) rs[c * 256 + tid] = dbs[c];
+    __syncthreads();
+    if (tid < CS) {
+      float t = 0.f;
+      if (tid < cr)
+        for (int i = 0; i < 256; ++i) t += rs[tid * 256 + i];
+      a.dbp[(size_t)slot * CS + tid] = t;
+    }
+    __syncthreads();
+  }
+  float* const red = reinterpret_cast<float*>(smem);               // [kh][rb][16][64]
+  if (s == 1) {
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[((kh * 2 + rb) * 16 + e) * 64 + lane] = acc[kh][e];
+  }
+  __syncthreads();
+  const size_t per = (size_t)K * K * a.Cin * CS;
+  float* const sl = a.dwp + (size_t)slot * per;
+  if (s == 0 && kwn < K) {
+    const int hq = lane >> 5;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = rb * 32 + 4 * hq + (e & 3) + 8 * (e >> 2);
+        if (ci < a.Cin) sl[(((size_t)kh * K + kwn) * a.Cin + ci) * CS + con] = acc[kh][e] + red[((kh * 2 + rb) * 16 + e) * 64 + lane];
+      }
+  }
+  for (int i = tid; i < K * K * a.Cin * CS; i += 256)
+    if ((i & (CS - 1)) >= cr) sl[i] = 0.f;
+}
+
+// whether the all-rows form takes this weight gradient (and its slabs are the compact [tap][ci][4] ones)
+bool lk_all_rows(const srk_wgrad_args& a) {
+  static const bool off = [] { const char* e = getenv("SRK_NO_LK_ALLROWS"); const char* p = getenv("SRK_NO_LK_PACKED"); return (e && e[0] == '1') || (p && p[0] == '1'); }();
+  return !off && a.cout_real > 0 && a.cout_real <= LK_CS && a.cout_real * a.KW <= 32 && a.KH >= 5;
+}
+
 int lk_wgrad_slabs_for(const srk_wgrad_args& a) {
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  if (lk_all_rows(a)) {                        // one workgroup per slab, all kernel rows inside
+    const long long nt8 = (long long)a.N * ((a.H + LK_TR - 1) / LK_TR) * ((a.W + 15) / 16);
+    return (int)(nt8 < cus ? nt8 : cus);
+  }
   const long long ntiles = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
   long long s = cus / a.KH;
   if (s < 1) s = 1;
@@ -514,6 +680,7 @@ bool srk_wgrad_lk_ok(const srk_wgrad_args& a) {
   return px * a.x_pitch * 2 < 0x7fff0000LL && px * a.dy_pitch * 2 < 0x7fff0000LL;
 }
 int srk_wgrad_lk_slabs(const srk_wgrad_args& a) { return lk_wgrad_slabs_for(a); }
+int srk_wgrad_lk_slab_cout(const srk_wgrad_args& a) { return lk_all_rows(a) ? LK_CS : a.Cout; }
 
 template <int DT, int K> static int lk_wgrad_launch_k(const srk_wgrad_args& a, hipStream_t st) {
   constexpr int XWP = (16 + K - 1 + 1) & ~1;
@@ -524,6 +691,18 @@ template <int DT, int K> static int lk_wgrad_launch_k(const srk_wgrad_args& a, h
   const long long ntiles = (long long)a.N * tilesX * tilesY;
   const int slabs = a.nslabs;
   const unsigned xb = (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2), db = (unsigned)((long long)a.N * a.H * a.W * a.dy_pitch * 2);
+  if (lk_all_rows(a)) {
+    constexpr int XR = LK_TR + K - 1;
+    constexpr int alds = 2 * (((XR * XWP * 128 + 1023) & ~1023) + LK_TR * 16 * 32) + 8 * LK_TR * (16 + 2 * (K - 1) + 16) * 2;
+    static_assert(alds <= 160 * 1024, "LDS");
+    static const hipError_t aattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_wgrad_allrows_kernel<DT, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (aattr != hipSuccess) { srk_set_error("srk_conv2d_wgrad: cannot reserve LDS"); return (int)aattr; }
+    const int tY8 = (a.H + LK_TR - 1) / LK_TR;
+    const long long nt8 = (long long)a.N * tY8 * tilesX;
+    hipLaunchKernelGGL((lk_wgrad_allrows_kernel<DT, K>), dim3(slabs), dim3(256), alds, st, a, tilesX, tY8, (int)nt8, (int)(nt8 / slabs), (int)(nt8 % slabs), xb, db);
+    SRK_LAUNCH_CHECK();
+    return 0;
+  }
   static const bool no_packed = [] { const char* e = getenv("SRK_NO_LK_PACKED"); return e && e[0] == '1'; }();      // A/B knob
   if (a.cout_real > 0 && a.cout_real <= 6 && a.cout_real * K <= 32 && !no_packed) {
     // few real output channels (SRResNet's tail: 3): MFMA columns = (kw, co) pairs

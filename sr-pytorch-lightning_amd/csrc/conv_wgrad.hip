@@ -751,6 +751,10 @@ extern "C" int srk_conv2d_wgrad(const srk_wgrad_args* a, srk_stream_t stream) {
 }
 
 extern "C" int srk_wgrad_slabs(const srk_wgrad_args* a) { return a ? wgrad_ws_slabs(*a) : 0; }
+extern "C" int srk_wgrad_slab_cout(const srk_wgrad_args* a) {
+  if (!a) return 0;
+  return (a->KH > 3 && srk_wgrad_lk_ok(*a)) ? srk_wgrad_lk_slab_cout(*a) : a->Cout;
+}
 
 // ---- grouped launch: planning (host) and dispatch --------------------------------------------------------------------------
 extern "C" int srk_wgrad_group_job_bytes(void) { return (int)sizeof(WgJob); }

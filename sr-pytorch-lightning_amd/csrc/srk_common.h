@@ -251,6 +251,7 @@ bool srk_conv_lk_ok(const srk_conv_args& a);
 int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st);
 bool srk_wgrad_lk_ok(const srk_wgrad_args& a);
 int srk_wgrad_lk_slabs(const srk_wgrad_args& a);
+int srk_wgrad_lk_slab_cout(const srk_wgrad_args& a);
 int srk_wgrad_lk_launch(const srk_wgrad_args& a, hipStream_t st);
 // conv1x1.hip: 1x1 conv with Cin <= 384 (all operands in LDS behind one wait)
 bool srk_conv1x1_ok(const srk_conv_args& a);

@@ -459,11 +459,12 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
                     N=N, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, dwp=0, dbp=0, nslabs=0, dtype=_DT[x.dtype],
                     cout_real=int(cout) if (ps_r <= 1 and not x_ps and not dy_ps) else 0)
     nslabs = L.load().srk_wgrad_slabs(a)
-    per = k * k * Cin * Cout
+    couts = L.load().srk_wgrad_slab_cout(a)     # channels per slab row: Cout, or 4 (compact slabs: large kernel, <= 4 real output channels)
+    per = k * k * Cin * couts
     if nslabs > 0:      # slab mode: every workgroup writes its own slab, nothing to zero
-        scratch = torch.empty(nslabs * (per + Cout), dtype=torch.float32, device=dev)
+        scratch = torch.empty(nslabs * (per + couts), dtype=torch.float32, device=dev)
     else:               # atomic mode: one zeroed slab
-        scratch = torch.zeros(per + Cout, dtype=torch.float32, device=dev)
+        scratch = torch.zeros(per + couts, dtype=torch.float32, device=dev)
     ns = max(nslabs, 1)
     dbp = scratch[ns * per:]
     a.dwp, a.dbp, a.nslabs = scratch.data_ptr(), (dbp.data_ptr() if want_bias else 0), nslabs
@@ -472,7 +473,7 @@ def wgrad_raw(x, dy, *, N, H, W, Cin, Cout, k, w_shape, ps_r=0, scale=1.0, x_ps=
     db = (out_b if out_b is not None else torch.empty(cout, dtype=torch.float32, device=dev)) if want_bias else None
     # the unfolded head conv presents its OIHW weight as a 1x1 conv over Cin*KH*KW channels
     f = L.WgradFinArgs(dwp=scratch.data_ptr(), dbp=dbp.data_ptr() if want_bias else 0, nslabs=nslabs, dw=dw.data_ptr(), db=_ptr(db),
-                       Cout=cout, Cin=(cin * kh * kw) // (k * k), KH=k, KW=k, CinP=Cin, CoutP=Cout,
+                       Cout=cout, Cin=(cin * kh * kw) // (k * k), KH=k, KW=k, CinP=Cin, CoutP=couts,
                        ps_r=int(ps_r), scale=float(scale), accumulate=0)
     L.call("srk_wgrad_finalize", f, _stream())
     return dw, db
