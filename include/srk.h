@@ -69,6 +69,9 @@ typedef struct {
   int dgrad;           /* 0 forward layout, 1 dgrad layout */
   int ps_r;            /* 0/1: none; r>1: NHWC pixel-shuffle permutation on the Cout axis */
   int dtype;
+  int rows_layout;     /* 1 (forward, Cin == 64, KH >= 5, Cout <= 4, Cout * KW <= 32, 16-bit): BEHIND the standard layout (KH*KW*KinP*CoutP elements)   */
+                       /* wpk also receives KH * 2048 elements in the (kw, co)-rows order of the direct large-kernel forward:           */
+                       /* [kh][ci / 16][64 lanes][8]: lane l = MFMA row m = l % 32 = kw * Cout + co (0 beyond KW * Cout), ci = 16 ks + 8 (l / 32) + e */
 } srk_pack_args;
 int srk_pack_conv_weights(const srk_pack_args* a, srk_stream_t stream);
 /* Same, for `n` convolutions in ONE launch: `table` is a DEVICE array of srk_pack_args (a training step re-packs
@@ -107,6 +110,7 @@ typedef struct {
   void* out; int out_pitch, out_coff; int out_mode; int ps_r;
   const float* post_add;               /* planar: per output channel c, or NULL                      */
   int dtype;
+  int cout_real;                       /* the conv's real output channels when wpk carries the rows layout (srk_pack_args.rows_layout), else 0 */
 } srk_conv_args;
 int srk_conv2d(const srk_conv_args* a, srk_stream_t stream);
 /* channel tile (32/64/128) the launcher uses for a given number of output channels */

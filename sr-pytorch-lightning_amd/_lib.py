@@ -20,7 +20,7 @@ _p, _i, _f = C.c_void_p, C.c_int, C.c_float
 class PackArgs(C.Structure):
     _fields_ = [("w", _p), ("bias", _p), ("wpk", _p), ("bias_pk", _p),
                 ("Cout", _i), ("Cin", _i), ("KH", _i), ("KW", _i),
-                ("KinP", _i), ("CoutP", _i), ("dgrad", _i), ("ps_r", _i), ("dtype", _i)]
+                ("KinP", _i), ("CoutP", _i), ("dgrad", _i), ("ps_r", _i), ("dtype", _i), ("rows_layout", _i)]
 
 
 class ConvArgs(C.Structure):
@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
                 ("res", _p), ("res_pitch", _i), ("res_coff", _i),
                 ("mask", _p), ("mask_pitch", _i), ("mask_coff", _i), ("mask_from", _i),
                 ("out", _p), ("out_pitch", _i), ("out_coff", _i), ("out_mode", _i), ("ps_r", _i),
-                ("post_add", _p), ("dtype", _i)]
+                ("post_add", _p), ("dtype", _i), ("cout_real", _i)]
 
 
 class ConvPairArgs(C.Structure):

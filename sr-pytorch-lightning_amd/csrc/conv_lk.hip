@@ -299,6 +299,105 @@ __global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, i
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Forward with FEW real output channels (SRResNet's 9x9 tail: 64 -> 3; cr * K <= 32): (kw, co) pairs on the MFMA ROWS.  For an output
+// row y and halo column u,
+//     acc[(kw, co)][u] = sum_{kh, ci} W[co][ci][kh][kw] * X[y + kh - P][u][ci]           (K kernel rows x 4 channel steps = 4 K MFMAs per row)
+// and the output is the diagonal sum  out[y][x][co] = bias[co] + sum_kw acc[(kw, co)][x + kw]  (through a wave-private LDS tile).
+// lk_conv_kernel spends K * K * 4 MFMAs on the same 16 pixels with 3 of its 32 rows real.  The weights ([kh][ci / 16] fragments in the
+// rows layout behind the standard pack: srk_pack_args.rows_layout) stay in registers; tiles of 8 x 16 output pixels, 16 x (16 + K - 1)
+// halo pixels in LDS, two workgroups per CU.
+// ------------------------------------------------------------------------------------------------------------------
+template <int DT, int K>
+__global__ __launch_bounds__(256, 2) void lk_conv_rows_kernel(const srk_conv_args a, int tilesX, int tilesY, unsigned x_bytes, unsigned rows_off) {
+  typedef DTraits<DT> Tr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TR = 8, XW = 16 + K - 1, XWP = (XW + 1) & ~1, XR = TR + K - 1;
+  constexpr int xbuf = (XR * XWP * 128 + 1023) & ~1023;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const Pw = reinterpret_cast<float*>(smem + xbuf) + wave * 1024;          // [32 rows][32 columns] fp32
+  char* const Ow = smem + xbuf + 4 * 4096 + wave * 512;                            // [16 pixels][16 stored channels] of one output row
+  const int H = a.H, W = a.W, P = K / 2, cr = a.cout_real;
+  int pt = blockIdx.x;
+  const int tX = pt % tilesX;
+  pt /= tilesX;
+  const int tY = pt % tilesY;
+  const int n = pt / tilesY;
+  const int y0 = tY * TR, x0 = tX * 16;
+
+  // halo tile: 1 KB pieces, chunk slot XOR-swizzled by the tile column
+  {
+    const i32x4 xrs = make_rsrc4(a.x, x_bytes);
+    const unsigned lds0 = lds_addr_of(smem);
+    constexpr int NPX = (XR * XWP * 8 + 63) / 64;
+#pragma unroll
+    for (int j = 0; j < (NPX + 3) / 4; ++j) {
+      const int k = wave + 4 * j;
+      if (k < NPX) {
+        const int i = k * 64 + lane, sl = i & 7, p = i >> 3;
+        const int iy = p / XWP, ix = p - iy * XWP, c = sl ^ swz(ix);
+        const int gy = y0 + iy - P, gx = x0 + ix - P;
+        const bool ok = iy < XR && ix < XW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * 8) * 2) : 0x80000000u;
+        dma16_hidden(xrs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (k << 10))));
+      }
+    }
+  }
+  // weights: K x 4 fragments per lane, straight from the packed buffer (L2)
+  i32x4 wf[K * 4];
+  {
+    const i32x4* wp = reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(a.wpk) + rows_off) + lane;
+#pragma unroll
+    for (int f = 0; f < K * 4; ++f) wf[f] = wp[f * 64];
+  }
+  if (lane < 32) lds_write16(Ow + lane * 16, i32x4{0, 0, 0, 0});                   // the pad channels stay zero
+  const int u = lane & 31, g = lane >> 5;
+  const int ox = lane & 15, oc = lane >> 4;                                       // epilogue: lane = (pixel, real channel)
+  float bias = 0.f;
+  if (a.bias && oc < cr) bias = a.bias[((oc >> 2) & 3) * 8 + ((oc >> 4) & 1) * 4 + (oc & 3)];      // bias_pk is indexed by MFMA row
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+#pragma unroll 1
+  for (int yy = 0; yy < TR / 4; ++yy) {
+    const int y = (TR / 4) * wave + yy;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const char* xr = smem + (y * XWP + u) * 128;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const i32x4 b = lds_read16(xr + kh * (XWP * 128) + (((2 * ks + g) ^ swz(u)) << 4));
+        acc = Tr::mma(wf[kh * 4 + ks], b, acc);
+      }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Pw[(8 * (e >> 2) + 4 * g + (e & 3)) * 32 + u] = acc[e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (oc < cr) {
+      float sum = bias;
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) sum += Pw[(kw * cr + oc) * 32 + ox + kw];
+      *reinterpret_cast<uint16_t*>(Ow + ox * 32 + oc * 2) = Tr::from_f32(sum);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 32) {
+      const int px = lane >> 1, hf = lane & 1;
+      const i32x4 o = lds_read16(Ow + lane * 16);
+      const int gy = y0 + y, gx = x0 + px;
+      if (gy < H && gx < W)
+        *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(a.out) + ((size_t)((n * H + gy) * W + gx) * a.out_pitch + a.out_coff + hf * 8) * 2) = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Weight gradient when the conv has FEW real output channels (SRResNet's 9x9 tail: 3; cr * K <= 32): the MFMA columns carry
 // (kw, co) pairs instead of 16 stored gradient channels of which 3 are real.  With u = x + kw - P (a column of the input halo):
 //     dW[co][ci][kh][kw] = sum_{y, u} X[y + kh - P][u][ci] * dY[y][u - kw + P][co]
@@ -668,7 +767,32 @@ template <int DT, int CPP, int NRB> static int lk_launch(const srk_conv_args& a,
   }
 }
 
+template <int DT, int K> static int lk_rows_launch_k(const srk_conv_args& a, hipStream_t st) {
+  constexpr int XWP = (16 + K - 1 + 1) & ~1, XR = 8 + K - 1;
+  constexpr int lds = ((XR * XWP * 128 + 1023) & ~1023) + 4 * 4096 + 4 * 512;
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk_conv_rows_kernel<DT, K>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (attr != hipSuccess) { srk_set_error("srk_conv2d: cannot reserve LDS for the large-kernel conv"); return (int)attr; }
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 7) / 8;
+  const long long nb = (long long)a.N * tilesX * tilesY;
+  SRK_CHECK_ARG(nb <= 0x7fffffffLL, "srk_conv2d: %lld workgroups", nb);
+  hipLaunchKernelGGL((lk_conv_rows_kernel<DT, K>), dim3((unsigned)nb), dim3(256), lds, st, a, tilesX, tilesY,
+                     (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2), (unsigned)((long long)K * K * 64 * a.CoutP * 2));
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+template <int DT> static int lk_rows_launch(const srk_conv_args& a, hipStream_t st) {
+  switch (a.KH) {
+    case 5: return lk_rows_launch_k<DT, 5>(a, st);
+    case 7: return lk_rows_launch_k<DT, 7>(a, st);
+    default: return lk_rows_launch_k<DT, 9>(a, st);
+  }
+}
+
 int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st) {
+  static const bool no_rows = [] { const char* e = getenv("SRK_NO_LK_ROWS"); return e && e[0] == '1'; }();      // A/B knob
+  if (!no_rows && a.Cin == 64 && a.cout_real > 0 && a.cout_real <= 4 && a.cout_real * a.KW <= 32 && a.Cout == 16 && !a.relu && !a.res && a.scale == 1.f)
+    return a.dtype == SRK_BF16 ? lk_rows_launch<SRK_BF16>(a, st) : lk_rows_launch<SRK_F16>(a, st);
   if (a.Cin == 16) return a.dtype == SRK_BF16 ? lk_launch<SRK_BF16, 2, 2>(a, st) : lk_launch<SRK_F16, 2, 2>(a, st);
   return a.dtype == SRK_BF16 ? lk_launch<SRK_BF16, 8, 1>(a, st) : lk_launch<SRK_F16, 8, 1>(a, st);
 }

@@ -132,6 +132,17 @@ template <int DT> __device__ void pack_body(const srk_pack_args& a, long long to
       out[idx] = Tr::from_f32(v);
     }
   }
+  if (a.rows_layout && !a.dgrad) {       // the (kw, co)-rows layout of the direct large-kernel forward, behind the standard one
+    typename Tr::elem* rows = out + total;
+    const long long extra = (long long)a.KH * 2048;
+    for (long long j = first; j < extra; j += stride) {
+      const int e = (int)(j & 7), lane = (int)((j >> 3) & 63), ks = (int)((j >> 9) & 3), kh = (int)(j >> 11);
+      const int m = lane & 31, kw = m / a.Cout, co = m - kw * a.Cout, ci = 16 * ks + 8 * (lane >> 5) + e;
+      float v = 0.f;
+      if (kw < a.KW && ci < a.Cin) v = a.w[(((size_t)co * a.Cin + ci) * a.KH + kh) * a.KW + kw];
+      rows[j] = Tr::from_f32(v);
+    }
+  }
   if (a.bias_pk && !a.dgrad) {
     for (long long i = first; i < a.CoutP; i += stride) {
       const int chan = (int)(i / blk) * blk + row_to_chan((int)(i % blk), blk);     // bias_pk is indexed by MFMA row

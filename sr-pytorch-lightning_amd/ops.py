@@ -58,7 +58,7 @@ def _pitch(t):
 # weight packing (cached on the parameter object, keyed by its in-place version counter)
 # --------------------------------------------------------------------------------------------
 class Packed:
-    __slots__ = ("wpk", "bias", "KinP", "CoutP", "k", "ps_r")
+    __slots__ = ("wpk", "bias", "KinP", "CoutP", "k", "ps_r", "cr")
 
 
 _PACK_CACHE_ENABLED = False
@@ -300,7 +300,12 @@ def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False, tok
     wf = w.detach()
     if wf.dtype != torch.float32 or not wf.is_contiguous():
         wf = wf.float().contiguous()
-    p.wpk = torch.empty(kh * kw * p.KinP * p.CoutP, dtype=dtype, device=w.device)
+    # large kernel with few output channels (SRResNet's 9x9 tail, 64 -> 3): the forward kernel wants (kw, co) pairs on the MFMA rows;
+    # that layout (kh * 2048 elements) rides behind the standard one
+    rows = (not dgrad and not as_1x1 and kh in (5, 7, 9) and cin == 64 and cout <= 4 and cout * kw <= 32 and int(ps_r) <= 1
+            and dtype in (torch.bfloat16, torch.float16) and p.CoutP == 32)
+    p.cr = int(cout) if rows else 0
+    p.wpk = torch.empty(kh * kw * p.KinP * p.CoutP + (kh * 2048 if rows else 0), dtype=dtype, device=w.device)
     p.bias = None
     bf = None
     if not dgrad:
@@ -311,7 +316,7 @@ def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False, tok
                 bf = bf.float().contiguous()
     a = L.PackArgs(w=wf.data_ptr(), bias=_ptr(bf), wpk=p.wpk.data_ptr(), bias_pk=_ptr(p.bias),
                    Cout=cout, Cin=cin, KH=kh, KW=kw, KinP=p.KinP, CoutP=p.CoutP,
-                   dgrad=int(dgrad), ps_r=int(ps_r), dtype=_DT[dtype])
+                   dgrad=int(dgrad), ps_r=int(ps_r), dtype=_DT[dtype], rows_layout=int(rows))
     L.call("srk_pack_conv_weights", a, _stream())
     if store is not None:
         store[key] = (ver, p)
@@ -360,7 +365,7 @@ def conv_raw(x, pk, *, N, H, W, Cin, Cout, out, out_mode=L.OUT_NHWC, ps_r=0, rel
         res=_ptr(res), res_pitch=0 if (res is None or planar) else _pitch(res), res_coff=0,
         mask=_ptr(mask), mask_pitch=0 if mask is None else _pitch(mask), mask_coff=0, mask_from=int(mask_from),
         out=out.data_ptr(), out_pitch=0 if planar else _pitch(out), out_coff=0, out_mode=out_mode, ps_r=int(ps_r),
-        post_add=_ptr(post_add), dtype=_DT[dt])
+        post_add=_ptr(post_add), dtype=_DT[dt], cout_real=getattr(pk, "cr", 0) or 0)
     L.call("srk_conv2d", a, _stream())
     return out
 
