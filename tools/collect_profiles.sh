@@ -21,6 +21,7 @@ tools/pmc_kernel.sh ${TAG}_wgrad_group_n256 conv_wgrad_ws_group_kernel tools/mic
 tools/pmc_kernel.sh ${TAG}_conv_ws_n256 conv_ws_kernel tools/microbench_variants.py --n 256 --variant residual --iters 5 > /dev/null 2>&1
 for k in fwd2 bwd wgrad; do tools/pmc_kernel.sh ${TAG}_pw_${k%2}_n256 pw_${k}_kernel tools/microbench_pw.py --n 256 --only ${k%2} --iters 5 > /dev/null 2>&1; done
 for n in 16 64 256; do python tools/microbench_proj.py --n $n --iters $((n > 64 ? 5 : 20)); done > $O/${TAG}_proj_microbench.txt 2>/dev/null; python tools/microbench_proj.py --n 16 --prelu >> $O/${TAG}_proj_microbench.txt 2>/dev/null; cat $O/${TAG}_proj_microbench.txt
+tools/pmc_kernel.sh ${TAG}_lk_conv_rows lk_conv_rows_kernel bench.py --model srresnet --batch 16 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs --sustain-seconds 0 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_lk_wgrad_allrows lk_wgrad_allrows_kernel bench.py --model srresnet --batch 16 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs --sustain-seconds 0 > /dev/null 2>&1
 for k in up down wgrad; do tools/pmc_kernel.sh ${TAG}_proj_${k}_n16 proj_${k}_kernel tools/microbench_proj.py --n 16 --only $k --iters 5 > /dev/null 2>&1; done
 for f in $O/${TAG}_*_pmc.txt; do echo "== $f"; grep -E "^void|MFMA pipe|HBM-side|BANK_CONFLICT" $f | cut -c1-140; done
