@@ -83,3 +83,25 @@ def test_conv_ks_hidden_loads_are_not_touched_before_their_wait(listing_ks):
     for k in KS_KERNELS:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hidden_loads.py"), listing_ks, k], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
+
+
+# ---- the round-3 kernels that keep a whole weight tensor or K accumulator tiles in registers (csrc/proj.hip, csrc/conv_lk.hip): a register
+# ---- spill there is not a correctness problem (their waits are full `vmcnt(0)` waits or the compiler's own) but a silent 2x slowdown
+@pytest.mark.parametrize("src,limits", [
+    ("proj.hip", {"proj_down_kernelILi0E": 16, "proj_down_kernelILi1E": 16, "proj_up_kernelILi0E": 32, "proj_up_kernelILi1E": 96,       # (a few spilled pointers; the fp16 conversions cost the fused-PReLU epilogue more)
+                  "proj_wgrad_kernelILi0E": 0, "proj_wgrad_kernelILi1E": 0}),
+    ("conv_lk.hip", {"lk_wgrad_allrows_kernelILi0ELi9E": 0, "lk_wgrad_packed_kernelILi0ELi9E": 0, "lk_conv_rows_kernelILi0ELi9E": 0,
+                     "lk_wgrad_allrows_kernelILi1ELi9E": 0, "lk_conv_rows_kernelILi1ELi9E": 0}),
+])
+def test_register_resident_kernels_do_not_spill(tmp_path, src, limits):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / (src + ".s"))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                        "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    for k, lim in limits.items():
+        m = re.search(r"\.name:\s+\S*" + k + r"\S*\n(?:.*\n){0,40}?\s+\.private_segment_fixed_size:\s+(\d+)", text)
+        assert m, f"{k}: kernel metadata not found"
+        assert int(m.group(1)) <= lim, f"{k} uses {m.group(1)} bytes of scratch per lane (allowed: {lim})"
