@@ -552,6 +552,36 @@ def _grad_slot(p, shape):
     return None
 
 
+def _pass_id():
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
+
+
+def _pass_slot(p, shape, device):
+    """Like `_grad_slot(p, shape)` for the [C]-sized parameters of BatchNorm / PReLU, which one module instance may see TWICE in one
+    forward (the reference's ResBlock appends the SAME norm / act instance behind both convs, common.py:94-100: SRResNet): returns
+    (tensor the finalize step adds into, or None;  tensor to hand to autograd, or None).  The first use of a pass hands a fresh
+    zero-free tensor to autograd and remembers it under the running backward pass's id; the second use ADDS into that tensor in
+    its own finalize step (autograd has not consumed it yet: AccumulateGrad runs after every use delivered) and hands over nothing --
+    else autograd adds the two [C]-sized gradients with a launch of its own, 33 of them per SRResNet step."""
+    sl = _grad_slot(p, shape)
+    if sl is not None and sl[0] == "acc":
+        return sl[1], None
+    pid = _pass_id()
+    if sl is None or pid < 0 or not isinstance(p, torch.Tensor):
+        return None, "new"
+    ent = p.__dict__.get("_srk_pass_grad")
+    if ent is not None and ent[0] == pid:
+        t = ent[1]()
+        if t is not None and tuple(t.shape) == tuple(shape) and t.device == device:
+            return t, None
+    return None, "new+remember"
+
+
+def _remember_pass_grad(p, t):
+    p.__dict__["_srk_pass_grad"] = (_pass_id(), weakref.ref(t))
+
+
 def _view_of(storage, shape, device, offset=0):
     return torch.empty(0, dtype=torch.float32, device=device).set_(storage, int(offset), tuple(shape))
 
@@ -2138,10 +2168,15 @@ class BatchNormFn(torch.autograd.Function):
         mean = mean.contiguous()                                         # the sums: sum dy, sum (x - mean)*dy
         # gamma's / beta's gradients go straight into the parameters' existing fp32 .grad buffers when they have them (the finalize
         # step adds them there: what autograd's AccumulateGrad would do with one more launch each), else to autograd as tensors
-        wslot = _grad_slot(ctx.params[0], (c,)) if ctx.needs_input_grad[1] else None
-        bslot = _grad_slot(ctx.params[1], (c,)) if ctx.needs_input_grad[2] else None
-        wacc = wslot[1] if (wslot is not None and wslot[0] == "acc") else None
-        bacc = bslot[1] if (bslot is not None and bslot[0] == "acc") else None
+        wacc, wmode = _pass_slot(ctx.params[0], (c,), x.device) if ctx.needs_input_grad[1] else (None, None)
+        bacc, bmode = _pass_slot(ctx.params[1], (c,), x.device) if ctx.needs_input_grad[2] else (None, None)
+
+        def hand(mode, t, p):           # (a second use of the same module in this pass added into the first use's tensor: nothing to hand over)
+            if mode is None:
+                return None
+            if mode == "new+remember":
+                _remember_pass_grad(p, t)
+            return t
         if training:
             # dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M),  xhat = (x - mean)*invstd
             r = chan_reduce(x, g, 1, mean, 2, 5, M=M, creal=c, mean=mean, invstd=invstd.contiguous(), gamma=gamma.contiguous(), dgamma_acc=wacc, dbeta_acc=bacc)
@@ -2151,7 +2186,7 @@ class BatchNormFn(torch.autograd.Function):
             r = chan_reduce(x, g, 1, mean, 3, 3, M=M, creal=c, invstd=invstd.contiguous(), gamma=gamma.contiguous(), dgamma_acc=wacc, dbeta_acc=bacc)
             dgamma, dbeta = r[0], r[1]
             gx = chan_apply(g, a=r[2])
-        return gx, (None if wacc is not None else dgamma[:c]), (None if bacc is not None else dbeta[:c]), None, None, None, None, None, (g if has_res else None), None
+        return gx, hand(wmode, dgamma[:c], ctx.params[0]), hand(bmode, dbeta[:c], ctx.params[1]), None, None, None, None, None, (g if has_res else None), None
 
 
 class BNPReLUFn(torch.autograd.Function):
@@ -2192,19 +2227,24 @@ class BNPReLUFn(torch.autograd.Function):
         c, M, ns = ctx.cfg
         g = g.contiguous()
 
-        def acc_of(p, shape, want):
-            slot = _grad_slot(p, shape) if want else None
-            return slot[1] if (slot is not None and slot[0] == "acc") else None
-        wacc = acc_of(ctx.params[0], (c,), ctx.needs_input_grad[1])
-        bacc = acc_of(ctx.params[1], (c,), ctx.needs_input_grad[2])
-        sacc = acc_of(ctx.params[2], tuple(ctx.params[2].shape), ctx.needs_input_grad[7])
+        dev = x.device
+        wacc, wmode = _pass_slot(ctx.params[0], (c,), dev) if ctx.needs_input_grad[1] else (None, None)
+        bacc, bmode = _pass_slot(ctx.params[1], (c,), dev) if ctx.needs_input_grad[2] else (None, None)
+        sacc, smode = _pass_slot(ctx.params[2], tuple(ctx.params[2].shape), dev) if ctx.needs_input_grad[7] else (None, None)
         r = chan_reduce(x, g, 3, mean.contiguous(), 2, 6, M=M, creal=c, mean=mean.contiguous(), invstd=invstd.contiguous(), gamma=gamma.contiguous(),
                         dgamma_acc=wacc, dbeta_acc=bacc, bn_gate=(a.contiguous(), d.contiguous(), sl), total2=ns == 1, dslope_acc=sacc)
         gx = chan_apply(g, y=x, z=x, a=r[2], b=r[3], d=r[4], slope=sl, gate_a=a.contiguous(), gate_d=d.contiguous())
-        gs = None
-        if ctx.needs_input_grad[7] and sacc is None:
-            gs = r[5][:1] if ns == 1 else r[5][:ns]
-        return (gx, (None if wacc is not None else r[0][:c]), (None if bacc is not None else r[1][:c]), None, None, None, None, gs, None)
+
+        def hand(mode, t, p):
+            if mode is None:
+                return None
+            if mode == "new+remember":
+                _remember_pass_grad(p, t)
+            return t
+        gw = hand(wmode, r[0][:c], ctx.params[0])
+        gb = hand(bmode, r[1][:c], ctx.params[1])
+        gs = hand(smode, r[5][:1] if ns == 1 else r[5][:ns], ctx.params[2])
+        return (gx, gw, gb, None, None, None, None, gs, None)
 
 
 _BN_PRELU_FUSED = os.environ.get("SRK_NO_BN_PRELU", "0") != "1"      # A/B knob

@@ -335,3 +335,34 @@ def test_fused_batchnorm_prelu_vs_float64(A, dt, npar, shape):
     for p, f, ptr in zip((bn.weight, bn.bias, a), first, ptrs):
         assert p.grad.data_ptr() == ptr
         torch.testing.assert_close(p.grad, 2 * f, rtol=1e-5, atol=1e-5)
+
+
+def test_shared_batchnorm_prelu_instance_used_twice_in_one_forward(A):
+    """The reference's ResBlock appends the SAME BatchNorm2d / PReLU instance behind both of its convs (common.py:94-100; SRResNet):
+    the second use of a backward pass adds its [C]-sized gradients into the tensor the first use handed to autograd (ops._pass_slot).
+    Against float64 torch, two passes in a row (the second with existing .grad buffers: accumulation)."""
+    import torch.nn.functional as F
+    from sr_amd import ops
+    g = torch.Generator().manual_seed(21)
+    c = 32
+    x = torch.randn(2, c, 10, 9, generator=g)
+    t = torch.randn(2, c, 10, 9, generator=g)
+    bn, ref = torch.nn.BatchNorm2d(c).cuda(), torch.nn.BatchNorm2d(c).double()
+    with torch.no_grad():
+        for m_ in (bn, ref):
+            m_.weight.copy_(torch.linspace(0.5, 1.5, c)); m_.bias.copy_(torch.linspace(-0.3, 0.3, c))
+    a = torch.nn.Parameter(torch.full((c,), 0.25).cuda())
+    ar = torch.full((c,), 0.25).double().requires_grad_(True)
+    rel = lambda got, want: float((got.double().cpu() - want).abs().max() / max(1e-9, float(want.abs().max())))
+    for rounds in (1, 2):
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)            # fp32 storage
+        h = ops.batch_norm_prelu(xd, bn, a)                                            # use 1: BatchNorm + PReLU
+        y = ops.batch_norm(h * 0.5 + 0.1, bn)                                          # use 2 of the same BatchNorm (no activation)
+        y = ops.prelu(y, a)                                                            # use 2 of the same PReLU
+        y.backward(t.permute(0, 2, 3, 1).contiguous().cuda())
+        xr = x.double().requires_grad_(True)
+        hr = F.prelu(ref(xr), ar)
+        yr = F.prelu(ref(hr * 0.5 + 0.1), ar)
+        yr.backward(t.double())
+        assert rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < 2e-3
+        assert rel(bn.weight.grad, ref.weight.grad) < 2e-3 and rel(bn.bias.grad, ref.bias.grad) < 2e-3 and rel(a.grad, ar.grad) < 2e-3
