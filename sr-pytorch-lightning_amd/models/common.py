@@ -48,8 +48,8 @@ class DefaultConv2d(_NCHWContract, nn.Conv2d):
     def _cout(self):
         return self.out_channels
 
-    def nhwc(self, x, res=None, scale=1.0, ps_r=0):
-        return ops.conv(x, self.weight, self.bias, res=res, scale=scale, ps_r=ps_r)
+    def nhwc(self, x, res=None, scale=1.0, ps_r=0, link=None):
+        return ops.conv(x, self.weight, self.bias, res=res, scale=scale, ps_r=ps_r, link=link)
 
 
 class BasicBlock(_NCHWContract, nn.Sequential):
@@ -165,19 +165,22 @@ class ResBlock(_NCHWContract, nn.Module):
         r = x
         fused_res = False
         skip = False
+        # the residual add rides in the last BatchNorm's apply launch; its gradient rides in the first conv's data-gradient launch
+        link = ops.ResLink() if (ops._RES_LINK and isinstance(mods[-1], nn.BatchNorm2d) and self.res_scale == 1 and isinstance(mods[0], nn.Conv2d)
+                                 and mods[0].kernel_size[0] == 3) else None
         for i, m in enumerate(mods):
             last = i == len(mods) - 1
             if skip:                                   # (the PReLU that rode in the BatchNorm before it)
                 skip = False
                 continue
             if isinstance(m, nn.Conv2d):
-                r = m.nhwc(r)
+                r = m.nhwc(r, link=link if i == 0 else None)
             elif isinstance(m, nn.BatchNorm2d) and not last and isinstance(mods[i + 1], nn.PReLU):
                 r = ops.batch_norm_prelu(r, m, mods[i + 1].weight)
                 skip = True
             elif isinstance(m, nn.BatchNorm2d):
                 if last and self.res_scale == 1:
-                    r = ops.batch_norm(r, m, res=x)
+                    r = ops.batch_norm(r, m, res=x, link=link)
                     fused_res = True
                 else:
                     r = ops.batch_norm(r, m)

@@ -867,6 +867,21 @@ def _f32c(t):
 # --------------------------------------------------------------------------------------------
 # autograd Functions
 # --------------------------------------------------------------------------------------------
+_RES_LINK = os.environ.get("SRK_NO_RES_LINK", "0") != "1"        # A/B knob
+
+
+class ResLink:
+    """Ties the residual add at the END of a block to the FIRST conv of the block (SRResNet's ResBlock: x -> conv -> norm -> act -> conv ->
+    norm, += x; common.py:74-109): in backward the block's input receives the upstream gradient g (through the add) plus the first
+    conv's data gradient -- autograd would add the two with a launch of its own.  With a link the op that owns the residual add
+    (`BatchNormFn` with `res`) parks g here instead of returning it, and the first conv's data-gradient launch adds it (`res`).  The park
+    only happens when that conv's backward will run with its input gradient wanted (`armed`, decided in its forward)."""
+    __slots__ = ("armed", "g")
+
+    def __init__(self):
+        self.armed, self.g = False, None
+
+
 class ConvFn(torch.autograd.Function):
     """y = conv_same(x, w, b) * scale (+ res), optional fused PixelShuffle(ps_r) store.
 
@@ -876,11 +891,14 @@ class ConvFn(torch.autograd.Function):
               pixel-shuffle addressing; wgrad = srk_conv2d_wgrad."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, scale, ps_r):
+    def forward(ctx, x, w, b, res, scale, ps_r, link=None):
         _need_gpu(x)
         n, h, wd, cinp = x.shape
         cout, cin, k, _ = w.shape
         assert cinp == pad16(cin), f"input has {cinp} channels, conv expects pad16({cin})"
+        ctx.link = link
+        if link is not None:
+            link.armed = bool(ctx.needs_input_grad[0]) and int(ps_r) <= 1
         pk = pack_conv(w, b, x.dtype, ps_r=ps_r)
         if ps_r > 1:
             c = cout // (ps_r * ps_r)
@@ -914,15 +932,18 @@ class ConvFn(torch.autograd.Function):
                 conv_raw(g, pkd, N=n, H=h, W=wd, Cin=coutp, Cout=cinp, out=gx, scale=scale, use_bias=False, res=gx if add else None)
             else:
                 gx = torch.empty_like(x)
-                conv_raw(g, pkd, N=n, H=h, W=wd, Cin=coutp, Cout=cinp, out=gx, scale=scale, x_ps=ps_r, use_bias=False)
+                parked = None
+                if ctx.link is not None and ctx.link.g is not None:        # the block's residual gradient: added by this launch
+                    parked, ctx.link.g = ctx.link.g, None
+                conv_raw(g, pkd, N=n, H=h, W=wd, Cin=coutp, Cout=cinp, out=gx, scale=scale, x_ps=ps_r, use_bias=False, res=parked)
         if ctx.needs_input_grad[1]:
             gw, gb = wgrad(x, g, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cinp, Cout=coutp, k=k,
                            w_shape=tuple(w.shape), ps_r=ps_r, scale=scale, dy_ps=ps_r, want_bias=has_b)
-        return gx, gw, gb, (g if has_res else None), None, None
+        return gx, gw, gb, (g if has_res else None), None, None, None
 
 
-def conv(x, w, b, *, res=None, scale=1.0, ps_r=0):
-    return ConvFn.apply(x, w, b, res, float(scale), int(ps_r))
+def conv(x, w, b, *, res=None, scale=1.0, ps_r=0, link=None):
+    return ConvFn.apply(x, w, b, res, float(scale), int(ps_r), link)
 
 
 class HeadConvFn(torch.autograd.Function):
@@ -2116,9 +2137,10 @@ class BatchNormFn(torch.autograd.Function):
     Statistics: srk_chan_stats (fp32 sums); apply and backward: srk_chan_apply; [C]-sized vector math stays in torch."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, res, nbt=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, res, nbt=None, link=None):
         x = x.contiguous()
         ctx.params = (weight, bias)
+        ctx.link = link
         c = weight.numel()
         cp = x.shape[-1]
         M = x.numel() // cp
@@ -2164,7 +2186,7 @@ class BatchNormFn(torch.autograd.Function):
         g = g.contiguous()
         if M == 0:
             z = torch.zeros(c, dtype=torch.float32, device=x.device)
-            return torch.empty_like(g), z, z.clone(), None, None, None, None, None, (g if has_res else None), None
+            return torch.empty_like(g), z, z.clone(), None, None, None, None, None, (g if has_res else None), None, None
         mean = mean.contiguous()                                         # the sums: sum dy, sum (x - mean)*dy
         # gamma's / beta's gradients go straight into the parameters' existing fp32 .grad buffers when they have them (the finalize
         # step adds them there: what autograd's AccumulateGrad would do with one more launch each), else to autograd as tensors
@@ -2186,7 +2208,10 @@ class BatchNormFn(torch.autograd.Function):
             r = chan_reduce(x, g, 1, mean, 3, 3, M=M, creal=c, invstd=invstd.contiguous(), gamma=gamma.contiguous(), dgamma_acc=wacc, dbeta_acc=bacc)
             dgamma, dbeta = r[0], r[1]
             gx = chan_apply(g, a=r[2])
-        return gx, hand(wmode, dgamma[:c], ctx.params[0]), hand(bmode, dbeta[:c], ctx.params[1]), None, None, None, None, None, (g if has_res else None), None
+        gres = g if has_res else None
+        if has_res and ctx.link is not None and ctx.link.armed:         # parked for the block's first conv (ResLink): its data-gradient launch adds it
+            ctx.link.g, gres = g, None
+        return gx, hand(wmode, dgamma[:c], ctx.params[0]), hand(bmode, dbeta[:c], ctx.params[1]), None, None, None, None, None, gres, None, None
 
 
 class BNPReLUFn(torch.autograd.Function):
@@ -2262,8 +2287,9 @@ def batch_norm_prelu(x, bn, slope):
     return prelu(batch_norm(x, bn), slope)
 
 
-def batch_norm(x, bn, res=None):
-    """`bn`: an nn.BatchNorm2d (parameters, running buffers, training flag, momentum, eps) applied to NHWC `x`."""
+def batch_norm(x, bn, res=None, link=None):
+    """`bn`: an nn.BatchNorm2d (parameters, running buffers, training flag, momentum, eps) applied to NHWC `x`.
+    link: a ResLink shared with the conv that consumes `res` (the residual's gradient then rides in that conv's data gradient)."""
     nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats and bn.num_batches_tracked is not None) else None
     if bn.momentum is not None:
         mom = bn.momentum                                   # num_batches_tracked += 1 rides in the statistics launch
@@ -2277,7 +2303,7 @@ def batch_norm(x, bn, res=None):
     if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
         nbt.add_(1)
         nbt = None
-    return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, res, nbt)
+    return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, res, nbt, link if res is not None else None)
 
 
 _LK_OFF = os.environ.get("SRK_NO_LK", "0") == "1"        # A/B knob: large kernels through im2col as in round 2
