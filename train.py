@@ -130,6 +130,7 @@ def main(argv=None):
         if tr.rank == 0:
             print("validation: " + ", ".join(f"{k} {float(v):.4f}" for k, v in metrics.items()), flush=True)
     if a.save and tr.rank == 0:
+        os.makedirs(os.path.dirname(os.path.abspath(a.save)), exist_ok=True)
         torch.save({"state_dict": model.state_dict()}, a.save)
     if tr.rank == 0 and tr.losses:
         print(f"done: {len(tr.losses)} steps, last loss {tr.losses[-1]:.6f}", flush=True)
