@@ -613,6 +613,47 @@ typedef struct {
 } srk_chan_apply_args;
 int srk_chan_apply(const srk_chan_apply_args* a, srk_stream_t stream);
 
+/* ---- the last upsampling stage and the tail conv as ONE linear map (csrc/hr_tail.hip) ----------------------------------------
+ * Replaces, on the 16-bit path, the end of EDSR / RCAN / RDN: UpscaleBlock's last `conv3x3(Ci -> 4C) -> nn.PixelShuffle(2)` stage
+ * (models/common.py:112-139, no activation on this path) followed by the tail `conv3x3(C -> O)` (edsr.py:37-38,49-52, rcan.py:83-87,
+ * 102-104, rdn.py:85-95), and their autograd.  Two convolutions with nothing non-linear between them are one linear map of the
+ * upsampler's input X: at X's resolution, with the 4 sub-pixel positions (a, b) of an output pixel as channels k = o*4 + a*2 + b,
+ *     T[(2y+a, 2x+b)][o] = beff[k] + sum_{ci, f in [-2,2]^2} weff[k][ci][f] X[(y,x) + f][ci]  -  (border terms on the outermost ring)
+ * a 5x5 convolution Ci -> 4O (srk_conv2d / srk_conv2d_wgrad: the direct large-kernel kernels) whose weights are sums of products
+ * Wt Wu.  The C-channel tensor at the doubled resolution (1.2 GB at EDSR-baseline's batch of 256) and its gradient never exist.
+ * The border terms make the result EXACT: the tail conv pads the shuffled tensor with zeros, so output pixels of the outermost ring
+ * lose the taps that leave the image; those terms are linear in X too (one row / column of 5 taps per edge, one tap per corner).
+ *   srk_hrtail_collapse   : (wt, bt, wu, bu) -> weff, beff, wedge, bedge, wcor, bcor                          (parameter-sized)
+ *   srk_hrtail_edge_fwd   : out -= border terms (out: what srk_conv2d wrote with weff, planar fp32 + PixelShuffle(2))
+ *   srk_hrtail_edge_bwd_x : dx -= (border terms)^T g    (dx: what the data-gradient srk_conv2d wrote)
+ *   srk_hrtail_edge_bwd_w : correlations of g and x over the edge rows / columns / corner pixels -> eedge, e0, ecor, k0
+ *   srk_hrtail_expand     : (r = dL/dweff, r0 = dL/dbeff from srk_conv2d_wgrad; eedge ...) -> dwt, dbt, dwu, dbu  (parameter-sized)
+ * Layouts (fp32): weff [4O][Ci][5][5]; wedge / eedge [4][2O][Ci][5] and bedge / e0 [4][2O]: edge 0 top, 1 bottom (row kk = o*2 + b, 5
+ * taps along x), 2 left, 3 right (kk = o*2 + a, 5 taps along y); wcor / ecor [4][O][Ci] and bcor / k0 [4][O]: corner a*2 + b.
+ * wu's output channels are in torch's PixelShuffle order c*4 + i*2 + j.  O <= 4.                                            */
+typedef struct {
+  const float* wt; const float* bt;     /* tail conv [O][C][3][3], [O] or NULL                                    */
+  const float* wu; const float* bu;     /* upsampler conv [4C][Ci][3][3], [4C] or NULL                            */
+  int O, C, Ci;
+  float* weff; float* beff;             /* collapse: out; the launches in between: srk_pack_conv_weights' input   */
+  float* wedge; float* bedge; float* wcor; float* bcor;
+  const void* x; int x_pitch;           /* NHWC 16-bit [N][H][W][>= Ci]                                           */
+  int N, H, W; int dtype;
+  float* out;                           /* edge_fwd: [N][O][2H][2W] fp32, corrected in place                      */
+  const float* g;                       /* edge_bwd_*: gradient of out, [N][O][2H][2W] fp32                       */
+  void* dx; int dx_pitch;               /* edge_bwd_x: NHWC 16-bit [N][H][W][>= Ci], corrected in place           */
+  float* eedge; float* e0; float* ecor; float* k0;   /* edge_bwd_w: out; expand: in                               */
+  float* scratch;                       /* edge_bwd_w: srk_hrtail_scratch_floats(N, Ci) floats                    */
+  const float* r; const float* r0;      /* expand: dL/dweff [4O][Ci][5][5], dL/dbeff [4O]                         */
+  float* dwt; float* dbt; float* dwu; float* dbu;    /* expand: out (dbt / dbu nullable)                          */
+} srk_hrtail_args;
+int srk_hrtail_collapse(const srk_hrtail_args* a, srk_stream_t stream);
+int srk_hrtail_edge_fwd(const srk_hrtail_args* a, srk_stream_t stream);
+int srk_hrtail_edge_bwd_x(const srk_hrtail_args* a, srk_stream_t stream);
+long long srk_hrtail_scratch_floats(int N, int Ci);
+int srk_hrtail_edge_bwd_w(const srk_hrtail_args* a, srk_stream_t stream);
+int srk_hrtail_expand(const srk_hrtail_args* a, srk_stream_t stream);
+
 /* ---- optimizer: Adam over every parameter tensor in one launch -----------------------------------
  * Replaces torch.optim.Adam(...).step() as models/srmodel.py:145-154 configures it (torch defaults; :602-603 drops every
  * user-supplied hyper-parameter).  fp32 parameters, gradients and moments.  The tensors are described by a DEVICE table

@@ -212,6 +212,15 @@ class ChanApplyArgs(C.Structure):
                 ("P", C.c_longlong), ("C", _i), ("dtype", _i), ("gate_a", _p), ("gate_d", _p)]
 
 
+class HrTailArgs(C.Structure):
+    _fields_ = [("wt", _p), ("bt", _p), ("wu", _p), ("bu", _p), ("O", _i), ("C", _i), ("Ci", _i),
+                ("weff", _p), ("beff", _p), ("wedge", _p), ("bedge", _p), ("wcor", _p), ("bcor", _p),
+                ("x", _p), ("x_pitch", _i), ("N", _i), ("H", _i), ("W", _i), ("dtype", _i),
+                ("out", _p), ("g", _p), ("dx", _p), ("dx_pitch", _i),
+                ("eedge", _p), ("e0", _p), ("ecor", _p), ("k0", _p), ("scratch", _p),
+                ("r", _p), ("r0", _p), ("dwt", _p), ("dbt", _p), ("dwu", _p), ("dbu", _p)]
+
+
 # every launcher declared in include/srk.h: name -> argument struct
 LAUNCHERS = {
     "srk_pack_conv_weights": PackArgs,
@@ -243,12 +252,18 @@ LAUNCHERS = {
     "srk_proj_down": ProjArgs,
     "srk_proj_up": ProjArgs,
     "srk_proj_wgrad": ProjWgradArgs,
+    "srk_hrtail_collapse": HrTailArgs,
+    "srk_hrtail_edge_fwd": HrTailArgs,
+    "srk_hrtail_edge_bwd_x": HrTailArgs,
+    "srk_hrtail_edge_bwd_w": HrTailArgs,
+    "srk_hrtail_expand": HrTailArgs,
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
                  "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges", "srk_l1_loss_mean", "srk_chan_stats_finalize", "srk_pack_group_tiles", "srk_pack_conv_weights_group_tiled",
-                 "srk_proj_pack", "srk_proj_pack_bytes", "srk_proj_wgrad_scratch_floats", "srk_proj_pack_group", "srk_wgrad_slab_cout")
+                 "srk_proj_pack", "srk_proj_pack_bytes", "srk_proj_wgrad_scratch_floats", "srk_proj_pack_group", "srk_wgrad_slab_cout",
+                 "srk_hrtail_scratch_floats")
 
 _lib = None
 
@@ -322,6 +337,8 @@ def load():
     lib.srk_proj_pack_bytes.restype = C.c_longlong
     lib.srk_proj_wgrad_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.srk_proj_wgrad_scratch_floats.restype = C.c_longlong
+    lib.srk_hrtail_scratch_floats.argtypes = [C.c_int, C.c_int]
+    lib.srk_hrtail_scratch_floats.restype = C.c_longlong
     lib.srk_last_error.restype = C.c_char_p
     lib.srk_version.restype = C.c_int
     lib.srk_device_cus.restype = C.c_int

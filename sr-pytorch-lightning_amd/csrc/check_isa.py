@@ -23,9 +23,14 @@ def _regs(line):
     return out
 
 
-def check_kernel(asm, dt, nks):
+def kernel_name(dt, nks, em=1):
+    """Mangled name of conv_ws_kernel<dt, 2, nks, FAST = true, EARLY = true, EM = em> (em: 1 = residual, 2 = mask prefetch)."""
+    return f"_ZN12_GLOBAL__N_114conv_ws_kernelILi{dt}ELi2ELi{nks}ELb1ELb1ELi{em}EEEv13srk_conv_args"
+
+
+def check_kernel(asm, dt, nks, em=1):
     """Raises AssertionError with the offending line; returns the number of instructions inspected."""
-    name = f"_ZN12_GLOBAL__N_114conv_ws_kernelILi{dt}ELi2ELi{nks}ELb1ELb1EEEv13srk_conv_args"
+    name = kernel_name(dt, nks, em)
     start = asm.index(name + "iiiijiiiiiii:")
     body = asm[start:asm.index(".Lfunc_end", start)].split("\n")
     loads = [k for k, l in enumerate(body)
@@ -58,12 +63,13 @@ def main(path):
     ok = True
     for dt in (0, 1):
         for nks in (4, 1):
-            try:
-                n = check_kernel(asm, dt, nks)
-                print(f"check_isa: conv_ws_kernel<dtype {dt}, NKS {nks}, EARLY>: ok ({n} instructions between prefetch and wait)")
-            except (AssertionError, ValueError) as e:
-                ok = False
-                print(f"check_isa: conv_ws_kernel<dtype {dt}, NKS {nks}, EARLY>: FAILED: {e}", file=sys.stderr)
+            for em in (1, 2):
+                try:
+                    n = check_kernel(asm, dt, nks, em)
+                    print(f"check_isa: conv_ws_kernel<dtype {dt}, NKS {nks}, EARLY, EM {em}>: ok ({n} instructions between prefetch and wait)")
+                except (AssertionError, ValueError) as e:
+                    ok = False
+                    print(f"check_isa: conv_ws_kernel<dtype {dt}, NKS {nks}, EARLY, EM {em}>: FAILED: {e}", file=sys.stderr)
     return 0 if ok else 1
 
 

@@ -388,6 +388,49 @@ SRK_DEV void quad_transpose4(uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t&
   }
 }
 
+// The same transpose for TWO register quartets at once with v_cndmask_b32_dpp: on gfx9 the DPP lane permutation is a modifier of the
+// select's first source (VOP2 encoding, lane mask in VCC), so one instruction per register and stage does what the form above needs
+// two for (select + v_mov_dpp + two selects per register pair): 16 vector instructions per 8 registers instead of 32.  The epilogue
+// phase is bound by vector-instruction ISSUE beside the other group's MFMA wave, and the chip is power-limited under this kernel, so
+// every instruction not issued counts twice.  The lane masks are constants (qi = lane & 3): b0 = odd lanes, b1 = lanes 2, 3 of a quad.
+// v_cndmask_b32: D = VCC ? src1 : dpp(src0).  Hazards (inline asm is invisible to the compiler's hazard recogniser): a DPP read needs two
+// wait states behind the VALU write of its source -- `s_nop 1` covers the inputs, the instruction order below covers the temporaries
+// (every stage-2 DPP source is written at least two instructions earlier).
+SRK_DEV void quad_transpose8_dpp(uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3,
+                                 uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3) {
+  const unsigned long long mb0 = 0xaaaaaaaaaaaaaaaaull, mn0 = 0x5555555555555555ull;
+  const unsigned long long mb1 = 0xccccccccccccccccull, mn1 = 0x3333333333333333ull;
+  uint32_t t0, t1, t2, t3, u0, u1, u2, u3, oa0, oa1, oa2, oa3, oc0, oc1, oc2, oc3;
+  asm("s_nop 1\n\t"
+      "s_mov_b64 vcc, %[mn0]\n\t"                                         // even lanes keep r0 / r2, odd lanes take the neighbour's r1 / r3
+      "v_cndmask_b32_dpp %[t0], %[a1], %[a0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[t2], %[a3], %[a2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[u0], %[c1], %[c0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[u2], %[c3], %[c2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[mb0]\n\t"                                         // odd lanes keep r1 / r3, even lanes take the neighbour's r0 / r2
+      "v_cndmask_b32_dpp %[t1], %[a0], %[a1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[t3], %[a2], %[a3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[u1], %[c0], %[c1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[u3], %[c2], %[c3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[mn1]\n\t"                                         // lanes 0, 1 keep r0 / r1, lanes 2, 3 take r2 / r3 from two lanes over
+      "v_cndmask_b32_dpp %[oa0], %[t2], %[t0], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oa1], %[t3], %[t1], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oc0], %[u2], %[u0], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oc1], %[u3], %[u1], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[mb1]\n\t"
+      "v_cndmask_b32_dpp %[oa2], %[t0], %[t2], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oa3], %[t1], %[t3], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oc2], %[u0], %[u2], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oc3], %[u1], %[u3], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3),
+        [oa0] "=&v"(oa0), [oa1] "=&v"(oa1), [oa2] "=&v"(oa2), [oa3] "=&v"(oa3), [oc0] "=&v"(oc0), [oc1] "=&v"(oc1), [oc2] "=&v"(oc2), [oc3] "=&v"(oc3)
+      : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3),
+        [mb0] "s"(mb0), [mn0] "s"(mn0), [mb1] "s"(mb1), [mn1] "s"(mn1)
+      : "vcc");
+  a0 = oa0; a1 = oa1; a2 = oa2; a3 = oa3;
+  c0 = oc0; c1 = oc1; c2 = oc2; c3 = oc3;
+}
+
 template <int DT>
 SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int pbase0, int pbase1, int okmask0, int okmask1,
                                 int pstep, int cl, bool use_mask, int qi) {
@@ -421,8 +464,8 @@ SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int
           P[k][d] = pack2<DT>(acc[k >> 1][pb][8 * (k & 1) + 2 * d], acc[k >> 1][pb][8 * (k & 1) + 2 * d + 1]);
           if (relu) P[k][d] = relu_pk16(P[k][d]);
         }
-#pragma unroll
-      for (int d = 0; d < 4; ++d) quad_transpose4(P[0][d], P[1][d], P[2][d], P[3][d], b0, b1);
+      quad_transpose8_dpp(P[0][0], P[1][0], P[2][0], P[3][0], P[0][1], P[1][1], P[2][1], P[3][1]);
+      quad_transpose8_dpp(P[0][2], P[1][2], P[2][2], P[3][2], P[0][3], P[1][3], P[2][3], P[3][3]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32x4 raw = {P[j][0], P[j][1], P[j][2], P[j][3]};
@@ -544,54 +587,74 @@ SRK_DEV void quad_early_wait(QuadRegs& e0, QuadRegs& e1) {
                : "n"(YOUNGER) : "memory");
 }
 
-// accumulators of pixel block pb -> the 4 packed 16-byte pieces this lane stores (out.r[j]: pixel j of the quad)
 // accumulators of pixel block pb (+ prefetched residual OR mask, natural layout) -> the 4 packed 16-byte pieces this
 // lane stores after the quad transpose (out.r[j]: pixel j of the quad).  No memory operation in here: a compiler-visible
 // load would put `s_waitcnt vmcnt(0)` at the merge point of every path, i.e. make every tile wait for the halo DMA issued
 // just before (measured: 4.6k of a 9.4k-cycle phase); the dispatcher sends residual + mask to the plain variant.
-template <int DT>
-SRK_DEV void quad_compute(const srk_conv_args& a, f32x16 (&acc)[2][2], int pb, const QuadRegs& e, bool use_mask_lo,
-                          bool use_mask_hi, int qi, QuadRegs& out) {
+// EM (compile time): 1 = residual, 2 = ReLU-backward mask.  Round 4: the run-time form of this function (flags tested per 16-byte
+// piece) compiled to 857 vector instructions per tile and wave against 144 MFMAs (PMC: 6 VALU per MFMA) -- canonicalising maxes,
+// scaled AND unscaled values with selects between them, float compares for the mask, 12 wave-uniform branches per pixel block --
+// and the phase it bounds is vector-ISSUE-bound (~4 cycles per instruction beside the other group's MFMA wave).  Now: flags are
+// template parameters or ONE uniform branch per pixel block, the mask is applied to the PACKED 16-bit results with packed integer
+// ops (2 instead of 3 instructions per element, no unpack), the transposes take one instruction per register and stage.
+// P (two packed 16-bit results) keeps the lanes whose mask element m is > 0 as a float (sign clear, magnitude non-zero; a NaN passes),
+// the others become +0: three packed-integer instructions per TWO elements (max with 0: negatives and -0.0 -> 0; min with 1: 0 / 1;
+// multiply).  Inline asm: from the vector builtins hipcc builds compares, selects and v_perm instead (6 instructions per dword).
+SRK_DEV void mask_apply_pk16(uint32_t& P, uint32_t m) {
+  uint32_t t;
+  asm("v_pk_max_i16 %0, %2, 0\n\t"
+      "v_pk_min_u16 %0, %0, %3\n\t"
+      "v_pk_mul_lo_u16 %1, %1, %0"
+      : "=&v"(t), "+v"(P) : "v"(m), "s"(0x00010001u));
+}
+
+template <int DT, int EM, bool SC, bool RL>
+SRK_DEV void quad_compute_t(float scale, f32x16 (&acc)[2][2], int pb, const QuadRegs& e, bool use_mask_lo, bool use_mask_hi, QuadRegs& out) {
   static_assert(DTraits<DT>::IS16, "16-bit types only");
-  const bool has_res = a.res != nullptr, has_mask = a.mask != nullptr && !has_res, relu = a.relu != 0;
-  const float scale = a.scale;
-  const bool b0 = qi & 1, b1 = qi & 2;
   uint32_t P[4][4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float v[8];
 #pragma unroll
     for (int x = 0; x < 8; ++x) v[x] = acc[k >> 1][pb][8 * (k & 1) + x];
-    if (relu) {
+    if constexpr (RL) {
 #pragma unroll
       for (int x = 0; x < 8; ++x) v[x] = fmaxf(v[x], 0.f);
     }
-    if (scale != 1.f) {
+    if constexpr (SC) {
 #pragma unroll
       for (int x = 0; x < 8; ++x) v[x] *= scale;
     }
-    if (has_res) {
+    if constexpr (EM == 1) {
       float r8[8];
       unpack2<DT>(e.r[k].x, r8[0], r8[1]); unpack2<DT>(e.r[k].y, r8[2], r8[3]);
       unpack2<DT>(e.r[k].z, r8[4], r8[5]); unpack2<DT>(e.r[k].w, r8[6], r8[7]);
 #pragma unroll
       for (int x = 0; x < 8; ++x) v[x] += r8[x];
     }
-    if (has_mask) {
-      const bool use = (k >> 1) ? use_mask_hi : use_mask_lo;      // channel block of piece k: 16 * (k >> 1)
-      float m8[8];
-      unpack2<DT>(e.r[k].x, m8[0], m8[1]); unpack2<DT>(e.r[k].y, m8[2], m8[3]);
-      unpack2<DT>(e.r[k].z, m8[4], m8[5]); unpack2<DT>(e.r[k].w, m8[6], m8[7]);
-#pragma unroll
-      for (int x = 0; x < 8; ++x) v[x] = (!use || m8[x] > 0.f) ? v[x] : 0.f;
-    }
 #pragma unroll
     for (int d = 0; d < 4; ++d) P[k][d] = pack2<DT>(v[2 * d], v[2 * d + 1]);
+    if constexpr (EM == 2) {
+      if ((k >> 1) ? use_mask_hi : use_mask_lo) {      // channel block of piece k: 16 * (k >> 1); wave-uniform
+        mask_apply_pk16(P[k][0], e.r[k].x); mask_apply_pk16(P[k][1], e.r[k].y);
+        mask_apply_pk16(P[k][2], e.r[k].z); mask_apply_pk16(P[k][3], e.r[k].w);
+      }
+    }
   }
-#pragma unroll
-  for (int d = 0; d < 4; ++d) quad_transpose4(P[0][d], P[1][d], P[2][d], P[3][d], b0, b1);
+  quad_transpose8_dpp(P[0][0], P[1][0], P[2][0], P[3][0], P[0][1], P[1][1], P[2][1], P[3][1]);
+  quad_transpose8_dpp(P[0][2], P[1][2], P[2][2], P[3][2], P[0][3], P[1][3], P[2][3], P[3][3]);
 #pragma unroll
   for (int j = 0; j < 4; ++j) out.r[j] = u32x4{P[j][0], P[j][1], P[j][2], P[j][3]};
+}
+
+// one wave-uniform branch per pixel block picks the instantiation (ReLU together with a residual or a mask is rare: it keeps one generic form)
+template <int DT, int EM>
+SRK_DEV void quad_compute(const srk_conv_args& a, f32x16 (&acc)[2][2], int pb, const QuadRegs& e, bool use_mask_lo,
+                          bool use_mask_hi, QuadRegs& out) {
+  const float scale = a.scale;
+  if (a.relu) quad_compute_t<DT, EM, true, true>(scale, acc, pb, e, use_mask_lo, use_mask_hi, out);
+  else if (scale != 1.f) quad_compute_t<DT, EM, true, false>(scale, acc, pb, e, use_mask_lo, use_mask_hi, out);
+  else quad_compute_t<DT, EM, false, false>(scale, acc, pb, e, use_mask_lo, use_mask_hi, out);
 }
 
 SRK_DEV void quad_store(const srk_conv_args& a, const QuadGeo& g, int pb, const QuadRegs& out) {
@@ -839,7 +902,7 @@ SRK_DEV void grp_barrier(unsigned addr, unsigned target, int lane) {
   while (grp_peek(addr) < target) __builtin_amdgcn_s_sleep(1);
 }
 
-template <int DT, int CBW, int NKS, bool FAST, bool EARLY>
+template <int DT, int CBW, int NKS, bool FAST, bool EARLY, int EM>
 __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
                                                           int nptiles, unsigned x_bytes, int tq, int trem, int /*unused*/,
                                                           int xs_img, int xs_row, int xs_col, int wtap) {
@@ -937,6 +1000,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   // residual / mask pieces, so the bias is parked in LDS behind the halo buffers and re-read per tile (8 broadcast
   // ds_read_b128 per lane)
   static_assert(!EARLY || (FAST && CBW == 2), "EARLY is a variant of the quad epilogue");
+  static_assert(EARLY ? (EM == 1 || EM == 2) : EM == 0, "EM: what the prefetch variant prefetches (1 = residual, 2 = ReLU-backward mask)");
   f32x16 bias16[EARLY ? 1 : CBW];
   float* const Bl = reinterpret_cast<float*>(smem + WPIECES * 16 + 2 * C::XS_BYTES);
   if constexpr (EARLY) {
@@ -1221,14 +1285,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
             const QuadGeo geo = quad_geo(j);
             const bool um_lo = ctile * TCW + 32 * h >= a.mask_from, um_hi = ctile * TCW + 32 * h + 16 >= a.mask_from;
             QuadRegs o0, o1;
-            quad_compute<DT>(a, acc, 0, e0, um_lo, um_hi, qi, o0);
+            quad_compute<DT, EM>(a, acc, 0, e0, um_lo, um_hi, o0);
 #if SRK_WS_STAMPS
             asm volatile("" :: "v"(o0.r[0].x), "v"(o0.r[3].w));
             if (p == 3) SRK_STAMP(31);
 #endif
             quad_store(a, geo, 0, o0);
             if (p == 3) SRK_STAMP(32);
-            quad_compute<DT>(a, acc, 1, e1, um_lo, um_hi, qi, o1);
+            quad_compute<DT, EM>(a, acc, 1, e1, um_lo, um_hi, o1);
 #if SRK_WS_STAMPS
             asm volatile("" :: "v"(o1.r[0].x), "v"(o1.r[3].w));
             if (p == 3) SRK_STAMP(33);
@@ -1319,19 +1383,19 @@ static bool conv_fast_ok(const srk_conv_args& a, int esz) {
 }
 
 // one launch; `early` picks the variant that prefetches the residual / mask (see quad_compute)
-template <int DT, int CBW, int NKS, bool FAST, bool EARLY>
+template <int DT, int CBW, int NKS, bool FAST, bool EARLY, int EM>
 static int launch_ws_one(const srk_conv_args& b, hipStream_t st, unsigned grid, int tilesX, int tilesY, int ctiles, int nptiles,
                          unsigned xb, int tq, int trem, int xs_img, int xs_row, int xs_col, int wtap) {
   typedef WsCfg C;
   constexpr int TCW = CBW * 32;
   constexpr int LDS = 9 * 2 * NKS * TCW * 16 + 2 * C::XS_BYTES + TCW * 4 + 16;      // weights, two halo buffers, bias, group-barrier counters
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<DT, CBW, NKS, FAST, EARLY>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<DT, CBW, NKS, FAST, EARLY, EM>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) {
     srk_set_error("srk_conv2d(ws): cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
     return (int)attr;
   }
-  hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST, EARLY>), dim3(grid), dim3(C::NT), LDS, st, b, tilesX, tilesY, ctiles, nptiles,
+  hipLaunchKernelGGL((conv_ws_kernel<DT, CBW, NKS, FAST, EARLY, EM>), dim3(grid), dim3(C::NT), LDS, st, b, tilesX, tilesY, ctiles, nptiles,
                      xb, tq, trem, 0, xs_img, xs_row, xs_col, wtap);
   SRK_LAUNCH_CHECK();
   return 0;
@@ -1357,10 +1421,12 @@ template <int DT, int CBW, int NKS, bool FAST> int launch_ws(const srk_conv_args
   // residual OR ReLU mask in the epilogue (not both): the variant that prefetches it during the MFMA phase
   auto one = [&](const srk_conv_args& b, int xs_img, int xs_row, int xs_col, int wtap) -> int {
     if constexpr (FAST && CBW == 2) {
-      if (((b.res != nullptr) != (b.mask != nullptr)) && !no_early)
-        return launch_ws_one<DT, CBW, NKS, FAST, true>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
+      if (((b.res != nullptr) != (b.mask != nullptr)) && !no_early) {
+        if (b.res) return launch_ws_one<DT, CBW, NKS, FAST, true, 1>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
+        return launch_ws_one<DT, CBW, NKS, FAST, true, 2>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
+      }
     }
-    return launch_ws_one<DT, CBW, NKS, FAST, false>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
+    return launch_ws_one<DT, CBW, NKS, FAST, false, 0>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
   };
   if (rin == 1) return one(a, a.H * a.W * a.x_pitch, a.W * a.x_pitch, a.x_pitch, 2 * NKS);
   // Input stored pixel-shuffled (the dgrad of a conv + PixelShuffle(r)): channel k = (i*r+j)*64 + c lives at sub-pixel

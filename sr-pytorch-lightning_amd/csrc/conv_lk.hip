@@ -112,6 +112,34 @@ __global__ __launch_bounds__(256) void lk_conv_kernel(const srk_conv_args a, int
   // epilogue: v = acc (+ bias already); relu; * scale; + res; store.  Lane (pixel, half h) holds 16 (NRB = 1) / 32 (NRB = 2) contiguous
   // channels of its pixel: channel = 16 h + 4 i + e  resp.  32 h + 16 rb + 4 i + e  (row_to_chan, srk_common.h)
   const float sc = a.scale;
+  if constexpr (NRB == 1) {
+    if (a.out_mode == SRK_OUT_PLANAR) {
+      // fp32 NCHW behind a PixelShuffle(2): channel k = o*4 + i*2 + j of pixel (gy, gx) is out[n][o][2 gy + i][2 gx + j] (+ post_add[o]); the
+      // collapsed HR stage's 5x5 conv (hr_tail.hip) writes the image this way.  Only the h = 0 lanes hold stored channels (Cout <= 16);
+      // a lane's (j = 0, 1) pair is one 8-byte store, 16 lanes cover 128 contiguous bytes of an output row.
+      const int O = a.Cout >> 2, H2 = 2 * H, W2 = 2 * W;
+      if (h == 0) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          const int gy = y0 + prow[pb], gx = x0 + px;
+          if (gy >= H || gx >= W) continue;
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            if (o >= O) break;
+            const float pa = a.post_add ? a.post_add[o] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              f32x2 v;
+              v.x = acc[0][pb][o * 4 + i * 2] * sc + pa;
+              v.y = acc[0][pb][o * 4 + i * 2 + 1] * sc + pa;
+              *reinterpret_cast<f32x2*>(reinterpret_cast<float*>(a.out) + (((size_t)n * O + o) * H2 + 2 * gy + i) * W2 + 2 * gx) = v;
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb) {
     const int gy = y0 + prow[pb], gx = x0 + px;
@@ -732,10 +760,16 @@ int lk_wgrad_slabs_for(const srk_wgrad_args& a) {
 // 16-bit, K in {5, 7, 9}, plain NHWC in / out, (Cin <= 64, <= 32 output rows) or (16 input channels, 64 rows): srk_conv2d
 bool srk_conv_lk_ok(const srk_conv_args& a) {
   if (a.dtype == SRK_F32 || a.KH != a.KW || a.KH < 5 || a.KH > 9 || !(a.KH & 1)) return false;
-  if (a.x_ps > 1 || a.out_mode != SRK_OUT_NHWC || a.post_add || a.mask) return false;
+  if (a.x_ps > 1 || a.mask) return false;
   const bool fwd = a.Cin == 64 && a.CoutP == 32;
   const bool bwd = a.Cin == 16 && a.CoutP == 64;
   if (!fwd && !bwd) return false;
+  if (a.out_mode == SRK_OUT_PLANAR) {
+    // the image store of the collapsed HR stage: fp32 NCHW behind PixelShuffle(2), <= 16 channels (4 sub-pixels x <= 4 colours)
+    if (!fwd || a.ps_r != 2 || a.res || a.relu || a.Cout % 4 || a.Cout > 16 || a.x_pitch % 8 || a.x_coff % 8) return false;
+    return (long long)a.N * a.H * a.W * a.x_pitch * 2 < 0x7fff0000LL;
+  }
+  if (a.out_mode != SRK_OUT_NHWC || a.post_add) return false;
   if (a.x_pitch % 8 || a.x_coff % 8 || a.out_pitch % 8 || a.out_coff % 8 || a.Cout % 8 || (a.res && (a.res_pitch % 8 || a.res_coff % 8))) return false;
   const long long px = (long long)a.N * a.H * a.W;
   long long mx = px * a.x_pitch;
@@ -791,7 +825,7 @@ template <int DT> static int lk_rows_launch(const srk_conv_args& a, hipStream_t 
 
 int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st) {
   static const bool no_rows = [] { const char* e = getenv("SRK_NO_LK_ROWS"); return e && e[0] == '1'; }();      // A/B knob
-  if (!no_rows && a.Cin == 64 && a.cout_real > 0 && a.cout_real <= 4 && a.cout_real * a.KW <= 32 && a.Cout == 16 && !a.relu && !a.res && a.scale == 1.f)
+  if (!no_rows && a.out_mode == SRK_OUT_NHWC && a.Cin == 64 && a.cout_real > 0 && a.cout_real <= 4 && a.cout_real * a.KW <= 32 && a.Cout == 16 && !a.relu && !a.res && a.scale == 1.f)
     return a.dtype == SRK_BF16 ? lk_rows_launch<SRK_BF16>(a, st) : lk_rows_launch<SRK_F16>(a, st);
   if (a.Cin == 16) return a.dtype == SRK_BF16 ? lk_launch<SRK_BF16, 2, 2>(a, st) : lk_launch<SRK_F16, 2, 2>(a, st);
   return a.dtype == SRK_BF16 ? lk_launch<SRK_BF16, 8, 1>(a, st) : lk_launch<SRK_F16, 8, 1>(a, st);

@@ -214,14 +214,36 @@ class UpscaleBlock(_NCHWContract, nn.Sequential):
     def _cout(self):
         return self[0].in_channels
 
-    def nhwc(self, x):
+    def nhwc(self, x, stop_before_last=False):
+        """stop_before_last: run every stage but the last and return (x, last conv, its PixelShuffle factor) -- the caller
+        (`upscale_tail`) may run that stage and the tail conv as one collapsed 5x5 convolution.  Only without an activation."""
         mods = list(self)
         i = 0
         while i < len(mods):
             conv, ps = mods[i], mods[i + 1]
+            if stop_before_last and i + 2 >= len(mods):
+                return x, conv, ps.upscale_factor
             x = conv.nhwc(x, ps_r=ps.upscale_factor)
             i += 2
             if i < len(mods) and isinstance(mods[i], (nn.PReLU, nn.ReLU)):
                 x = ops.prelu(x, mods[i].weight) if isinstance(mods[i], nn.PReLU) else torch.relu(x)
                 i += 1
         return x
+
+
+def upscale_tail(x, stages, tail, post_add=None):
+    """The upsampler stages `[(conv, ps_r), ...]` followed by the tail conv -> NCHW fp32 image (edsr.py:48-52, rcan.py:102-104,
+    rdn.py:85-95 / 110).  Nothing non-linear sits between the LAST stage and the tail conv, so on the 16-bit path the two run as one
+    5x5 convolution whose weights are built from theirs (`ops.hr_tail`: no C-channel tensor at the output resolution, 8x fewer
+    multiply-adds, same function and gradients up to rounding); everything else -- fp32, other shapes, PixelShuffle(3) -- keeps the
+    layer-by-layer form."""
+    def stage(x, conv, r):
+        return conv.nhwc(x, ps_r=r) if hasattr(conv, "nhwc") else ops.conv(x, conv.weight, conv.bias, ps_r=r)
+    for conv, r in stages[:-1]:
+        x = stage(x, conv, r)
+    if stages:
+        conv, r = stages[-1]
+        if conv.kernel_size == (3, 3) and tail.kernel_size == (3, 3) and ops.hr_tail_ok(x, conv.weight, tail.weight, r):
+            return ops.hr_tail(x, conv.weight, conv.bias, tail.weight, tail.bias, post_add=post_add)
+        x = stage(x, conv, r)
+    return ops.tail_conv(x, tail.weight, tail.bias, post_add=post_add)

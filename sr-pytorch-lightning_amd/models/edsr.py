@@ -4,7 +4,7 @@ from typing import Any
 import torch.nn as nn
 
 from .. import ops
-from .common import DefaultConv2d, MeanShift, ResBlock, UpscaleBlock
+from .common import DefaultConv2d, MeanShift, ResBlock, UpscaleBlock, upscale_tail
 from .srmodel import SRModel
 
 
@@ -35,6 +35,8 @@ class EDSR(SRModel):
             for blk in list(self.body)[:-1]:
                 r = ops.cut(blk.nhwc(r))
             r = self.body[-1].nhwc(r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
-            r = self.tail[0].nhwc(r)                              # upsampler, PixelShuffle fused into the conv store
-            t = self.tail[1]
-            return ops.tail_conv(r, t.weight, t.bias, post_add=self.add_mean.shift() if rgb else None)
+            # upsampler (PixelShuffle = the conv's store addressing) + tail conv + add_mean; the last stage and the tail conv as ONE
+            # collapsed 5x5 convolution on the 16-bit path (common.upscale_tail)
+            up = list(self.tail[0])
+            return upscale_tail(r, [(c, p.upscale_factor) for c, p in zip(up[0::2], up[1::2])], self.tail[1],
+                                post_add=self.add_mean.shift() if rgb else None)

@@ -4,7 +4,7 @@ from typing import Any
 import torch.nn as nn
 
 from .. import ops
-from .common import DefaultConv2d, MeanShift, UpscaleBlock, _NCHWContract
+from .common import DefaultConv2d, MeanShift, UpscaleBlock, _NCHWContract, upscale_tail
 from .srmodel import SRModel
 
 
@@ -99,6 +99,6 @@ class RCAN(SRModel):
             for grp in list(self.body)[:-1]:
                 r = ops.cut(grp.nhwc(r))
             r = self.body[-1].nhwc(r, res=f)
-            r = self.tail[0].nhwc(r)
-            t = self.tail[1]
-            return ops.tail_conv(r, t.weight, t.bias, post_add=self.add_mean.shift() if rgb else None)
+            up = list(self.tail[0])
+            return upscale_tail(r, [(c, p.upscale_factor) for c, p in zip(up[0::2], up[1::2])], self.tail[1],
+                                post_add=self.add_mean.shift() if rgb else None)

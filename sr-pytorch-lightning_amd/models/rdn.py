@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .common import _NCHWContract
+from .common import _NCHWContract, upscale_tail
 from .srmodel import SRModel
 
 
@@ -74,7 +74,4 @@ class RDN(SRModel):
             x = ops.conv(ops.concat_slices(cat, outs), self.GFF[0].weight, self.GFF[0].bias)    # 1x1 over D*G0 channels
             x = ops.conv(x, self.GFF[1].weight, self.GFF[1].bias, res=f1)                  # `x += f__1`
             mods = list(self.UPNet)
-            for conv, ps in zip(mods[0:-1:2], mods[1:-1:2]):
-                x = ops.conv(x, conv.weight, conv.bias, ps_r=ps.upscale_factor)
-            last = mods[-1]
-            return ops.tail_conv(x, last.weight, last.bias)
+            return upscale_tail(x, [(c, p.upscale_factor) for c, p in zip(mods[0:-1:2], mods[1:-1:2])], mods[-1])

@@ -1067,6 +1067,105 @@ def skip_conv(x, w, b, sub, ps_r, dtype):
     return SkipConvFn.apply(x, w, b, sub, int(ps_r), dtype)
 
 
+# --------------------------------------------------------------------------------------------
+# the last upsampling stage + tail conv as one 5x5 convolution (csrc/hr_tail.hip)
+# --------------------------------------------------------------------------------------------
+_HR_COLLAPSE = os.environ.get("SRK_NO_HR_COLLAPSE", "0") != "1"       # A/B knob: 1 = the two layers one after the other
+
+
+def hr_tail_ok(x, wu, wt, ps_r):
+    """Whether `conv3x3(x; wu) -> PixelShuffle(2) -> conv3x3(. ; wt) -> NCHW fp32` runs as ONE collapsed 5x5 convolution: 16-bit
+    storage, 64 input channels (what the direct large-kernel kernels take), <= 4 image channels, both kernels 3x3."""
+    if not _HR_COLLAPSE or int(ps_r) != 2 or x.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    cu, ci, ku, _ = wu.shape
+    o, c, kt, _ = wt.shape
+    if ku != 3 or kt != 3 or cu != 4 * c or ci != 64 or x.shape[3] != 64 or not 1 <= o <= 4:
+        return False
+    n, h, w, _ = x.shape
+    return n > 0 and x.numel() * 2 < _ADDR_LIMIT and n * o * 4 * h * w < (1 << 31)
+
+
+class HrTailFn(torch.autograd.Function):
+    """NHWC features -> NCHW fp32 image: conv3x3(Ci -> 4C) -> PixelShuffle(2) -> conv3x3(C -> O) [+ post_add] as ONE linear map.
+
+    UpscaleBlock's last stage + the tail conv of EDSR / RCAN / RDN (models/common.py:112-139, edsr.py:48-52, rcan.py:102-104,
+    rdn.py:85-95): no activation sits between the two convolutions, so the image is a 5x5 convolution Ci -> 4 O of x whose
+    weights are sums of products of the two layers' weights (include/srk.h, csrc/hr_tail.hip) -- 8x fewer multiply-adds and no
+    C-channel tensor at the doubled resolution, forward or backward.  The parameters of record stay the two layers' own
+    (state_dict unchanged); their gradients come from the chain rule through the collapse, exact up to rounding, border pixels
+    included (the tail conv's zero padding of the shuffled tensor is restored by `srk_hrtail_edge_*`)."""
+
+    @staticmethod
+    def _args(x, wu, bu, wt, bt, bufs, **kw):
+        n, h, w, _ = x.shape
+        o, c = wt.shape[0], wt.shape[1]
+        return L.HrTailArgs(wt=wt.data_ptr(), bt=_ptr(bt), wu=wu.data_ptr(), bu=_ptr(bu), O=o, C=c, Ci=wu.shape[1],
+                            weff=bufs["weff"].data_ptr(), beff=bufs["beff"].data_ptr(), wedge=bufs["wedge"].data_ptr(),
+                            bedge=bufs["bedge"].data_ptr(), wcor=bufs["wcor"].data_ptr(), bcor=bufs["bcor"].data_ptr(),
+                            x=x.data_ptr(), x_pitch=_pitch(x), N=n, H=h, W=w, dtype=_DT[x.dtype], **kw)
+
+    @staticmethod
+    def forward(ctx, x, wu, bu, wt, bt, post_add):
+        _need_gpu(x)
+        n, h, w, ci = x.shape
+        o = wt.shape[0]
+        dev, f32 = x.device, torch.float32
+        wu_, wt_ = _f32c(wu), _f32c(wt)
+        bu_, bt_ = (None if bu is None else _f32c(bu)), (None if bt is None else _f32c(bt))
+        bufs = dict(weff=torch.empty((4 * o, ci, 5, 5), dtype=f32, device=dev), beff=torch.empty(4 * o, dtype=f32, device=dev),
+                    wedge=torch.empty((4, 2 * o, ci, 5), dtype=f32, device=dev), bedge=torch.empty((4, 2 * o), dtype=f32, device=dev),
+                    wcor=torch.empty((4, o, ci), dtype=f32, device=dev), bcor=torch.empty((4, o), dtype=f32, device=dev))
+        L.call("srk_hrtail_collapse", HrTailFn._args(x, wu_, bu_, wt_, bt_, bufs), _stream())
+        pk = pack_conv(bufs["weff"], bufs["beff"], x.dtype, cache=False)
+        out = torch.empty((n, o, 2 * h, 2 * w), dtype=f32, device=dev)
+        conv_raw(x, pk, N=n, H=h, W=w, Cin=ci, Cout=4 * o, out=out, out_mode=L.OUT_PLANAR, ps_r=2, post_add=post_add)
+        L.call("srk_hrtail_edge_fwd", HrTailFn._args(x, wu_, bu_, wt_, bt_, bufs, out=out.data_ptr()), _stream())
+        ctx.save_for_backward(x, wu_, wt_, *( [bu_] if bu_ is not None else []))
+        ctx.has = (bu is not None, bt is not None)
+        ctx.bufs = bufs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wu_, wt_ = ctx.saved_tensors[:3]
+        has_bu, has_bt = ctx.has
+        bu_ = ctx.saved_tensors[3] if has_bu else None
+        bufs = ctx.bufs
+        n, h, w, ci = x.shape
+        o, c = wt_.shape[0], wt_.shape[1]
+        dev, f32 = x.device, torch.float32
+        g = _f32c(g)
+        st = _stream()
+        g12 = to_nhwc(g, x.dtype, ps_r=2)                      # [n, h, w, 16]: channel o*4 + a*2 + b = the un-shuffled gradient
+        need_x = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[1:5])
+        gx = None
+        if need_x:
+            pkd = pack_conv(bufs["weff"], None, x.dtype, dgrad=True, cache=False)
+            gx = torch.empty_like(x)
+            conv_raw(g12, pkd, N=n, H=h, W=w, Cin=g12.shape[3], Cout=ci, out=gx, use_bias=False)
+            L.call("srk_hrtail_edge_bwd_x", HrTailFn._args(x, wu_, bu_, wt_, None, bufs, g=g.data_ptr(), dx=gx.data_ptr(), dx_pitch=_pitch(gx)), st)
+        gwu = gbu = gwt = gbt = None
+        if need_w:
+            r, r0 = wgrad_raw(x, g12, N=n, H=h, W=w, Cin=ci, Cout=g12.shape[3], k=5, w_shape=(4 * o, ci, 5, 5), want_bias=True)
+            red = dict(eedge=torch.empty((4, 2 * o, ci, 5), dtype=f32, device=dev), e0=torch.empty((4, 2 * o), dtype=f32, device=dev),
+                       ecor=torch.empty((4, o, ci), dtype=f32, device=dev), k0=torch.empty((4, o), dtype=f32, device=dev))
+            scratch = torch.empty(int(L.load().srk_hrtail_scratch_floats(n, ci)), dtype=f32, device=dev)
+            ptrs = {k: v.data_ptr() for k, v in red.items()}
+            L.call("srk_hrtail_edge_bwd_w", HrTailFn._args(x, wu_, bu_, wt_, None, bufs, g=g.data_ptr(), scratch=scratch.data_ptr(), **ptrs), st)
+            gwu, gwt = torch.empty_like(wu_), torch.empty_like(wt_)
+            gbu = torch.empty(4 * c, dtype=f32, device=dev) if has_bu else None
+            gbt = torch.empty(o, dtype=f32, device=dev) if has_bt else None
+            L.call("srk_hrtail_expand", HrTailFn._args(x, wu_, bu_, wt_, None, bufs, r=r.data_ptr(), r0=r0.data_ptr(), dwt=gwt.data_ptr(),
+                                                       dbt=_ptr(gbt), dwu=gwu.data_ptr(), dbu=_ptr(gbu), **ptrs), st)
+        return gx, gwu, gbu, gwt, gbt, None
+
+
+def hr_tail(x, wu, bu, wt, bt, *, post_add=None):
+    return HrTailFn.apply(x, wu, bu, wt, bt, post_add)
+
+
 class ConvChainFn(torch.autograd.Function):
     """out = chain(x) * scale + x, chain = conv_1 [ReLU] conv_2 [ReLU] ... conv_L  (residual blocks).
 

@@ -122,6 +122,23 @@ class Adam(torch.optim.Adam):
         if hasattr(self, "_plans"):
             self._plans.pop(len(self.param_groups) - 1, None)
 
+    # -- capture bookkeeping ---------------------------------------------------------------------------
+    def reserve_capture_tables(self):
+        """Call OUTSIDE a capture, right before one: every plan gets the table (device bytes + page-locked staging buffer) the
+        capture will own.  Page-locked allocations (hipHostMalloc) are not capturable, and a capture consumes the spare without
+        a non-capturing step in between to refill it (a re-capture after an lr change in the single-process form, where the
+        optimizer step lives inside the graph)."""
+        for gi, group in enumerate(self.param_groups):
+            plan = self._plan(gi, group)
+            if plan is not None and plan.spare is None:
+                plan.spare = _Table(plan.cap, plan.m.device)
+
+    def release_captured_tables(self):
+        """Call after the graphs that captured this optimizer's step have been destroyed (a re-capture): their tables are
+        unreferenced bytes from then on."""
+        for plan in self._plans.values():
+            plan.captured = []
+
     # -- device table --------------------------------------------------------------------------------
     def _table(self, plan, group):
         """The table this step's launch reads: the eager one (rebuilt / re-pointed when gradient addresses moved), or a
@@ -132,6 +149,8 @@ class Adam(torch.optim.Adam):
         if capturing:
             # owned by this capture and never rewritten: eager steps between replays (a short last batch, validation-time
             # fallbacks) keep using `plan.eager`
+            # (no spare: the caller did not `reserve_capture_tables()`; the page-locked allocation below only succeeds in a
+            # relaxed-mode capture)
             t, plan.spare = (plan.spare or _Table(plan.cap, plan.m.device)), None
             plan.captured.append(t)
         else:

@@ -296,6 +296,8 @@ class GraphedStep:
     def _capture(self, batch):
         self.static = {"lr": batch["lr"].clone(), "hr": batch["hr"].clone()}
         self.hyper = self._hyper()
+        if hasattr(self.opt, "reserve_capture_tables"):
+            self.opt.reserve_capture_tables()    # page-locked staging buffers cannot be allocated inside the capture
         if self.gsync is not None:
             self.gsync.remove_hooks()            # no collective from inside backward any more: pack() / reduce() around the graphs
         side = torch.cuda.Stream()
@@ -325,7 +327,13 @@ class GraphedStep:
                 return self.ogs.eager_step(batch)          # (the buckets were re-cut along the segments: its own eager form)
             return _eager_step(self.model, self.net, self.opt, self.gsync, None, batch)
         if self.graphs is not None and self._hyper() != self.hyper:
-            self.graphs = None                   # lr / betas / ... changed: capture again with the new values
+            # lr / betas / ... changed: capture again with the new values (the old graphs go first, then the tables they read)
+            self.graphs = None
+            if self.ogs is not None:
+                self.ogs.graphs = None
+            if hasattr(self.opt, "release_captured_tables"):
+                torch.cuda.synchronize()
+                self.opt.release_captured_tables()
         if self.graphs is None and self.segments > 1 and self.gsync is not None:
             if self.ogs is None:                 # (two ordinary eager steps: the segments' parameter groups, the re-cut buckets)
                 self.gsync.detach()

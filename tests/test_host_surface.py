@@ -63,7 +63,7 @@ def _header_struct_fields(name):
                                         ("srk_chan_stats_args", "ChanStatsArgs"), ("srk_chan_apply_args", "ChanApplyArgs"),
                                         ("srk_conv_pair_args", "ConvPairArgs"), ("srk_adam_slot", "AdamSlot"),
                                         ("srk_adam_block", "AdamBlock"), ("srk_adam_args", "AdamArgs"), ("srk_rowsum_job", "RowsumJob"),
-                                        ("srk_chan_finalize_args", "ChanFinalizeArgs")])
+                                        ("srk_chan_finalize_args", "ChanFinalizeArgs"), ("srk_hrtail_args", "HrTailArgs")])
 def test_ctypes_structs_mirror_header(cname, cls):
     want = _header_struct_fields(cname)
     st = getattr(sr_amd._lib, cls)

@@ -36,16 +36,17 @@ def asm(tmp_path_factory):
     return out.read_text()
 
 
+@pytest.mark.parametrize("em", [1, 2])
 @pytest.mark.parametrize("nks", [4, 1])
 @pytest.mark.parametrize("dt", [0, 1])
-def test_prefetch_registers_untouched_until_wait(asm, dt, nks):
-    """The same check the Makefile runs as a build gate (csrc/check_isa.py)."""
-    assert check_isa.check_kernel(asm, dt, nks) > 100
+def test_prefetch_registers_untouched_until_wait(asm, dt, nks, em):
+    """The same check the Makefile runs as a build gate (csrc/check_isa.py); em: 1 = residual, 2 = mask prefetch."""
+    assert check_isa.check_kernel(asm, dt, nks, em) > 100
 
 
 def test_gate_rejects_a_touched_register(asm):
     """Plant a read of a prefetch destination between a load and the wait: the gate must fail."""
-    name = "_ZN12_GLOBAL__N_114conv_ws_kernelILi0ELi2ELi4ELb1ELb1EEEv13srk_conv_args"
+    name = check_isa.kernel_name(0, 4, 1)
     start = asm.index(name + "iiiijiiiiiii:")
     body = asm[start:asm.index(".Lfunc_end", start)].split("\n")
     k = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l and " lds" not in l and "ASMSTART" in body[i - 1]][0]
