@@ -43,8 +43,19 @@ struct Wts {
   int O, C, Ci;
 };
 
+// sum of one value per lane over an aligned group of 16 lanes (fixed order), returned in every lane of the group
+SRK_DEV float sum16(float v) {
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+
+// One output element per group of 16 lanes; lane `sub` of the group takes the channels c = sub, sub + 16, ... of the contraction
+// (one thread per output walked 64 x 9 strided products on its own: 121 us for 28k outputs, all of it load latency).
 // sum over the taps d in [dy0, dy1] x [dx0, dx1] of  sum_c Wt[o][c][d] Wu[(c,i,j)][ci][f - s(d)]   (terms whose e = f - s is not a tap drop out)
-SRK_DEV float collapse_w(const Wts& p, int o, int a, int b, int ci, int dy0, int dy1, int dx0, int dx1, int fy, int fx) {
+SRK_DEV float collapse_w(const Wts& p, int sub, int o, int a, int b, int ci, int dy0, int dy1, int dx0, int dx1, int fy, int fx) {
   float acc = 0.f;
   for (int dy = dy0; dy <= dy1; ++dy) {
     int i, sy; sub_of(a, dy, i, sy);
@@ -56,27 +67,24 @@ SRK_DEV float collapse_w(const Wts& p, int o, int a, int b, int ci, int dy0, int
       if (ex < -1 || ex > 1) continue;
       const float* wt = p.wt + (size_t)o * p.C * 9 + (dy + 1) * 3 + (dx + 1);
       const float* wu = p.wu + ((size_t)(i * 2 + j) * p.Ci + ci) * 9 + (ey + 1) * 3 + (ex + 1);
-      float s = 0.f;
-      for (int c = 0; c < p.C; ++c) s += wt[(size_t)c * 9] * wu[(size_t)c * 4 * p.Ci * 9];
-      acc += s;
+      for (int c = sub; c < p.C; c += 16) acc += wt[(size_t)c * 9] * wu[(size_t)c * 4 * p.Ci * 9];
     }
   }
-  return acc;
+  return sum16(acc);
 }
-SRK_DEV float collapse_b(const Wts& p, int o, int a, int b, int dy0, int dy1, int dx0, int dx1) {
-  if (!p.bu) return 0.f;
+SRK_DEV float collapse_b(const Wts& p, int sub, int o, int a, int b, int dy0, int dy1, int dx0, int dx1) {
   float acc = 0.f;
-  for (int dy = dy0; dy <= dy1; ++dy) {
-    int i, sy; sub_of(a, dy, i, sy);
-    for (int dx = dx0; dx <= dx1; ++dx) {
-      int j, sx; sub_of(b, dx, j, sx);
-      const float* wt = p.wt + (size_t)o * p.C * 9 + (dy + 1) * 3 + (dx + 1);
-      float s = 0.f;
-      for (int c = 0; c < p.C; ++c) s += wt[(size_t)c * 9] * p.bu[c * 4 + i * 2 + j];
-      acc += s;
+  if (p.bu) {
+    for (int dy = dy0; dy <= dy1; ++dy) {
+      int i, sy; sub_of(a, dy, i, sy);
+      for (int dx = dx0; dx <= dx1; ++dx) {
+        int j, sx; sub_of(b, dx, j, sx);
+        const float* wt = p.wt + (size_t)o * p.C * 9 + (dy + 1) * 3 + (dx + 1);
+        for (int c = sub; c < p.C; c += 16) acc += wt[(size_t)c * 9] * p.bu[c * 4 + i * 2 + j];
+      }
     }
   }
-  return acc;
+  return sum16(acc);
 }
 
 // edge type 0 top (a = 0, dy = -1), 1 bottom (a = 1, dy = +1): kk = o*2 + b;  2 left (b = 0, dx = -1), 3 right (b = 1, dx = +1): kk = o*2 + a
@@ -86,163 +94,187 @@ __global__ __launch_bounds__(256) void hrtail_collapse_kernel(const srk_hrtail_a
   const int O = a.O, Ci = a.Ci;
   const int n_eff = 4 * O * Ci * 25, n_edge = 4 * 2 * O * Ci * 5, n_cor = 4 * O * Ci;
   const int n_b = 4 * O + 4 * 2 * O + 4 * O;
-  int t = blockIdx.x * 256 + threadIdx.x;
+  const int sub = threadIdx.x & 15;
+  int t = blockIdx.x * 16 + (threadIdx.x >> 4);          // output element of this 16-lane group (uniform in the group: no divergence inside)
+  if (t >= n_eff + n_edge + n_cor + n_b) t = n_eff + n_edge + n_cor + n_b;      // idle groups still take part in the shuffles of their wave
+  float v = 0.f;
+  float* dst = nullptr;
   if (t < n_eff) {
     const int f = t % 25, ci = (t / 25) % Ci, k = t / (25 * Ci);
-    a.weff[t] = collapse_w(p, k >> 2, (k >> 1) & 1, k & 1, ci, -1, 1, -1, 1, f / 5 - 2, f % 5 - 2);
-    return;
-  }
-  t -= n_eff;
-  if (t < n_edge) {
-    const int tt = t % 5, ci = (t / 5) % Ci, kk = (t / (5 * Ci)) % (2 * O), ty = t / (5 * Ci * 2 * O);
+    v = collapse_w(p, sub, k >> 2, (k >> 1) & 1, k & 1, ci, -1, 1, -1, 1, f / 5 - 2, f % 5 - 2);
+    dst = a.weff + t;
+  } else if (t < n_eff + n_edge) {
+    const int u = t - n_eff;
+    const int tt = u % 5, ci = (u / 5) % Ci, kk = (u / (5 * Ci)) % (2 * O), ty = u / (5 * Ci * 2 * O);
     const int o = kk >> 1, q = kk & 1;
-    float v;
-    if (ty == 0) v = collapse_w(p, o, 0, q, ci, -1, -1, -1, 1, 0, tt - 2);
-    else if (ty == 1) v = collapse_w(p, o, 1, q, ci, 1, 1, -1, 1, 0, tt - 2);
-    else if (ty == 2) v = collapse_w(p, o, q, 0, ci, -1, 1, -1, -1, tt - 2, 0);
-    else v = collapse_w(p, o, q, 1, ci, -1, 1, 1, 1, tt - 2, 0);
-    a.wedge[t] = v;
-    return;
-  }
-  t -= n_edge;
-  if (t < n_cor) {
-    const int ci = t % Ci, o = (t / Ci) % O, c = t / (Ci * O);
+    if (ty == 0) v = collapse_w(p, sub, o, 0, q, ci, -1, -1, -1, 1, 0, tt - 2);
+    else if (ty == 1) v = collapse_w(p, sub, o, 1, q, ci, 1, 1, -1, 1, 0, tt - 2);
+    else if (ty == 2) v = collapse_w(p, sub, o, q, 0, ci, -1, 1, -1, -1, tt - 2, 0);
+    else v = collapse_w(p, sub, o, q, 1, ci, -1, 1, 1, 1, tt - 2, 0);
+    dst = a.wedge + u;
+  } else if (t < n_eff + n_edge + n_cor) {
+    const int u = t - n_eff - n_edge;
+    const int ci = u % Ci, o = (u / Ci) % O, c = u / (Ci * O);
     const int ca = c >> 1, cb = c & 1;
-    a.wcor[t] = collapse_w(p, o, ca, cb, ci, ca ? 1 : -1, ca ? 1 : -1, cb ? 1 : -1, cb ? 1 : -1, 0, 0);
-    return;
-  }
-  t -= n_cor;
-  if (t < n_b) {
-    if (t < 4 * O) {
-      const int k = t;
-      a.beff[k] = (a.bt ? a.bt[k >> 2] : 0.f) + collapse_b(p, k >> 2, (k >> 1) & 1, k & 1, -1, 1, -1, 1);
-    } else if (t < 4 * O + 8 * O) {
-      const int u = t - 4 * O, kk = u % (2 * O), ty = u / (2 * O), o = kk >> 1, q = kk & 1;
-      float v;
-      if (ty == 0) v = collapse_b(p, o, 0, q, -1, -1, -1, 1);
-      else if (ty == 1) v = collapse_b(p, o, 1, q, 1, 1, -1, 1);
-      else if (ty == 2) v = collapse_b(p, o, q, 0, -1, 1, -1, -1);
-      else v = collapse_b(p, o, q, 1, -1, 1, 1, 1);
-      a.bedge[u] = v;
+    v = collapse_w(p, sub, o, ca, cb, ci, ca ? 1 : -1, ca ? 1 : -1, cb ? 1 : -1, cb ? 1 : -1, 0, 0);
+    dst = a.wcor + u;
+  } else if (t < n_eff + n_edge + n_cor + n_b) {
+    const int w = t - n_eff - n_edge - n_cor;
+    if (w < 4 * O) {
+      const int k = w;
+      v = (a.bt ? a.bt[k >> 2] : 0.f) + collapse_b(p, sub, k >> 2, (k >> 1) & 1, k & 1, -1, 1, -1, 1);
+      dst = a.beff + k;
+    } else if (w < 4 * O + 8 * O) {
+      const int u = w - 4 * O, kk = u % (2 * O), ty = u / (2 * O), o = kk >> 1, q = kk & 1;
+      if (ty == 0) v = collapse_b(p, sub, o, 0, q, -1, -1, -1, 1);
+      else if (ty == 1) v = collapse_b(p, sub, o, 1, q, 1, 1, -1, 1);
+      else if (ty == 2) v = collapse_b(p, sub, o, q, 0, -1, 1, -1, -1);
+      else v = collapse_b(p, sub, o, q, 1, -1, 1, 1, 1);
+      dst = a.bedge + u;
     } else {
-      const int u = t - 12 * O, o = u % O, c = u / O, ca = c >> 1, cb = c & 1;
-      a.bcor[u] = collapse_b(p, o, ca, cb, ca ? 1 : -1, ca ? 1 : -1, cb ? 1 : -1, cb ? 1 : -1);
+      const int u = w - 12 * O, o = u % O, c = u / O, ca = c >> 1, cb = c & 1;
+      v = collapse_b(p, sub, o, ca, cb, ca ? 1 : -1, ca ? 1 : -1, cb ? 1 : -1, cb ? 1 : -1);
+      dst = a.bcor + u;
     }
   }
+  if (dst && sub == 0) *dst = v;
 }
 
 template <int DT> SRK_DEV float ld_act(const void* base, size_t idx) {
   return DTraits<DT>::to_f32(reinterpret_cast<const typename DTraits<DT>::elem*>(base)[idx]);
 }
 
-// ---- forward: one thread per (image, ring pixel of the 2H x 2W output); all O channels -----------------------------------------
+// ---- border terms, forward and data gradient: one workgroup per (image, edge) ----------------------------------------------------
+// An edge is a LINE of `len` pixels of X (row 0 / H-1 or column 0 / W-1) and the 2 len output pixels beside it; position s along the
+// line, sub-pixel q of the output.  The line of X (fp32, two zero pixels on both ends) and the edge's weights sit in LDS.  Row edges
+// (launch 0) and column edges (launch 1) are separate launches because the four corner pixels belong to one of each -- in sequence
+// their read-modify-writes cannot meet -- and the column launch also applies the corner terms.  (First form: one thread, then one
+// wave per ring pixel, 411 / 242 us forward and 216 us backward at 256 x 96 x 96: ~200k waves of a few dependent round trips each.)
 constexpr int MAXO = 4;
+SRK_DEV float wave_total(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+struct EdgeGeo {
+  int ty, len; bool row;      // edge type, pixels along the line, row edge?
+  int fix_lr, fix_hr;         // the fixed coordinate of the line in X / in the output
+};
+SRK_DEV EdgeGeo edge_geo(int ty, int H, int W) {
+  EdgeGeo e;
+  e.ty = ty; e.row = ty < 2; e.len = e.row ? W : H;
+  e.fix_lr = ty == 0 ? 0 : ty == 1 ? H - 1 : ty == 2 ? 0 : W - 1;
+  e.fix_hr = ty == 0 ? 0 : ty == 1 ? 2 * H - 1 : ty == 2 ? 0 : 2 * W - 1;
+  return e;
+}
+// stage the line of X: Xl[(s + 2) * pitch + ci], s = -2 .. len + 1 (zeros outside)
 template <int DT>
-__global__ __launch_bounds__(256) void hrtail_edge_fwd_kernel(const srk_hrtail_args a, int ring) {
-  const int H = a.H, W = a.W, O = a.O, Ci = a.Ci, H2 = 2 * H, W2 = 2 * W;
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long long)a.N * ring) return;
-  const int n = (int)(t / ring);
-  int r = (int)(t % ring), Py, Px;
-  if (r < W2) { Py = 0; Px = r; }
-  else if (r < 2 * W2) { Py = H2 - 1; Px = r - W2; }
-  else { r -= 2 * W2; if (r < H2 - 2) { Py = 1 + r; Px = 0; } else { Py = 1 + r - (H2 - 2); Px = W2 - 1; } }
-  const int y = Py >> 1, pa = Py & 1, x = Px >> 1, pb = Px & 1;
-  const bool top = Py == 0, bot = Py == H2 - 1, left = Px == 0, right = Px == W2 - 1;
-  float corr[MAXO];
-#pragma unroll
-  for (int o = 0; o < MAXO; ++o) corr[o] = 0.f;
-  const size_t xn = (size_t)n * H * W;
-  for (int e = 0; e < 2; ++e) {                 // e = 0: the row edge of this pixel (if any), e = 1: its column edge
-    const int ty = e == 0 ? (top ? 0 : (bot ? 1 : -1)) : (left ? 2 : (right ? 3 : -1));
-    if (ty < 0) continue;
-    const int q = e == 0 ? pb : pa;             // the free sub-pixel index of kk
-    for (int tt = 0; tt < 5; ++tt) {
-      const int yy = e == 0 ? y : y + tt - 2, xx = e == 0 ? x + tt - 2 : x;
-      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-      const size_t px = (xn + (size_t)yy * W + xx) * a.x_pitch;
-      for (int ci = 0; ci < Ci; ++ci) {
-        const float xv = ld_act<DT>(a.x, px + ci);
-#pragma unroll
-        for (int o = 0; o < MAXO; ++o)
-          if (o < O) corr[o] += a.wedge[(((size_t)ty * 2 * O + o * 2 + q) * Ci + ci) * 5 + tt] * xv;
-      }
+SRK_DEV void stage_line(const srk_hrtail_args& a, const EdgeGeo& e, int n, float* Xl, int pitch) {
+  const int Ci = a.Ci;
+  for (int i = threadIdx.x; i < (e.len + 4) * Ci; i += 256) {
+    const int s = i / Ci - 2, ci = i % Ci;
+    float v = 0.f;
+    if (s >= 0 && s < e.len) {
+      const int yy = e.row ? e.fix_lr : s, xx = e.row ? s : e.fix_lr;
+      v = ld_act<DT>(a.x, ((size_t)(n * a.H + yy) * a.W + xx) * a.x_pitch + ci);
     }
-#pragma unroll
-    for (int o = 0; o < MAXO; ++o)
-      if (o < O) corr[o] += a.bedge[ty * 2 * O + o * 2 + q];
+    Xl[(s + 2) * pitch + ci] = v;
   }
-  if ((top || bot) && (left || right)) {
-    const int c = pa * 2 + pb;                  // top-left: (a, b) = (0, 0) ...
-    const size_t px = (xn + (size_t)y * W + x) * a.x_pitch;
-    for (int ci = 0; ci < Ci; ++ci) {
-      const float xv = ld_act<DT>(a.x, px + ci);
-#pragma unroll
-      for (int o = 0; o < MAXO; ++o)
-        if (o < O) corr[o] -= a.wcor[((size_t)c * O + o) * Ci + ci] * xv;
-    }
-#pragma unroll
-    for (int o = 0; o < MAXO; ++o)
-      if (o < O) corr[o] -= a.bcor[c * O + o];
-  }
-#pragma unroll
-  for (int o = 0; o < MAXO; ++o)
-    if (o < O) a.out[(((size_t)n * O + o) * H2 + Py) * W2 + Px] -= corr[o];
 }
 
-// ---- data gradient: one wave per (image, ring pixel of X), lane = input channel (+64 per pass) ---------------------------------
 template <int DT>
-__global__ __launch_bounds__(256) void hrtail_edge_bwd_x_kernel(const srk_hrtail_args a, int ring) {
+__global__ __launch_bounds__(256) void hrtail_edge_fwd_kernel(const srk_hrtail_args a, int phase) {
+  const int H = a.H, W = a.W, O = a.O, Ci = a.Ci, H2 = 2 * H, W2 = 2 * W;
+  const int n = blockIdx.x;
+  const EdgeGeo e = edge_geo(2 * phase + blockIdx.y, H, W);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int pitch = Ci + 1;                                        // consecutive pixels in consecutive banks
+  float* const Xl = reinterpret_cast<float*>(smem_raw);           // [len + 4][Ci + 1]
+  float* const Wl = Xl + (size_t)(e.len + 4) * pitch;             // [2 O][Ci][5]
+  stage_line<DT>(a, e, n, Xl, pitch);
+  for (int i = threadIdx.x; i < 2 * O * Ci * 5; i += 256) Wl[i] = a.wedge[(size_t)e.ty * 2 * O * Ci * 5 + i];
+  __syncthreads();
+  const size_t oplane = (size_t)H2 * W2;
+  float* const out = a.out + (size_t)n * O * oplane;
+  for (int idx = threadIdx.x; idx < 2 * e.len * O; idx += 256) {
+    const int p = idx % (2 * e.len), o = idx / (2 * e.len);        // consecutive threads: consecutive output pixels of one colour
+    const int s = p >> 1, q = p & 1;
+    const float* const w = Wl + (size_t)(o * 2 + q) * Ci * 5;
+    const float* const x = Xl + (size_t)s * pitch;                 // tap tt reads pixel s + tt - 2 = Xl row s + tt
+    float acc = a.bedge[e.ty * 2 * O + o * 2 + q];
+    for (int ci = 0; ci < Ci; ++ci) {
+#pragma unroll
+      for (int tt = 0; tt < 5; ++tt) acc += w[ci * 5 + tt] * x[tt * pitch + ci];
+    }
+    if (!e.row && (p == 0 || p == 2 * e.len - 1)) {
+      // corner output pixel (column launch): give back the tap both of its edges removed
+      const int ca = p == 0 ? 0 : 1, cb = e.ty == 2 ? 0 : 1, c = ca * 2 + cb;
+      float cc = a.bcor[c * O + o];
+      const float* const xc = Xl + (size_t)(s + 2) * pitch;
+      for (int ci = 0; ci < Ci; ++ci) cc += a.wcor[((size_t)c * O + o) * Ci + ci] * xc[ci];
+      acc -= cc;
+    }
+    const size_t at = e.row ? (size_t)e.fix_hr * W2 + p : (size_t)p * W2 + e.fix_hr;
+    out[(size_t)o * oplane + at] -= acc;
+  }
+}
+
+// data gradient: dX[line pixel s'][ci] -= sum_{kk, tt} wedge[kk][ci][tt] g[kk][s' - (tt - 2)]  (+ the corner term in the column launch)
+template <int DT>
+__global__ __launch_bounds__(256) void hrtail_edge_bwd_x_kernel(const srk_hrtail_args a, int phase) {
   typedef DTraits<DT> Tr;
   const int H = a.H, W = a.W, O = a.O, Ci = a.Ci, H2 = 2 * H, W2 = 2 * W;
-  const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wv >= (long long)a.N * ring) return;
-  const int lane = threadIdx.x & 63;
-  const int n = (int)(wv / ring);
-  int r = (int)(wv % ring), y, x;
-  // ring of the H x W grid: row 0, row H-1 (if H > 1), then column 0 and column W-1 (if W > 1) of rows 1 .. H-2
-  if (r < W) { y = 0; x = r; }
-  else if (H > 1 && r < 2 * W) { y = H - 1; x = r - W; }
-  else { r -= (H > 1 ? 2 : 1) * W; if (r < H - 2) { y = 1 + r; x = 0; } else { y = 1 + r - (H - 2); x = W - 1; } }
+  const int n = blockIdx.x;
+  // a 1-pixel-high (wide) image: both row (column) edges are the SAME line of dX -- one workgroup takes them one after the other
+  const bool shared_line = phase == 0 ? H == 1 : W == 1;
+  if (shared_line && blockIdx.y == 1) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const size_t gplane = (size_t)H2 * W2;
   const float* const g = a.g + (size_t)n * O * gplane;
-  for (int ci = lane; ci < Ci; ci += 64) {
+  for (int rep = 0; rep < (shared_line ? 2 : 1); ++rep) {
+  const EdgeGeo e = edge_geo(2 * phase + (shared_line ? rep : (int)blockIdx.y), H, W);
+  float* const Gl = reinterpret_cast<float*>(smem_raw);           // [2 O][len + 4]: g of sub-pixel row kk along the line, zeros outside
+  float* const Wl = Gl + (size_t)2 * O * (e.len + 4);             // [2 O][Ci][5]
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * O * (e.len + 4); i += 256) {
+    const int kk = i / (e.len + 4), s = i % (e.len + 4) - 2, o = kk >> 1, q = kk & 1;
+    float v = 0.f;
+    if (s >= 0 && s < e.len) v = e.row ? g[(size_t)o * gplane + (size_t)e.fix_hr * W2 + 2 * s + q] : g[(size_t)o * gplane + (size_t)(2 * s + q) * W2 + e.fix_hr];
+    Gl[i] = v;
+  }
+  for (int i = threadIdx.x; i < 2 * O * Ci * 5; i += 256) Wl[i] = a.wedge[(size_t)e.ty * 2 * O * Ci * 5 + i];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < e.len * Ci; idx += 256) {
+    const int ci = idx % Ci, s = idx / Ci;
     float corr = 0.f;
-    for (int e = 0; e < 2; ++e) {               // row edges (0: top, 1: bottom), both can hold when H == 1
-      if (!(e == 0 ? y == 0 : y == H - 1)) continue;
-      const int Py = e == 0 ? 0 : H2 - 1;
-      for (int tt = 0; tt < 5; ++tt) {
-        const int xs = x - (tt - 2);            // the edge pixel whose tap tt reads this pixel
-        if (xs < 0 || xs >= W) continue;
-        for (int kk = 0; kk < 2 * O; ++kk)
-          corr += a.wedge[(((size_t)e * 2 * O + kk) * Ci + ci) * 5 + tt] * g[(size_t)(kk >> 1) * gplane + (size_t)Py * W2 + 2 * xs + (kk & 1)];
+    for (int kk = 0; kk < 2 * O; ++kk) {
+      const float* const w = Wl + ((size_t)kk * Ci + ci) * 5;
+      const float* const gl = Gl + (size_t)kk * (e.len + 4) + s + 2;      // the edge pixel whose tap tt reads pixel s: s - (tt - 2)
+#pragma unroll
+      for (int tt = 0; tt < 5; ++tt) corr += w[tt] * gl[2 - tt];
+    }
+    if (!e.row && (s == 0 || s == e.len - 1)) {
+      for (int ca = 0; ca < 2; ++ca) {                               // (H == 1: the pixel is the top AND the bottom corner)
+        if (!(ca ? s == e.len - 1 : s == 0)) continue;
+        const int cb = e.ty == 2 ? 0 : 1, c = ca * 2 + cb;
+        const size_t at = (size_t)(ca ? H2 - 1 : 0) * W2 + e.fix_hr;
+        for (int o = 0; o < O; ++o) corr -= a.wcor[((size_t)c * O + o) * Ci + ci] * g[(size_t)o * gplane + at];
       }
     }
-    for (int e = 0; e < 2; ++e) {               // column edges (2: left, 3: right)
-      if (!(e == 0 ? x == 0 : x == W - 1)) continue;
-      const int Px = e == 0 ? 0 : W2 - 1;
-      for (int tt = 0; tt < 5; ++tt) {
-        const int ys = y - (tt - 2);
-        if (ys < 0 || ys >= H) continue;
-        for (int kk = 0; kk < 2 * O; ++kk)
-          corr += a.wedge[(((size_t)(2 + e) * 2 * O + kk) * Ci + ci) * 5 + tt] * g[(size_t)(kk >> 1) * gplane + (size_t)(2 * ys + (kk & 1)) * W2 + Px];
-      }
-    }
-    for (int c = 0; c < 4; ++c) {               // corners: this pixel IS the corner pixel (the corner term has the single tap f = 0)
-      const int ca = c >> 1, cb = c & 1;
-      if ((ca ? y == H - 1 : y == 0) && (cb ? x == W - 1 : x == 0)) {
-        const int Py = ca ? H2 - 1 : 0, Px = cb ? W2 - 1 : 0;
-        for (int o = 0; o < O; ++o) corr -= a.wcor[((size_t)c * O + o) * Ci + ci] * g[(size_t)o * gplane + (size_t)Py * W2 + Px];
-      }
-    }
-    typename Tr::elem* const d = reinterpret_cast<typename Tr::elem*>(a.dx) + ((size_t)(n * H + y) * W + x) * a.dx_pitch + ci;
+    const int yy = e.row ? e.fix_lr : s, xx = e.row ? s : e.fix_lr;
+    typename Tr::elem* const d = reinterpret_cast<typename Tr::elem*>(a.dx) + ((size_t)(n * H + yy) * W + xx) * a.dx_pitch + ci;
     *d = Tr::from_f32(Tr::to_f32(*d) - corr);
+  }
   }
 }
 
 // ---- weight-gradient side: correlations of g and X restricted to one edge (types 0..3: 2 O x 5 combos) or one corner (types 4..7:
-// O combos), summed over a chunk of images by one workgroup; thread = (input channel, combo group) ----------------------------------
-constexpr int EW_CHUNK = 1;         // images per workgroup (2048 workgroups at 256 images: the loops are latency-bound)
+// O combos).  One workgroup per (type, chunk of EW_CHUNK images): per image the edge's row / column of X (fp32, zero-padded by two
+// pixels on both sides) and its 2 O rows of g go to LDS, then thread (ci, combo group) walks them.  Column Ci of a combo row holds
+// the sum of g alone (the bias terms; kept once, under the centre tap).  Partial sums per chunk; a second launch adds the chunks in a
+// fixed order (reproducible). ------------------------------------------------------------------------------------------------------------
+constexpr int EW_CHUNK = 2;          // images per workgroup
+constexpr int EW_MAXLEN = 512;       // longest edge the LDS staging takes (longer: the direct-from-memory loop)
 template <int DT>
 __global__ __launch_bounds__(256) void hrtail_edge_bwd_w_kernel(const srk_hrtail_args a, int nchunks) {
   const int H = a.H, W = a.W, O = a.O, Ci = a.Ci, H2 = 2 * H, W2 = 2 * W;
@@ -250,48 +282,81 @@ __global__ __launch_bounds__(256) void hrtail_edge_bwd_w_kernel(const srk_hrtail
   const int n0 = chunk * EW_CHUNK, n1 = min(a.N, n0 + EW_CHUNK);
   const int ncombo = ty < 4 ? 2 * O * 5 : O;
   const size_t gplane = (size_t)H2 * W2;
-  // scratch row of this (type, chunk): [ncombo][Ci + 1] (the last column: the sums of g alone, for the bias terms)
   float* const dst = a.scratch + ((size_t)ty * nchunks + chunk) * (size_t)(2 * MAXO * 5) * (Ci + 1);
-  for (int item = threadIdx.x; item < ncombo * (Ci + 1); item += 256) {
-    const int ci = item % (Ci + 1), cb = item / (Ci + 1);
-    float acc = 0.f;
-    if (ty < 4) {
-      const int tt = cb % 5, kk = cb / 5, o = kk >> 1, q = kk & 1;
-      const bool rowedge = ty < 2;
-      const int len = rowedge ? W : H;
-      if (ci == Ci && tt != 2) { dst[item] = 0.f; continue; }        // the g-only sums are kept once (under the centre tap)
-      for (int n = n0; n < n1; ++n) {
-        const float* const g = a.g + ((size_t)n * O + o) * gplane;
-        for (int s = 0; s < len; ++s) {
-          const int sx = s + tt - 2;
-          if (ci < Ci && (sx < 0 || sx >= len)) continue;
-          float gv, xv = 1.f;
-          if (rowedge) {
-            const int Py = ty == 0 ? 0 : H2 - 1, yy = ty == 0 ? 0 : H - 1;
-            gv = g[(size_t)Py * W2 + 2 * s + q];
-            if (ci < Ci) xv = ld_act<DT>(a.x, ((size_t)(n * H + yy) * W + sx) * a.x_pitch + ci);
-          } else {
-            const int Px = ty == 2 ? 0 : W2 - 1, xx = ty == 2 ? 0 : W - 1;
-            gv = g[(size_t)(2 * s + q) * W2 + Px];
-            if (ci < Ci) xv = ld_act<DT>(a.x, ((size_t)(n * H + sx) * W + xx) * a.x_pitch + ci);
-          }
-          acc += gv * xv;
-        }
-      }
-    } else {
-      const int c = ty - 4, ca = c >> 1, cbb = c & 1, o = cb;
-      const int Py = ca ? H2 - 1 : 0, Px = cbb ? W2 - 1 : 0, yy = ca ? H - 1 : 0, xx = cbb ? W - 1 : 0;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const Xl = reinterpret_cast<float*>(smem_raw);          // [len + 4][Ci]
+  if (ty >= 4) {
+    const int c = ty - 4, ca = c >> 1, cbb = c & 1;
+    const int Py = ca ? H2 - 1 : 0, Px = cbb ? W2 - 1 : 0, yy = ca ? H - 1 : 0, xx = cbb ? W - 1 : 0;
+    for (int item = threadIdx.x; item < ncombo * (Ci + 1); item += 256) {
+      const int ci = item % (Ci + 1), o = item / (Ci + 1);
+      float acc = 0.f;
       for (int n = n0; n < n1; ++n) {
         const float gv = a.g[((size_t)n * O + o) * gplane + (size_t)Py * W2 + Px];
         const float xv = ci < Ci ? ld_act<DT>(a.x, ((size_t)(n * H + yy) * W + xx) * a.x_pitch + ci) : 1.f;
         acc += gv * xv;
       }
+      dst[item] = acc;
     }
-    dst[item] = acc;
+    return;
+  }
+  const bool rowedge = ty < 2;
+  const int len = rowedge ? W : H;
+  float* const Gl = Xl + (size_t)(len + 4) * Ci;                  // [2 O][len]
+  // thread -> items: ci = tid % (Ci + 1) would not divide 256; walk items as (combo, ci) pairs with a fixed per-thread set instead
+  constexpr int MAXIT = (2 * MAXO * 5 * 65 + 255) / 256;          // items per thread for Ci = 64 (larger Ci: the loop below just runs longer)
+  const int nitems = ncombo * (Ci + 1);
+  float acc[MAXIT];
+#pragma unroll
+  for (int k = 0; k < MAXIT; ++k) acc[k] = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < (len + 4) * Ci; i += 256) {
+      const int s = i / Ci - 2, ci = i % Ci;
+      float v = 0.f;
+      if (s >= 0 && s < len) {
+        const int yy = rowedge ? (ty == 0 ? 0 : H - 1) : s, xx = rowedge ? s : (ty == 2 ? 0 : W - 1);
+        v = ld_act<DT>(a.x, ((size_t)(n * H + yy) * W + xx) * a.x_pitch + ci);
+      }
+      Xl[i] = v;
+    }
+    for (int i = threadIdx.x; i < 2 * O * len; i += 256) {
+      const int kk = i / len, s = i % len, o = kk >> 1, q = kk & 1;
+      const float* const g = a.g + ((size_t)n * O + o) * gplane;
+      Gl[i] = rowedge ? g[(size_t)(ty == 0 ? 0 : H2 - 1) * W2 + 2 * s + q] : g[(size_t)(2 * s + q) * W2 + (ty == 2 ? 0 : W2 - 1)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k) {
+      const int item = threadIdx.x + k * 256;
+      if (item >= nitems) break;
+      const int ci = item % (Ci + 1), cb = item / (Ci + 1), tt = cb % 5, kk = cb / 5;
+      const float* const gr = Gl + kk * len;
+      // four interleaved partial sums (fixed order): the dependent add chain, not the LDS reads, paced the single-sum form
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      int p = 0;
+      if (ci < Ci) {
+        const float* const xr = Xl + (size_t)tt * Ci + ci;        // X[s + tt - 2] = Xl[(s + tt) * Ci + ci]
+        for (; p + 3 < len; p += 4) {
+          t0 += gr[p] * xr[(size_t)p * Ci]; t1 += gr[p + 1] * xr[(size_t)(p + 1) * Ci];
+          t2 += gr[p + 2] * xr[(size_t)(p + 2) * Ci]; t3 += gr[p + 3] * xr[(size_t)(p + 3) * Ci];
+        }
+        for (; p < len; ++p) t0 += gr[p] * xr[(size_t)p * Ci];
+      } else if (tt == 2) {
+        for (; p + 3 < len; p += 4) { t0 += gr[p]; t1 += gr[p + 1]; t2 += gr[p + 2]; t3 += gr[p + 3]; }
+        for (; p < len; ++p) t0 += gr[p];
+      }
+      acc[k] += (t0 + t1) + (t2 + t3);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXIT; ++k) {
+    const int item = threadIdx.x + k * 256;
+    if (item < nitems) dst[item] = acc[k];
   }
 }
 
-// chunk partials -> eedge / e0 / ecor / k0 (fixed order: reproducible)
+// chunk partials -> eedge / e0 / ecor / k0 (fixed order: four interleaved partial sums, then their sum: reproducible)
 __global__ __launch_bounds__(256) void hrtail_edge_reduce_kernel(const srk_hrtail_args a, int nchunks) {
   const int O = a.O, Ci = a.Ci;
   const int per = 2 * MAXO * 5 * (Ci + 1);
@@ -301,8 +366,14 @@ __global__ __launch_bounds__(256) void hrtail_edge_reduce_kernel(const srk_hrtai
   int ty, item;
   if (t < n_edge) { ty = t / (2 * O * 5 * (Ci + 1)); item = t % (2 * O * 5 * (Ci + 1)); }
   else { const int u = t - n_edge; ty = 4 + u / (O * (Ci + 1)); item = u % (O * (Ci + 1)); }
-  float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += a.scratch[((size_t)ty * nchunks + c) * per + item];
+  const float* const src = a.scratch + (size_t)ty * nchunks * per + item;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 3 < nchunks; c += 4) {
+    s0 += src[(size_t)c * per]; s1 += src[(size_t)(c + 1) * per]; s2 += src[(size_t)(c + 2) * per]; s3 += src[(size_t)(c + 3) * per];
+  }
+  for (; c < nchunks; ++c) s0 += src[(size_t)c * per];
+  const float s = (s0 + s1) + (s2 + s3);
   const int ci = item % (Ci + 1), cb = item / (Ci + 1);
   if (ty < 4) {
     const int tt = cb % 5, kk = cb / 5;
@@ -339,10 +410,36 @@ SRK_DEV float g_b(const Gr& q, int o, int a, int b, int dy, int dx) {
   return v;
 }
 
+// dWu / dbu / dbt: one thread per element (27 O terms each).  dWt: one WAVE per element, lane = input channel (4 x Ci x 9 terms each:
+// as one thread per element this was 240 of the launch's 361 us on 27 waves).
 __global__ __launch_bounds__(256) void hrtail_expand_kernel(const srk_hrtail_args a) {
   const Gr q{a.r, a.r0, a.eedge, a.e0, a.ecor, a.k0, a.O, a.Ci};
   const int O = a.O, C = a.C, Ci = a.Ci;
-  const int n_wu = 4 * C * Ci * 9, n_bu = 4 * C, n_wt = O * C * 9, n_bt = O;
+  const int n_wu = 4 * C * Ci * 9, n_bu = 4 * C, n_bt = O;
+  const int nb_thread = (n_wu + n_bu + n_bt + 255) / 256;         // blocks of the per-thread part; the rest: 4 dWt elements per block
+  if ((int)blockIdx.x >= nb_thread) {
+    const int t = ((int)blockIdx.x - nb_thread) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= O * C * 9) return;
+    // dWt[o][c][d] = sum_{a,b} ( sum_{ci,e} G(a,b,d)[o][ci][s+e] Wu[(c,i,j)][ci][e]  +  Gb(a,b,d)[o] bu[(c,i,j)] )
+    const int d = t % 9, c = (t / 9) % C, o = t / (9 * C);
+    const int dy = d / 3 - 1, dx = d % 3 - 1;
+    float acc = 0.f;
+    for (int pa = 0; pa < 2; ++pa) {
+      int i, sy; sub_of(pa, dy, i, sy);
+      for (int pb = 0; pb < 2; ++pb) {
+        int j, sx; sub_of(pb, dx, j, sx);
+        const int cu = c * 4 + i * 2 + j;
+        if (a.bu && lane == 0) acc += g_b(q, o, pa, pb, dy, dx) * a.bu[cu];
+        for (int ci = lane; ci < Ci; ci += 64)
+#pragma unroll
+          for (int e = 0; e < 9; ++e)
+            acc += g_w(q, o, pa, pb, dy, dx, ci, sy + e / 3 - 1, sx + e % 3 - 1) * a.wu[((size_t)cu * Ci + ci) * 9 + e];
+      }
+    }
+    acc = wave_total(acc);
+    if (lane == 0) a.dwt[t] = acc;
+    return;
+  }
   int t = blockIdx.x * 256 + threadIdx.x;
   if (t < n_wu) {
     // dWu[(c,i,j)][ci][e] = sum over the (a, dy) that land on sub-pixel i, the (b, dx) on j, and o of  Wt[o][c][d] G(a,b,d)[o][ci][s+e]
@@ -384,26 +481,6 @@ __global__ __launch_bounds__(256) void hrtail_expand_kernel(const srk_hrtail_arg
     return;
   }
   t -= n_bu;
-  if (t < n_wt) {
-    // dWt[o][c][d] = sum_{a,b} ( sum_{ci,e} G(a,b,d)[o][ci][s+e] Wu[(c,i,j)][ci][e]  +  Gb(a,b,d)[o] bu[(c,i,j)] )
-    const int d = t % 9, c = (t / 9) % C, o = t / (9 * C);
-    const int dy = d / 3 - 1, dx = d % 3 - 1;
-    float acc = 0.f;
-    for (int pa = 0; pa < 2; ++pa) {
-      int i, sy; sub_of(pa, dy, i, sy);
-      for (int pb = 0; pb < 2; ++pb) {
-        int j, sx; sub_of(pb, dx, j, sx);
-        const int cu = c * 4 + i * 2 + j;
-        if (a.bu) acc += g_b(q, o, pa, pb, dy, dx) * a.bu[cu];
-        for (int ci = 0; ci < Ci; ++ci)
-          for (int e = 0; e < 9; ++e)
-            acc += g_w(q, o, pa, pb, dy, dx, ci, sy + e / 3 - 1, sx + e % 3 - 1) * a.wu[((size_t)cu * Ci + ci) * 9 + e];
-      }
-    }
-    a.dwt[t] = acc;
-    return;
-  }
-  t -= n_wt;
   if (t < n_bt && a.dbt) a.dbt[t] = a.r0[t * 4] + a.r0[t * 4 + 1] + a.r0[t * 4 + 2] + a.r0[t * 4 + 3];
 }
 
@@ -418,17 +495,21 @@ int check_act(const srk_hrtail_args* a, const char* who) {
   SRK_CHECK_ARG((long long)a->N * a->O * 4 * a->H * a->W < (1ll << 31), "%s: output too large", who);
   return 0;
 }
-int out_ring(int H, int W) { return 2 * (2 * W) + 2 * (2 * H - 2); }
-int in_ring(int H, int W) { return (H > 1 ? 2 : 1) * W + (W > 1 ? 2 : 1) * (H > 2 ? H - 2 : 0); }
 
 }  // namespace
 
 extern "C" int srk_hrtail_collapse(const srk_hrtail_args* a, srk_stream_t stream) {
   if (int rc = check_common(a, "srk_hrtail_collapse")) return rc;
   SRK_CHECK_ARG(a->wt && a->wu && a->weff && a->beff && a->wedge && a->bedge && a->wcor && a->bcor, "srk_hrtail_collapse: null pointer");
-  const int total = 4 * a->O * a->Ci * 25 + 4 * 2 * a->O * a->Ci * 5 + 4 * a->O * a->Ci + 16 * a->O;
-  hipLaunchKernelGGL(hrtail_collapse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  const int total = 4 * a->O * a->Ci * 25 + 4 * 2 * a->O * a->Ci * 5 + 4 * a->O * a->Ci + 16 * a->O;      // outputs: 16 per workgroup
+  hipLaunchKernelGGL(hrtail_collapse_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
   SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename K> static int edge_lds_attr(K kernel, const char* who) {
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { srk_set_error("%s: cannot reserve LDS: %s", who, hipGetErrorString(e)); return (int)e; }
   return 0;
 }
 
@@ -436,12 +517,18 @@ extern "C" int srk_hrtail_edge_fwd(const srk_hrtail_args* a, srk_stream_t stream
   if (int rc = check_common(a, "srk_hrtail_edge_fwd")) return rc;
   if (int rc = check_act(a, "srk_hrtail_edge_fwd")) return rc;
   SRK_CHECK_ARG(a->x && a->out && a->wedge && a->bedge && a->wcor && a->bcor, "srk_hrtail_edge_fwd: null pointer");
-  const int ring = out_ring(a->H, a->W);
-  const long long total = (long long)a->N * ring;
+  const int len = a->H > a->W ? a->H : a->W;
+  const size_t lds = ((size_t)(len + 4) * (a->Ci + 1) + (size_t)2 * a->O * a->Ci * 5) * 4;
+  SRK_CHECK_ARG(lds <= 160 * 1024, "srk_hrtail_edge_fwd: edge of %d pixels x %d channels does not fit the LDS", len, a->Ci);
+  static const int rc0 = edge_lds_attr(&hrtail_edge_fwd_kernel<SRK_BF16>, "srk_hrtail_edge_fwd");
+  static const int rc1 = edge_lds_attr(&hrtail_edge_fwd_kernel<SRK_F16>, "srk_hrtail_edge_fwd");
+  if (rc0 || rc1) return rc0 ? rc0 : rc1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_fwd_kernel<SRK_BF16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *a, ring);
-  else hipLaunchKernelGGL(hrtail_edge_fwd_kernel<SRK_F16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *a, ring);
-  SRK_LAUNCH_CHECK();
+  for (int phase = 0; phase < 2; ++phase) {      // row edges, then column edges + corners (see the kernel)
+    if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_fwd_kernel<SRK_BF16>, dim3((unsigned)a->N, 2), dim3(256), lds, st, *a, phase);
+    else hipLaunchKernelGGL(hrtail_edge_fwd_kernel<SRK_F16>, dim3((unsigned)a->N, 2), dim3(256), lds, st, *a, phase);
+    SRK_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -449,12 +536,18 @@ extern "C" int srk_hrtail_edge_bwd_x(const srk_hrtail_args* a, srk_stream_t stre
   if (int rc = check_common(a, "srk_hrtail_edge_bwd_x")) return rc;
   if (int rc = check_act(a, "srk_hrtail_edge_bwd_x")) return rc;
   SRK_CHECK_ARG(a->g && a->dx && a->wedge && a->wcor, "srk_hrtail_edge_bwd_x: null pointer");
-  const int ring = in_ring(a->H, a->W);
-  const long long waves = (long long)a->N * ring;
+  const int len = a->H > a->W ? a->H : a->W;
+  const size_t lds = ((size_t)2 * a->O * (len + 4) + (size_t)2 * a->O * a->Ci * 5) * 4;
+  SRK_CHECK_ARG(lds <= 160 * 1024, "srk_hrtail_edge_bwd_x: edge of %d pixels does not fit the LDS", len);
+  static const int rc0 = edge_lds_attr(&hrtail_edge_bwd_x_kernel<SRK_BF16>, "srk_hrtail_edge_bwd_x");
+  static const int rc1 = edge_lds_attr(&hrtail_edge_bwd_x_kernel<SRK_F16>, "srk_hrtail_edge_bwd_x");
+  if (rc0 || rc1) return rc0 ? rc0 : rc1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_bwd_x_kernel<SRK_BF16>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *a, ring);
-  else hipLaunchKernelGGL(hrtail_edge_bwd_x_kernel<SRK_F16>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, *a, ring);
-  SRK_LAUNCH_CHECK();
+  for (int phase = 0; phase < 2; ++phase) {
+    if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_bwd_x_kernel<SRK_BF16>, dim3((unsigned)a->N, 2), dim3(256), lds, st, *a, phase);
+    else hipLaunchKernelGGL(hrtail_edge_bwd_x_kernel<SRK_F16>, dim3((unsigned)a->N, 2), dim3(256), lds, st, *a, phase);
+    SRK_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -468,9 +561,15 @@ extern "C" int srk_hrtail_edge_bwd_w(const srk_hrtail_args* a, srk_stream_t stre
   if (int rc = check_act(a, "srk_hrtail_edge_bwd_w")) return rc;
   SRK_CHECK_ARG(a->x && a->g && a->scratch && a->eedge && a->e0 && a->ecor && a->k0, "srk_hrtail_edge_bwd_w: null pointer");
   const int nchunks = (a->N + EW_CHUNK - 1) / EW_CHUNK;
+  const int len = a->H > a->W ? a->H : a->W;
+  SRK_CHECK_ARG(a->Ci <= 64 && len <= EW_MAXLEN, "srk_hrtail_edge_bwd_w: Ci=%d (<= 64) edge length %d (<= %d)", a->Ci, len, EW_MAXLEN);
+  const size_t lds = ((size_t)(len + 4) * a->Ci + (size_t)2 * a->O * len) * 4;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_bwd_w_kernel<SRK_BF16>, dim3((unsigned)nchunks, 8), dim3(256), 0, st, *a, nchunks);
-  else hipLaunchKernelGGL(hrtail_edge_bwd_w_kernel<SRK_F16>, dim3((unsigned)nchunks, 8), dim3(256), 0, st, *a, nchunks);
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&hrtail_edge_bwd_w_kernel<SRK_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&hrtail_edge_bwd_w_kernel<SRK_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr0 != hipSuccess || attr1 != hipSuccess) { srk_set_error("srk_hrtail_edge_bwd_w: cannot reserve LDS"); return (int)(attr0 != hipSuccess ? attr0 : attr1); }
+  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_bwd_w_kernel<SRK_BF16>, dim3((unsigned)nchunks, 8), dim3(256), lds, st, *a, nchunks);
+  else hipLaunchKernelGGL(hrtail_edge_bwd_w_kernel<SRK_F16>, dim3((unsigned)nchunks, 8), dim3(256), lds, st, *a, nchunks);
   SRK_LAUNCH_CHECK();
   const int total = (4 * 2 * a->O * 5 + 4 * a->O) * (a->Ci + 1);
   hipLaunchKernelGGL(hrtail_edge_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *a, nchunks);
@@ -481,8 +580,9 @@ extern "C" int srk_hrtail_edge_bwd_w(const srk_hrtail_args* a, srk_stream_t stre
 extern "C" int srk_hrtail_expand(const srk_hrtail_args* a, srk_stream_t stream) {
   if (int rc = check_common(a, "srk_hrtail_expand")) return rc;
   SRK_CHECK_ARG(a->wt && a->wu && a->r && a->r0 && a->eedge && a->e0 && a->ecor && a->k0 && a->dwt && a->dwu, "srk_hrtail_expand: null pointer");
-  const int total = 4 * a->C * a->Ci * 9 + 4 * a->C + a->O * a->C * 9 + a->O;
-  hipLaunchKernelGGL(hrtail_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  const int per_thread = 4 * a->C * a->Ci * 9 + 4 * a->C + a->O, per_wave = a->O * a->C * 9;
+  const int nblocks = (per_thread + 255) / 256 + (per_wave + 3) / 4;
+  hipLaunchKernelGGL(hrtail_expand_kernel, dim3((unsigned)nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
   SRK_LAUNCH_CHECK();
   return 0;
 }

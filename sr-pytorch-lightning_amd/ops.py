@@ -1083,7 +1083,7 @@ def hr_tail_ok(x, wu, wt, ps_r):
     if ku != 3 or kt != 3 or cu != 4 * c or ci != 64 or x.shape[3] != 64 or not 1 <= o <= 4:
         return False
     n, h, w, _ = x.shape
-    return n > 0 and x.numel() * 2 < _ADDR_LIMIT and n * o * 4 * h * w < (1 << 31)
+    return n > 0 and max(h, w) <= 512 and x.numel() * 2 < _ADDR_LIMIT and n * o * 4 * h * w < (1 << 31)
 
 
 class HrTailFn(torch.autograd.Function):
@@ -1124,6 +1124,7 @@ class HrTailFn(torch.autograd.Function):
         ctx.save_for_backward(x, wu_, wt_, *( [bu_] if bu_ is not None else []))
         ctx.has = (bu is not None, bt is not None)
         ctx.bufs = bufs
+        ctx.wb = (wu, bu, wt, bt)
         return out
 
     @staticmethod
@@ -1154,9 +1155,14 @@ class HrTailFn(torch.autograd.Function):
             scratch = torch.empty(int(L.load().srk_hrtail_scratch_floats(n, ci)), dtype=f32, device=dev)
             ptrs = {k: v.data_ptr() for k, v in red.items()}
             L.call("srk_hrtail_edge_bwd_w", HrTailFn._args(x, wu_, bu_, wt_, None, bufs, g=g.data_ptr(), scratch=scratch.data_ptr(), **ptrs), st)
-            gwu, gwt = torch.empty_like(wu_), torch.empty_like(wt_)
-            gbu = torch.empty(4 * c, dtype=f32, device=dev) if has_bu else None
-            gbt = torch.empty(o, dtype=f32, device=dev) if has_bt else None
+            # (written straight into trainer.GradSync's flat buffer when the parameters name a slice of it: _grad_target)
+            def dest(p, shape):
+                t = _grad_target(p, shape, dev) if p is not None and p.dtype == f32 else None
+                return t if t is not None else torch.empty(shape, dtype=f32, device=dev)
+            pu, pbu, pt, pbt = ctx.wb
+            gwu, gwt = dest(pu, tuple(wu_.shape)), dest(pt, tuple(wt_.shape))
+            gbu = dest(pbu, (4 * c,)) if has_bu else None
+            gbt = dest(pbt, (o,)) if has_bt else None
             L.call("srk_hrtail_expand", HrTailFn._args(x, wu_, bu_, wt_, None, bufs, r=r.data_ptr(), r0=r0.data_ptr(), dwt=gwt.data_ptr(),
                                                        dbt=_ptr(gbt), dwu=gwu.data_ptr(), dbu=_ptr(gbu), **ptrs), st)
         return gx, gwu, gbu, gwt, gbt, None
