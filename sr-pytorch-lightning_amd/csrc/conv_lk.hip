@@ -737,6 +737,167 @@ __global__ __launch_bounds__(256) void lk_wgrad_allrows_kernel(const srk_wgrad_a
 }
 
 // whether the all-rows form takes this weight gradient (and its slabs are the compact [tap][ci][4] ones)
+// ---- 5x5 weight gradient, 64 input x 16 stored gradient channels: the collapsed HR stage (hr_tail.hip) -----------------------------
+// dW[f][ci][co] = sum_q X[q][ci] dY[q - f][co]: the TAP SHIFT IS ON THE GRADIENT, not on x.  So a tile is the 16 x 16 pixels of x
+// WITHOUT a halo (32 KB instead of the 51 KB of a 20 x 20 halo: x is the operand that costs bandwidth, 302 MB per launch at 256 x 96 x 96)
+// plus the 20 x 20 halo of the 32-byte-per-pixel gradient (12.8 KB), and one workgroup owns ALL 25 taps (lk_wgrad_kernel gives a
+// workgroup one kernel row: five workgroups re-read every x tile, 828 us for this shape, DMA-bound).  The 16 gradient channels fill
+// only half of a 32-column MFMA, so each MFMA carries TWO taps: columns 0-15 read the gradient shifted by tap A, columns 16-31 by
+// tap B (the transposing LDS read takes its address per 16-lane group).  Pairs are (fy, fx) & (fy + 1, fx): the two groups' 128-byte
+// runs then sit 640 bytes apart = in opposite halves of the 256-byte bank row (conflict-free); (2,-2) & (2,2) likewise (128 bytes
+// apart); the last three taps of row fy = 2 ride alone.  14 pair tiles x 2 input-channel blocks = 28 accumulator tiles, 7 per wave.
+// K = the 16 pixels of a tile row; x fragments by the same transposing read from the swizzled 128-byte image (srk_common.h).
+// Double-buffered by hidden LDS-DMA; partial sums to per-workgroup slabs in srk_wgrad_finalize's layout [tap][ci][16].
+SRK_DEV void lk5_pair(int t, int& fyA, int& fxA, int& fyB, int& fxB, bool& hasB) {
+  hasB = true;
+  if (t < 5) { fyA = -2; fxA = t - 2; fyB = -1; fxB = t - 2; }
+  else if (t < 10) { fyA = 0; fxA = t - 7; fyB = 1; fxB = t - 7; }
+  else if (t == 10) { fyA = 2; fxA = -2; fyB = 2; fxB = 2; }
+  else { fyA = 2; fxA = t - 12; fyB = 2; fxB = t - 12; hasB = false; }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void lk5_wgrad_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int tq, int trem,
+                                                        unsigned x_bytes, unsigned dy_bytes) {
+  typedef DTraits<DT> Tr;
+  constexpr int XB = 16 * 16 * 128, DP = 20, DB = 13 * 1024, BUF = XB + DB;      // gradient halo: 20 x 20 x 32 B = 12,800 (+ DMA slack)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = blockIdx.x;
+  const int H = a.H, W = a.W;
+  const int t0 = slot * tq + min(slot, trem), nt = tq + (slot < trem ? 1 : 0);
+  const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+
+  // per-lane DMA constants.  x piece i = tid + 256 k: chunk slot i & 7 of tile pixel i >> 3 (the image IS piece order);
+  // gradient piece i = tid + 256 j (< 800): chunk i & 1 of halo pixel i >> 1
+  int xconst[8], xyx[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = tid + 256 * k, sl = i & 7, p = i >> 3, iy = p >> 4, ix = p & 15, c = sl ^ swz(ix);
+    xconst[k] = ((iy * W + ix) * a.x_pitch + a.x_coff + c * 8) * 2;
+    xyx[k] = iy | (ix << 8);
+  }
+  int dconst[4], dyx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j, c = i & 1, pp = i >> 1, iy = pp / DP, ix = pp - iy * DP;
+    dconst[j] = (((iy - 2) * W + (ix - 2)) * a.dy_pitch + a.dy_coff + c * 8) * 2;
+    dyx[j] = i < 2 * DP * DP ? (((iy - 2) & 0xffff) | ((ix - 2) << 16)) : (int)0x7fff7fff;      // never inside
+  }
+  auto dma_tile = [&](int tile, int b) {
+    int pt = tile;
+    const int tX = pt % tilesX;
+    pt /= tilesX;
+    const int tY = pt % tilesY;
+    const int n = pt / tilesY;
+    const int y0 = tY * 16, x0 = tX * 16;
+    const int xbase = ((n * H + y0) * W + x0) * a.x_pitch * 2, dbase = ((n * H + y0) * W + x0) * a.dy_pitch * 2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = y0 + (xyx[k] & 255) < H && x0 + (xyx[k] >> 8) < W;
+      dma16_hidden(xrs, ok ? (unsigned)(xbase + xconst[k]) : 0x80000000u,
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * BUF + ((k * 256 + wave * 64) << 4))));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j * 256 + wave * 64 >= 2 * DP * DP) continue;        // wave-uniform: nothing of this piece row is inside the halo image
+      const int gy = y0 + (int)(short)(dyx[j] & 0xffff), gx = x0 + (dyx[j] >> 16);
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      dma16_hidden(drs, ok ? (unsigned)(dbase + dconst[j]) : 0x80000000u,
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * BUF + XB + ((j * 256 + wave * 64) << 4))));
+    }
+  };
+
+  const int rb = wave & 1, half = wave >> 1;
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  int aoff[2], boff[7][2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) aoff[rd] = tr_lane_off(0, rd, rb, lane);
+  {
+    const int G = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      int fyA, fxA, fyB, fxB; bool hasB;
+      lk5_pair(half * 7 + j, fyA, fxA, fyB, fxB, hasB);
+      const int fy = (G & 1) ? fyB : fyA, fx = (G & 1) ? fxB : fxA;      // (a lone tap: its columns 16-31 repeat tap A and are not stored)
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+        const int col = 8 * (G >> 1) + 4 * rd + q;
+        boff[j][rd] = ((2 - fy) * DP + (col - fx + 2)) * 32 + pq * 8;
+      }
+    }
+  }
+  const bool do_bias = a.dbp != nullptr && wave == 2;      // wave 2's first pair is (0,0) & (1,0): its group-0 lanes see the unshifted gradient
+  float dbz = 0.f;
+
+  if (nt > 0) dma_tile(t0, 0);
+  for (int it = 0; it < nt; ++it) {
+    const char* const X = smem + (it & 1) * BUF;
+    const char* const D = X + XB;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tile `it` landed for every wave; the other buffer is free
+    if (it + 1 < nt) dma_tile(t0 + it + 1, (it + 1) & 1);
+    i32x4 afn, bfn[7];
+    auto fetch = [&](int y) {
+      afn = tr_read2(X + y * 2048 + aoff[0], X + y * 2048 + aoff[1]);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) bfn[j] = tr_read2(D + y * (DP * 32) + boff[j][0], D + y * (DP * 32) + boff[j][1]);
+    };
+    fetch(0);
+#pragma unroll 2
+    for (int y = 0; y < 16; ++y) {
+      const i32x4 af = afn;
+      i32x4 bf[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) bf[j] = bfn[j];
+      if (y + 1 < 16) fetch(y + 1);
+      if (do_bias) {
+        const int qw[4] = {bf[0].x, bf[0].y, bf[0].z, bf[0].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float f0, f1;
+          unpack2<DT>((uint32_t)qw[e], f0, f1);
+          dbz += f0 + f1;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc[j] = Tr::mma(af, bf[j], acc[j]);
+    }
+  }
+
+  if (do_bias) {
+    dbz += __shfl_xor(dbz, 32, 64);                              // the two K halves of a read
+    if (lane < 16) a.dbp[(size_t)slot * 16 + lane] = dbz;
+  }
+  {
+    const int hq = lane >> 5, n = lane & 31, co = n & 15;
+    float* const sl = a.dwp + (size_t)slot * (25 * 64 * 16);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      int fyA, fxA, fyB, fxB; bool hasB;
+      lk5_pair(half * 7 + j, fyA, fxA, fyB, fxB, hasB);
+      if (n >= 16 && !hasB) continue;
+      const int tap = n < 16 ? (fyA + 2) * 5 + fxA + 2 : (fyB + 2) * 5 + fxB + 2;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = rb * 32 + 4 * hq + (e & 3) + 8 * (e >> 2);
+        sl[((size_t)tap * 64 + ci) * 16 + co] = acc[j][e];
+      }
+    }
+  }
+}
+
+bool lk5_wgrad_ok(const srk_wgrad_args& a) {
+  static const bool off = [] { const char* e = getenv("SRK_NO_LK5"); return e && e[0] == '1'; }();      // A/B knob
+  return !off && a.KH == 5 && a.Cin == 64 && a.Cout == 16 && (a.cout_real == 0 || a.cout_real > 6) && a.x_pitch % 8 == 0 && a.dy_pitch % 8 == 0 &&
+         a.x_coff % 8 == 0 && a.dy_coff % 8 == 0;
+}
+
 bool lk_all_rows(const srk_wgrad_args& a) {
   static const bool off = [] { const char* e = getenv("SRK_NO_LK_ALLROWS"); const char* p = getenv("SRK_NO_LK_PACKED"); return (e && e[0] == '1') || (p && p[0] == '1'); }();
   return !off && a.cout_real > 0 && a.cout_real <= LK_CS && a.cout_real * a.KW <= 32 && a.KH >= 5;
@@ -749,6 +910,7 @@ int lk_wgrad_slabs_for(const srk_wgrad_args& a) {
     return (int)(nt8 < cus ? nt8 : cus);
   }
   const long long ntiles = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+  if (lk5_wgrad_ok(a)) return (int)(ntiles < cus ? ntiles : cus);      // one workgroup per slab, all 25 taps inside
   long long s = cus / a.KH;
   if (s < 1) s = 1;
   if (s > ntiles) s = ntiles;
@@ -860,6 +1022,16 @@ template <int DT, int K> static int lk_wgrad_launch_k(const srk_wgrad_args& a, h
     hipLaunchKernelGGL((lk_wgrad_allrows_kernel<DT, K>), dim3(slabs), dim3(256), alds, st, a, tilesX, tY8, (int)nt8, (int)(nt8 / slabs), (int)(nt8 % slabs), xb, db);
     SRK_LAUNCH_CHECK();
     return 0;
+  }
+  if constexpr (K == 5) {
+    if (lk5_wgrad_ok(a)) {
+      constexpr int l5 = 2 * (16 * 16 * 128 + 13 * 1024);
+      static const hipError_t a5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_wgrad_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (a5 != hipSuccess) { srk_set_error("srk_conv2d_wgrad: cannot reserve LDS"); return (int)a5; }
+      hipLaunchKernelGGL((lk5_wgrad_kernel<DT>), dim3(slabs), dim3(256), l5, st, a, tilesX, tilesY, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db);
+      SRK_LAUNCH_CHECK();
+      return 0;
+    }
   }
   static const bool no_packed = [] { const char* e = getenv("SRK_NO_LK_PACKED"); return e && e[0] == '1'; }();      // A/B knob
   if (a.cout_real > 0 && a.cout_real <= 6 && a.cout_real * K <= 32 && !no_packed) {
