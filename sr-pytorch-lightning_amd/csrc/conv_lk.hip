@@ -737,6 +737,155 @@ __global__ __launch_bounds__(256) void lk_wgrad_allrows_kernel(const srk_wgrad_a
 }
 
 // whether the all-rows form takes this weight gradient (and its slabs are the compact [tap][ci][4] ones)
+// ---- 5x5 forward, 64 input -> <= 16 stored output channels, fp32 NCHW store behind PixelShuffle(2): the collapsed HR stage -------------
+// (hr_tail.hip: the image = one 5x5 conv of the upsampler's input.)  lk_conv_kernel gives every 16 x 16 tile its own workgroup and streams
+// the weights per kernel row: one workgroup per CU (91 KB of LDS), nothing of tile t + 1 overlaps tile t -- 375 us at 256 x 96 x 96 for
+// 160 us of MFMA work.  Here: PERSISTENT workgroups (one per CU, a contiguous range of tiles), the weights of all 25 taps stationary in
+// LDS -- only the 16 MFMA rows that carry real channels (row_to_chan: rows 8 i + e, i, e < 4), 51 KB; the other 16 row lanes read a
+// duplicate and their results are never stored -- and the 20 x 20 halo tile double-buffered by hidden LDS-DMA (2 x 51 KB): the next
+// tile's DMA is issued right behind the barrier that releases its buffer and lands under the current tile's 200 MFMAs per wave.
+template <int DT>
+__global__ __launch_bounds__(256) void lk5_fwd_kernel(const srk_conv_args a, int tilesX, int tilesY, int tq, int trem, unsigned x_bytes) {
+  typedef DTraits<DT> Tr;
+  constexpr int XT = 20, XB = XT * XT * 128, WB = 25 * 8 * 16 * 16;      // halo tile 51,200 B; compact weights 51,200 B
+  constexpr int NPC = XB / 1024;                                         // 50 pieces of 1 KB per halo tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Wl = smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W;
+  const int slot = blockIdx.x;
+  const int t0 = slot * tq + min(slot, trem), nt = tq + (slot < trem ? 1 : 0);
+  if (nt <= 0) return;
+  const i32x4 xrsrc = make_rsrc4(a.x, x_bytes), wrsrc = make_rsrc4(a.wpk, 25u * 8u * 32u * 16u);
+  const unsigned lds0 = lds_addr_of(smem);
+
+  // bias -> registers first (the vector-memory counter retires in order: nothing hidden may be queued in front of a visible load)
+  f32x16 bias16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + 4 * h + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bias16[4 * i + 0] = b.x; bias16[4 * i + 1] = b.y; bias16[4 * i + 2] = b.z; bias16[4 * i + 3] = b.w;
+  }
+  float pa[4] = {0.f, 0.f, 0.f, 0.f};
+  const int O = a.Cout >> 2;
+  if (a.post_add) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) pa[o] = o < O ? a.post_add[o] : 0.f;
+  }
+  asm volatile("" : "+v"(bias16), "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // stationary weights: compact row j = 4 i + e  <-  packed row 8 i + e of (tap, chunk); piece p = (tap*8 + chunk)*16 + j
+#pragma unroll 1
+  for (int k = wave; k < WB / 1024; k += 4) {
+    const int p = k * 64 + lane, j = p & 15, tc = p >> 4;
+    dma16_hidden(wrsrc, (unsigned)((tc * 32 + 8 * (j >> 2) + (j & 3)) * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (k << 10))));
+  }
+  // halo pieces of this lane: piece k = wave + 4 m (m < 13): slot sl of halo pixel (iy, ix), source chunk sl ^ swz(ix)
+  constexpr int NPW = (NPC + 3) / 4;
+  int hconst[NPW], hyx[NPW];
+#pragma unroll
+  for (int m = 0; m < NPW; ++m) {
+    const int k = wave + 4 * m, i = k * 64 + lane, sl = i & 7, p = i >> 3;
+    const int iy = p / XT, ix = p - iy * XT, c = sl ^ swz(ix);
+    hconst[m] = (((iy - 2) * W + (ix - 2)) * a.x_pitch + a.x_coff + c * 8) * 2;
+    hyx[m] = ((iy - 2) & 0xffff) | ((ix - 2) << 16);
+  }
+  auto tile_of = [&](int t, int& n, int& y0, int& x0) {
+    int pt = t0 + t;
+    const int tX = pt % tilesX;
+    pt /= tilesX;
+    const int tY = pt % tilesY;
+    n = pt / tilesY; y0 = tY * 16; x0 = tX * 16;
+  };
+  auto dma_tile = [&](int t, int b) {
+    int n, y0, x0;
+    tile_of(t, n, y0, x0);
+    const int tbase = ((n * H + y0) * W + x0) * a.x_pitch * 2;
+#pragma unroll
+    for (int m = 0; m < NPW; ++m) {
+      const int k = wave + 4 * m;
+      if (k >= NPC) continue;                                            // wave-uniform
+      const int gy = y0 + (int)(short)(hyx[m] & 0xffff), gx = x0 + (hyx[m] >> 16);
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      dma16_hidden(xrsrc, ok ? (unsigned)(tbase + hconst[m]) : 0x80000000u,
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + WB + b * XB + (k << 10))));
+    }
+  };
+  dma_tile(0, 0);
+
+  const int px = r & 15;
+  int prow[2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) prow[pb] = 4 * wave + 2 * pb + (r >> 4);
+  // A fragment: row lane r -> compact row (real rows 8 i + e; the others take a duplicate), chunk half h
+  const int jrow = ((r >> 2) & 1) ? 0 : 4 * (r >> 3) + (r & 3);
+  const char* const wl = Wl + ((h * 16 + jrow) << 4);
+  int gsw[5];
+#pragma unroll
+  for (int kw = 0; kw < 5; ++kw) gsw[kw] = swz(px + kw);
+
+  const int H2 = 2 * H, W2 = 2 * W;
+  const float sc = a.scale;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7fffffff, 0x00020000);
+  for (int t = 0; t < nt; ++t) {
+    const char* const Xs = smem + WB + (t & 1) * XB;
+    // tile t (and, first, the weights) landed; the other buffer is free.  The counted wait leaves the previous tile's 4 O image stores
+    // (always issued, out-of-range offsets for pixels outside the image) in flight: they are the youngest vector-memory operations,
+    // the DMA pieces of tile t are older.  (vmcnt(0) here made every tile wait for its predecessor's stores to be acknowledged.)
+    if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (O == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (O == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (O == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + 1 < nt) dma_tile(t + 1, (t + 1) & 1);
+    f32x16 acc[2] = {bias16, bias16};
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const i32x4 af = lds_read16(wl + ((((kh * 5 + kw) * 8 + 2 * ks) * 16) << 4));
+          i32x4 bf[2];
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb)
+            bf[pb] = lds_read16(Xs + ((prow[pb] + kh) * XT + px + kw) * 128 + (((2 * ks + h) ^ gsw[kw]) << 4));
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) acc[pb] = Tr::mma(af, bf[pb], acc[pb]);
+        }
+      }
+    }
+    // fp32 NCHW behind PixelShuffle(2): channel k = o*4 + i*2 + j of pixel (gy, gx) -> out[n][o][2 gy + i][2 gx + j] (+ post_add[o]); the h = 0
+    // lanes hold the stored channels (register index = channel); a lane's (j = 0, 1) pair is one 8-byte store
+    {
+      int n, y0, x0;
+      tile_of(t, n, y0, x0);
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const int gy = y0 + prow[pb], gx = x0 + px;
+        const bool ok = h == 0 && gy < H && gx < W;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          if (o >= O) break;                                             // wave-uniform
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+            u32x2_t v;
+            v.x = __float_as_uint(acc[pb][o * 4 + i * 2] * sc + pa[o]);
+            v.y = __float_as_uint(acc[pb][o * 4 + i * 2 + 1] * sc + pa[o]);
+            const unsigned off = ok ? (unsigned)((((n * O + o) * H2 + 2 * gy + i) * W2 + 2 * gx) * 4) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b64(v, orsrc, off, 0, 0);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- 5x5 weight gradient, 64 input x 16 stored gradient channels: the collapsed HR stage (hr_tail.hip) -----------------------------
 // dW[f][ci][co] = sum_q X[q][ci] dY[q - f][co]: the TAP SHIFT IS ON THE GRADIENT, not on x.  So a tile is the 16 x 16 pixels of x
 // WITHOUT a halo (32 KB instead of the 51 KB of a 20 x 20 halo: x is the operand that costs bandwidth, 302 MB per launch at 256 x 96 x 96)
@@ -836,12 +985,19 @@ __global__ __launch_bounds__(256) void lk5_wgrad_kernel(const srk_wgrad_args a, 
   const bool do_bias = a.dbp != nullptr && wave == 2;      // wave 2's first pair is (0,0) & (1,0): its group-0 lanes see the unshifted gradient
   float dbz = 0.f;
 
+  // THREE buffers, the DMA two tiles ahead: a tile's 45 KB need 3-5k cycles to land under load, its MFMAs take 3.6k -- one tile ahead
+  // every tile waited for its data (6.6k cycles per tile).  Per tile and wave 8 + 3 or 4 DMA pieces (pieces_of: wave-uniform).
+  const int pieces_of = 8 + (wave == 0 ? 4 : 3);      // gradient piece rows j = 0..2 all waves, j = 3 (pieces 768..799): wave 0 only
   if (nt > 0) dma_tile(t0, 0);
+  if (nt > 1) dma_tile(t0 + 1, 1);
   for (int it = 0; it < nt; ++it) {
-    const char* const X = smem + (it & 1) * BUF;
+    const char* const X = smem + (it % 3) * BUF;
     const char* const D = X + XB;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tile `it` landed for every wave; the other buffer is free
-    if (it + 1 < nt) dma_tile(t0 + it + 1, (it + 1) & 1);
+    // tile `it` landed (tile it + 1 may still be in flight: the younger pieces_of operations)
+    if (it + 1 < nt) { if (pieces_of == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... for every wave; buffer (it + 2) % 3 (tile it - 1's) is free
+    if (it + 2 < nt) dma_tile(t0 + it + 2, (it + 2) % 3);
     i32x4 afn, bfn[7];
     auto fetch = [&](int y) {
       afn = tr_read2(X + y * 2048 + aoff[0], X + y * 2048 + aoff[1]);
@@ -985,7 +1141,24 @@ template <int DT> static int lk_rows_launch(const srk_conv_args& a, hipStream_t 
   }
 }
 
+template <int DT> static int lk5_fwd_launch(const srk_conv_args& a, hipStream_t st) {
+  constexpr int lds = 25 * 8 * 16 * 16 + 2 * 20 * 20 * 128;
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_fwd_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) { srk_set_error("srk_conv2d: cannot reserve LDS for the 5x5 image conv"); return (int)attr; }
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
+  const long long ntiles = (long long)a.N * tilesX * tilesY;
+  SRK_CHECK_ARG(ntiles <= 0x7fffffffLL, "srk_conv2d: %lld tiles", ntiles);
+  const int slots = (int)(ntiles < cus ? ntiles : cus);
+  hipLaunchKernelGGL((lk5_fwd_kernel<DT>), dim3(slots), dim3(256), lds, st, a, tilesX, tilesY, (int)(ntiles / slots), (int)(ntiles % slots),
+                     (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2));
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
 int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st) {
+  static const bool no_lk5 = [] { const char* e = getenv("SRK_NO_LK5"); return e && e[0] == '1'; }();      // A/B knob
+  if (a.out_mode == SRK_OUT_PLANAR && a.KH == 5 && !no_lk5) return a.dtype == SRK_BF16 ? lk5_fwd_launch<SRK_BF16>(a, st) : lk5_fwd_launch<SRK_F16>(a, st);
   static const bool no_rows = [] { const char* e = getenv("SRK_NO_LK_ROWS"); return e && e[0] == '1'; }();      // A/B knob
   if (!no_rows && a.out_mode == SRK_OUT_NHWC && a.Cin == 64 && a.cout_real > 0 && a.cout_real <= 4 && a.cout_real * a.KW <= 32 && a.Cout == 16 && !a.relu && !a.res && a.scale == 1.f)
     return a.dtype == SRK_BF16 ? lk_rows_launch<SRK_BF16>(a, st) : lk_rows_launch<SRK_F16>(a, st);
@@ -1025,7 +1198,7 @@ template <int DT, int K> static int lk_wgrad_launch_k(const srk_wgrad_args& a, h
   }
   if constexpr (K == 5) {
     if (lk5_wgrad_ok(a)) {
-      constexpr int l5 = 2 * (16 * 16 * 128 + 13 * 1024);
+      constexpr int l5 = 3 * (16 * 16 * 128 + 13 * 1024);
       static const hipError_t a5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_wgrad_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (a5 != hipSuccess) { srk_set_error("srk_conv2d_wgrad: cannot reserve LDS"); return (int)a5; }
       hipLaunchKernelGGL((lk5_wgrad_kernel<DT>), dim3(slabs), dim3(256), l5, st, a, tilesX, tilesY, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db);
