@@ -176,27 +176,28 @@ def _time_replays(fn, iters, sustain_s=0.0):
     return burst, e0.elapsed_time(e1) * 1e3 / (iters * (nrep - nrep // 2))
 
 
-def csrc_sha():
-    """Fingerprint of the kernel sources a PMC measurement belongs to (profiles/r3_pmc_traffic.json carries the same)."""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "sr-pytorch-lightning_amd", "csrc")
-    for f in ("conv_igemm.hip", "srk_common.h"):          # the sources of the kernel the committed traffic figure belongs to
-        with open(os.path.join(d, f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+def kernel_fingerprint(key="conv_ws_plain_bf16"):
+    """Fingerprint of the GENERATED ISA of one kernel of the library being timed (csrc/kernel_isa.json, written by every build:
+    csrc/check_isa.py hashes the kernel's own instructions, so an edit elsewhere in the sources -- another kernel, a prototype in
+    a shared header -- does not orphan a PMC measurement; round 3 hashed whole source files and lost `roofline.traffic` to one)."""
+    try:
+        with open(os.path.join(ROOT, "sr-pytorch-lightning_amd", "csrc", "kernel_isa.json")) as fh:
+            return json.load(fh).get(key)
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic(key):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
     KiB -> B; MI355X_MICROARCH.md "HBM"), written by tools/pmc_traffic.sh.  None unless an entry exists for this exact
-    kernel / shape AND was measured on the kernel sources being timed now."""
+    kernel / shape AND was measured on the very instructions being timed now (`isa_sha` == this build's fingerprint)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")) as fh:
             tab = json.load(fh)
     except (OSError, ValueError):
         return None
     e = tab.get(key)
-    if not e or e.get("csrc_sha") != csrc_sha():
+    if not e or not e.get("isa_sha") or e.get("isa_sha") != kernel_fingerprint(e.get("isa_key", "conv_ws_plain_bf16")):
         return None
     return (2.0 * e["fetch_kib"] + e["write_kib"]) * 1024.0
 
@@ -374,6 +375,20 @@ def dominant_kernel_roofline(A, model_name, batch, patch, feats, dtype, iters=10
     return r
 
 
+def executed_gflop_fwd(model_name, gflop_fwd, patch, scale, dtype, collapsed):
+    """Conv GFLOP per patch the HIP path EXECUTES in a forward pass.  The reference's module graph ends EDSR / RCAN /
+    RDN with conv3x3(64 -> 256) -> PixelShuffle(2) -> conv3x3(64 -> 3); on the 16-bit path those two layers run as ONE 5x5 convolution
+    64 -> 12 at the lower resolution (ops.hr_tail, csrc/hr_tail.hip: same function and gradients, 8x fewer multiply-adds), so the executed
+    count is lower than the reference graph's.  Both are reported; `model_mfma_frac` stays on the reference graph's count."""
+    g = gflop_fwd * (patch / 48.0) ** 2
+    if collapsed and dtype != "f32" and model_name in ("edsr_baseline", "rcan", "rdn_b") and scale in (2, 4):
+        hw = patch * scale // 2                      # resolution of the last upsampler stage's input
+        two_layers = 2.0 * hw * hw * (256 * 64 * 9 + 4 * 3 * 64 * 9) / 1e9
+        one_conv = 2.0 * hw * hw * (12 * 64 * 25) / 1e9
+        g = g - two_layers + one_conv
+    return g
+
+
 def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5):
     """One more BASELINE config in this process (after the timed region): the training step of `name` at `batch` as one
     hipGraph, replayed for >= `seconds`; returns patches/s and the model-level MFMA fraction."""
@@ -413,8 +428,10 @@ def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5):
     el = time.perf_counter() - t0
     value = batch * k / el
     flop = gflop_fwd * 3.0 * (patch / 48.0) ** 2
+    flop_x = 3.0 * executed_gflop_fwd(name, gflop_fwd, patch, scale, dtype, A.ops._HR_COLLAPSE)
     out = {"model": name, "batch": batch, "value": round(value, 1), "unit": "LR patches/s", "ms_per_step": round(el / k * 1e3, 4), "steps": k,
-           "model_mfma_frac": round(value * flop / 1e3 / PEAK_TFLOPS[dtype], 4), "loss": float(loss.detach().float())}
+           "model_mfma_frac": round(value * flop / 1e3 / PEAK_TFLOPS[dtype], 4),
+           "model_mfma_frac_executed": round(value * flop_x / 1e3 / PEAK_TFLOPS[dtype], 4), "loss": float(loss.detach().float())}
     del g, model, opt, batch_t
     torch.cuda.empty_cache()
     return out
@@ -607,6 +624,17 @@ def main():
                        "loss_after_warmup": loss_first, "loss_after_timed_steps": loss_last},
             "model_mfma_frac": round(value / world * flop_per_patch / 1e3 / PEAK_TFLOPS[a.dtype], 4),
         }
+        # what the path executes against what the reference's module graph counts (executed_gflop_fwd): the last upsampler stage + tail
+        # conv of EDSR / RCAN / RDN run as one 5x5 convolution on the 16-bit path
+        gx = executed_gflop_fwd(a.model, gflop_fwd, a.patch, a.scale, a.dtype, A.ops._HR_COLLAPSE) * (1.0 if a.inference else 3.0)
+        out["model_mfma_frac_executed"] = round(value / world * gx / 1e3 / PEAK_TFLOPS[a.dtype], 4)
+        out["config"]["gflop_per_patch"] = {"reference_graph": round(flop_per_patch, 3), "executed": round(gx, 3)}
+        out["config"]["hr_stage"] = ("collapsed: conv3x3(64->256) + PixelShuffle(2) + conv3x3(64->3) as one 5x5 conv 64->12 with exact border terms "
+                                     "(ops.hr_tail; SRK_NO_HR_COLLAPSE=1 = layer by layer)"
+                                     if (gx != flop_per_patch) else "layer by layer")
+        if ddp:
+            out["config"]["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
+            out["config"]["backend"] = dist.get_backend() if dist.is_initialized() else None
         if sustained is not None:
             out["sustained_ms_per_step"] = round(sustained * 1e3, 4)
             out["sustained_value"] = round(a.batch * world / sustained, 2)
@@ -622,10 +650,39 @@ def main():
             torch.cuda.empty_cache()
             for name in ("edsr_baseline", "rcan", "edsr_large", "wdsr_b", "rdn_b", "srresnet", "ddbpn"):
                 try:
-                    oc.append(quick_train_rate(A, T, name, 16, a.patch, a.scale, a.dtype))
+                    e_ = quick_train_rate(A, T, name, 16, a.patch, a.scale, a.dtype)
+                    try:      # the dominant kernel of THAT model at THAT batch against its roofline (short sustained window)
+                        r_ = dominant_kernel_roofline(A, name, 16, a.patch, MODELS[name][3], a.dtype, iters=60, sustain_s=0.25)
+                        e_["roofline"] = {k: r_[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "us_per_launch", "step_weighted_frac") if k in r_}
+                    except Exception as e:  # noqa: BLE001
+                        e_["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+                    oc.append(e_)
                 except Exception as e:  # noqa: BLE001
                     oc.append({"model": name, "batch": 16, "error": f"{type(e).__name__}: {e}"})
+                torch.cuda.empty_cache()
+            if a.dtype == "bf16":
+                # BASELINE.json config 5 is fp16 (configs/all.yml:122): WDSR-B and RDN-B at the reference's batch in fp16
+                for name in ("wdsr_b", "rdn_b"):
+                    try:
+                        e_ = quick_train_rate(A, T, name, 16, a.patch, a.scale, "f16")
+                        e_["dtype"] = "f16"
+                        oc.append(e_)
+                    except Exception as e:  # noqa: BLE001
+                        oc.append({"model": name, "batch": 16, "dtype": "f16", "error": f"{type(e).__name__}: {e}"})
+                    torch.cuda.empty_cache()
             out["other_configs"] = oc
+            if A.ops._HR_COLLAPSE and gx != flop_per_patch:
+                # the same step with the HR stage layer by layer (every multiply-add of the reference's module graph executed), for comparison
+                A.ops._HR_COLLAPSE = False
+                try:
+                    lw = quick_train_rate(A, T, a.model, a.batch, a.patch, a.scale, a.dtype, seconds=1.0)
+                    out["layerwise_hr_stage"] = {"value": lw["value"], "unit": lw["unit"], "ms_per_step": lw["ms_per_step"], "model_mfma_frac": lw["model_mfma_frac"],
+                                                 "note": "same model, batch and step with SRK_NO_HR_COLLAPSE=1: the upsampler's last stage and the tail conv as two layers"}
+                except Exception as e:  # noqa: BLE001
+                    out["layerwise_hr_stage"] = {"error": f"{type(e).__name__}: {e}"}
+                finally:
+                    A.ops._HR_COLLAPSE = True
+                torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.model, a.scale, a.patch, model=model, lr=batch["lr"], hr=batch["hr"])

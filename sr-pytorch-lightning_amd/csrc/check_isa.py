@@ -58,7 +58,31 @@ def check_kernel(asm, dt, nks, em=1):
     return seen
 
 
-def main(path):
+def isa_fingerprint(asm, name):
+    """sha256 (16 hex digits) of the generated ISA of ONE kernel, comments / blank lines / block-label numbering removed: what a PMC
+    measurement of that kernel belongs to (bench.py quotes `roofline.traffic` only for the fingerprint it was collected on).  A change
+    anywhere else in the translation unit, or in a header the kernel does not use, leaves it alone."""
+    import hashlib
+    start = asm.index(name)
+    body = asm[start:asm.index(".Lfunc_end", start)].split("\n")[1:]
+    keep = []
+    for l in body:
+        l = l.split(";")[0].strip()
+        if not l or l.startswith(".") and not l.startswith(".LBB"):
+            continue
+        keep.append(re.sub(r"\.LBB\d+_", ".LBB_", l))
+    return hashlib.sha256("\n".join(keep).encode()).hexdigest()[:16]
+
+
+# the kernels whose PMC figures bench.py quotes: key -> mangled-name prefix
+FINGERPRINTED = {
+    "conv_ws_plain_bf16": "_ZN12_GLOBAL__N_114conv_ws_kernelILi0ELi2ELi4ELb1ELb0ELi0EEEv13srk_conv_argsiiiijiiiiiii:",
+    "conv_ws_residual_bf16": kernel_name(0, 4, 1) + "iiiijiiiiiii:",
+    "conv_ws_mask_bf16": kernel_name(0, 4, 2) + "iiiijiiiiiii:",
+}
+
+
+def main(path, fp_out=None):
     asm = open(path).read()
     ok = True
     for dt in (0, 1):
@@ -70,8 +94,12 @@ def main(path):
                 except (AssertionError, ValueError) as e:
                     ok = False
                     print(f"check_isa: conv_ws_kernel<dtype {dt}, NKS {nks}, EARLY, EM {em}>: FAILED: {e}", file=sys.stderr)
+    if fp_out:
+        import json
+        with open(fp_out, "w") as fh:
+            json.dump({k: isa_fingerprint(asm, v) for k, v in FINGERPRINTED.items()}, fh, indent=1)
     return 0 if ok else 1
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1]))
+    sys.exit(main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None))

@@ -2,12 +2,12 @@
 # ON THE GPU BOX: everything profiles/ carries for a round, from ONE box (so that bench.py's event timings and the rocprofv3
 # averages can be compared): bench lines, rocprofv3 kernel traces, PMC passes (one counter group per run, FETCH_SIZE and
 # WRITE_SIZE in separate passes, program directly behind `--`).   usage: tools/collect_profiles.sh [tag]   -> gpurun_out/<tag>_*
-TAG=${1:-r3}
+TAG=${1:-r4}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$REPO"; O=gpurun_out
 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -c 600 $O/${TAG}_bench_default.json; echo
 tools/variants_trace.sh 256 $TAG > /dev/null 2>&1; cat $O/${TAG}_variants_n256.txt
-tools/pmc_traffic.sh 256 > /dev/null 2>&1; cat $O/r3_pmc_traffic.json | head -12
+tools/pmc_traffic.sh 256 > /dev/null 2>&1; cat $O/r4_pmc_traffic.json | head -12
 for m in edsr_baseline rcan edsr_large wdsr_b rdn_b ddbpn srresnet; do
   python bench.py --model $m --batch 16 --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 > $O/${TAG}_bench_b16_$m.json
   python3 -c "import json,sys; d=json.load(open('$O/${TAG}_bench_b16_$m.json')); print('$m b16', d['value'], d['roofline']['variants_us'], d['roofline'].get('step_weighted_frac'))"

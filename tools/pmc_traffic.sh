@@ -1,8 +1,8 @@
 #!/bin/bash
 # ON THE GPU BOX: HBM traffic of the dominant kernel (conv_ws_kernel, 64->64 3x3 bf16 @48x48, conv+bias+ReLU) per launch
 # from rocprofv3 PMC passes -- FETCH_SIZE and WRITE_SIZE in SEPARATE runs, no trace domains (MI355X_MICROARCH.md "HBM" /
-# "rocprofv3 PMC slots") -- written to gpurun_out/r3_pmc_traffic.json together with the fingerprint of the kernel
-# sources it was measured on (bench.py only quotes a figure whose fingerprint matches the sources it is timing).
+# "rocprofv3 PMC slots") -- written to gpurun_out/r4_pmc_traffic.json together with the fingerprint of the kernel's
+# generated ISA (csrc/kernel_isa.json; bench.py only quotes a figure whose fingerprint matches the instructions it is timing).
 # usage: tools/pmc_traffic.sh [batch sizes...]   (default: 256)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_traffic; mkdir -p "$OUT"
@@ -30,10 +30,10 @@ for d in sorted(glob.glob(os.path.join(out, "n*_FETCH_SIZE"))):
         vals[c] = sum(v) / max(len(v), 1)
         vals[c + "_n"] = len(v)
     tab[f"conv_bias_relu:edsr_baseline:64x48x{n}xbf16"] = {"fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "launches": vals["FETCH_SIZE_n"],
-                             "csrc_sha": bench.csrc_sha(),
+                             "isa_key": "conv_ws_plain_bf16", "isa_sha": bench.kernel_fingerprint("conv_ws_plain_bf16"),
                              "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) -- python3 tools/microbench_conv.py --n %d" % n,
                              "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
                              "algorithmic_bytes_per_launch": 2.0 * n * 48 * 48 * 64 * 2}
-json.dump(tab, open(os.path.join(repo, "gpurun_out", "r3_pmc_traffic.json"), "w"), indent=1)
+json.dump(tab, open(os.path.join(repo, "gpurun_out", "r4_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(tab, indent=1))
 PY
