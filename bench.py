@@ -401,12 +401,17 @@ def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         opt = A.optim.Adam([p for p in model.parameters() if p.requires_grad])
+        scaler = A.optim.DeviceGradScaler(dev) if dtype == "f16" else None      # fp16: device-resident dynamic loss scaling
 
         def step():
             opt.zero_grad(set_to_none=True)
             loss = model._calculate_losses(img_sr=model(batch_t["lr"]), img_hr=batch_t["hr"])["loss"]
-            loss.backward()
-            opt.step()
+            if scaler is None:
+                loss.backward()
+                opt.step()
+            else:
+                scaler.scale(loss).backward()
+                opt.step(grad_scaler=scaler)
             return loss
         for _ in range(3):
             step()
@@ -432,6 +437,8 @@ def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5):
     out = {"model": name, "batch": batch, "value": round(value, 1), "unit": "LR patches/s", "ms_per_step": round(el / k * 1e3, 4), "steps": k,
            "model_mfma_frac": round(value * flop / 1e3 / PEAK_TFLOPS[dtype], 4),
            "model_mfma_frac_executed": round(value * flop_x / 1e3 / PEAK_TFLOPS[dtype], 4), "loss": float(loss.detach().float())}
+    if scaler is not None:
+        out["loss_scale"] = {"scale": scaler.get_scale(), "skipped_steps": scaler.skipped_steps}
     del g, model, opt, batch_t
     torch.cuda.empty_cache()
     return out
@@ -489,18 +496,29 @@ def main():
         else:
             opt = A.optim.Adam(params)
 
+    # fp16 (BASELINE config 5; the reference's `precision: 16` = autocast + GradScaler): dynamic loss scaling with its state on the
+    # device (optim.DeviceGradScaler), so the fp16 step is a hipGraph like the bf16 one; without scaling the L1 gradient
+    # (1 / 28M per element at batch 256) is below fp16's smallest subnormal
+    scaler = A.optim.DeviceGradScaler(dev) if (a.dtype == "f16" and isinstance(opt, A.optim.Adam)) else None
+
+    def opt_step():
+        if scaler is None:
+            opt.step()
+        else:
+            opt.step(grad_scaler=scaler)
+
     def fwd_bwd():
         opt.zero_grad(set_to_none=True)
         sr = net(batch["lr"])
         loss = model._calculate_losses(img_sr=sr, img_hr=batch["hr"])["loss"]
-        loss.backward()
+        (loss if scaler is None else scaler.scale(loss)).backward()
         return loss
 
     def train_step():
         loss = fwd_bwd()
         if gsync is not None:
             gsync.sync()
-        opt.step()
+        opt_step()
         return loss
 
     def infer_step():
@@ -520,7 +538,7 @@ def main():
                 for _ in range(8):
                     step()
                 gsync.detach()
-                ogs = T.OverlappedGraphStep(model, opt, nseg)
+                ogs = T.OverlappedGraphStep(model, opt, nseg, scaler=scaler)
                 ogs.prepare(batch)
                 for _ in range(2):
                     ogs.eager_step(batch)
@@ -570,7 +588,7 @@ def main():
         else:
             graphs[0].replay()
             gsync.reduce()
-            opt.step()                      # three launches: cheaper issued eagerly than a second graph's launch floor
+            opt_step()                      # three launches: cheaper issued eagerly than a second graph's launch floor
 
     def timed(nsteps):
         if world > 1:
@@ -632,6 +650,8 @@ def main():
         out["config"]["hr_stage"] = ("collapsed: conv3x3(64->256) + PixelShuffle(2) + conv3x3(64->3) as one 5x5 conv 64->12 with exact border terms "
                                      "(ops.hr_tail; SRK_NO_HR_COLLAPSE=1 = layer by layer)"
                                      if (gx != flop_per_patch) else "layer by layer")
+        if scaler is not None:
+            out["config"]["loss_scale"] = {"kind": "dynamic, device-resident (optim.DeviceGradScaler)", "scale": scaler.get_scale(), "skipped_steps": scaler.skipped_steps}
         if ddp:
             out["config"]["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
             out["config"]["backend"] = dist.get_backend() if dist.is_initialized() else None

@@ -675,6 +675,16 @@ typedef struct {
   float one_minus_beta1, one_minus_beta2;   /* 1 - beta rounded from double, as torch forms them */
 } srk_adam_args;
 int srk_adam_step(const srk_adam_args* a, srk_stream_t stream);
+/* The same update under DYNAMIC LOSS SCALING kept on the device (fp16 training: the reference's `precision: 16` runs Lightning's
+ * "16-mixed" = autocast + torch.amp.GradScaler, configs/all.yml:122; GradScaler decides on the HOST whether to call
+ * optimizer.step, which a hipGraph replay cannot do).  scaler_state: 8 device floats {scale, growth tracker, found_inf, growth
+ * factor, backoff factor, growth interval, skipped steps, reserved}.  The gradients in the table are still multiplied by `scale`:
+ *   srk_adam_step_scaled : found_inf |= any gradient not finite; if not found_inf: the update on g / scale, step counts += 1
+ *                          (a step with a non-finite gradient changes NOTHING, like GradScaler.step)
+ *   srk_loss_scale_update: once per step behind the last parameter group: found_inf ? scale *= backoff, tracker = 0
+ *                          : (++tracker == interval ? scale *= growth, tracker = 0);  found_inf = 0     (GradScaler.update)      */
+int srk_adam_step_scaled(const srk_adam_args* a, float* scaler_state, srk_stream_t stream);
+int srk_loss_scale_update(float* scaler_state, srk_stream_t stream);
 
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* srk_last_error(void);

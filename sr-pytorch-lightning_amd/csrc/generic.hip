@@ -251,7 +251,12 @@ template <int DT, bool FUSED> __global__ __launch_bounds__(GEN_NT) void chan_sta
   }
   if constexpr (FUSED) {
     __shared__ int last;
-    __syncthreads();                                             // every wave's stores are acknowledged (the barrier waits for them)
+    // every storing thread waits for ITS OWN write-through stores to be acknowledged before the barrier (the barrier orders at
+    // workgroup scope only and the compiler may drop its vmcnt wait: without this the arrival count could become visible on another
+    // XCD before a wave's partial sums -- rare, nondeterministically wrong statistics).  The stores are sc1 (agent-scope
+    // atomic stores): acknowledged = visible to every XCD, so the relaxed count behind the barrier needs no cache write-back.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (tid == 0) last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     __syncthreads();
     if (!last) return;

@@ -18,7 +18,45 @@ namespace {
 
 constexpr int ADAM_NT = 256;
 
-__global__ __launch_bounds__(ADAM_NT) void adam_group_kernel(const srk_adam_args a) {
+// Dynamic loss scaling on the DEVICE (fp16 training, the reference's `precision: 16` = Lightning's "16-mixed": autocast +
+// torch.amp.GradScaler, configs/all.yml:122): state = {scale, growth tracker, found_inf, growth factor, backoff factor, growth
+// interval, skipped steps}.  GradScaler reads found_inf on the HOST every step (`optimizer.step` is skipped from Python), which a
+// hipGraph replay cannot do; here the check, the skip and the scale update are launches of the captured step:
+//   adam_check_kernel  : found_inf = any gradient not finite           (the gradients are still multiplied by `scale`)
+//   adam_group_kernel  : found_inf ? nothing : the update on g / scale
+//   adam_bump_kernel   : found_inf ? nothing : step counts += 1
+//   scaler_update      : found_inf ? (scale *= backoff, tracker = 0) : (++tracker == interval ? scale *= growth, tracker = 0); found_inf = 0
+// -- torch.amp.GradScaler.step / update, same constants, same order.
+__global__ __launch_bounds__(ADAM_NT) void adam_check_kernel(const srk_adam_args a, float* __restrict__ state) {
+  const srk_adam_block blk = a.blocks[blockIdx.x];
+  const srk_adam_slot sl = a.slots[blk.slot];
+  const long long e0 = blk.start, e1 = (e0 + blk.count < sl.n) ? e0 + blk.count : sl.n;
+  bool bad = false;
+  for (long long e = e0 + threadIdx.x; e < e1; e += ADAM_NT) bad |= !isfinite(sl.g[e]);
+  if (bad) state[2] = 1.f;                  // every writer stores the same value
+}
+
+__global__ void scaler_update_kernel(float* __restrict__ state) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state[2] != 0.f) {
+    state[0] *= state[4];
+    state[1] = 0.f;
+    state[6] += 1.f;
+  } else {
+    const float t = state[1] + 1.f;
+    if (t >= state[5]) { state[0] *= state[3]; state[1] = 0.f; }
+    else state[1] = t;
+  }
+  state[2] = 0.f;
+}
+
+template <bool SCALED>
+__global__ __launch_bounds__(ADAM_NT) void adam_group_kernel(const srk_adam_args a, const float* __restrict__ state) {
+  float inv_scale = 1.f;
+  if constexpr (SCALED) {
+    if (state[2] != 0.f) return;            // a non-finite gradient somewhere: the whole step is skipped
+    inv_scale = 1.f / state[0];
+  }
   const srk_adam_block blk = a.blocks[blockIdx.x];
   const srk_adam_slot sl = a.slots[blk.slot];
   const float t = a.steps[sl.step_idx] + 1.f;
@@ -31,6 +69,7 @@ __global__ __launch_bounds__(ADAM_NT) void adam_group_kernel(const srk_adam_args
   float* const m = a.m + sl.state_off;
   float* const v = a.v + sl.state_off;
   auto upd = [&](float& pv, float gv, float& mv, float& vv) {
+    if constexpr (SCALED) gv *= inv_scale;
     if (a.maximize) gv = -gv;
     if (wd != 0.f) gv += wd * pv;
     mv = mv + (gv - mv) * omb1;                             // torch: exp_avg.lerp_(grad, 1 - beta1)
@@ -78,7 +117,8 @@ __global__ __launch_bounds__(ADAM_NT) void adam_group_kernel(const srk_adam_args
 
 // second launch of a step: the update has read every count, advance the counts of the tensors in the table.  (A "last block
 // bumps" ticket inside the update costs one same-address atomic per block: 5k blocks serialise to 0.3 ms.)
-__global__ __launch_bounds__(ADAM_NT) void adam_bump_kernel(const srk_adam_args a) {
+__global__ __launch_bounds__(ADAM_NT) void adam_bump_kernel(const srk_adam_args a, const float* __restrict__ state) {
+  if (state && state[2] != 0.f) return;
   for (int i = blockIdx.x * ADAM_NT + threadIdx.x; i < a.nslots; i += gridDim.x * ADAM_NT) a.steps[a.slots[i].step_idx] += 1.f;
 }
 
@@ -90,8 +130,29 @@ extern "C" int srk_adam_step(const srk_adam_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps >= 0.f && a->lr >= 0.f,
                 "srk_adam_step: lr=%g betas=(%g, %g) eps=%g", a->lr, a->beta1, a->beta2, a->eps);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(adam_group_kernel, dim3((unsigned)a->nblocks), dim3(ADAM_NT), 0, st, *a);
-  hipLaunchKernelGGL(adam_bump_kernel, dim3((unsigned)((a->nslots + ADAM_NT - 1) / ADAM_NT)), dim3(ADAM_NT), 0, st, *a);
+  hipLaunchKernelGGL(adam_group_kernel<false>, dim3((unsigned)a->nblocks), dim3(ADAM_NT), 0, st, *a, (const float*)nullptr);
+  hipLaunchKernelGGL(adam_bump_kernel, dim3((unsigned)((a->nslots + ADAM_NT - 1) / ADAM_NT)), dim3(ADAM_NT), 0, st, *a, (const float*)nullptr);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_adam_step_scaled(const srk_adam_args* a, float* scaler_state, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->slots && a->blocks && a->m && a->v && a->steps && scaler_state, "srk_adam_step_scaled: null pointer");
+  SRK_CHECK_ARG(a->nblocks > 0 && a->nslots > 0, "srk_adam_step_scaled: %d blocks, %d tensors", a->nblocks, a->nslots);
+  SRK_CHECK_ARG(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps >= 0.f && a->lr >= 0.f,
+                "srk_adam_step_scaled: lr=%g betas=(%g, %g) eps=%g", a->lr, a->beta1, a->beta2, a->eps);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(adam_check_kernel, dim3((unsigned)a->nblocks), dim3(ADAM_NT), 0, st, *a, scaler_state);
+  hipLaunchKernelGGL(adam_group_kernel<true>, dim3((unsigned)a->nblocks), dim3(ADAM_NT), 0, st, *a, (const float*)scaler_state);
+  hipLaunchKernelGGL(adam_bump_kernel, dim3((unsigned)((a->nslots + ADAM_NT - 1) / ADAM_NT)), dim3(ADAM_NT), 0, st, *a, (const float*)scaler_state);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+/* after the LAST parameter group's srk_adam_step_scaled of a step: the scale / growth-tracker update (one thread) */
+extern "C" int srk_loss_scale_update(float* scaler_state, srk_stream_t stream) {
+  SRK_CHECK_ARG(scaler_state, "srk_loss_scale_update: null pointer");
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), scaler_state);
   SRK_LAUNCH_CHECK();
   return 0;
 }

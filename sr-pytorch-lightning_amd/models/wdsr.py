@@ -61,6 +61,11 @@ class _Block_B(_NCHWContract, nn.Module):
 
 
 class WDSR(SRModel):
+    # all 51 effective weights come from ONE autograd node (ops.WeightNormGroup): a backward pass cut into segments (trainer.
+    # OverlappedGraphStep) would run that node in the first segment's pass with the top blocks' gradients only and find its saved
+    # tensors freed in the second -- the multi-rank step keeps WDSR's backward in one piece (trainer.auto_segments)
+    supports_backward_segments = False
+
     def __init__(self, type: str = 'B', n_feats: int = 128, n_resblocks: int = 16, res_scale: int = 1, **kwargs: dict[str, Any]):
         super().__init__(**kwargs)
         kernel_size = 3

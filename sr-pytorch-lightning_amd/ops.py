@@ -432,6 +432,14 @@ def _grad_target(p, shape, dev):
     t = p.__dict__.get("_srk_grad_target")
     if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
         return None
+    # only the FIRST use of the parameter in a backward pass gets the slice: `.grad` stays None until AccumulateGrad has seen every
+    # use, so a second use (a conv shared between two places of a user's model) would overwrite the first one's result in the same
+    # memory and autograd would then add two aliases of it (2 g_last instead of g_1 + g_2).  Later uses return fresh tensors.
+    pid = _pass_id()
+    if pid >= 0:
+        if p.__dict__.get("_srk_target_pass") == pid:
+            return None
+        p.__dict__["_srk_target_pass"] = pid
     return t.detach()           # a fresh tensor object on the same memory (AccumulateGrad adopts a gradient nobody else references)
 
 

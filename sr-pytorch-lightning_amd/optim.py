@@ -17,6 +17,42 @@ from . import _lib as L
 _CHUNK = 4096           # elements per workgroup (256 threads x 4 x float4)
 
 
+class DeviceGradScaler:
+    """Dynamic loss scaling whose state lives on the GPU: torch.amp.GradScaler's arithmetic (init_scale 2^16, growth factor 2,
+    backoff 0.5, growth interval 2000 -- what Lightning's "16-mixed" precision wraps around the reference's training_step for
+    `precision: 16`, configs/all.yml:122) without its per-step host read.  GradScaler.step() asks the HOST whether a gradient was
+    non-finite and then calls or skips optimizer.step() from Python; a hipGraph replay cannot branch on the host, so fp16 training
+    ran launch by launch (RCAN: 72.8 ms per step against 19 ms replayed).  Here the check, the skip and the scale update are
+    launches of the step itself (`srk_adam_step_scaled`, `srk_loss_scale_update`):
+
+        loss_s = scaler.scale(loss)            # loss * scale (a device scalar: the backward pass carries it)
+        loss_s.backward()
+        optimizer.step(grad_scaler=scaler)     # non-finite gradient anywhere -> nothing is updated; scale halves; else g / scale
+
+    state (8 device floats): scale, growth tracker, found_inf, growth factor, backoff factor, growth interval, skipped steps, -."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.tensor([init_scale, 0.0, 0.0, growth_factor, backoff_factor, float(growth_interval), 0.0, 0.0],
+                                  dtype=torch.float32, device=device)
+
+    def scale(self, loss):
+        return loss * self.state[0]            # a view of the state: no host read, capturable
+
+    def get_scale(self):
+        return float(self.state[0])            # (host read: logging only)
+
+    @property
+    def skipped_steps(self):
+        return int(self.state[6])
+
+    def state_dict(self):
+        return {"scale": self.get_scale(), "growth_tracker": int(self.state[1])}
+
+    def load_state_dict(self, d):
+        self.state[0] = float(d["scale"])
+        self.state[1] = float(d.get("growth_tracker", 0))
+
+
 class _Table:
     """One device copy of the (parameter, gradient) table with its page-locked staging buffer.  The eager steps own one;
     every hipGraph capture gets ITS OWN (a captured upload is a memcpy node that re-reads the staging buffer on every
@@ -204,9 +240,13 @@ class Adam(torch.optim.Adam):
 
     # -- step -------------------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scaler=None):
+        """grad_scaler: a `DeviceGradScaler` whose scale the gradients still carry (fp16 training): the launch checks them for
+        non-finite values, skips the whole update if it finds one, divides by the scale otherwise, and adjusts the scale."""
         on_gpu = {p.is_cuda for group in self.param_groups for p in group["params"]}
         if on_gpu == {False}:
+            if grad_scaler is not None:
+                raise RuntimeError("DeviceGradScaler needs GPU parameters")
             return super().step(closure)
         if on_gpu != {True}:
             raise RuntimeError("Adam: parameters on both CPU and GPU")
@@ -230,8 +270,14 @@ class Adam(torch.optim.Adam):
                                lr=float(group["lr"]), beta1=float(b1), beta2=float(b2), eps=float(group["eps"]),
                                weight_decay=float(group["weight_decay"]), maximize=int(bool(group["maximize"])),
                                one_minus_beta1=1.0 - float(b1), one_minus_beta2=1.0 - float(b2))
-                L.call("srk_adam_step", a, stream)
+                if grad_scaler is None:
+                    L.call("srk_adam_step", a, stream)
+                else:
+                    L.check(L.load().srk_adam_step_scaled(C.byref(a), grad_scaler.state.data_ptr(), stream), "srk_adam_step_scaled")
                 # the kernel wrote through raw pointers: tell autograd (and the packed-weight cache, which keys on it) that
                 # the parameters changed, as an in-place torch op would
                 torch.autograd.graph.increment_version(t.live)
+        if grad_scaler is not None:
+            with torch.cuda.device(grad_scaler.state.device):
+                L.check(L.load().srk_loss_scale_update(grad_scaler.state.data_ptr(), torch.cuda.current_stream().cuda_stream), "srk_loss_scale_update")
         return loss

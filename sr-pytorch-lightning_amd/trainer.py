@@ -49,7 +49,8 @@ def wrap_ddp(model, device, force=False):
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return model
     from . import ops
-    ops.set_defer_wgrad(False)           # process-wide while a DDP-wrapped model trains; `unwrap_ddp` restores it
+    prev = ops.set_defer_wgrad(False)    # process-wide while a DDP-wrapped model trains; `unwrap_ddp` restores what it was
+    model.__dict__["_srk_prev_defer"] = prev
     nbytes = sum(p.numel() * 4 for p in model.parameters() if p.requires_grad)
     cap_mb = max(1, int(nbytes / 2 ** 20) + 1)
     kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=cap_mb, broadcast_buffers=False, find_unused_parameters=False)
@@ -62,7 +63,7 @@ def unwrap_ddp(net):
     """Undo `wrap_ddp`'s process-wide switch once the wrapped model is done training."""
     from . import ops
     if isinstance(net, DDP):
-        ops.set_defer_wgrad(True)
+        ops.set_defer_wgrad(net.module.__dict__.pop("_srk_prev_defer", True))      # (SRK_NO_DEFER_WGRAD=1 stays off)
         return net.module
     return net
 
@@ -140,6 +141,7 @@ class GradSync:
         self.remove_hooks()
         for p in self.params:
             p.__dict__.pop("_srk_grad_target", None)
+            p.__dict__.pop("_srk_target_pass", None)
 
     def broadcast(self):
         if self.world > 1:
@@ -214,6 +216,8 @@ def auto_segments(model, bucket_bytes=32 << 20):
     """How many backward segments the graph-replayed multi-rank step uses: SRK_DDP_SEGMENTS if set, else one per ~32 MB of
     gradients (at most 8) once there are more than 48 MB of them -- below that one all-reduce is latency-bound and extra
     graph launches (~15 us each) cost more than the overlap returns."""
+    if not getattr(model, "supports_backward_segments", True):       # (WDSR: one autograd node owns every weight norm)
+        return 1
     env = os.environ.get("SRK_DDP_SEGMENTS", "auto")
     if env != "auto":
         return max(1, int(env))
@@ -236,7 +240,13 @@ def _eager_step(model, net, optimizer, gsync, scaler, batch):
     optimizer.zero_grad(set_to_none=True)
     img_sr = net(batch["lr"])
     loss = model._calculate_losses(img_sr=img_sr, img_hr=batch["hr"])["loss"]
-    if scaler is not None:
+    if scaler is not None and hasattr(scaler, "state"):      # optim.DeviceGradScaler: check / skip / unscale inside the optimizer's launch
+        scaler.scale(loss).backward()
+        ops.flush_wgrads()
+        if gsync is not None:
+            gsync.sync()
+        optimizer.step(grad_scaler=scaler)
+    elif scaler is not None:                                  # torch.amp.GradScaler (an optimizer that is not the HIP Adam)
         scaler.scale(loss).backward()
         ops.flush_wgrads()
         if gsync is not None:
@@ -267,8 +277,9 @@ class GraphedStep:
     the loop stays eager (and says so once).  Callers must not keep a loss WITH its autograd graph from an earlier eager step
     alive across the capture (`_eager_step` returns it detached for that reason)."""
 
-    def __init__(self, model, net, optimizer, gsync, warm_steps=3):
+    def __init__(self, model, net, optimizer, gsync, warm_steps=3, scaler=None):
         self.model, self.net, self.opt, self.gsync = model, net, optimizer, gsync
+        self.scaler = scaler                 # optim.DeviceGradScaler (fp16) or None: its launches are part of the captured step
         self.warm_steps = int(warm_steps)
         self.segments = auto_segments(model) if gsync is not None else 1
         self.ogs = None                      # OverlappedGraphStep (several ranks, large models): all-reduces beside backward
@@ -290,8 +301,14 @@ class GraphedStep:
         self.opt.zero_grad(set_to_none=True)
         sr = self.net(self.static["lr"])
         loss = self.model._calculate_losses(img_sr=sr, img_hr=self.static["hr"])["loss"]
-        loss.backward()
+        (loss if self.scaler is None else self.scaler.scale(loss)).backward()
         return loss
+
+    def _opt_step(self):
+        if self.scaler is None:
+            self.opt.step()
+        else:
+            self.opt.step(grad_scaler=self.scaler)
 
     def _capture(self, batch):
         self.static = {"lr": batch["lr"].clone(), "hr": batch["hr"].clone()}
@@ -307,7 +324,7 @@ class GraphedStep:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side, capture_error_mode=cem):
                 self.loss = self._fwd_bwd()
-                self.opt.step()
+                self._opt_step()
             self.graphs = (g,)
         else:
             # forward + backward (+ the few gradients that still need packing) are ONE graph; the bucket all-reduces and the
@@ -325,7 +342,7 @@ class GraphedStep:
         if self.failed or self.seen <= self.warm_steps or (self.graphs is not None and not same):
             if self.ogs is not None and self.ogs.gsync is not None:
                 return self.ogs.eager_step(batch)          # (the buckets were re-cut along the segments: its own eager form)
-            return _eager_step(self.model, self.net, self.opt, self.gsync, None, batch)
+            return _eager_step(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
         if self.graphs is not None and self._hyper() != self.hyper:
             # lr / betas / ... changed: capture again with the new values (the old graphs go first, then the tables they read)
             self.graphs = None
@@ -336,9 +353,21 @@ class GraphedStep:
                 self.opt.release_captured_tables()
         if self.graphs is None and self.segments > 1 and self.gsync is not None:
             if self.ogs is None:                 # (two ordinary eager steps: the segments' parameter groups, the re-cut buckets)
-                self.gsync.detach()
-                self.ogs = OverlappedGraphStep(self.model, self.opt, self.segments)
-                return self.ogs.prepare(batch)
+                bucket_bytes = int(os.environ.get("SRK_BUCKET_BYTES", 32 << 20))
+                try:
+                    self.gsync.detach()
+                    ogs = OverlappedGraphStep(self.model, self.opt, self.segments, bucket_bytes=bucket_bytes, scaler=self.scaler)
+                    loss = ogs.prepare(batch)
+                    self.ogs = ogs
+                    return loss
+                except Exception as e:  # noqa: BLE001  (a model whose graph cannot be cut: every rank fails the same way, before any update)
+                    import sys
+                    from . import ops
+                    ops.discard_wgrads()
+                    print(f"[trainer] segmented backward not possible for this model ({type(e).__name__}: {e}); one backward graph", file=sys.stderr)
+                    self.segments, self.ogs = 1, None
+                    self.gsync = GradSync(self.model, bucket_bytes=bucket_bytes)
+                    return _eager_step(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
             try:
                 torch.cuda.synchronize()
                 self.ogs.capture(batch)
@@ -365,14 +394,14 @@ class GraphedStep:
                 print(f"[trainer] hipGraph capture failed ({type(e).__name__}: {e}); training continues eagerly", file=sys.stderr)
                 self.failed, self.graphs, self.static = True, None, None
                 torch.cuda.synchronize()
-                return _eager_step(self.model, self.net, self.opt, self.gsync, None, batch)
+                return _eager_step(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
         else:
             self.static["lr"].copy_(batch["lr"], non_blocking=True)
             self.static["hr"].copy_(batch["hr"], non_blocking=True)
         self.graphs[0].replay()
         if len(self.graphs) == 2:
             self.gsync.reduce()
-            self.opt.step()
+            self._opt_step()
         return self.loss.detach()
 
 
@@ -391,8 +420,9 @@ class OverlappedGraphStep:
 
     prepare(batch) is ONE ordinary eager training step (it finds which parameters each segment completes and re-cuts the buckets)."""
 
-    def __init__(self, model, optimizer, segments, bucket_bytes=32 << 20):
+    def __init__(self, model, optimizer, segments, bucket_bytes=32 << 20, scaler=None):
         self.model, self.opt, self.want = model, optimizer, max(2, int(segments))
+        self.scaler = scaler                 # optim.DeviceGradScaler or None
         self.bucket_bytes = bucket_bytes
         self.gsync = self.graphs = self.static = self.loss = None
         self.every, self.limit = 1, None
@@ -401,41 +431,75 @@ class OverlappedGraphStep:
         from . import ops
         with ops.record_segments(every, limit=self.limit) as rec:
             loss = self.model._calculate_losses(img_sr=self.model(batch["lr"]), img_hr=batch["hr"])["loss"]
+            if self.scaler is not None:      # the backward passes start from the scaled loss; callers report `self.raw_loss`
+                self.raw_loss = loss.detach()
+                loss = self.scaler.scale(loss)
+            else:
+                self.raw_loss = loss.detach()
         return loss, rec
+
+    def _opt_step(self):
+        if self.scaler is None:
+            self.opt.step()
+        else:
+            self.opt.step(grad_scaler=self.scaler)
 
     def prepare(self, batch):
         """Counts the model's cut points, picks the stride, finds the parameter groups with one eager training step on `batch`
         and builds the GradSync along them."""
         from . import ops
+        # the probe forward only counts cut points: BatchNorm running statistics / num_batches_tracked must not see the batch twice
+        bufs = [(b, b.detach().clone()) for b in self.model.buffers()]
         with torch.no_grad():
             _, rec = self._forward(batch, 1)
+            for b, keep in bufs:
+                b.copy_(keep)
         ncut = rec.count
         # the model's mandatory cuts (long skip connections, `ops.cut(..., keep=True)`) count towards the wanted segments; the
         # optional ones (block boundaries) are thinned to spread the rest evenly
         self.limit = max(0, self.want - 1 - rec.keeps)
         self.every = max(1, ncut // (self.limit + 1)) if ncut else 1
         params = [p for p in self.model.parameters() if p.requires_grad]
-        seen, groups = set(), []
+        first, sums = {}, []                                  # id -> segment of the first gradient; per segment: checksums of every gradient so far
 
         def collect(k):
             ops.flush_wgrads()
-            g = [p for p in params if p.grad is not None and id(p) not in seen]
-            seen.update(id(p) for p in g)
-            groups.append(g)
+            for p in params:
+                if p.grad is not None and id(p) not in first:
+                    first[id(p)] = k
+            have = [p for p in params if p.grad is not None]
+            sums.append((have, torch.stack([p.grad.detach().double().sum() for p in have]) if have else None))
         self.opt.zero_grad(set_to_none=True)
         loss, rec = self._forward(batch, self.every)
         ops.backward_segments(loss, rec.cuts, after=collect)
-        rest = [p for p in params if id(p) not in seen]           # parameters without a gradient this step: one more group at the end
-        groups.append(rest)                                       # (empty groups stay: group k = segment k)
-        if dist.is_initialized() and dist.get_world_size() > 1:   # the first step's gradients still have to be averaged
-            for p in params:
-                if p.grad is not None:
-                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-                    p.grad.div_(dist.get_world_size())
-        self.opt.step()
+        # a parameter used on both sides of a cut (a shared module) keeps changing after its first segment: its bucket may only be
+        # reduced behind the LAST segment that touches it (one host read for all checksums)
+        last = dict(first)
+        prev = {}
+        for k, (have, cs) in enumerate(sums):
+            vals = cs.tolist() if cs is not None else []
+            for p, v in zip(have, vals):
+                if id(p) in prev and prev[id(p)] != v:
+                    last[id(p)] = k
+                prev[id(p)] = v
+        nseg = len(sums)
+        groups = [[p for p in params if last.get(id(p)) == k] for k in range(nseg)]
+        groups.append([p for p in params if id(p) not in last])   # parameters without a gradient this step: one more group at the end
+        if dist.is_initialized() and dist.get_world_size() > 1:   # the first step's gradients still have to be averaged: ONE collective
+            have = [p for p in params if p.grad is not None]
+            if have:
+                flat = torch.cat([p.grad.reshape(-1) for p in have])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.div_(dist.get_world_size())
+                off = 0
+                for p in have:
+                    n = p.numel()
+                    p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                    off += n
+        self._opt_step()
         self.groups = groups
         self.gsync = GradSync(self.model, overlap=False, bucket_bytes=self.bucket_bytes, groups=groups)
-        return loss.detach()
+        return self.raw_loss
 
     def _reduce_group(self, k, works):
         for i in self.gsync.group_buckets[k] if k < len(self.gsync.group_buckets) else ():
@@ -446,7 +510,7 @@ class OverlappedGraphStep:
             w.wait()
         if not self.gsync._avg and self.gsync.world > 1:
             self.gsync.flat.mul_(1.0 / self.gsync.world)
-        self.opt.step()
+        self._opt_step()
 
     def eager_step(self, batch):
         """The same step launch by launch (warm-up, batches of another shape)."""
@@ -468,7 +532,7 @@ class OverlappedGraphStep:
                     self.gsync._pack_bucket(i)
                 self._reduce_group(k, works)
         self._finish(works)
-        return loss.detach()
+        return self.raw_loss
 
     def capture(self, batch, capture_error_mode="thread_local"):
         from . import ops
@@ -500,7 +564,7 @@ class OverlappedGraphStep:
                         for i in self.gsync.group_buckets[kk]:
                             self.gsync._pack_bucket(i)
             graphs.append(g)
-        self.graphs, self.loss, self.nseg = graphs, loss, nseg
+        self.graphs, self.loss, self.nseg = graphs, self.raw_loss, nseg
         self._keep = (rec, cuts)                         # the cut tensors are the graphs' static memory
 
     def step(self, batch=None):
@@ -559,28 +623,34 @@ class Trainer:
         if use_scaler is None:
             use_scaler = getattr(model, "compute_dtype", torch.float32) == torch.float16 and self.device.type == "cuda"
         if use_scaler:
-            scaler = torch.amp.GradScaler("cuda")
+            # fp16 (the reference's `precision: 16` = Lightning "16-mixed": autocast + GradScaler, configs/all.yml:122): dynamic loss
+            # scaling with its state on the device when the optimizer is the HIP Adam, so that the step can still be a hipGraph
+            from .optim import Adam as _HipAdam, DeviceGradScaler
+            scaler = DeviceGradScaler(self.device) if isinstance(optimizer, _HipAdam) else torch.amp.GradScaler("cuda")
+        self.scaler = scaler
         graphed = None
-        if self.use_graph and scaler is None and self.device.type == "cuda" and not use_ddp:
-            graphed = GraphedStep(model, net, optimizer, gsync, warm_steps=11 if gsync is not None else 3)
-        for step, batch in enumerate(batches):
-            if 0 <= self.max_steps <= step:
-                break
-            batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
-            if graphed is not None:
-                loss = graphed(batch)
-            else:
-                loss = _eager_step(model, net, optimizer, gsync, scaler, batch)
-            # a replayed step returns the graph's static loss tensor: clone (one tiny asynchronous launch), never float()
-            self._loss_dev.append(loss.detach().clone())
-            if self.log_every and (step + 1) % self.log_every == 0:
-                last = self.losses[-1]
-                if self.rank == 0:
-                    print(f"step {step + 1}: loss {last:.6f}", flush=True)
-            elif len(self._loss_dev) >= 1024:
-                self.losses  # noqa: B018  (drain to the host list)
-        self.graphed = graphed
-        if gsync is not None:
-            gsync.detach()
-        unwrap_ddp(net)
+        if self.use_graph and (scaler is None or hasattr(scaler, "state")) and self.device.type == "cuda" and not use_ddp:
+            graphed = GraphedStep(model, net, optimizer, gsync, warm_steps=11 if gsync is not None else 3, scaler=scaler)
+        try:
+            for step, batch in enumerate(batches):
+                if 0 <= self.max_steps <= step:
+                    break
+                batch = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                if graphed is not None:
+                    loss = graphed(batch)
+                else:
+                    loss = _eager_step(model, net, optimizer, gsync, scaler, batch)
+                # a replayed step returns the graph's static loss tensor: clone (one tiny asynchronous launch), never float()
+                self._loss_dev.append(loss.detach().clone())
+                if self.log_every and (step + 1) % self.log_every == 0:
+                    last = self.losses[-1]
+                    if self.rank == 0:
+                        print(f"step {step + 1}: loss {last:.6f}", flush=True)
+                elif len(self._loss_dev) >= 1024:
+                    self.losses  # noqa: B018  (drain to the host list)
+        finally:                 # whatever ended the loop: nothing stays attached to the parameters, the deferral switch is what it was
+            self.graphed = graphed
+            for gs in {id(g): g for g in (gsync, getattr(graphed, "gsync", None), getattr(getattr(graphed, "ogs", None), "gsync", None)) if g is not None}.values():
+                gs.detach()
+            unwrap_ddp(net)
         return model
