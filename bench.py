@@ -567,11 +567,24 @@ def main():
                     last["out"] = step()
                 graphs = (g,)
             else:
+                # ONE graph per step also with several ranks: [optimizer step on the gradients the previous step reduced] + forward +
+                # backward + packing; only the bucket all-reduce is issued eagerly between two replays.  (Round 3 issued the optimizer
+                # step's three launches eagerly behind the all-reduce: 15 us of host-paced launches per step, half of the multi-rank
+                # structure's 3 % overhead at batch 16.)  Same arithmetic, shifted: step k's update opens replay k + 1; one eager
+                # forward + backward + reduce primes the first replay, one eager optimizer step closes the timed region's last.
+                with torch.cuda.stream(side):
+                    fwd_bwd()
+                    gsync.sync()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                if hasattr(opt, "reserve_capture_tables"):
+                    opt.reserve_capture_tables()
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga, stream=side, capture_error_mode=cem):
+                    opt_step()
                     last["out"] = fwd_bwd()
                     gsync.pack()
-                graphs = (ga, None)
+                graphs = (ga, "opt_first")
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 print(f"[bench] hipGraph capture ({mode}) failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
@@ -586,9 +599,8 @@ def main():
         elif len(graphs) == 1:
             graphs[0].replay()
         else:
-            graphs[0].replay()
+            graphs[0].replay()              # [update from the previous step's reduced gradients] forward, backward, packing
             gsync.reduce()
-            opt_step()                      # three launches: cheaper issued eagerly than a second graph's launch floor
 
     def timed(nsteps):
         if world > 1:
@@ -625,6 +637,21 @@ def main():
             ns = int(t.item())
         sustained = timed(ns) / ns
 
+    # the collective alone (all buckets back to back, every rank), HIP events on the launch stream: what a step exposes when nothing
+    # overlaps it -- so that the first multi-GPU run explains itself (`config.allreduce_ms`, `config.rccl_ranks`)
+    ar_ms, ar_sync = None, (ogs.gsync if (ogs is not None and ogs.gsync is not None) else gsync)
+    if ddp and ar_sync is not None and ar_sync.flat is not None:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            ar_sync.reduce()
+        e0.record()
+        for _ in range(10):
+            ar_sync.reduce()
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 10.0
+
     if rank == 0:
         total = a.batch * world * a.steps
         value = total / el
@@ -652,6 +679,9 @@ def main():
                                      if (gx != flop_per_patch) else "layer by layer")
         if scaler is not None:
             out["config"]["loss_scale"] = {"kind": "dynamic, device-resident (optim.DeviceGradScaler)", "scale": scaler.get_scale(), "skipped_steps": scaler.skipped_steps}
+        if ar_ms is not None:
+            out["config"]["allreduce_ms"] = round(ar_ms, 4)
+            out["config"]["allreduce_buckets"] = [int((b[1] - b[0]) * 4) for b in ar_sync.buckets]
         if ddp:
             out["config"]["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
             out["config"]["backend"] = dist.get_backend() if dist.is_initialized() else None

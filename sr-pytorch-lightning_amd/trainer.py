@@ -233,6 +233,20 @@ def synthetic_batch(n, channels, lr_size, scale, seed, device):
     return {"lr": lr.to(device), "hr": hr.to(device), "path": [f"synthetic/{i}" for i in range(n)]}
 
 
+def _eager_fwd_bwd_reduce(model, net, optimizer, gsync, scaler, batch):
+    """An eager step WITHOUT its optimizer step: forward, losses, backward, gradient average (what primes `GraphedStep`'s
+    optimizer-first graph)."""
+    from . import ops
+    ops.discard_wgrads()
+    optimizer.zero_grad(set_to_none=True)
+    loss = model._calculate_losses(img_sr=net(batch["lr"]), img_hr=batch["hr"])["loss"]
+    (loss if (scaler is None or not hasattr(scaler, "state")) else scaler.scale(loss)).backward()
+    ops.flush_wgrads()
+    if gsync is not None:
+        gsync.sync()
+    return loss.detach()
+
+
 def _eager_step(model, net, optimizer, gsync, scaler, batch):
     """forward -> losses -> backward -> [gradient average] -> optimizer step, launch by launch."""
     from . import ops
@@ -280,6 +294,7 @@ class GraphedStep:
     def __init__(self, model, net, optimizer, gsync, warm_steps=3, scaler=None):
         self.model, self.net, self.opt, self.gsync = model, net, optimizer, gsync
         self.scaler = scaler                 # optim.DeviceGradScaler (fp16) or None: its launches are part of the captured step
+        self.pending = False                 # several ranks, graph form: reduced gradients whose optimizer step opens the NEXT replay
         self.warm_steps = int(warm_steps)
         self.segments = auto_segments(model) if gsync is not None else 1
         self.ogs = None                      # OverlappedGraphStep (several ranks, large models): all-reduces beside backward
@@ -327,14 +342,32 @@ class GraphedStep:
                 self._opt_step()
             self.graphs = (g,)
         else:
-            # forward + backward (+ the few gradients that still need packing) are ONE graph; the bucket all-reduces and the
-            # optimizer step (three launches) are issued eagerly behind it: a second graph would cost its ~15 us launch floor
-            # per step, more than the launches it holds
+            # ONE graph per step: [optimizer step on the gradients the previous step reduced] + forward + backward + packing; only the
+            # bucket all-reduces are issued eagerly between two replays (round 3 also issued the optimizer step's three launches
+            # eagerly: host-paced, half of the structure's overhead at batch 16).  Same arithmetic, shifted by one replay: the
+            # caller's batch trains eagerly up to the reduce (its update opens the first replay), `finish()` applies the last one.
+            if self.pending:                 # (a re-capture after a hyper-parameter change: the previous replay's update first)
+                self._opt_step()
+            now = _eager_fwd_bwd_reduce(self.model, self.net, self.opt, self.gsync, self.scaler, self.static)
+            self.pending = True
+            if hasattr(self.opt, "reserve_capture_tables"):
+                self.opt.reserve_capture_tables()
+            torch.cuda.synchronize()
+            side.wait_stream(torch.cuda.current_stream())
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=side, capture_error_mode=cem):
+                self._opt_step()
                 self.loss = self._fwd_bwd()
                 self.gsync.pack()
-            self.graphs = (ga, None)
+            self.graphs = (ga, "opt_first")
+            return now
+        return None
+
+    def finish(self):
+        """Call when training ends: the update of the last replayed step (multi-rank graph form) is still pending."""
+        if self.pending:
+            self._opt_step()
+            self.pending = False
 
     def __call__(self, batch):
         self.seen += 1
@@ -342,6 +375,9 @@ class GraphedStep:
         if self.failed or self.seen <= self.warm_steps or (self.graphs is not None and not same):
             if self.ogs is not None and self.ogs.gsync is not None:
                 return self.ogs.eager_step(batch)          # (the buckets were re-cut along the segments: its own eager form)
+            if self.pending:                               # optimizer-first graph form: keep "reduced gradients, update pending" invariant
+                self._opt_step()
+                return _eager_fwd_bwd_reduce(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
             return _eager_step(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
         if self.graphs is not None and self._hyper() != self.hyper:
             # lr / betas / ... changed: capture again with the new values (the old graphs go first, then the tables they read)
@@ -386,7 +422,7 @@ class GraphedStep:
         if self.graphs is None:
             try:
                 torch.cuda.synchronize()
-                self._capture(batch)
+                now = self._capture(batch)
             except Exception as e:  # noqa: BLE001
                 import sys
                 from . import ops
@@ -394,14 +430,18 @@ class GraphedStep:
                 print(f"[trainer] hipGraph capture failed ({type(e).__name__}: {e}); training continues eagerly", file=sys.stderr)
                 self.failed, self.graphs, self.static = True, None, None
                 torch.cuda.synchronize()
+                if self.pending:
+                    self._opt_step()
+                    self.pending = False
                 return _eager_step(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
+            if now is not None:              # several ranks: this batch trained eagerly up to the reduce; its update opens the first replay
+                return now
         else:
             self.static["lr"].copy_(batch["lr"], non_blocking=True)
             self.static["hr"].copy_(batch["hr"], non_blocking=True)
         self.graphs[0].replay()
-        if len(self.graphs) == 2:
+        if len(self.graphs) == 2:            # [pending update] forward, backward, packing were the graph; the collective is eager
             self.gsync.reduce()
-            self._opt_step()
         return self.loss.detach()
 
 
@@ -648,6 +688,8 @@ class Trainer:
                         print(f"step {step + 1}: loss {last:.6f}", flush=True)
                 elif len(self._loss_dev) >= 1024:
                     self.losses  # noqa: B018  (drain to the host list)
+            if graphed is not None:
+                graphed.finish()         # (multi-rank graph form: the last replay's update)
         finally:                 # whatever ended the loop: nothing stays attached to the parameters, the deferral switch is what it was
             self.graphed = graphed
             for gs in {id(g): g for g in (gsync, getattr(graphed, "gsync", None), getattr(getattr(graphed, "ogs", None), "gsync", None)) if g is not None}.values():

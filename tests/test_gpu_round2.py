@@ -313,6 +313,7 @@ if mode == "graphed":
     for b in full:
         gstep({{k: v[rank * per:(rank + 1) * per].to(dev) for k, v in b.items()}})
     assert gstep.graphs is not None and len(gstep.graphs) == 2 and not gstep.failed
+    gstep.finish()          # (the last replay's update: the multi-rank graph opens with the optimizer step of the previous one)
     full = []
 if mode == "segments":
     # large-model form: the backward pass as three graph segments with the bucket all-reduces issued between them
