@@ -196,7 +196,9 @@ __global__ __launch_bounds__(256) void hrtail_edge_fwd_kernel(const srk_hrtail_a
   __syncthreads();
   const size_t oplane = (size_t)H2 * W2;
   float* const out = a.out + (size_t)n * O * oplane;
-  for (int idx = threadIdx.x; idx < 2 * e.len * O; idx += 256) {
+  // (gridDim.z workgroups share an edge: at the reference's batch of 16 there are only 2 N = 32 edges per launch -- every workgroup stages
+  // the whole line, a few KB from L2, and takes its slice of the outputs)
+  for (int idx = threadIdx.x + 256 * blockIdx.z; idx < 2 * e.len * O; idx += 256 * gridDim.z) {
     const int p = idx % (2 * e.len), o = idx / (2 * e.len);        // consecutive threads: consecutive output pixels of one colour
     const int s = p >> 1, q = p & 1;
     const float* const w = Wl + (size_t)(o * 2 + q) * Ci * 5;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void hrtail_edge_bwd_x_kernel(const srk_hrtail
   }
   for (int i = threadIdx.x; i < 2 * O * Ci * 5; i += 256) Wl[i] = a.wedge[(size_t)e.ty * 2 * O * Ci * 5 + i];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < e.len * Ci; idx += 256) {
+  for (int idx = threadIdx.x + 256 * blockIdx.z; idx < e.len * Ci; idx += 256 * gridDim.z) {
     const int ci = idx % Ci, s = idx / Ci;
     float corr = 0.f;
     for (int kk = 0; kk < 2 * O; ++kk) {
@@ -273,19 +275,20 @@ __global__ __launch_bounds__(256) void hrtail_edge_bwd_x_kernel(const srk_hrtail
 // pixels on both sides) and its 2 O rows of g go to LDS, then thread (ci, combo group) walks them.  Column Ci of a combo row holds
 // the sum of g alone (the bias terms; kept once, under the centre tap).  Partial sums per chunk; a second launch adds the chunks in a
 // fixed order (reproducible). ------------------------------------------------------------------------------------------------------------
-constexpr int EW_CHUNK = 2;          // images per workgroup
+// images per workgroup: srk_hrtail_ew_chunk(N) (1 up to 64 images, then N / 64); the items of an edge are split over gridDim.z workgroups
 constexpr int EW_MAXLEN = 512;       // longest edge the LDS staging takes (longer: the direct-from-memory loop)
 template <int DT>
-__global__ __launch_bounds__(256) void hrtail_edge_bwd_w_kernel(const srk_hrtail_args a, int nchunks) {
+__global__ __launch_bounds__(256) void hrtail_edge_bwd_w_kernel(const srk_hrtail_args a, int nchunks, int ew_chunk) {
   const int H = a.H, W = a.W, O = a.O, Ci = a.Ci, H2 = 2 * H, W2 = 2 * W;
   const int ty = blockIdx.y, chunk = blockIdx.x;
-  const int n0 = chunk * EW_CHUNK, n1 = min(a.N, n0 + EW_CHUNK);
+  const int n0 = chunk * ew_chunk, n1 = min(a.N, n0 + ew_chunk);
   const int ncombo = ty < 4 ? 2 * O * 5 : O;
   const size_t gplane = (size_t)H2 * W2;
   float* const dst = a.scratch + ((size_t)ty * nchunks + chunk) * (size_t)(2 * MAXO * 5) * (Ci + 1);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* const Xl = reinterpret_cast<float*>(smem_raw);          // [len + 4][Ci]
   if (ty >= 4) {
+    if (blockIdx.z != 0) return;
     const int c = ty - 4, ca = c >> 1, cbb = c & 1;
     const int Py = ca ? H2 - 1 : 0, Px = cbb ? W2 - 1 : 0, yy = ca ? H - 1 : 0, xx = cbb ? W - 1 : 0;
     for (int item = threadIdx.x; item < ncombo * (Ci + 1); item += 256) {
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(256) void hrtail_edge_bwd_w_kernel(const srk_hrtail
   // thread -> items: ci = tid % (Ci + 1) would not divide 256; walk items as (combo, ci) pairs with a fixed per-thread set instead
   constexpr int MAXIT = (2 * MAXO * 5 * 65 + 255) / 256;          // items per thread for Ci = 64 (larger Ci: the loop below just runs longer)
   const int nitems = ncombo * (Ci + 1);
+  const int ipb = (nitems + gridDim.z - 1) / gridDim.z, item0 = blockIdx.z * ipb, item1 = min(nitems, item0 + ipb);      // this workgroup's items
   float acc[MAXIT];
 #pragma unroll
   for (int k = 0; k < MAXIT; ++k) acc[k] = 0.f;
@@ -328,8 +332,8 @@ __global__ __launch_bounds__(256) void hrtail_edge_bwd_w_kernel(const srk_hrtail
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < MAXIT; ++k) {
-      const int item = threadIdx.x + k * 256;
-      if (item >= nitems) break;
+      const int item = item0 + threadIdx.x + k * 256;
+      if (item >= item1) break;
       const int ci = item % (Ci + 1), cb = item / (Ci + 1), tt = cb % 5, kk = cb / 5;
       const float* const gr = Gl + kk * len;
       // four interleaved partial sums (fixed order): the dependent add chain, not the LDS reads, paced the single-sum form
@@ -351,8 +355,8 @@ __global__ __launch_bounds__(256) void hrtail_edge_bwd_w_kernel(const srk_hrtail
   }
 #pragma unroll
   for (int k = 0; k < MAXIT; ++k) {
-    const int item = threadIdx.x + k * 256;
-    if (item < nitems) dst[item] = acc[k];
+    const int item = item0 + threadIdx.x + k * 256;
+    if (item < item1) dst[item] = acc[k];
   }
 }
 
@@ -507,6 +511,12 @@ extern "C" int srk_hrtail_collapse(const srk_hrtail_args* a, srk_stream_t stream
   return 0;
 }
 
+// workgroups per edge: enough of them to reach ~512 per launch at small batches
+static unsigned edge_split(int N) {
+  const int z = (512 + 2 * N - 1) / (2 * N);
+  return (unsigned)(z < 1 ? 1 : (z > 8 ? 8 : z));
+}
+
 template <typename K> static int edge_lds_attr(K kernel, const char* who) {
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) { srk_set_error("%s: cannot reserve LDS: %s", who, hipGetErrorString(e)); return (int)e; }
@@ -525,8 +535,8 @@ extern "C" int srk_hrtail_edge_fwd(const srk_hrtail_args* a, srk_stream_t stream
   if (rc0 || rc1) return rc0 ? rc0 : rc1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   for (int phase = 0; phase < 2; ++phase) {      // row edges, then column edges + corners (see the kernel)
-    if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_fwd_kernel<SRK_BF16>, dim3((unsigned)a->N, 2), dim3(256), lds, st, *a, phase);
-    else hipLaunchKernelGGL(hrtail_edge_fwd_kernel<SRK_F16>, dim3((unsigned)a->N, 2), dim3(256), lds, st, *a, phase);
+    if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_fwd_kernel<SRK_BF16>, dim3((unsigned)a->N, 2, edge_split(a->N)), dim3(256), lds, st, *a, phase);
+    else hipLaunchKernelGGL(hrtail_edge_fwd_kernel<SRK_F16>, dim3((unsigned)a->N, 2, edge_split(a->N)), dim3(256), lds, st, *a, phase);
     SRK_LAUNCH_CHECK();
   }
   return 0;
@@ -544,15 +554,18 @@ extern "C" int srk_hrtail_edge_bwd_x(const srk_hrtail_args* a, srk_stream_t stre
   if (rc0 || rc1) return rc0 ? rc0 : rc1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   for (int phase = 0; phase < 2; ++phase) {
-    if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_bwd_x_kernel<SRK_BF16>, dim3((unsigned)a->N, 2), dim3(256), lds, st, *a, phase);
-    else hipLaunchKernelGGL(hrtail_edge_bwd_x_kernel<SRK_F16>, dim3((unsigned)a->N, 2), dim3(256), lds, st, *a, phase);
+    if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_bwd_x_kernel<SRK_BF16>, dim3((unsigned)a->N, 2, edge_split(a->N)), dim3(256), lds, st, *a, phase);
+    else hipLaunchKernelGGL(hrtail_edge_bwd_x_kernel<SRK_F16>, dim3((unsigned)a->N, 2, edge_split(a->N)), dim3(256), lds, st, *a, phase);
     SRK_LAUNCH_CHECK();
   }
   return 0;
 }
 
+static int ew_chunk_of(int N) { return N <= 64 ? 1 : (N + 63) / 64; }
+
 extern "C" long long srk_hrtail_scratch_floats(int N, int Ci) {
-  const long long nchunks = (N + EW_CHUNK - 1) / EW_CHUNK;
+  const int ewc = ew_chunk_of(N);
+  const long long nchunks = (N + ewc - 1) / ewc;
   return 8 * nchunks * (long long)(2 * MAXO * 5) * (Ci + 1);
 }
 
@@ -560,7 +573,9 @@ extern "C" int srk_hrtail_edge_bwd_w(const srk_hrtail_args* a, srk_stream_t stre
   if (int rc = check_common(a, "srk_hrtail_edge_bwd_w")) return rc;
   if (int rc = check_act(a, "srk_hrtail_edge_bwd_w")) return rc;
   SRK_CHECK_ARG(a->x && a->g && a->scratch && a->eedge && a->e0 && a->ecor && a->k0, "srk_hrtail_edge_bwd_w: null pointer");
-  const int nchunks = (a->N + EW_CHUNK - 1) / EW_CHUNK;
+  const int ewc = ew_chunk_of(a->N);
+  const int nchunks = (a->N + ewc - 1) / ewc;
+  const unsigned nz = nchunks * 8 >= 512 ? 2 : (nchunks * 8 >= 256 ? 4 : 8);      // workgroups per (chunk, edge): their items are sliced
   const int len = a->H > a->W ? a->H : a->W;
   SRK_CHECK_ARG(a->Ci <= 64 && len <= EW_MAXLEN, "srk_hrtail_edge_bwd_w: Ci=%d (<= 64) edge length %d (<= %d)", a->Ci, len, EW_MAXLEN);
   const size_t lds = ((size_t)(len + 4) * a->Ci + (size_t)2 * a->O * len) * 4;
@@ -568,8 +583,8 @@ extern "C" int srk_hrtail_edge_bwd_w(const srk_hrtail_args* a, srk_stream_t stre
   static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&hrtail_edge_bwd_w_kernel<SRK_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&hrtail_edge_bwd_w_kernel<SRK_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr0 != hipSuccess || attr1 != hipSuccess) { srk_set_error("srk_hrtail_edge_bwd_w: cannot reserve LDS"); return (int)(attr0 != hipSuccess ? attr0 : attr1); }
-  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_bwd_w_kernel<SRK_BF16>, dim3((unsigned)nchunks, 8), dim3(256), lds, st, *a, nchunks);
-  else hipLaunchKernelGGL(hrtail_edge_bwd_w_kernel<SRK_F16>, dim3((unsigned)nchunks, 8), dim3(256), lds, st, *a, nchunks);
+  if (a->dtype == SRK_BF16) hipLaunchKernelGGL(hrtail_edge_bwd_w_kernel<SRK_BF16>, dim3((unsigned)nchunks, 8, nz), dim3(256), lds, st, *a, nchunks, ewc);
+  else hipLaunchKernelGGL(hrtail_edge_bwd_w_kernel<SRK_F16>, dim3((unsigned)nchunks, 8, nz), dim3(256), lds, st, *a, nchunks, ewc);
   SRK_LAUNCH_CHECK();
   const int total = (4 * 2 * a->O * 5 + 4 * a->O) * (a->Ci + 1);
   hipLaunchKernelGGL(hrtail_edge_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *a, nchunks);
