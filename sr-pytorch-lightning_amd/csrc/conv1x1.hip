@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const srk_conv_args a, int
 // inside the last 64-row block of the packed weights.
 // SRK_NO_P1=1 keeps the streaming kernel (A/B runs).
 bool srk_conv1x1_ok(const srk_conv_args& a) {
-  static const bool off = [] { const char* e = getenv("SRK_NO_P1"); return e && e[0] == '1'; }();
+  static const bool off = [] { const char* e = srk_dbg_getenv("SRK_NO_P1"); return e && e[0] == '1'; }();
   if (off || a.dtype == SRK_F32 || a.KH != 1 || a.KW != 1) return false;
   if (a.x_ps > 1 || a.out_mode != SRK_OUT_NHWC || a.post_add) return false;
   if (a.Cin < 64 || a.Cin % 16 != 0 || a.CoutP % 64 != 0 || a.Cout % 8 != 0 || a.Cout > a.CoutP || a.Cout <= a.CoutP - 64) return false;

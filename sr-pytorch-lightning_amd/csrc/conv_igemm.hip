@@ -1404,7 +1404,7 @@ static int launch_ws_one(const srk_conv_args& b, hipStream_t st, unsigned grid, 
 template <int DT, int CBW, int NKS, bool FAST> int launch_ws(const srk_conv_args& a, hipStream_t st) {
   constexpr int TCW = CBW * 32;
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
-  static const bool no_early = getenv("SRK_NO_EARLY") != nullptr;
+  static const bool no_early = srk_dbg_getenv("SRK_NO_EARLY") != nullptr;
   const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16, ctiles = a.CoutP / TCW;
   const long long nptiles = (long long)a.N * tilesX * tilesY;
   if (nptiles <= 0 || nptiles > 0x7fffffffLL) {
@@ -1477,7 +1477,7 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
     // 3x3 with ONE 128-byte input block: weights stay in LDS, persistent workgroups (conv_ws_kernel)
     const int rin = a.x_ps > 1 ? a.x_ps : 1;
     const long long xbytes = ((long long)a.N * a.H * a.W * rin * rin * a.x_pitch) * 2;
-    static const bool no_ws = getenv("SRK_NO_WS") != nullptr;      // diagnostics knob, read once
+    static const bool no_ws = srk_dbg_getenv("SRK_NO_WS") != nullptr;      // diagnostics knob, read once
     if (a.KH == 3 && xbytes < 0x7fffffffLL && !no_ws) {
       if (a.CoutP % 64 == 0 && conv_fast_ok(a, 2)) {
         if (rin == 1 && a.Cin == 64) return launch_ws<DT, 2, 4, true>(a, st);

@@ -477,7 +477,7 @@ extern "C" int srk_ks_read_stamps(unsigned long long* host64) {
 // NHWC in and out, optionally a pixel-shuffled input -- dgrad of an upsampler conv -- or the fused PixelShuffle store).
 // SRK_NO_KS=1 keeps the streaming kernel (A/B runs).
 bool srk_conv_ks_ok(const srk_conv_args& a) {
-  static const bool off = [] { const char* e = getenv("SRK_NO_KS"); return e && e[0] == '1'; }();
+  static const bool off = [] { const char* e = srk_dbg_getenv("SRK_NO_KS"); return e && e[0] == '1'; }();
   if (off || a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3) return false;
   if (a.out_mode == SRK_OUT_PLANAR || a.post_add) return false;
   if (a.Cin < 96 || a.Cin % 16 != 0 || a.CoutP % 64 != 0 || a.Cout % 8 != 0 || a.Cout > a.CoutP || a.Cout <= a.CoutP - 64) return false;

@@ -1049,13 +1049,13 @@ __global__ __launch_bounds__(256) void lk5_wgrad_kernel(const srk_wgrad_args a, 
 }
 
 bool lk5_wgrad_ok(const srk_wgrad_args& a) {
-  static const bool off = [] { const char* e = getenv("SRK_NO_LK5"); return e && e[0] == '1'; }();      // A/B knob
+  static const bool off = [] { const char* e = srk_dbg_getenv("SRK_NO_LK5"); return e && e[0] == '1'; }();      // A/B knob
   return !off && a.KH == 5 && a.Cin == 64 && a.Cout == 16 && (a.cout_real == 0 || a.cout_real > 6) && a.x_pitch % 8 == 0 && a.dy_pitch % 8 == 0 &&
          a.x_coff % 8 == 0 && a.dy_coff % 8 == 0;
 }
 
 bool lk_all_rows(const srk_wgrad_args& a) {
-  static const bool off = [] { const char* e = getenv("SRK_NO_LK_ALLROWS"); const char* p = getenv("SRK_NO_LK_PACKED"); return (e && e[0] == '1') || (p && p[0] == '1'); }();
+  static const bool off = [] { const char* e = srk_dbg_getenv("SRK_NO_LK_ALLROWS"); const char* p = srk_dbg_getenv("SRK_NO_LK_PACKED"); return (e && e[0] == '1') || (p && p[0] == '1'); }();
   return !off && a.cout_real > 0 && a.cout_real <= LK_CS && a.cout_real * a.KW <= 32 && a.KH >= 5;
 }
 
@@ -1157,9 +1157,9 @@ template <int DT> static int lk5_fwd_launch(const srk_conv_args& a, hipStream_t 
 }
 
 int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st) {
-  static const bool no_lk5 = [] { const char* e = getenv("SRK_NO_LK5"); return e && e[0] == '1'; }();      // A/B knob
+  static const bool no_lk5 = [] { const char* e = srk_dbg_getenv("SRK_NO_LK5"); return e && e[0] == '1'; }();      // A/B knob
   if (a.out_mode == SRK_OUT_PLANAR && a.KH == 5 && !no_lk5) return a.dtype == SRK_BF16 ? lk5_fwd_launch<SRK_BF16>(a, st) : lk5_fwd_launch<SRK_F16>(a, st);
-  static const bool no_rows = [] { const char* e = getenv("SRK_NO_LK_ROWS"); return e && e[0] == '1'; }();      // A/B knob
+  static const bool no_rows = [] { const char* e = srk_dbg_getenv("SRK_NO_LK_ROWS"); return e && e[0] == '1'; }();      // A/B knob
   if (!no_rows && a.out_mode == SRK_OUT_NHWC && a.Cin == 64 && a.cout_real > 0 && a.cout_real <= 4 && a.cout_real * a.KW <= 32 && a.Cout == 16 && !a.relu && !a.res && a.scale == 1.f)
     return a.dtype == SRK_BF16 ? lk_rows_launch<SRK_BF16>(a, st) : lk_rows_launch<SRK_F16>(a, st);
   if (a.Cin == 16) return a.dtype == SRK_BF16 ? lk_launch<SRK_BF16, 2, 2>(a, st) : lk_launch<SRK_F16, 2, 2>(a, st);
@@ -1206,7 +1206,7 @@ template <int DT, int K> static int lk_wgrad_launch_k(const srk_wgrad_args& a, h
       return 0;
     }
   }
-  static const bool no_packed = [] { const char* e = getenv("SRK_NO_LK_PACKED"); return e && e[0] == '1'; }();      // A/B knob
+  static const bool no_packed = [] { const char* e = srk_dbg_getenv("SRK_NO_LK_PACKED"); return e && e[0] == '1'; }();      // A/B knob
   if (a.cout_real > 0 && a.cout_real <= 6 && a.cout_real * K <= 32 && !no_packed) {
     // few real output channels (SRResNet's tail: 3): MFMA columns = (kw, co) pairs
     constexpr int plds = 2 * (16 * XWP * 128 + 16 * 16 * 32) + 8 * 16 * (16 + 2 * (K - 1) + 16) * 2 + 2 * 16 * 64 * 4;

@@ -619,7 +619,7 @@ static void wgrad1x1_shape(const srk_wgrad_args& a, int& cib, int& cob) {
 }
 static int wgrad1x1_slabs(const srk_wgrad_args& a) {
   if (a.dtype == SRK_F32 || a.KH != 1 || a.KW != 1 || a.x_ps > 1 || a.dy_ps > 1) return 0;
-  static const bool no_ws = getenv("SRK_NO_WS") != nullptr;      // diagnostics knob, read once
+  static const bool no_ws = srk_dbg_getenv("SRK_NO_WS") != nullptr;      // diagnostics knob, read once
   if (no_ws) return 0;
   const long long P = (long long)a.N * a.H * a.W;
   if (P * a.x_pitch * 2 >= 0x7fff0000LL || P * a.dy_pitch * 2 >= 0x7fff0000LL) return 0;
@@ -638,7 +638,7 @@ static int wgrad_ws_slabs(const srk_wgrad_args& a) {
   if (a.KH == 1 && a.KW == 1) return wgrad1x1_slabs(a);
   if (a.KH > 3) return srk_wgrad_lk_ok(a) ? srk_wgrad_lk_slabs(a) : 0;
   if (a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3 || a.x_ps > 1) return 0;
-  static const bool no_ws = getenv("SRK_NO_WS") != nullptr;      // diagnostics knob, read once
+  static const bool no_ws = srk_dbg_getenv("SRK_NO_WS") != nullptr;      // diagnostics knob, read once
   if (no_ws) return 0;
   const int rd = a.dy_ps > 1 ? a.dy_ps : 1;
   const long long xb = (long long)a.N * a.H * a.W * a.x_pitch * 2, db = (long long)a.N * a.H * a.W * rd * rd * a.dy_pitch * 2;

@@ -332,7 +332,7 @@ inline unsigned grid_for(long long total) {
 inline int stats_blocks(long long P) {
   // >= 256 pixels per block = ONE round of the 8 loads a thread keeps in flight (512: two dependent rounds; measured on SRResNet at
   // batch 16, 67 reductions per step: 4,846 -> 4,950 patches/s; 1,024 pixels per block: 4,498), at most 1024 blocks
-  static const int ppb = [] { const char* e = getenv("SRK_STATS_PPB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();   // A/B knob
+  static const int ppb = [] { const char* e = srk_dbg_getenv("SRK_STATS_PPB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();   // A/B knob
   long long b = (P + ppb - 1) / ppb;
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(1024) void proj_wgrad_finalize_kernel(const float* 
 
 int grid_for(int ntiles) {
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
-  static const int env = [] { const char* e = getenv("SRK_PROJ_WGS_PER_CU"); return e ? atoi(e) : 0; }();     // A/B knob
+  static const int env = [] { const char* e = srk_dbg_getenv("SRK_PROJ_WGS_PER_CU"); return e ? atoi(e) : 0; }();     // A/B knob
   const int g = (env > 0 ? env : 2) * cus;
   return ntiles < g ? ntiles : g;
 }
@@ -610,7 +610,7 @@ extern "C" int srk_proj_up(const srk_proj_args* a, srk_stream_t stream) {
 
 static int wgrad_slices(long long ntiles) {
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
-  static const int env = [] { const char* e = getenv("SRK_PROJ_WG_SLICES"); return e ? atoi(e) : 0; }();     // A/B knob
+  static const int env = [] { const char* e = srk_dbg_getenv("SRK_PROJ_WG_SLICES"); return e ? atoi(e) : 0; }();     // A/B knob
   // 4 kernel-row pairs x slices workgroups: 2 per CU when every slice still gets >= 16 tiles, else 1 per CU (the slices' partial sums
   // are 256 KB each: measured at 16 x 48 x 48, 64 slices 26.3 us, 128 slices 30.3; at 256 x 48 x 48, 254 vs 218 us)
   long long s = env > 0 ? env : (ntiles >= 16LL * (cus / 2) ? cus / 2 : cus / 4);

@@ -17,6 +17,14 @@ typedef __attribute__((ext_vector_type(4))) short i16x4;
 
 // thread-local error text (host)
 void srk_set_error(const char* fmt, ...);
+// A/B switches of tools/ (SRK_NO_WS, SRK_NO_EARLY, SRK_NO_LK5, ...): honoured only under SRK_DEBUG=1 (a stray variable in a user's
+// environment must not route the product path through a diagnostic form)
+#include <stdlib.h>
+#include <string.h>
+static inline const char* srk_dbg_getenv(const char* name) {
+  const char* d = getenv("SRK_DEBUG");
+  return (d && d[0] == '1') ? getenv(name) : nullptr;
+}
 #define SRK_CHECK_ARG(cond, ...)            \
   do {                                      \
     if (!(cond)) {                          \

@@ -1,9 +1,11 @@
 """D-DBPN on the HIP path.  Reference: models/ddbpn.py:10-137 (same ctor, same state_dict keys).
 
 The up / down projection units use nn.ConvTranspose2d / nn.Conv2d with kernel 6/8/12, stride 2/4/8, padding 2
-(ddbpn.py:10-24).  Here: strided conv = NHWC im2col + 1x1 MFMA conv, transposed conv = 1x1 MFMA conv + col2im gather
-(ops.conv_general / ops.conv_transpose_general), PReLU = srk_chan_apply.  The dense concatenations and the two
-elementwise ops of a projection unit (`b_0.sub(x)`, `a_0.add(a_1)`, ddbpn.py:57-62) stay torch ops on NHWC tensors."""
+(ddbpn.py:10-24).  Scale 4 (kernel 8, stride 4) in 16-bit runs on the DIRECT projection kernels (csrc/proj.hip through ops.proj_prelu /
+ops.conv_general / ops.conv_transpose_general: no column tensor, the PReLU behind every projection fused into the launch); scales 2 and 8
+and fp32 keep the NHWC im2col / col2im forms (strided conv = unfold + 1x1 MFMA conv, transposed conv = 1x1 MFMA conv + fold).  The
+dense concatenations and the two elementwise ops of a projection unit (`b_0.sub(x)`, `a_0.add(a_1)`, ddbpn.py:57-62) stay torch
+ops on NHWC tensors."""
 from typing import Any
 
 import torch

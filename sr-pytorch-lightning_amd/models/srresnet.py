@@ -33,5 +33,5 @@ class SRResNet(SRModel):
             r = blocks[-1].nhwc(r, res=f)                       # conv + BatchNorm, `+ x` fused into the BatchNorm apply
             r = self.tail[0].nhwc(r)
             t = self.tail[1]
-            y = ops.conv_general(r, t.weight, t.bias, stride=1, pad=t.kernel_size[0] // 2)               # 9x9 over 64 channels: NHWC im2col + 1x1 MFMA
+            y = ops.conv_general(r, t.weight, t.bias, stride=1, pad=t.kernel_size[0] // 2)               # 9x9 over 64 channels: the direct large-kernel kernels in 16-bit (csrc/conv_lk.hip), im2col + 1x1 MFMA in fp32
             return ops.nhwc_to_nchw(y, self._channels)

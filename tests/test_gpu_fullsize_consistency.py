@@ -50,7 +50,7 @@ def _run(env_extra):
 
 def test_three_implementations_agree_at_full_size():
     ref = _run({})
-    for env in ({"SRK_NO_EARLY": "1"}, {"SRK_NO_WS": "1"}):
+    for env in ({"SRK_DEBUG": "1", "SRK_NO_EARLY": "1"}, {"SRK_DEBUG": "1", "SRK_NO_WS": "1"}):      # (diagnostic switches: honoured under SRK_DEBUG=1 only)
         got = _run(env)
         for name in ("relu", "res", "mask"):
             a, b = ref[name], got[name]

@@ -267,3 +267,9 @@ def test_pw_wgrad_raw(A, dt, f, npix):
     assert l2err(db1, db1r) < L2TOL[dt] / 4
     assert l2err(dw2.view(cmid, chid), dw2r) < L2TOL[dt] / 4
     assert l2err(db2, db2r) < 1e-3
+    # per ELEMENT: the reference above is built from the ROUNDED operands incl. the 16-bit-rounded h and gh, so what
+    # is left is accumulation order plus the few h / gh elements whose fp32 pre-activation sits on a rounding boundary -- a fragment
+    # permutation slip that moved one (row, column) pair would be an O(1) error in that element, far above these bounds
+    assert relerr(dw1.view(chid, f), dw1r) < 6e-3
+    assert relerr(dw2.view(cmid, chid), dw2r) < 6e-3
+    assert relerr(db1, db1r) < 6e-3

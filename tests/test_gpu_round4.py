@@ -205,3 +205,44 @@ def test_wdsr_keeps_one_backward_graph_under_the_multi_rank_step(A):
         assert T.auto_segments(A.EDSR(n_feats=64, n_resblocks=2, scale_factor=2)) == 3
     finally:
         os.environ.pop("SRK_DDP_SEGMENTS", None)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the direct large-kernel kernels per ELEMENT against float64 computed from the 16-bit-ROUNDED
+# inputs (what is left is accumulation order, <= 1e-3 relative): a packing-permutation slip that touched one (kw, co) pair in 32
+# passes a relative-L2 bound of 8 %, not this one
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("k,cout,n,h,w,path", [(9, 3, 2, 40, 33, "lk_wgrad_allrows / lk_conv_rows"), (9, 1, 1, 35, 20, "allrows"), (5, 6, 1, 33, 33, "lk_wgrad_packed"),
+                                                (7, 4, 2, 16, 47, "allrows, 7x7"), (7, 16, 2, 17, 30, "lk_wgrad"), (5, 8, 1, 21, 19, "lk5_wgrad"),
+                                                (5, 12, 3, 48, 48, "lk5_wgrad (the collapsed HR stage's shape)")])
+def test_large_kernel_convs_per_element_on_rounded_inputs(A, dt, k, cout, n, h, w, path):
+    import torch.nn.functional as F
+    from sr_amd import ops
+    g = torch.Generator().manual_seed(17 + k + cout)
+    x = (torch.rand(n, 64, h, w, generator=g) * 2 - 1).to(dt)
+    wt = (((torch.rand(cout, 64, k, k, generator=g) * 2 - 1) / np.sqrt(64 * k * k)).to(dt)).float()      # weights already representable
+    b = (torch.rand(cout, generator=g) * 2 - 1) * 0.1
+    gy = (torch.rand(n, cout, h, w, generator=g) * 2 - 1).to(dt)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.conv_general(xd, wd, bd, stride=1, pad=k // 2)
+    cp = y.shape[3]
+    gyd = torch.zeros(n, h, w, cp, dtype=dt)
+    gyd[..., :cout] = gy.permute(0, 2, 3, 1)
+    y.backward(gyd.cuda())
+    torch.cuda.synchronize()
+    x64, w64, b64 = x.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(x64, w64, b64, padding=k // 2)
+    ref.backward(gy.double())
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    yy = y.detach().float().cpu()[..., :cout].permute(0, 3, 1, 2).double()
+    r = ref.detach()
+    # forward: one rounding of the stored output per element
+    assert float((yy - r).abs().max()) <= 1.1 * eps * float(r.abs().max()) + 1e-6, path
+    assert float(y.detach().float()[..., cout:].abs().max()) == 0.0 if cp > cout else True
+    gx = xd.grad.float().cpu().permute(0, 3, 1, 2).double()
+    assert float((gx - x64.grad).abs().max()) <= 1.1 * eps * float(x64.grad.abs().max()) + 1e-6, path
+    # weight / bias gradients: fp32 sums of exact products of 16-bit values
+    assert float((wd.grad.cpu().double() - w64.grad).abs().max()) <= 1e-3 * float(w64.grad.abs().max()), path
+    assert float((bd.grad.cpu().double() - b64.grad).abs().max()) <= 1e-3 * float(b64.grad.abs().max()) + 1e-5, path

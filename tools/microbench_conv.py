@@ -40,4 +40,4 @@ g.replay(); torch.cuda.synchronize()
 e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / a.iters
 fl = 2.0 * a.n * a.hw * a.hw * a.cin * a.cout * a.k * a.k
-print(f"{a.mode} {a.dtype} n={a.n} {a.hw}x{a.hw} {a.cin}->{a.cout} k{a.k}: {us:.2f} us/iter  {fl/us/1e6:.1f} TFLOP/s  ws={'off' if os.environ.get('SRK_NO_WS') else 'on'}")
+print(f"{a.mode} {a.dtype} n={a.n} {a.hw}x{a.hw} {a.cin}->{a.cout} k{a.k}: {us:.2f} us/iter  {fl/us/1e6:.1f} TFLOP/s  ws={'off' if (os.environ.get('SRK_NO_WS') and os.environ.get('SRK_DEBUG') == '1') else 'on'}")
