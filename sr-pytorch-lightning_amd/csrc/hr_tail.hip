@@ -167,10 +167,28 @@ SRK_DEV EdgeGeo edge_geo(int ty, int H, int W) {
   e.fix_hr = ty == 0 ? 0 : ty == 1 ? 2 * H - 1 : ty == 2 ? 0 : 2 * W - 1;
   return e;
 }
-// stage the line of X: Xl[(s + 2) * pitch + ci], s = -2 .. len + 1 (zeros outside)
+// stage the line of X: Xl[(s + 2) * pitch + ci], s = -2 .. len + 1 (zeros outside); 16-byte loads (8 channels) where the layout allows
 template <int DT>
 SRK_DEV void stage_line(const srk_hrtail_args& a, const EdgeGeo& e, int n, float* Xl, int pitch) {
+  typedef DTraits<DT> Tr;
   const int Ci = a.Ci;
+  if ((Ci & 7) == 0 && (a.x_pitch & 7) == 0) {
+    const int nch = Ci >> 3;
+    for (int i = threadIdx.x; i < (e.len + 4) * nch; i += 256) {
+      const int sp = i / nch, c8 = i - sp * nch, s = sp - 2;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (s >= 0 && s < e.len) {
+        const int yy = e.row ? e.fix_lr : s, xx = e.row ? s : e.fix_lr;
+        const i32x4 raw = gload16(reinterpret_cast<const typename Tr::elem*>(a.x) + ((size_t)(n * a.H + yy) * a.W + xx) * a.x_pitch + c8 * 8);
+        const int w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) unpack2<DT>((uint32_t)w4[k], v[2 * k], v[2 * k + 1]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) Xl[sp * pitch + c8 * 8 + k] = v[k];
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < (e.len + 4) * Ci; i += 256) {
     const int s = i / Ci - 2, ci = i % Ci;
     float v = 0.f;
@@ -198,16 +216,20 @@ __global__ __launch_bounds__(256) void hrtail_edge_fwd_kernel(const srk_hrtail_a
   float* const out = a.out + (size_t)n * O * oplane;
   // (gridDim.z workgroups share an edge: at the reference's batch of 16 there are only 2 N = 32 edges per launch -- every workgroup stages
   // the whole line, a few KB from L2, and takes its slice of the outputs)
+  // (gridDim.z workgroups share an edge: at the reference's batch of 16 there are only 2 N = 32 edges per launch -- every workgroup stages
+  // the whole line, a few KB from L2, and takes its slice of the outputs.  One OUTPUT per thread: a thread that took all O colours of
+  // its pixel read a third fewer operands and ran 2.5x longer -- these loops are bound by their dependent chain, not by LDS traffic.)
   for (int idx = threadIdx.x + 256 * blockIdx.z; idx < 2 * e.len * O; idx += 256 * gridDim.z) {
     const int p = idx % (2 * e.len), o = idx / (2 * e.len);        // consecutive threads: consecutive output pixels of one colour
     const int s = p >> 1, q = p & 1;
     const float* const w = Wl + (size_t)(o * 2 + q) * Ci * 5;
     const float* const x = Xl + (size_t)s * pitch;                 // tap tt reads pixel s + tt - 2 = Xl row s + tt
-    float acc = a.bedge[e.ty * 2 * O + o * 2 + q];
+    float a0 = a.bedge[e.ty * 2 * O + o * 2 + q], a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;      // one chain per tap
     for (int ci = 0; ci < Ci; ++ci) {
-#pragma unroll
-      for (int tt = 0; tt < 5; ++tt) acc += w[ci * 5 + tt] * x[tt * pitch + ci];
+      a0 += w[ci * 5 + 0] * x[0 * pitch + ci]; a1 += w[ci * 5 + 1] * x[1 * pitch + ci]; a2 += w[ci * 5 + 2] * x[2 * pitch + ci];
+      a3 += w[ci * 5 + 3] * x[3 * pitch + ci]; a4 += w[ci * 5 + 4] * x[4 * pitch + ci];
     }
+    float acc = ((a0 + a1) + (a2 + a3)) + a4;
     if (!e.row && (p == 0 || p == 2 * e.len - 1)) {
       // corner output pixel (column launch): give back the tap both of its edges removed
       const int ca = p == 0 ? 0 : 1, cb = e.ty == 2 ? 0 : 1, c = ca * 2 + cb;
@@ -246,26 +268,61 @@ __global__ __launch_bounds__(256) void hrtail_edge_bwd_x_kernel(const srk_hrtail
   }
   for (int i = threadIdx.x; i < 2 * O * Ci * 5; i += 256) Wl[i] = a.wedge[(size_t)e.ty * 2 * O * Ci * 5 + i];
   __syncthreads();
-  for (int idx = threadIdx.x + 256 * blockIdx.z; idx < e.len * Ci; idx += 256 * gridDim.z) {
-    const int ci = idx % Ci, s = idx / Ci;
-    float corr = 0.f;
-    for (int kk = 0; kk < 2 * O; ++kk) {
-      const float* const w = Wl + ((size_t)kk * Ci + ci) * 5;
-      const float* const gl = Gl + (size_t)kk * (e.len + 4) + s + 2;      // the edge pixel whose tap tt reads pixel s: s - (tt - 2)
+  // one thread = 8 channels of one pixel: ONE 16-byte read-modify-write of dX (2-byte scalar updates were 24 dependent global round
+  // trips per thread)
+  const int nch = (Ci + 7) >> 3;
+  const bool vec = (Ci & 7) == 0 && (a.dx_pitch & 7) == 0;
+  for (int idx = threadIdx.x + 256 * blockIdx.z; idx < e.len * nch; idx += 256 * gridDim.z) {
+    const int c8 = idx % nch, s = idx / nch;
+    float corr[8];
 #pragma unroll
-      for (int tt = 0; tt < 5; ++tt) corr += w[tt] * gl[2 - tt];
+    for (int k = 0; k < 8; ++k) corr[k] = 0.f;
+    for (int kk = 0; kk < 2 * O; ++kk) {
+      const float* const gl = Gl + (size_t)kk * (e.len + 4) + s + 2;      // the edge pixel whose tap tt reads pixel s: s - (tt - 2)
+      float gv[5];
+#pragma unroll
+      for (int tt = 0; tt < 5; ++tt) gv[tt] = gl[2 - tt];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int ci = c8 * 8 + k;
+        if (ci < Ci) {
+          const float* const w = Wl + ((size_t)kk * Ci + ci) * 5;
+#pragma unroll
+          for (int tt = 0; tt < 5; ++tt) corr[k] += w[tt] * gv[tt];
+        }
+      }
     }
     if (!e.row && (s == 0 || s == e.len - 1)) {
       for (int ca = 0; ca < 2; ++ca) {                               // (H == 1: the pixel is the top AND the bottom corner)
         if (!(ca ? s == e.len - 1 : s == 0)) continue;
         const int cb = e.ty == 2 ? 0 : 1, c = ca * 2 + cb;
         const size_t at = (size_t)(ca ? H2 - 1 : 0) * W2 + e.fix_hr;
-        for (int o = 0; o < O; ++o) corr -= a.wcor[((size_t)c * O + o) * Ci + ci] * g[(size_t)o * gplane + at];
+        for (int o = 0; o < O; ++o) {
+          const float gc = g[(size_t)o * gplane + at];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (c8 * 8 + k < Ci) corr[k] -= a.wcor[((size_t)c * O + o) * Ci + c8 * 8 + k] * gc;
+        }
       }
     }
     const int yy = e.row ? e.fix_lr : s, xx = e.row ? s : e.fix_lr;
-    typename Tr::elem* const d = reinterpret_cast<typename Tr::elem*>(a.dx) + ((size_t)(n * H + yy) * W + xx) * a.dx_pitch + ci;
-    *d = Tr::from_f32(Tr::to_f32(*d) - corr);
+    typename Tr::elem* const d = reinterpret_cast<typename Tr::elem*>(a.dx) + ((size_t)(n * H + yy) * W + xx) * a.dx_pitch + c8 * 8;
+    if (vec) {
+      const i32x4 raw = *reinterpret_cast<const i32x4*>(d);
+      const int w4[4] = {raw.x, raw.y, raw.z, raw.w};
+      int o4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float f0, f1;
+        unpack2<DT>((uint32_t)w4[k], f0, f1);
+        o4[k] = (int)pack2<DT>(f0 - corr[2 * k], f1 - corr[2 * k + 1]);
+      }
+      *reinterpret_cast<i32x4*>(d) = i32x4{o4[0], o4[1], o4[2], o4[3]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (c8 * 8 + k < Ci) d[k] = Tr::from_f32(Tr::to_f32(d[k]) - corr[k]);
+    }
   }
   }
 }
@@ -315,15 +372,7 @@ __global__ __launch_bounds__(256) void hrtail_edge_bwd_w_kernel(const srk_hrtail
   for (int k = 0; k < MAXIT; ++k) acc[k] = 0.f;
   for (int n = n0; n < n1; ++n) {
     __syncthreads();
-    for (int i = threadIdx.x; i < (len + 4) * Ci; i += 256) {
-      const int s = i / Ci - 2, ci = i % Ci;
-      float v = 0.f;
-      if (s >= 0 && s < len) {
-        const int yy = rowedge ? (ty == 0 ? 0 : H - 1) : s, xx = rowedge ? s : (ty == 2 ? 0 : W - 1);
-        v = ld_act<DT>(a.x, ((size_t)(n * H + yy) * W + xx) * a.x_pitch + ci);
-      }
-      Xl[i] = v;
-    }
+    stage_line<DT>(a, edge_geo(ty, H, W), n, Xl, Ci);          // Xl[(s + 2) * Ci + ci], zeros outside (16-byte loads)
     for (int i = threadIdx.x; i < 2 * O * len; i += 256) {
       const int kk = i / len, s = i % len, o = kk >> 1, q = kk & 1;
       const float* const g = a.g + ((size_t)n * O + o) * gplane;
