@@ -111,7 +111,15 @@ typedef struct {
   const float* post_add;               /* planar: per output channel c, or NULL                      */
   int dtype;
   int cout_real;                       /* the conv's real output channels when wpk carries the rows layout (srk_pack_args.rows_layout), else 0 */
+  /* ReLU sign BITS (3x3, 64 -> 64 channels, 16-bit, NHWC out: the weight-stationary kernel; srk_conv_bits_ok): 4 bytes per pixel and
+   * 32-channel half, [N*H*W][2] u32; bit i resp. 16 + i of word h <-> channel 32 h + 2 i resp. + 1 > 0 after the ReLU.
+   *   relu_bits (out, nullable): written by a conv + ReLU launch (relu = 1, no res / mask / scale) next to its output;
+   *   mask_bits (in, nullable, instead of `mask`): the data gradient `v = bit ? v : 0` reads these 8 bytes per pixel instead of the
+   *   128-byte activation (ResBlock / RCAB backward, models/common.py:99-100: 75 MB -> 4.7 MB per launch at 256 x 48 x 48).     */
+  void* relu_bits; const void* mask_bits;
 } srk_conv_args;
+/* 1 when srk_conv2d honours relu_bits / mask_bits for these arguments (else they must be NULL) */
+int srk_conv_bits_ok(const srk_conv_args* a);
 int srk_conv2d(const srk_conv_args* a, srk_stream_t stream);
 /* channel tile (32/64/128) the launcher uses for a given number of output channels */
 int srk_conv_tile(int Cout);

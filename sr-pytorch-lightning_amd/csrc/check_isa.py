@@ -33,9 +33,13 @@ def check_kernel(asm, dt, nks, em=1):
     name = kernel_name(dt, nks, em)
     start = asm.index(name + "iiiijiiiiiii:")
     body = asm[start:asm.index(".Lfunc_end", start)].split("\n")
-    loads = [k for k, l in enumerate(body)
-             if "buffer_load_dwordx4" in l and " lds" not in l and "ASMSTART" in body[k - 1]]
-    assert len(loads) == 8, f"expected 4 pieces x 2 pixel blocks, found {len(loads)}"
+    if em == 3:       # sign bits: one 4-byte word per pixel block
+        loads = [k for k, l in enumerate(body) if re.search(r"buffer_load_dword\s", l) and " lds" not in l and "ASMSTART" in body[k - 1]]
+        assert len(loads) == 2, f"expected one word x 2 pixel blocks, found {len(loads)}"
+    else:
+        loads = [k for k, l in enumerate(body)
+                 if "buffer_load_dwordx4" in l and " lds" not in l and "ASMSTART" in body[k - 1]]
+        assert len(loads) == 8, f"expected 4 pieces x 2 pixel blocks, found {len(loads)}"
     mfma = [k for k, l in enumerate(body) if "v_mfma" in l]
     assert len(mfma) == 36 * nks, f"{len(mfma)} MFMAs"
     waits = [k for k, l in enumerate(body) if "s_waitcnt vmcnt(0)" in l and "ASMSTART" in body[k - 1] and k > mfma[-1]]
@@ -45,8 +49,12 @@ def check_kernel(asm, dt, nks, em=1):
     assert not [k for k in range(loads[0], wait) if body[k].startswith(".LBB")], "branch target between a prefetch and its wait"
     seen = 0
     for k in loads:
-        dst = _regs(re.search(r"v\[\d+:\d+\]", body[k]).group(0))
-        assert len(dst) == 4
+        if em == 3:
+            dst = _regs(re.search(r"buffer_load_dword\s+(v\d+)", body[k]).group(1))
+            assert len(dst) == 1
+        else:
+            dst = _regs(re.search(r"v\[\d+:\d+\]", body[k]).group(0))
+            assert len(dst) == 4
         for x in range(k + 1, wait):
             line = body[x].strip()
             if not line or line.startswith((";", ".")):
@@ -79,6 +87,7 @@ FINGERPRINTED = {
     "conv_ws_plain_bf16": "_ZN12_GLOBAL__N_114conv_ws_kernelILi0ELi2ELi4ELb1ELb0ELi0EEEv13srk_conv_argsiiiijiiiiiii:",
     "conv_ws_residual_bf16": kernel_name(0, 4, 1) + "iiiijiiiiiii:",
     "conv_ws_mask_bf16": kernel_name(0, 4, 2) + "iiiijiiiiiii:",
+    "conv_ws_maskbits_bf16": kernel_name(0, 4, 3) + "iiiijiiiiiii:",
 }
 
 
@@ -87,7 +96,7 @@ def main(path, fp_out=None):
     ok = True
     for dt in (0, 1):
         for nks in (4, 1):
-            for em in (1, 2):
+            for em in (1, 2, 3):
                 try:
                     n = check_kernel(asm, dt, nks, em)
                     print(f"check_isa: conv_ws_kernel<dtype {dt}, NKS {nks}, EARLY, EM {em}>: ok ({n} instructions between prefetch and wait)")

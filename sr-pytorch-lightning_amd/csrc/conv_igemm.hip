@@ -433,7 +433,7 @@ SRK_DEV void quad_transpose8_dpp(uint32_t& a0, uint32_t& a1, uint32_t& a2, uint3
 
 template <int DT>
 SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int pbase0, int pbase1, int okmask0, int okmask1,
-                                int pstep, int cl, bool use_mask, int qi) {
+                                int pstep, int cl, bool use_mask, int qi, int hbit = 0) {
   // pbaseX: destination pixel index of the quad's first pixel for pixel block X; okmaskX bit j: pixel j of the quad
   // is inside the image; pstep: destination pixel stride between x-neighbours (r for a pixel-shuffled store);
   // cl: destination channel of this lane's 8-channel piece AFTER the transpose; qi = lane & 3
@@ -464,6 +464,21 @@ SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int
           P[k][d] = pack2<DT>(acc[k >> 1][pb][8 * (k & 1) + 2 * d], acc[k >> 1][pb][8 * (k & 1) + 2 * d + 1]);
           if (relu) P[k][d] = relu_pk16(P[k][d]);
         }
+      if (a.relu_bits) {
+        // ReLU sign bits of this lane's pixel (natural layout: pixel qi of the quad, channels 32 h ..): dword i = 4 k + d of the packed
+        // results holds channels 32 h + 2 i, + 1 -> bits i and 16 + i (set = the stored value is > 0).  The data gradient of this conv's
+        // INPUT masks with these 4 bytes per pixel and half instead of re-reading the 64-byte activation (include/srk.h: relu_bits)
+        uint32_t word = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          uint32_t t;
+          asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(P[i >> 2][i & 3]), "s"(0x00010001u));
+          word |= t << i;
+        }
+        const bool ok = (okm >> qi) & 1;
+        const unsigned off = ok ? (unsigned)(((pbase + qi * pstep) * 2 + hbit) * 4) : SRK_OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(word, big_rsrc(a.relu_bits), off, 0, 0);
+      }
       quad_transpose8_dpp(P[0][0], P[1][0], P[2][0], P[3][0], P[0][1], P[1][1], P[2][1], P[3][1]);
       quad_transpose8_dpp(P[0][2], P[1][2], P[2][2], P[3][2], P[0][3], P[1][3], P[2][3], P[3][3]);
 #pragma unroll
@@ -561,6 +576,23 @@ SRK_DEV u32x4 buf_load16_hidden(i32x4 rsrc, unsigned voff) {
 // transposes, all operands already in registers).  The 16-byte-per-line load pattern this needs is the slow one for
 // the memory path, but it is issued in the MFMA phase, where this group has no other memory traffic.
 struct QuadPre { i32x4 rs; unsigned base[2]; };
+// EM = 3: the 4-byte sign words of this lane's pixel (pixel qi of the quad) and half h: [pixel][2] u32
+SRK_DEV QuadPre quad_early_setup_bits(const srk_conv_args& a, const QuadGeo& g, int qi, int h) {
+  QuadPre p;
+  p.rs = make_rsrc4(a.mask_bits, 0x7fffffffu);
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const bool ok = (g.okmask[pb] >> qi) & 1;
+    p.base[pb] = ok ? (unsigned)(((g.pbase[pb] + qi * g.pstep) * 2 + h) * 4) : SRK_OOB;
+  }
+  return p;
+}
+SRK_DEV void quad_early_word(const QuadPre& p, int pb, QuadRegs& e) {
+  uint32_t r;
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(r) : "v"(p.base[pb]), "s"(p.rs) : "memory");
+  e.r[0].x = r;      // NOT valid until quad_early_wait
+}
+
 SRK_DEV QuadPre quad_early_setup(const srk_conv_args& a, const QuadGeo& g, int qi) {
   QuadPre p;
   const bool has_res = a.res != nullptr, has_mask = a.mask != nullptr;
@@ -638,6 +670,15 @@ SRK_DEV void quad_compute_t(float scale, f32x16 (&acc)[2][2], int pb, const Quad
       if ((k >> 1) ? use_mask_hi : use_mask_lo) {      // channel block of piece k: 16 * (k >> 1); wave-uniform
         mask_apply_pk16(P[k][0], e.r[k].x); mask_apply_pk16(P[k][1], e.r[k].y);
         mask_apply_pk16(P[k][2], e.r[k].z); mask_apply_pk16(P[k][3], e.r[k].w);
+      }
+    }
+    if constexpr (EM == 3) {
+      // sign BITS (srk_conv_args.mask_bits): one dword per pixel and 32-channel half, bit i / 16 + i <-> the two elements of dword i
+      const uint32_t word = e.r[0].x;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t sel = (word >> (4 * k + d)) & 0x00010001u;
+        asm("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(P[k][d]) : "v"(sel));
       }
     }
   }
@@ -1000,7 +1041,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   // residual / mask pieces, so the bias is parked in LDS behind the halo buffers and re-read per tile (8 broadcast
   // ds_read_b128 per lane)
   static_assert(!EARLY || (FAST && CBW == 2), "EARLY is a variant of the quad epilogue");
-  static_assert(EARLY ? (EM == 1 || EM == 2) : EM == 0, "EM: what the prefetch variant prefetches (1 = residual, 2 = ReLU-backward mask)");
+  static_assert(EARLY ? (EM >= 1 && EM <= 3) : EM == 0, "EM: what the prefetch variant prefetches (1 = residual, 2 = ReLU-backward mask, 3 = its sign bits)");
   f32x16 bias16[EARLY ? 1 : CBW];
   float* const Bl = reinterpret_cast<float*>(smem + WPIECES * 16 + 2 * C::XS_BYTES);
   if constexpr (EARLY) {
@@ -1224,7 +1265,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
         frag(0, fa[0], fb0[0], fb1[0]);
         frag(1, fa[1], fb0[1], fb1[1]);
         QuadPre pre;
-        if constexpr (EARLY) pre = quad_early_setup(a, quad_geo(j), qi);     // behind the first LDS reads: overlaps their latency
+        if constexpr (EARLY) pre = EM == 3 ? quad_early_setup_bits(a, quad_geo(j), qi, h) : quad_early_setup(a, quad_geo(j), qi);     // behind the first LDS reads: overlaps their latency
         __builtin_amdgcn_s_setprio(1);
 #if SRK_WS_STAMPS
         if (p == 2) SRK_STAMP(40);
@@ -1248,7 +1289,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
             // and eight of them back to back stall the wave's (in-order) issue for ~1k cycles with the matrix pipe idle
             constexpr int PST = NSTEP >= 33 ? 4 : 1;       // all 8 pieces must fit: steps 1, 1+PST, ..., 1+7*PST < NSTEP
             static_assert(1 + 7 * PST < NSTEP, "prefetch schedule does not fit the K loop");
-            if (s >= 1 && (s - 1) % PST == 0 && (s - 1) / PST < 8 && !(dbg & 2)) {
+            if constexpr (EM == 3) {
+              if ((s == 1 || s == 2) && !(dbg & 2)) quad_early_word(pre, s - 1, s == 1 ? e0 : e1);      // two 4-byte loads per tile
+            } else if (s >= 1 && (s - 1) % PST == 0 && (s - 1) / PST < 8 && !(dbg & 2)) {
               const int pi = (s - 1) / PST;
               quad_early_piece(pre, pi >> 2, pi & 3, pi < 4 ? e0 : e1);
             }
@@ -1272,7 +1315,8 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
         // the pieces requested 5k cycles ago are the wave's only outstanding vector-memory operations: make them
         // architecturally complete HERE, in the straight-line code that issued them.  (Waiting in the epilogue phase
         // instead lets the compiler place its loop-carried register copies of e0 / e1 in front of the wait.)
-        if constexpr (EARLY) quad_early_wait<0>(e0, e1);
+        if constexpr (EM == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(e0.r[0].x), "+v"(e1.r[0].x) : : "memory");
+        else if constexpr (EARLY) quad_early_wait<0>(e0, e1);
         }
       } else {
         // ---------------- epilogue phase: next halo tile's DMA first (this group's MFMAs on the buffer are done),
@@ -1320,7 +1364,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
             const int pb1 = pb0 + 2 * fdst.rr * (W * fdst.rr);            // pyb[1] = pyb[0] + 2
             const int cq = 32 * h + 8 * qi;
             conv_epilogue_quad<DT>(a, acc, pb0, pb1, gy0 < H ? xmask : 0, gy1 < H ? xmask : 0, fdst.rr, fdst.cbase + cq,
-                                   ctile * TCW + (cq & ~15) >= a.mask_from, qi);
+                                   ctile * TCW + (cq & ~15) >= a.mask_from, qi, h);
           } else if constexpr (FAST) {
             int opix[2];
             opix[0] = fast_opix(a, fdst, n, y0 + pyb[0], x0 + px);
@@ -1421,6 +1465,8 @@ template <int DT, int CBW, int NKS, bool FAST> int launch_ws(const srk_conv_args
   // residual OR ReLU mask in the epilogue (not both): the variant that prefetches it during the MFMA phase
   auto one = [&](const srk_conv_args& b, int xs_img, int xs_row, int xs_col, int wtap) -> int {
     if constexpr (FAST && CBW == 2) {
+      if (b.mask_bits && !b.res && !b.mask)
+        return launch_ws_one<DT, CBW, NKS, FAST, true, 3>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
       if (((b.res != nullptr) != (b.mask != nullptr)) && !no_early) {
         if (b.res) return launch_ws_one<DT, CBW, NKS, FAST, true, 1>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
         return launch_ws_one<DT, CBW, NKS, FAST, true, 2>(b, st, grid, tilesX, tilesY, ctiles, (int)nptiles, xb, tq, trem, xs_img, xs_row, xs_col, wtap);
@@ -1504,6 +1550,17 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
 
 }  // namespace
 
+// relu_bits / mask_bits: only the weight-stationary 64 -> 64 kernel implements them
+static bool conv_bits_ok(const srk_conv_args& a) {
+  static const bool no_ws = srk_dbg_getenv("SRK_NO_WS") != nullptr;
+  if (no_ws || a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3 || a.Cin != 64 || a.CoutP != 64 || a.Cout != 64 || a.x_ps > 1 || a.out_mode != SRK_OUT_NHWC) return false;
+  if (!conv_fast_ok(a, 2) || ((long long)a.N * a.H * a.W * a.x_pitch) * 2 >= 0x7fffffffLL || (long long)a.N * a.H * a.W * 8 >= 0x7fffffffLL) return false;
+  if (a.relu_bits && !(a.relu && !a.res && !a.mask && a.scale == 1.f)) return false;
+  if (a.mask_bits && (a.res || a.mask)) return false;
+  return true;
+}
+extern "C" int srk_conv_bits_ok(const srk_conv_args* a) { return a && conv_bits_ok(*a) ? 1 : 0; }
+
 extern "C" int srk_conv_tile(int Cout) {
   if (Cout <= 32) return 32;
   if (Cout <= 64) return 64;
@@ -1539,6 +1596,8 @@ extern "C" int srk_conv2d(const srk_conv_args* a, srk_stream_t stream) {
   if (a->res && a->out_mode != SRK_OUT_PLANAR)
     SRK_CHECK_ARG(a->res_pitch % 4 == 0 && a->res_coff % 4 == 0, "srk_conv2d: residual alignment");
   if (a->mask) SRK_CHECK_ARG(a->mask_pitch % 4 == 0 && a->mask_coff % 4 == 0 && a->mask_from % 4 == 0, "srk_conv2d: mask alignment");
+  if (a->relu_bits || a->mask_bits)
+    SRK_CHECK_ARG(!lk && conv_bits_ok(*a), "srk_conv2d: relu_bits / mask_bits are implemented by the weight-stationary 3x3 64 -> 64 kernel only (srk_conv_bits_ok)");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (lk) return srk_conv_lk_launch(*a, st);
   switch (a->dtype) {

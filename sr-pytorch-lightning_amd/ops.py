@@ -348,11 +348,40 @@ def _batch_chunks(n, *tensors):
     return min(n, -(-worst // (_ADDR_LIMIT // 2)))
 
 
+_SIGN_BITS = _knob("SRK_NO_SIGN_BITS") != "1"       # A/B knob: ReLU backward masks re-read the activation instead of its sign bits
+
+
 def conv_raw(x, pk, *, N, H, W, Cin, Cout, out, out_mode=L.OUT_NHWC, ps_r=0, relu=False, scale=1.0,
-             res=None, mask=None, mask_from=0, post_add=None, x_ps=0, use_bias=True):
+             res=None, mask=None, mask_from=0, post_add=None, x_ps=0, use_bias=True, relu_bits=None, mask_bits=None):
     """One srk_conv2d launch.  `x`, `out`, `res`, `mask` are NHWC tensors or channel-slice views
-    (planar mode: `out`/`res` are NCHW fp32).  (N,H,W) are the conv-space dims."""
+    (planar mode: `out`/`res` are NCHW fp32).  (N,H,W) are the conv-space dims.
+    relu_bits: "want" -> the launch also writes the ReLU sign bits of its output ([N*H*W, 2] int32, include/srk.h) when the kernel that
+    serves this shape can (returned as `out._srk_bits`, else None); mask_bits: such a tensor, used INSTEAD of `mask` (the caller
+    passes both: `mask` is the fallback when the kernel cannot take bits)."""
     _need_gpu(x)
+    if relu_bits is not None or mask_bits is not None:
+        ok = _SIGN_BITS and _batch_chunks(N, x, out, res, mask) == 1 and mask_from == 0 and out_mode == L.OUT_NHWC
+        bits_t = None
+        if ok:
+            bits_t = mask_bits if mask_bits is not None else torch.empty((N * H * W, 2), dtype=torch.int32, device=x.device)
+            probe = L.ConvArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=int(x_ps), N=N, H=H, W=W, Cin=Cin, wpk=pk.wpk.data_ptr(), bias=0,
+                               CoutP=pk.CoutP, Cout=Cout, KH=pk.k, KW=pk.k, relu=int(relu), scale=float(scale), res=_ptr(res),
+                               res_pitch=0 if res is None else _pitch(res), res_coff=0, mask=0, mask_pitch=0, mask_coff=0, mask_from=0,
+                               out=out.data_ptr(), out_pitch=_pitch(out), out_coff=0, out_mode=out_mode, ps_r=int(ps_r), post_add=0,
+                               dtype=_DT[x.dtype], cout_real=0, relu_bits=bits_t.data_ptr() if relu_bits is not None else 0,
+                               mask_bits=bits_t.data_ptr() if mask_bits is not None else 0)
+            ok = bool(L.load().srk_conv_bits_ok(probe))
+        if not ok:
+            conv_raw(x, pk, N=N, H=H, W=W, Cin=Cin, Cout=Cout, out=out, out_mode=out_mode, ps_r=ps_r, relu=relu, scale=scale, res=res, mask=mask,
+                     mask_from=mask_from, post_add=post_add, x_ps=x_ps, use_bias=use_bias)
+            out.__dict__["_srk_bits"] = None
+            return out
+        a = probe
+        a.bias = _ptr(pk.bias) if use_bias else 0
+        a.cout_real = getattr(pk, "cr", 0) or 0
+        L.call("srk_conv2d", a, _stream())
+        out.__dict__["_srk_bits"] = bits_t if relu_bits is not None else None
+        return out
     nck = _batch_chunks(N, x, out, res, mask)
     if nck > 1:         # a tensor of 2 GiB or more: the persistent kernels address 31 bits -> several launches over the batch
         step = -(-N // nck)
@@ -371,7 +400,7 @@ def conv_raw(x, pk, *, N, H, W, Cin, Cout, out, out_mode=L.OUT_NHWC, ps_r=0, rel
         res=_ptr(res), res_pitch=0 if (res is None or planar) else _pitch(res), res_coff=0,
         mask=_ptr(mask), mask_pitch=0 if mask is None else _pitch(mask), mask_coff=0, mask_from=int(mask_from),
         out=out.data_ptr(), out_pitch=0 if planar else _pitch(out), out_coff=0, out_mode=out_mode, ps_r=int(ps_r),
-        post_add=_ptr(post_add), dtype=_DT[dt], cout_real=getattr(pk, "cr", 0) or 0)
+        post_add=_ptr(post_add), dtype=_DT[dt], cout_real=getattr(pk, "cr", 0) or 0, relu_bits=0, mask_bits=0)
     L.call("srk_conv2d", a, _stream())
     return out
 
@@ -1201,6 +1230,7 @@ class ConvChainFn(torch.autograd.Function):
         ws, bs = params[0::2], params[1::2]
         n, h, wd, _ = x.shape
         acts = [x]
+        bits = []
         a = x
         paired = L_ == 2 and tuple(relus) == (True, False) and pair_ok(x, ws[0], ws[1])
         if paired:      # small batch: the whole block is one launch, the intermediate goes to HBM only for the backward pass
@@ -1215,10 +1245,13 @@ class ConvChainFn(torch.autograd.Function):
             out = torch.empty((n, h, wd, pad16(cout)), dtype=x.dtype, device=x.device)
             last = i == L_ - 1
             conv_raw(a, pk, N=n, H=h, W=wd, Cin=a.shape[3], Cout=out.shape[3], out=out, relu=relus[i],
-                     scale=scale if last else 1.0, res=x if last else None)
+                     scale=scale if last else 1.0, res=x if last else None,
+                     relu_bits="want" if (relus[i] and not last and ctx.needs_input_grad[0]) else None)
             a = out
             if not last:
                 acts.append(a)
+                bits.append(out.__dict__.pop("_srk_bits", None))
+        ctx.bits = bits                           # bits[i]: ReLU sign bits of acts[i + 1] (4 bytes per pixel and half instead of 64), or None
         ctx.save_for_backward(*acts, *ws)
         ctx.cfg = (scale, tuple(relus), tuple(b is not None for b in bs))
         ctx.wb = (tuple(ws), tuple(bs))
@@ -1258,9 +1291,10 @@ class ConvChainFn(torch.autograd.Function):
                 grads[2 * i], grads[2 * i + 1] = gw, gb
             pkd = pack_conv(w, None, g.dtype, dgrad=True, token=ctx.pg)
             gin = torch.empty_like(a_in)
+            mk = a_in if (i > 0 and relus[i - 1]) else None
+            mb = ctx.bits[i - 1] if (mk is not None and i - 1 < len(ctx.bits)) else None
             conv_raw(dy, pkd, N=n, H=h, W=wd, Cin=dy.shape[3], Cout=a_in.shape[3], out=gin, scale=sc,
-                     res=g if i == 0 else None,
-                     mask=a_in if (i > 0 and relus[i - 1]) else None, use_bias=False)
+                     res=g if i == 0 else None, mask=mk, mask_bits=mb, use_bias=False)
             dy = gin
         return (dy, None, None, *grads)
 
@@ -1654,7 +1688,8 @@ class RCABFn(torch.autograd.Function):
                               ca_fwd=dict(x2=lazy_in.x, sums=lazy_in.sums, w1=lazy_in.w[0], b1=lazy_in.w[1], w2=lazy_in.w[2],
                                           b2=lazy_in.w[3], s_out=lazy_in.s, z_out=lazy_in.z), xo=x)
         else:
-            conv_raw(x, pack_conv(w1, b1, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=y1, relu=True)
+            conv_raw(x, pack_conv(w1, b1, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=y1, relu=True, relu_bits="want")
+            ctx.bits = y1.__dict__.pop("_srk_bits", None)
             conv_raw(y1, pack_conv(w2, b2, dt), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=t)
             ns = L.load().srk_ca_splits(n, h * wd)
             sums = torch.empty((n, ns, cp), dtype=torch.float32, device=x.device)      # per-block partials: nothing to zero
@@ -1739,7 +1774,8 @@ class RCABFn(torch.autograd.Function):
             if pool is not None:
                 hi.gsum, hi.g_ptr, hi.g_ver = pool, gx.data_ptr(), gx._version
         else:
-            conv_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1, use_bias=False)
+            conv_raw(gt, pack_conv(w2, None, dt, dgrad=True, token=ctx.pg), N=n, H=h, W=wd, Cin=cp, Cout=cp, out=g1, mask=y1,
+                     mask_bits=getattr(ctx, "bits", None), use_bias=False)
         gw2, gb2 = wgrad(y1, gt, wparam=ctx.wb[2], bparam=ctx.wb[3], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w2.shape[2],
                          w_shape=tuple(w2.shape), want_bias=ctx.wb[3] is not None)
         gw1, gb1 = wgrad(x, g1, wparam=ctx.wb[0], bparam=ctx.wb[1], N=n, H=h, W=wd, Cin=cp, Cout=cp, k=w1.shape[2],

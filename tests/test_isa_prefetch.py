@@ -36,11 +36,11 @@ def asm(tmp_path_factory):
     return out.read_text()
 
 
-@pytest.mark.parametrize("em", [1, 2])
+@pytest.mark.parametrize("em", [1, 2, 3])
 @pytest.mark.parametrize("nks", [4, 1])
 @pytest.mark.parametrize("dt", [0, 1])
 def test_prefetch_registers_untouched_until_wait(asm, dt, nks, em):
-    """The same check the Makefile runs as a build gate (csrc/check_isa.py); em: 1 = residual, 2 = mask prefetch."""
+    """The same check the Makefile runs as a build gate (csrc/check_isa.py); em: 1 = residual, 2 = mask, 3 = mask sign bits."""
     assert check_isa.check_kernel(asm, dt, nks, em) > 100
 
 
