@@ -853,7 +853,19 @@ __global__ __launch_bounds__(512) void pw_wgrad_kernel(const srk_pw_wgrad_args a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int NSP = a.Chid >> 7;                                   // slice pairs
-  const int sp = blockIdx.x % NSP, rg = blockIdx.x / NSP;
+  // Which (slice pair, pixel range) this workgroup owns.  The NSP workgroups of one pixel range read the SAME x / gz tiles: when the
+  // number of ranges is a multiple of 8 they are given block ids that differ by multiples of 8, i.e. the same XCD under round-robin
+  // dispatch (placement only affects speed), so that XCD's L2 serves five of the six reads -- round 3's mapping (consecutive ids)
+  // spread them over six XCDs: 1,734 MB of L2-fabric traffic per launch against 283 MB of x + gz (profiles/r3_pw_wgrad_n256_pmc.txt).
+  int sp, rg;
+  if ((NR & 7) == 0) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    sp = k % NSP;
+    rg = (k / NSP) * 8 + xcd;
+  } else {
+    sp = blockIdx.x % NSP;
+    rg = blockIdx.x / NSP;
+  }
   const long long P = a.P;
   const int t0 = rg * tq + min(rg, trem), nt = tq + (rg < trem ? 1 : 0);
 
@@ -1235,7 +1247,11 @@ template <int DT, int KC1, int NRB> int pw_wgrad_launch(const srk_pw_wgrad_args&
 int pw_wgrad_ranges(long long P, int Chid) {
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
   const long long ntiles = (P + 63) / 64;
-  long long nr = cus / (Chid / 128);
+  const int nsp = Chid / 128;
+  long long nr = cus / nsp;
+  // a multiple of 8 ranges with all workgroups of a range on one XCD (cus / 8 workgroups fit there: one per CU)
+  const long long nr8 = (long long)((cus / 8) / nsp) * 8;
+  if (nr8 >= 8 && nr8 <= ntiles) nr = nr8;
   if (nr < 1) nr = 1;
   if (nr > ntiles) nr = ntiles;
   return (int)nr;
