@@ -316,9 +316,18 @@ def _flavours(A, model_name, batch, patch, feats, dtype):
               wg_flavour(x, x2, feats, feats, 3, flops, 2)]
         return f"conv_pair_kernel: two 3x3 {feats}->{feats} convs per launch (csrc/conv_pair.hip)", fl
     kwc = dict(N=n, H=hw, W=hw, Cin=feats, Cout=feats, out=out)
-    fl = [dict(name="conv_bias_relu", fn=lambda: ops.conv_raw(x, pk, relu=True, **kwc), flops=flops, count=1),
+    # the launches a ResBlock issues in a TRAINING step (ops.ConvChainFn): conv + bias + ReLU also writes the ReLU sign bits (4 bytes per
+    # pixel and 32-channel half), the data gradient behind the ReLU masks with them (the 16-bit activation `mask=` is the fallback for
+    # kernels without the bit path: conv_raw picks)
+    ops.conv_raw(x, pk, relu=True, relu_bits="want", **kwc)
+    bits = out.__dict__.pop("_srk_bits", None)
+
+    def fwd_relu():
+        ops.conv_raw(x, pk, relu=True, relu_bits="want", **kwc)
+        out.__dict__.pop("_srk_bits", None)
+    fl = [dict(name="conv_bias_relu", fn=fwd_relu, flops=flops, count=1),
           dict(name="conv_scale_residual", fn=lambda: ops.conv_raw(x, pk, scale=0.1, res=x2, **kwc), flops=flops, count=2),
-          dict(name="dgrad_relu_mask", fn=lambda: ops.conv_raw(x, pkd, mask=x2, use_bias=False, **kwc), flops=flops, count=1),
+          dict(name="dgrad_relu_mask", fn=lambda: ops.conv_raw(x, pkd, mask=x2, mask_bits=bits, scale=0.1, use_bias=False, **kwc), flops=flops, count=1),
           wg_flavour(x, x2, feats, feats, 3, flops, 2)]
     kern = "conv_ws_kernel" if feats == 64 else "conv_ks_kernel"
     return f"{kern} 3x3 {feats}->{feats}, fwd = dgrad kernel", fl

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Writes the NUMBER tables of profiles/README.md and DESIGN.md (section 7c) from the files under profiles/ -- nothing in those two
+blocks is typed by hand (three documents quoted three sets of numbers for one profile file).
+usage: tools/gen_results.py [tag]            rewrite the blocks between `<!-- results:<tag>:begin -->` / `<!-- results:<tag>:end -->`
+       tools/gen_results.py [tag] --check    exit 1 if a block differs from what the files give (tests/test_docs_numbers.py)"""
+import collections
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def _load(name):
+    try:
+        with open(os.path.join(P, name)) as fh:
+            return json.loads(fh.read().strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def _text(name):
+    try:
+        with open(os.path.join(P, name)) as fh:
+            return fh.read()
+    except OSError:
+        return None
+
+
+def _stage_of(kernel):
+    k = kernel
+    if k.startswith("hrtail_") or k.startswith("lk5_") or k.startswith("lk_conv_kernel") or k.startswith("to_nhwc16") or k.startswith("pack_kernel"):
+        return "collapsed HR stage (5x5 conv, border terms, collapse / expand)"
+    if k.startswith("conv_wgrad_ws_group") or k.startswith("wgrad_finalize_group") or k.startswith("upload_kernel"):
+        return "grouped 3x3 weight gradients (body + first upsampler stage)"
+    if k.startswith("conv_ws_kernel"):
+        return "conv_ws forward / data-gradient launches (body, first upsampler stage)"
+    if k.startswith("l1_") or "FillFunctor" in k:
+        return "L1 loss"
+    if k.startswith("adam_") or "copyBuffer" in k:
+        return "Adam (one launch) + its table"
+    return "head conv, packing, layout, the long skip's gradient add"
+
+
+def step_anatomy(name):
+    t = _text(name)
+    if not t:
+        return None
+    agg = collections.OrderedDict()
+    total = None
+    for line in t.splitlines():
+        m = re.match(r"^(.*?)\s+(x?\d+)\s+([\d.]+)(\s+\(.*\))?$", line)
+        if line.startswith("sum of kernel durations"):
+            total = float(line.split()[4])
+            continue
+        if not m:
+            continue
+        kern, cnt, us = m.group(1).strip(), m.group(2), float(m.group(3))
+        n = int(cnt[1:]) if cnt.startswith("x") else 1
+        st = _stage_of(kern)
+        a = agg.setdefault(st, [0, 0.0])
+        a[0] += n
+        a[1] += us
+    return agg, total
+
+
+def block(tag):
+    out = []
+    d = _load(f"{tag}_bench_default.json")
+    if d:
+        c, r = d["config"], d.get("roofline", {})
+        out.append(f"**Default line** (`profiles/{tag}_bench_default.json`, `python bench.py`): **{d['value']:,.0f} LR patches/s**, {d['ms_per_step']:.3f} ms per step "
+                   f"(sustained {d.get('sustained_value', 0):,.0f}); `model_mfma_frac` {d['model_mfma_frac']:.4f} on the reference graph's {c['gflop_per_patch']['reference_graph']} GFLOP per patch, "
+                   f"{d['model_mfma_frac_executed']:.4f} on the {c['gflop_per_patch']['executed']} GFLOP the path executes; HR stage: {c['hr_stage'].split(':')[0]}.")
+        lw = d.get("layerwise_hr_stage")
+        if lw and "value" in lw:
+            out.append(f"Same process, same step with the HR stage layer by layer (`layerwise_hr_stage`): {lw['value']:,.0f} patches/s, {lw['ms_per_step']:.3f} ms per step "
+                       f"(`model_mfma_frac` {lw['model_mfma_frac']:.4f}): the collapsed form is {d['value'] / lw['value']:.2f}x.")
+        if r and "variants_us" in r:
+            v, vb = r["variants_us"], r.get("variants_us_burst", {})
+            out.append("")
+            out.append(f"`roofline` ({r['kernel']}): sustained {r['us_per_launch']} us per launch = {r['achieved']} TFLOP/s = **{r['frac']:.4f}** of 2.5 PFLOP/s "
+                       f"(burst {r.get('frac_burst')}); HBM-side traffic per launch {('%.1f MB' % (r['traffic'] / 1e6)) if r.get('traffic') else 'null'} "
+                       f"against {r['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic; step-weighted over a ResBlock's launches **{r.get('step_weighted_frac')}** (burst {r.get('step_weighted_frac_burst')}).")
+            out.append("")
+            out.append("| flavour (HIP events, this line) | sustained us | burst us | launches per ResBlock |")
+            out.append("|---|---|---|---|")
+            for k in v:
+                out.append(f"| {k} | {v[k]} | {vb.get(k)} | {r.get('launches_per_block', {}).get(k)} |")
+        cb = d.get("cpu_baseline")
+        if cb and "value" in cb:
+            out.append("")
+            out.append(f"`cpu_baseline`: {cb['value']} patches/s ({cb['sample']}); parity of the build on the bench's own weights: PSNR(build, oracle) {cb.get('parity', {}).get('psnr_build_vs_oracle_db')} dB, max |err| {cb.get('parity', {}).get('max_abs_err')}.")
+        oc = d.get("other_configs")
+        if oc:
+            out.append("")
+            out.append("| `other_configs` (batch 16, training step as one hipGraph) | patches/s | ms / step | model_mfma_frac (reference graph / executed) | dominant kernel frac (sustained) | step-weighted |")
+            out.append("|---|---|---|---|---|---|")
+            for e in oc:
+                if "value" not in e:
+                    out.append(f"| {e.get('model')} {e.get('dtype', '')} | error: {e.get('error')} | | | | |")
+                    continue
+                rr = e.get("roofline") or {}
+                out.append(f"| {e['model']}{' fp16' if e.get('dtype') == 'f16' else ''} | {e['value']:,.0f} | {e['ms_per_step']} | {e['model_mfma_frac']} / {e.get('model_mfma_frac_executed')} | "
+                           f"{rr.get('frac', '')} {('(' + rr.get('unit', '') + ')') if rr else ''} | {rr.get('step_weighted_frac', '')} |")
+    for nm, what in ((f"{tag}_bench_default_f16.json", "fp16 (`--dtype f16`, device-resident dynamic loss scaling, the step still ONE hipGraph)"),
+                     (f"{tag}_bench_inference.json", "forward only (`--inference`)")):
+        e = _load(nm)
+        if e:
+            extra = ""
+            ls = e.get("config", {}).get("loss_scale")
+            if ls:
+                extra = f"; loss scale {ls['scale']:g}, {ls['skipped_steps']} skipped steps"
+            out.append("")
+            out.append(f"{what}: **{e['value']:,.0f} patches/s**, {e['ms_per_step']:.3f} ms per step (`profiles/{nm}`{extra}).")
+    t = _text(f"{tag}_variants_n256.txt")
+    if t:
+        out.append("")
+        out.append(f"The same flavours under rocprofv3 (`profiles/{tag}_variants_n256.txt`: isolated launches replayed for 1.5 s, second half of the dispatches averaged):")
+        out.append("")
+        out.append("```")
+        out += [l[:170] for l in t.strip().splitlines()[2:]]
+        out.append("```")
+    for nm, title in ((f"{tag}_step_edsr_baseline_b256.txt", "Where the default step goes (one step of the rocprofv3 kernel trace in dispatch order, grouped by stage)"),
+                      (f"{tag}_step_edsr_baseline_b256_layerwise.txt", "The same with the HR stage layer by layer (`SRK_DEBUG=1 SRK_NO_HR_COLLAPSE=1`)"),
+                      (f"{tag}_step_edsr_baseline_b16.txt", "EDSR-baseline at the reference's batch of 16"), (f"{tag}_step_rcan_b16.txt", "RCAN at batch 16")):
+        sa = step_anatomy(nm)
+        if sa:
+            agg, total = sa
+            out.append("")
+            out.append(f"{title} (`profiles/{nm}`; sum of kernel durations {total:,.0f} us):")
+            out.append("")
+            out.append("| stage | launches | us | share |")
+            out.append("|---|---|---|---|")
+            for k, (n, us) in agg.items():
+                out.append(f"| {k} | {n} | {us:,.0f} | {100 * us / total:.1f} % |")
+    t = _text(f"{tag}_sweep.txt")
+    if t:
+        out.append("")
+        out.append(f"All models, one box (`profiles/{tag}_sweep.txt`):")
+        out.append("")
+        out.append("```")
+        out += t.strip().splitlines()
+        out.append("```")
+    pm = sorted(f for f in os.listdir(P) if f.startswith(tag + "_") and f.endswith("_pmc.txt")) if os.path.isdir(P) else []
+    if pm:
+        out.append("")
+        out.append("PMC passes (`tools/pmc_kernel.sh`: one counter group per rocprofv3 run, FETCH_SIZE and WRITE_SIZE separately, FETCH_SIZE x 2 on gfx950):")
+        out.append("")
+        out.append("| file | kernel | MFMA pipe busy | HBM-side traffic per launch | LDS bank conflicts |")
+        out.append("|---|---|---|---|---|")
+        for f in pm:
+            t = _text(f)
+            kern = busy = hbm = conf = ""
+            for line in t.splitlines():
+                if not line.startswith((" ", "#")) and line.strip() and not kern:
+                    kern = line.strip().replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+                m = re.search(r"MFMA pipe busy ([\d.]+)", line)
+                busy = m.group(1) if m and not busy else busy
+                m = re.search(r"HBM-side traffic per launch: ([\d.]+ MB)", line)
+                hbm = m.group(1) if m and not hbm else hbm
+                m = re.search(r"SQ_LDS_BANK_CONFLICT\s+n=\s*\d+ mean=\s*([\d.]+)", line)
+                conf = m.group(1) if m and not conf else conf
+            out.append(f"| `{f}` | {kern} | {busy} | {hbm} | {conf} |")
+    for nm, title in ((f"{tag}_hrtail_microbench.txt", "The HR stage alone, forward + backward, eager launches (`tools/microbench_hrtail.py`)"),
+                      (f"{tag}_ab_ddp.txt", "Single process against a forced 1-rank RCCL group, same box (`tools/ab_ddp.sh`: value, ms per step, sustained value, graph form, gradient sync)")):
+        t = _text(nm)
+        if t:
+            out.append("")
+            out.append(f"{title}, `profiles/{nm}`:")
+            out.append("")
+            out.append("```")
+            out += t.strip().splitlines()
+            out.append("```")
+    return "\n".join(out) + "\n"
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    tag = args[0] if args else "r4"
+    check = "--check" in sys.argv
+    body = block(tag)
+    b, e = f"<!-- results:{tag}:begin -->\n", f"<!-- results:{tag}:end -->"
+    bad = 0
+    for path in (os.path.join(ROOT, "DESIGN.md"), os.path.join(P, "README.md")):
+        s = open(path).read()
+        if b not in s or e not in s:
+            print(f"{path}: markers for {tag} not found")
+            bad += 1
+            continue
+        i, j = s.index(b) + len(b), s.index(e)
+        if check:
+            if s[i:j] != body:
+                print(f"{path}: the generated block is out of date (run tools/gen_results.py {tag})")
+                bad += 1
+        else:
+            open(path, "w").write(s[:i] + body + s[j:])
+            print(f"{path}: block {tag} written ({len(body.splitlines())} lines)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

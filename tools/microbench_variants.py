@@ -24,8 +24,14 @@ def wg():
     with A.ops.hold_wgrads():
         for wi, bi in zip(ws, bs):
             A.ops.wgrad(x, x2, wparam=wi, bparam=bi, N=a.n, H=48, W=48, Cin=F, Cout=F, k=3, w_shape=(F, F, 3, 3))
-fn = {"plain": lambda: A.ops.conv_raw(x, pk, relu=True, **kw), "residual": lambda: A.ops.conv_raw(x, pk, scale=0.1, res=x2, **kw),
-      "mask": lambda: A.ops.conv_raw(x, pkd, mask=x2, use_bias=False, **kw), "wgrad": wg}[a.variant]
+# what a training step issues (ops.ConvChainFn): conv + ReLU also writes the ReLU sign bits, the data gradient behind it masks with them
+A.ops.conv_raw(x, pk, relu=True, relu_bits="want", **kw)
+bits = out.__dict__.pop("_srk_bits", None)
+def plain():
+    A.ops.conv_raw(x, pk, relu=True, relu_bits="want", **kw); out.__dict__.pop("_srk_bits", None)
+fn = {"plain": plain, "plain_nobits": lambda: A.ops.conv_raw(x, pk, relu=True, **kw), "residual": lambda: A.ops.conv_raw(x, pk, scale=0.1, res=x2, **kw),
+      "mask": lambda: A.ops.conv_raw(x, pkd, mask=x2, mask_bits=bits, scale=0.1, use_bias=False, **kw),
+      "mask_activation": lambda: A.ops.conv_raw(x, pkd, mask=x2, scale=0.1, use_bias=False, **kw), "wgrad": wg}[a.variant]
 for _ in range(3): fn()
 torch.cuda.synchronize()
 st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())

@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/pmc_traffic; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for n in ${@:-256}; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d "$OUT/n${n}_$c" -- python3 "$REPO/tools/microbench_conv.py" --n $n --iters 5 > "$OUT/n${n}_$c.log" 2>&1
+    rocprofv3 --pmc $c --output-format csv -d "$OUT/n${n}_$c" -- python3 "$REPO/tools/microbench_variants.py" --n $n --variant plain --iters 5 > "$OUT/n${n}_$c.log" 2>&1
   done
 done
 python3 - "$OUT" "$REPO" <<'PY'
@@ -31,9 +31,9 @@ for d in sorted(glob.glob(os.path.join(out, "n*_FETCH_SIZE"))):
         vals[c + "_n"] = len(v)
     tab[f"conv_bias_relu:edsr_baseline:64x48x{n}xbf16"] = {"fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "launches": vals["FETCH_SIZE_n"],
                              "isa_key": "conv_ws_plain_bf16", "isa_sha": bench.kernel_fingerprint("conv_ws_plain_bf16"),
-                             "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) -- python3 tools/microbench_conv.py --n %d" % n,
+                             "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) -- python3 tools/microbench_variants.py --n %d --variant plain --iters 5 (conv + bias + ReLU + sign bits: the launch a training step issues)" % n,
                              "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
-                             "algorithmic_bytes_per_launch": 2.0 * n * 48 * 48 * 64 * 2}
+                             "algorithmic_bytes_per_launch": 2.0 * n * 48 * 48 * 64 * 2 + n * 48 * 48 * 8}
 json.dump(tab, open(os.path.join(repo, "gpurun_out", "r4_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(tab, indent=1))
 PY
