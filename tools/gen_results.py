@@ -32,11 +32,15 @@ def _text(name):
 def _stage_of(kernel):
     k = kernel
     if k.startswith("hrtail_") or k.startswith("lk5_") or k.startswith("lk_conv_kernel") or k.startswith("to_nhwc16") or k.startswith("pack_kernel"):
-        return "collapsed HR stage (5x5 conv, border terms, collapse / expand)"
+        return "HR stage's own kernels (5x5 conv, border terms, collapse / expand, layout of the image gradient)"
+    if k.startswith("conv_pair_kernel"):
+        return "conv_pair: one launch per ResBlock / RCAB conv pair and direction"
+    if k.startswith("ca_") or k.startswith("rowsum_group"):
+        return "channel attention (stand-alone launches)"
     if k.startswith("conv_wgrad_ws_group") or k.startswith("wgrad_finalize_group") or k.startswith("upload_kernel"):
         return "grouped 3x3 weight gradients (body + first upsampler stage)"
     if k.startswith("conv_ws_kernel"):
-        return "conv_ws forward / data-gradient launches (body, first upsampler stage)"
+        return "conv_ws forward / data-gradient launches (body, first upsampler stage; layer by layer: the HR stage too)"
     if k.startswith("l1_") or "FillFunctor" in k:
         return "L1 loss"
     if k.startswith("adam_") or "copyBuffer" in k:
@@ -153,16 +157,31 @@ def block(tag):
         out.append("|---|---|---|---|---|")
         for f in pm:
             t = _text(f)
-            kern = busy = hbm = conf = ""
+            # one section per kernel name; quote the one with the most dispatches (a variant's file also holds the single set-up launch)
+            secs, cur = [], None
             for line in t.splitlines():
-                if not line.startswith((" ", "#")) and line.strip() and not kern:
-                    kern = line.strip().replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+                if line.strip() and not line.startswith((" ", "#")):
+                    cur = dict(kern=line.strip().replace("void ", "").replace("(anonymous namespace)::", "")[:60], n=0, busy="", hbm="", conf="")
+                    secs.append(cur)
+                    continue
+                if cur is None:
+                    continue
+                m = re.search(r"\sn=\s*(\d+) mean=", line)
+                if m:
+                    cur["n"] = max(cur["n"], int(m.group(1)))
                 m = re.search(r"MFMA pipe busy ([\d.]+)", line)
-                busy = m.group(1) if m and not busy else busy
+                if m:
+                    cur["busy"] = m.group(1)
                 m = re.search(r"HBM-side traffic per launch: ([\d.]+ MB)", line)
-                hbm = m.group(1) if m and not hbm else hbm
+                if m:
+                    cur["hbm"] = m.group(1)
                 m = re.search(r"SQ_LDS_BANK_CONFLICT\s+n=\s*\d+ mean=\s*([\d.]+)", line)
-                conf = m.group(1) if m and not conf else conf
+                if m:
+                    cur["conf"] = f"{float(m.group(1)):,.0f}"
+            if not secs:
+                continue
+            best = max(secs, key=lambda c: c["n"])
+            kern, busy, hbm, conf = best["kern"], best["busy"], best["hbm"], best["conf"]
             out.append(f"| `{f}` | {kern} | {busy} | {hbm} | {conf} |")
     for nm, title in ((f"{tag}_hrtail_microbench.txt", "The HR stage alone, forward + backward, eager launches (`tools/microbench_hrtail.py`)"),
                       (f"{tag}_ab_ddp.txt", "Single process against a forced 1-rank RCCL group, same box (`tools/ab_ddp.sh`: value, ms per step, sustained value, graph form, gradient sync)")):
