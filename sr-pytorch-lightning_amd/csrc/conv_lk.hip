@@ -12,6 +12,7 @@
 //                                 (srk_wgrad_finalize's layout).
 // Packed weights, epilogue order and slab format are srk_conv2d's / srk_conv2d_wgrad's: those entry points dispatch here.
 #include <stdlib.h>
+#include <type_traits>
 #include "srk_common.h"
 
 namespace {
@@ -886,6 +887,173 @@ __global__ __launch_bounds__(256) void lk5_fwd_kernel(const srk_conv_args a, int
   }
 }
 
+// ---- the same conv with (kernel column, channel) PAIRS on the MFMA rows (<= 12 stored channels = 3 colours x 4 sub-pixels) ---------------
+// lk5_fwd_kernel gives every tap its own MFMA although only 12 of its 32 rows carry a channel, and reads 1.5 fragments from LDS per MFMA:
+// LDS-bound (313 us at 256 x 96 x 96; 36 tiles x 800 MFMAs per image).  Here the 5 kernel columns share an MFMA pair: row R = kw * 12 + co of a
+// 64-row block (60 used), column = one INPUT pixel of a 32-pixel run of one image row, K = 16 input channels:
+//     D[kw * 12 + co][c] = sum_{kh, ci} W[co][ci][kh][kw] * X[y + kh - 2][x0 - 2 + c][ci]        out[co][y][x0 + x] = sum_kw D[kw * 12 + co][x + kw]
+// -- the kernel rows and the input channels accumulate inside the MFMA chain (5 x 4 steps x 2 row blocks = 40 MFMAs per output row of 28
+// pixels: 1.9x fewer than the tap form), the five column taps meet in a 10 KB per-wave fp32 scratch (written in the accumulator layout, read
+// back shifted).  The 40 weight fragments of a lane are STATIONARY IN REGISTERS (160 VGPRs, loaded once per persistent workgroup), so an MFMA
+// pair costs ONE 16-byte LDS read per lane (0.5 per MFMA).  A workgroup walks a 28-column band of an image downwards, four output rows per
+// step (one per wave), over a 12-row ring of the swizzled 128-byte image (srk_common.h) fed by hidden LDS-DMA one step ahead: every input row
+// is read once per band (x 32 / 28 for the column halo).  The epilogue of step s - 1 (scratch, shifted sums, PixelShuffle(2) store) is
+// issued BETWEEN the MFMAs of step s.
+template <int DT>
+__global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a, int nb, int segs, int seg_rows, int units, unsigned x_bytes) {
+  typedef DTraits<DT> Tr;
+  constexpr int RING = 12, ROWB = 32 * 128, SP = 40, SCR = 64 * SP * 4;      // ring row 4,096 B; scratch pitch (floats); scratch per wave 10,240 B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W, O = a.Cout >> 2;
+  float* const scr = reinterpret_cast<float*>(smem + RING * ROWB + wave * SCR);
+  const unsigned lds0 = lds_addr_of(smem);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpk), 0, 25 * 8 * 32 * 16, 0x00020000);
+  const i32x4 xrsrc = make_rsrc4(a.x, x_bytes);
+
+  // ---- stationary operands: bias / post_add of this lane's six outputs, the 40 weight fragments ----------------------------------------
+  // epilogue lane (x = lane & 31, i = lane >> 5) owns out[o][2 y + i][2 (x0 + x) + j], channel co = o*4 + i*2 + j (packed bias row 8 (co >> 2) + (co & 3))
+  float bias6[6], pa3[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    pa3[o] = (a.post_add && o < O) ? a.post_add[o] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bias6[o * 2 + j] = (a.bias && o < O) ? a.bias[8 * o + h * 2 + j] : 0.f;
+  }
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  i32x4 A[5][4][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int R = m * 32 + r, kw = R / 12, co = R - kw * 12;
+    const bool ok = R < 60 && co < a.Cout;
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const unsigned off = ok ? (unsigned)(((((kh * 5 + kw) * 8 + 2 * ks + h) * 32 + 8 * (co >> 2) + (co & 3)) << 4)) : 0x80000000u;
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0);
+        A[kh][ks][m] = i32x4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+      }
+  }
+  // per-lane constants of the four 1 KB pieces of an input row: piece pc holds pixels 8 pc .. 8 pc + 7, lane -> (pixel, chunk slot)
+  int ccol[4], cpx[4];
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) {
+    const int px = pc * 8 + (lane >> 3), sl = lane & 7, c = sl ^ swz(px);
+    cpx[pc] = px - 2;
+    ccol[pc] = ((px - 2) * a.x_pitch + a.x_coff + c * 8) * 2;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing visible may be queued behind a hidden load (in-order retirement)
+
+  const int bsw = swz(r);
+  const int H2 = 2 * H, W2 = 2 * W;
+  const float sc = a.scale;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7fffffff, 0x00020000);
+
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int sgm = u % segs, bb = (u / segs) % nb, n = u / (segs * nb);
+    const int x0 = bb * 28, ys = sgm * seg_rows;
+    const int ye = min(H, ys + seg_rows), nx = min(28, W - x0);
+    const int steps = (ye - ys + 3) >> 2, qmax = (ye - ys) + 4;      // input rows q = 0 .. qmax - 1 <-> image rows ys - 2 + q
+    auto dma_row = [&](int q) {                                       // wave-uniform q
+      if (q >= qmax) return;
+      const int gy = ys - 2 + q;
+      const bool rok = (unsigned)gy < (unsigned)H;
+      const int base = ((n * H + gy) * W + x0) * a.x_pitch * 2;
+      const unsigned dst = lds0 + (unsigned)((q % RING) * ROWB);
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+        const bool ok = rok && (unsigned)(x0 + cpx[pc]) < (unsigned)W;
+        dma16_hidden(xrsrc, ok ? (unsigned)(base + ccol[pc]) : 0x80000000u, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + pc * 1024)));
+      }
+    };
+    // the previous unit's last MFMAs have read the ring: its waves meet before the first rows of this unit overwrite it
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    dma_row(wave);
+    dma_row(4 + wave);
+
+    f32x16 accp[2];                                      // the step whose epilogue is still owed
+    int gyp = 0;
+    auto epi_write = [&](int j0, int cnt) {              // accumulator registers j0 .. j0 + cnt - 1 (of 32) -> scratch, accumulator layout
+#pragma unroll
+      for (int j = j0; j < j0 + cnt; ++j) {
+        const int m = j >> 4, e = j & 15;
+        scr[(m * 32 + 8 * (e >> 2) + 4 * h + (e & 3)) * SP + r] = accp[m][e];
+      }
+    };
+    float ev[6];
+    auto epi_read = [&](int t0, int cnt) {               // terms t = (o*2 + j)*5 + kw of the six outputs of this lane
+#pragma unroll
+      for (int t = t0; t < t0 + cnt; ++t) {
+        const int oj = t / 5, kw = t - oj * 5, o = oj >> 1, j = oj & 1;
+        const float v = scr[(kw * 12 + o * 4 + h * 2 + j) * SP + r + kw];
+        ev[oj] = kw == 0 ? v : ev[oj] + v;
+      }
+    };
+    auto epi_store = [&]() {
+      const bool ok = r < nx && gyp < ye;
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {                      // always three stores: the counted waits below rely on it
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+        u32x2_t v;
+        v.x = __float_as_uint((ev[o * 2] + bias6[o * 2]) * sc + pa3[o]);
+        v.y = __float_as_uint((ev[o * 2 + 1] + bias6[o * 2 + 1]) * sc + pa3[o]);
+        const unsigned off = (ok && o < O) ? (unsigned)((((n * O + o) * H2 + 2 * gyp + h) * W2 + 2 * (x0 + r)) * 4) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b64(v, orsrc, off, 0, 0);
+      }
+    };
+    auto step = [&](int s, auto epi_tag) {
+      constexpr bool EPI = decltype(epi_tag)::value;
+      // rows q < 4 s + 8 have landed: the DMA pieces are older than the three image stores step s - 1 issued behind them (steps 0 and 1
+      // have no such stores in front of them: step 0 owes no epilogue)
+      if (!EPI || s == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      dma_row(4 * s + 8 + wave);
+      const int q0 = 4 * s + wave;
+      const char* rowp[5];
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh) rowp[kh] = smem + ((q0 + kh) % RING) * ROWB + r * 128;
+      f32x16 acc[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+      // all 20 pixel fragments of the step are requested at once (80 registers): one LDS latency per step instead of one per MFMA pair
+      i32x4 bf[5][4];
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bf[kh][ks] = lds_read16(rowp[kh] + (((2 * ks + h) ^ bsw) << 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int k = kh * 4 + ks;
+          if (EPI) {                                      // the previous step's epilogue, a few LDS operations per MFMA pair
+            if (k < 8) epi_write(4 * k, 4);
+            else if (k == 8) asm volatile("" ::: "memory");      // lanes read what OTHER lanes wrote: the compiler must not carry scratch values across
+            else if (k >= 9 && k < 19) epi_read(3 * (k - 9), 3);
+            else if (k == 19) epi_store();
+          }
+          acc[0] = Tr::mma(A[kh][ks][0], bf[kh][ks], acc[0]);
+          acc[1] = Tr::mma(A[kh][ks][1], bf[kh][ks], acc[1]);
+        }
+      }
+      accp[0] = acc[0]; accp[1] = acc[1];
+      gyp = ys + q0;
+    };
+    step(0, std::false_type{});
+#pragma unroll 1
+    for (int s = 1; s < steps; ++s) step(s, std::true_type{});
+    epi_write(0, 32);
+    asm volatile("" ::: "memory");      // (the LDS itself executes a wave's operations in order: no wait is needed, only the compiler's)
+    epi_read(0, 30);
+    epi_store();
+  }
+}
+
 // ---- 5x5 weight gradient, 64 input x 16 stored gradient channels: the collapsed HR stage (hr_tail.hip) -----------------------------
 // dW[f][ci][co] = sum_q X[q][ci] dY[q - f][co]: the TAP SHIFT IS ON THE GRADIENT, not on x.  So a tile is the 16 x 16 pixels of x
 // WITHOUT a halo (32 KB instead of the 51 KB of a 20 x 20 halo: x is the operand that costs bandwidth, 302 MB per launch at 256 x 96 x 96)
@@ -1141,6 +1309,28 @@ template <int DT> static int lk_rows_launch(const srk_conv_args& a, hipStream_t 
   }
 }
 
+template <int DT> static int lk5_rows_fwd_launch(const srk_conv_args& a, hipStream_t st) {
+  constexpr int lds = 12 * 32 * 128 + 4 * 64 * 40 * 4;
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_rows_fwd_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (attr != hipSuccess) { srk_set_error("srk_conv2d: cannot reserve LDS for the 5x5 image conv"); return (int)attr; }
+  const int nb = (a.W + 27) / 28;
+  // row segments per band: enough units for every CU at small batches (a segment re-reads four halo rows), at least 8 rows each
+  int segs = (int)((cus + (long long)a.N * nb - 1) / ((long long)a.N * nb));
+  const int max_segs = (a.H + 7) / 8;
+  if (segs > max_segs) segs = max_segs;
+  if (segs < 1) segs = 1;
+  const int seg_rows = (((a.H + segs - 1) / segs) + 3) & ~3;
+  segs = (a.H + seg_rows - 1) / seg_rows;
+  const long long units = (long long)a.N * nb * segs;
+  SRK_CHECK_ARG(units <= 0x7fffffffLL, "srk_conv2d: %lld units", units);
+  const int grid = (int)(units < cus ? units : cus);
+  hipLaunchKernelGGL((lk5_rows_fwd_kernel<DT>), dim3(grid), dim3(256), lds, st, a, nb, segs, seg_rows, (int)units,
+                     (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2));
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int DT> static int lk5_fwd_launch(const srk_conv_args& a, hipStream_t st) {
   constexpr int lds = 25 * 8 * 16 * 16 + 2 * 20 * 20 * 128;
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
@@ -1158,6 +1348,9 @@ template <int DT> static int lk5_fwd_launch(const srk_conv_args& a, hipStream_t 
 
 int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st) {
   static const bool no_lk5 = [] { const char* e = srk_dbg_getenv("SRK_NO_LK5"); return e && e[0] == '1'; }();      // A/B knob
+  static const bool no_lk5_rows = [] { const char* e = srk_dbg_getenv("SRK_NO_LK5_ROWS"); return e && e[0] == '1'; }();      // A/B knob
+  if (a.out_mode == SRK_OUT_PLANAR && a.KH == 5 && !no_lk5 && !no_lk5_rows && a.Cout <= 12)
+    return a.dtype == SRK_BF16 ? lk5_rows_fwd_launch<SRK_BF16>(a, st) : lk5_rows_fwd_launch<SRK_F16>(a, st);
   if (a.out_mode == SRK_OUT_PLANAR && a.KH == 5 && !no_lk5) return a.dtype == SRK_BF16 ? lk5_fwd_launch<SRK_BF16>(a, st) : lk5_fwd_launch<SRK_F16>(a, st);
   static const bool no_rows = [] { const char* e = srk_dbg_getenv("SRK_NO_LK_ROWS"); return e && e[0] == '1'; }();      // A/B knob
   if (!no_rows && a.out_mode == SRK_OUT_NHWC && a.Cin == 64 && a.cout_real > 0 && a.cout_real <= 4 && a.cout_real * a.KW <= 32 && a.Cout == 16 && !a.relu && !a.res && a.scale == 1.f)
