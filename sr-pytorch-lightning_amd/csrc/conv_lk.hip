@@ -893,16 +893,16 @@ __global__ __launch_bounds__(256) void lk5_fwd_kernel(const srk_conv_args a, int
 // 64-row block (60 used), column = one INPUT pixel of a 32-pixel run of one image row, K = 16 input channels:
 //     D[kw * 12 + co][c] = sum_{kh, ci} W[co][ci][kh][kw] * X[y + kh - 2][x0 - 2 + c][ci]        out[co][y][x0 + x] = sum_kw D[kw * 12 + co][x + kw]
 // -- the kernel rows and the input channels accumulate inside the MFMA chain (5 x 4 steps x 2 row blocks = 40 MFMAs per output row of 28
-// pixels: 1.9x fewer than the tap form), the five column taps meet in a 10 KB per-wave fp32 scratch (written in the accumulator layout, read
+// pixels: 1.9x fewer than the tap form), the five column taps meet in a 8.5 KB per-wave fp32 scratch (written in the accumulator layout, read
 // back shifted).  The 40 weight fragments of a lane are STATIONARY IN REGISTERS (160 VGPRs, loaded once per persistent workgroup), so an MFMA
 // pair costs ONE 16-byte LDS read per lane (0.5 per MFMA).  A workgroup walks a 28-column band of an image downwards, four output rows per
-// step (one per wave), over a 12-row ring of the swizzled 128-byte image (srk_common.h) fed by hidden LDS-DMA one step ahead: every input row
+// step (one per wave), over a 16-row ring of the swizzled 128-byte image (srk_common.h) fed by hidden LDS-DMA two steps ahead: every input row
 // is read once per band (x 32 / 28 for the column halo).  The epilogue of step s - 1 (scratch, shifted sums, PixelShuffle(2) store) is
 // issued BETWEEN the MFMAs of step s.
 template <int DT>
 __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a, int nb, int segs, int seg_rows, int units, unsigned x_bytes) {
   typedef DTraits<DT> Tr;
-  constexpr int RING = 12, ROWB = 32 * 128, SP = 40, SCR = 64 * SP * 4;      // ring row 4,096 B; scratch pitch (floats); scratch per wave 10,240 B
+  constexpr int RING = 16, ROWB = 32 * 128, SP = 68, SCR = 32 * SP * 4;      // ring row 4,096 B; scratch [column][row], pitch 68 floats: 8,704 B per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -957,10 +957,9 @@ __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a
     const int x0 = bb * 28, ys = sgm * seg_rows;
     const int ye = min(H, ys + seg_rows), nx = min(28, W - x0);
     const int steps = (ye - ys + 3) >> 2, qmax = (ye - ys) + 4;      // input rows q = 0 .. qmax - 1 <-> image rows ys - 2 + q
-    auto dma_row = [&](int q) {                                       // wave-uniform q
-      if (q >= qmax) return;
-      const int gy = ys - 2 + q;
-      const bool rok = (unsigned)gy < (unsigned)H;
+    auto dma_row = [&](int q) {                                       // wave-uniform q; ALWAYS four operations (the counted waits rely on it):
+      const int gy = ys - 2 + q;                                      // rows behind the segment's last land as zeros in a free slot
+      const bool rok = (unsigned)gy < (unsigned)H && q < qmax;
       const int base = ((n * H + gy) * W + x0) * a.x_pitch * 2;
       const unsigned dst = lds0 + (unsigned)((q % RING) * ROWB);
 #pragma unroll
@@ -969,27 +968,31 @@ __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a
         dma16_hidden(xrsrc, ok ? (unsigned)(base + ccol[pc]) : 0x80000000u, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + pc * 1024)));
       }
     };
-    // the previous unit's last MFMAs have read the ring: its waves meet before the first rows of this unit overwrite it
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the previous unit's last MFMAs have read the ring and its last (zero) rows have landed -- LDS-DMA of different waves is not ordered --
+    // before the first rows of this unit are requested
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     dma_row(wave);
     dma_row(4 + wave);
+    dma_row(8 + wave);
 
     f32x16 accp[2];                                      // the step whose epilogue is still owed
     int gyp = 0;
-    auto epi_write = [&](int j0, int cnt) {              // accumulator registers j0 .. j0 + cnt - 1 (of 32) -> scratch, accumulator layout
+    // scratch[c][R]: the four registers 4 i .. 4 i + 3 of an accumulator are rows 8 i + 4 h .. + 3 of column r: one 16-byte write
+    auto epi_write = [&](int g0, int cnt) {              // register groups g0 .. g0 + cnt - 1 (of 8: m = g >> 2, i = g & 3)
 #pragma unroll
-      for (int j = j0; j < j0 + cnt; ++j) {
-        const int m = j >> 4, e = j & 15;
-        scr[(m * 32 + 8 * (e >> 2) + 4 * h + (e & 3)) * SP + r] = accp[m][e];
+      for (int g = g0; g < g0 + cnt; ++g) {
+        const int m = g >> 2, i = g & 3;
+        *reinterpret_cast<f32x4*>(scr + r * SP + m * 32 + 8 * i + 4 * h) = f32x4{accp[m][4 * i], accp[m][4 * i + 1], accp[m][4 * i + 2], accp[m][4 * i + 3]};
       }
     };
     float ev[6];
-    auto epi_read = [&](int t0, int cnt) {               // terms t = (o*2 + j)*5 + kw of the six outputs of this lane
+    auto epi_read = [&](int t0, int cnt) {               // terms t = o*5 + kw: both sub-pixel columns j = 0, 1 of colour o in one 8-byte read
 #pragma unroll
       for (int t = t0; t < t0 + cnt; ++t) {
-        const int oj = t / 5, kw = t - oj * 5, o = oj >> 1, j = oj & 1;
-        const float v = scr[(kw * 12 + o * 4 + h * 2 + j) * SP + r + kw];
-        ev[oj] = kw == 0 ? v : ev[oj] + v;
+        const int o = t / 5, kw = t - o * 5;
+        const f32x2 v = *reinterpret_cast<const f32x2*>(scr + (r + kw) * SP + kw * 12 + o * 4 + h * 2);
+        ev[o * 2] = kw == 0 ? v.x : ev[o * 2] + v.x;
+        ev[o * 2 + 1] = kw == 0 ? v.y : ev[o * 2 + 1] + v.y;
       }
     };
     auto epi_store = [&]() {
@@ -1006,12 +1009,14 @@ __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a
     };
     auto step = [&](int s, auto epi_tag) {
       constexpr bool EPI = decltype(epi_tag)::value;
-      // rows q < 4 s + 8 have landed: the DMA pieces are older than the three image stores step s - 1 issued behind them (steps 0 and 1
-      // have no such stores in front of them: step 0 owes no epilogue)
-      if (!EPI || s == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      // rows q < 4 s + 8 have landed.  Issue order per wave: P (rows 0 .. 11), then per step s: D_s (row 4 s + 12 + wave: four pieces) and,
+      // from step 1 on, E_s (the three image stores of step s - 1's epilogue).  Step s needs D_(s-2): behind it sit E_(s-2), D_(s-1), E_(s-1).
+      if (!EPI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (s == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (s == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      dma_row(4 * s + 8 + wave);
+      dma_row(4 * s + 12 + wave);
       const int q0 = 4 * s + wave;
       const char* rowp[5];
 #pragma unroll
@@ -1019,27 +1024,25 @@ __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a
       f32x16 acc[2];
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-      // all 20 pixel fragments of the step are requested at once (80 registers): one LDS latency per step instead of one per MFMA pair
-      i32x4 bf[5][4];
+      // the pixel fragments run PF MFMA pairs ahead of their use (PF x 4 registers: the 160 registers of weights must stay in VGPRs)
+      constexpr int PF = 6;
+      i32x4 bf[PF];
+      auto bfrag = [&](int k) { return lds_read16(rowp[k >> 2] + (((2 * (k & 3) + h) ^ bsw) << 4)); };
 #pragma unroll
-      for (int kh = 0; kh < 5; ++kh)
+      for (int k = 0; k < PF; ++k) bf[k] = bfrag(k);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) bf[kh][ks] = lds_read16(rowp[kh] + (((2 * ks + h) ^ bsw) << 4));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kh = 0; kh < 5; ++kh) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int k = kh * 4 + ks;
-          if (EPI) {                                      // the previous step's epilogue, a few LDS operations per MFMA pair
-            if (k < 8) epi_write(4 * k, 4);
-            else if (k == 8) asm volatile("" ::: "memory");      // lanes read what OTHER lanes wrote: the compiler must not carry scratch values across
-            else if (k >= 9 && k < 19) epi_read(3 * (k - 9), 3);
-            else if (k == 19) epi_store();
-          }
-          acc[0] = Tr::mma(A[kh][ks][0], bf[kh][ks], acc[0]);
-          acc[1] = Tr::mma(A[kh][ks][1], bf[kh][ks], acc[1]);
+      for (int k = 0; k < 20; ++k) {
+        const i32x4 b = bf[k % PF];
+        if (k + PF < 20) bf[k % PF] = bfrag(k + PF);
+        if (EPI) {                                        // the previous step's epilogue, a few LDS operations per MFMA pair
+          if (k < 8) epi_write(k, 1);
+          else if (k == 8) asm volatile("" ::: "memory");      // lanes read what OTHER lanes wrote: the compiler must not carry scratch values across
+          else if (k >= 9 && k < 19) epi_read((k - 9) * 3 / 2, (k - 8) * 3 / 2 - (k - 9) * 3 / 2);
+          else if (k == 19) epi_store();
         }
+        acc[0] = Tr::mma(A[k >> 2][k & 3][0], b, acc[0]);
+        acc[1] = Tr::mma(A[k >> 2][k & 3][1], b, acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       accp[0] = acc[0]; accp[1] = acc[1];
       gyp = ys + q0;
@@ -1047,9 +1050,9 @@ __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a
     step(0, std::false_type{});
 #pragma unroll 1
     for (int s = 1; s < steps; ++s) step(s, std::true_type{});
-    epi_write(0, 32);
+    epi_write(0, 8);
     asm volatile("" ::: "memory");      // (the LDS itself executes a wave's operations in order: no wait is needed, only the compiler's)
-    epi_read(0, 30);
+    epi_read(0, 15);
     epi_store();
   }
 }
@@ -1310,7 +1313,7 @@ template <int DT> static int lk_rows_launch(const srk_conv_args& a, hipStream_t 
 }
 
 template <int DT> static int lk5_rows_fwd_launch(const srk_conv_args& a, hipStream_t st) {
-  constexpr int lds = 12 * 32 * 128 + 4 * 64 * 40 * 4;
+  constexpr int lds = 16 * 32 * 128 + 4 * 32 * 68 * 4;
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_rows_fwd_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) { srk_set_error("srk_conv2d: cannot reserve LDS for the 5x5 image conv"); return (int)attr; }
