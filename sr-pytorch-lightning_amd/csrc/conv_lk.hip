@@ -15,6 +15,11 @@
 #include <type_traits>
 #include "srk_common.h"
 
+// diagnostics build only (make stamp, tools/stamp_lk5.py): s_memtime stamps of wave 0 of workgroup 0 of lk5_dgrad_kernel through `post_add`
+#ifndef SRK_LK5_STAMPS
+#define SRK_LK5_STAMPS 0
+#endif
+
 namespace {
 
 template <int DT, int CPP, int NRB, int K>
@@ -1057,6 +1062,144 @@ __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a
   }
 }
 
+// ---- 5x5 data gradient of the same stage: 16 stored gradient channels -> 64 channels, NHWC ------------------------------------------------
+// lk_conv_kernel<DT, 2, 2, 5> streams the weights through LDS per kernel row and reads 1.5 fragments per MFMA pair from a 32-byte-per-pixel
+// tile whose rows are 640 bytes apart (7.4 M bank conflicts per launch at 256 x 96 x 96: 151 us).  K is ONE MFMA step here (16 channels), so
+// a tap is an MFMA pair (2 x 32 output rows) and the 50 weight fragments of a lane stay in registers (200 VGPRs) for the life of a
+// persistent workgroup; a pixel fragment (32 pixels of one image row x 16 channels, 1 KB) feeds both MFMAs: 0.5 LDS reads per MFMA, and
+// consecutive lanes read consecutive 32-byte pixels (conflict-free without a swizzle).  Same walk as lk5_rows_fwd_kernel: a workgroup
+// owns a 32-column band, four output rows per step (one per wave), a 16-row ring of 36-pixel rows fed two steps ahead by hidden LDS-DMA.
+template <int DT>
+__global__ __launch_bounds__(256) void lk5_dgrad_kernel(const srk_conv_args a, int nb, int segs, int seg_rows, int units, unsigned x_bytes) {
+  typedef DTraits<DT> Tr;
+  typedef typename Tr::elem elem;
+  constexpr int RING = 16, ROWB = 36 * 32;               // ring row: 36 pixels x 32 bytes = 72 chunks
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W;
+  const unsigned lds0 = lds_addr_of(smem);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpk), 0, 25 * 2 * 64 * 16, 0x00020000);
+  const i32x4 xrsrc = make_rsrc4(a.x, x_bytes);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  i32x4 A[25][2];
+#pragma unroll
+  for (int t = 0; t < 25; ++t)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)((((t * 2 + h) * 64 + m * 32 + r) << 4)), 0, 0);
+      A[t][m] = i32x4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    }
+  // a ring row is 72 chunks of 16 bytes: chunk ch = pixel (ch >> 1), channel half (ch & 1); DMA 0 moves chunks 0 .. 63, DMA 1 (lanes 0 .. 7) 64 .. 71
+  const int c0 = ((lane >> 1) - 2) * a.x_pitch * 2 + (a.x_coff + (lane & 1) * 8) * 2, p0 = (lane >> 1) - 2;
+  const int c1 = ((32 + (lane >> 1)) - 2) * a.x_pitch * 2 + (a.x_coff + (lane & 1) * 8) * 2, p1 = 32 + (lane >> 1) - 2;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing visible may be queued behind a hidden load (in-order retirement)
+
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7fffffff, 0x00020000);
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int sgm = u % segs, bb = (u / segs) % nb, n = u / (segs * nb);
+    const int x0 = bb * 32, ys = sgm * seg_rows;
+    const int ye = min(H, ys + seg_rows);
+    const int steps = (ye - ys + 3) >> 2, qmax = (ye - ys) + 4;      // input rows q = 0 .. qmax - 1 <-> image rows ys - 2 + q
+    auto dma_row = [&](int q) {                                       // wave-uniform q; ALWAYS two operations (the counted waits rely on it)
+      const int gy = ys - 2 + q;
+      const bool rok = (unsigned)gy < (unsigned)H && q < qmax;
+      const int base = ((n * H + gy) * W + x0) * a.x_pitch * 2;
+      const unsigned dst = lds0 + (unsigned)((q % RING) * ROWB);
+      dma16_hidden(xrsrc, (rok && (unsigned)(x0 + p0) < (unsigned)W) ? (unsigned)(base + c0) : 0x80000000u, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+      if (lane < 8)
+        dma16_hidden(xrsrc, (rok && (unsigned)(x0 + p1) < (unsigned)W) ? (unsigned)(base + c1) : 0x80000000u, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + 1024)));
+    };
+    // the previous unit's last MFMAs have read the ring and its last rows have landed (LDS-DMA of different waves is not ordered)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    dma_row(wave);
+    dma_row(4 + wave);
+    dma_row(8 + wave);
+#if SRK_LK5_STAMPS
+    unsigned long long* const stamp = (blockIdx.x == 0 && tid == 0 && u == blockIdx.x) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.post_add)) : nullptr;
+#define SRK_LSTAMP(i) do { if (stamp && s < 24) stamp[s * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SRK_LSTAMP(i) do { } while (0)
+#endif
+    // The epilogue of step s - 1 is issued BETWEEN the MFMAs of step s (stand-alone it was 910 of a step's 3,220 cycles: the wave is alone
+    // on its SIMD).  Lane (pixel r, half h) holds channels 32 h + 8 k + 0 .. 7, k = 0 .. 3, of its pixel (row_to_chan).  Stored as they
+    // sit, a store instruction is 64 separate 16-byte requests (16.6 M per launch at 256 x 96 x 96); after a 4 x 4 transpose of the pieces
+    // inside every quad of lanes, lane qi holds piece qi of the quad's four pixels and four neighbouring lanes write 64 contiguous bytes.
+    f32x16 accp[2];
+    int gyp = 0;
+    uint32_t P[4][4];
+    auto epi_cvt = [&](int k) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) P[k][d] = pack2<DT>(accp[k >> 1][8 * (k & 1) + 2 * d], accp[k >> 1][8 * (k & 1) + 2 * d + 1]);
+    };
+    auto epi_store = [&](int j) {                          // always issued (the counted waits rely on it)
+      const int qi = r & 3, gxq = x0 + (r & ~3);
+      const bool ok = gyp < ye && gxq + j < W;
+      const unsigned off = (unsigned)((((n * H + gyp) * W + gxq + j) * a.out_pitch + a.out_coff + 32 * h + 8 * qi) * 2);
+      const u32x4_t ov = {P[j][0], P[j][1], P[j][2], P[j][3]};
+      __builtin_amdgcn_raw_buffer_store_b128(ov, orsrc, ok ? off : 0x80000000u, 0, 0);
+    };
+    auto step = [&](int s, auto epi_tag) {
+      constexpr bool EPI = decltype(epi_tag)::value;
+      SRK_LSTAMP(0);
+      // rows q < 4 s + 8 have landed.  Issue order per wave: P (6 operations), then per step s: D_s (2) and, from step 1 on, E_s (the four
+      // stores of step s - 1's epilogue).  Step s needs D_(s-2): behind it sit E_(s-2), D_(s-1), E_(s-1).
+      if (!EPI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (s == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (s == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      SRK_LSTAMP(1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      SRK_LSTAMP(2);
+      dma_row(4 * s + 12 + wave);
+      const int q0 = 4 * s + wave;
+      const char* rowp[5];
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh) rowp[kh] = smem + ((q0 + kh) % RING) * ROWB + r * 32 + h * 16;
+      f32x16 acc[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+      constexpr int PF = 6;
+      i32x4 bf[PF];
+      auto bfrag = [&](int t) { return lds_read16(rowp[t / 5] + (t % 5) * 32); };
+#pragma unroll
+      for (int t = 0; t < PF; ++t) bf[t] = bfrag(t);
+      // taps in pairs, a0 a0 a1 a1: an MFMA that accumulates onto the result of the one issued right before it starts without a bubble,
+      // one that follows a DIFFERENT accumulator's waits for its own predecessor to drain (alternating a0 a1 measured 37.6 cycles per MFMA)
+#pragma unroll
+      for (int t = 0; t < 25; t += 2) {
+        const i32x4 b0 = bf[t % PF], b1 = bf[(t + 1) % PF];
+        if (t + PF < 25) bf[t % PF] = bfrag(t + PF);
+        if (t + 1 + PF < 25) bf[(t + 1) % PF] = bfrag(t + 1 + PF);
+        if (EPI) {
+          if (t >= 2 && t < 10) epi_cvt((t - 2) >> 1);
+          else if (t == 10) quad_transpose8_dpp(P[0][0], P[1][0], P[2][0], P[3][0], P[0][1], P[1][1], P[2][1], P[3][1]);
+          else if (t == 12) quad_transpose8_dpp(P[0][2], P[1][2], P[2][2], P[3][2], P[0][3], P[1][3], P[2][3], P[3][3]);
+          else if (t >= 14 && t < 22) epi_store((t - 14) >> 1);
+        }
+        acc[0] = Tr::mma(A[t][0], b0, acc[0]);
+        if (t + 1 < 25) acc[0] = Tr::mma(A[t + 1][0], b1, acc[0]);
+        acc[1] = Tr::mma(A[t][1], b0, acc[1]);
+        if (t + 1 < 25) acc[1] = Tr::mma(A[t + 1][1], b1, acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      SRK_LSTAMP(3);
+      accp[0] = acc[0]; accp[1] = acc[1];
+      gyp = ys + q0;
+    };
+    step(0, std::false_type{});
+#pragma unroll 1
+    for (int s = 1; s < steps; ++s) step(s, std::true_type{});
+#pragma unroll
+    for (int k = 0; k < 4; ++k) epi_cvt(k);
+    quad_transpose8_dpp(P[0][0], P[1][0], P[2][0], P[3][0], P[0][1], P[1][1], P[2][1], P[3][1]);
+    quad_transpose8_dpp(P[0][2], P[1][2], P[2][2], P[3][2], P[0][3], P[1][3], P[2][3], P[3][3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) epi_store(j);
+  }
+}
+
 // ---- 5x5 weight gradient, 64 input x 16 stored gradient channels: the collapsed HR stage (hr_tail.hip) -----------------------------
 // dW[f][ci][co] = sum_q X[q][ci] dY[q - f][co]: the TAP SHIFT IS ON THE GRADIENT, not on x.  So a tile is the 16 x 16 pixels of x
 // WITHOUT a halo (32 KB instead of the 51 KB of a 20 x 20 halo: x is the operand that costs bandwidth, 302 MB per launch at 256 x 96 x 96)
@@ -1258,7 +1401,7 @@ bool srk_conv_lk_ok(const srk_conv_args& a) {
     if (!fwd || a.ps_r != 2 || a.res || a.relu || a.Cout % 4 || a.Cout > 16 || a.x_pitch % 8 || a.x_coff % 8) return false;
     return (long long)a.N * a.H * a.W * a.x_pitch * 2 < 0x7fff0000LL;
   }
-  if (a.out_mode != SRK_OUT_NHWC || a.post_add) return false;
+  if (a.out_mode != SRK_OUT_NHWC || (a.post_add && !SRK_LK5_STAMPS)) return false;
   if (a.x_pitch % 8 || a.x_coff % 8 || a.out_pitch % 8 || a.out_coff % 8 || a.Cout % 8 || (a.res && (a.res_pitch % 8 || a.res_coff % 8))) return false;
   const long long px = (long long)a.N * a.H * a.W;
   long long mx = px * a.x_pitch;
@@ -1334,6 +1477,30 @@ template <int DT> static int lk5_rows_fwd_launch(const srk_conv_args& a, hipStre
   return 0;
 }
 
+// the data gradient of the collapsed HR stage: 5x5, 16 stored channels -> 64, plain NHWC store
+static bool lk5_dgrad_ok(const srk_conv_args& a) {
+  return a.KH == 5 && a.Cin == 16 && a.CoutP == 64 && a.Cout == 64 && a.out_mode == SRK_OUT_NHWC && !a.bias && !a.res && !a.relu && !a.mask &&
+         (SRK_LK5_STAMPS || !a.post_add) && a.scale == 1.f && (long long)a.N * a.H * a.W * a.out_pitch * 2 < 0x7fff0000LL;
+}
+template <int DT> static int lk5_dgrad_launch(const srk_conv_args& a, hipStream_t st) {
+  constexpr int lds = 16 * 36 * 32;
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  const int nb = (a.W + 31) / 32;
+  int segs = (int)((cus + (long long)a.N * nb - 1) / ((long long)a.N * nb));
+  const int max_segs = (a.H + 7) / 8;
+  if (segs > max_segs) segs = max_segs;
+  if (segs < 1) segs = 1;
+  const int seg_rows = (((a.H + segs - 1) / segs) + 3) & ~3;
+  segs = (a.H + seg_rows - 1) / seg_rows;
+  const long long units = (long long)a.N * nb * segs;
+  SRK_CHECK_ARG(units <= 0x7fffffffLL, "srk_conv2d: %lld units", units);
+  const int grid = (int)(units < cus ? units : cus);
+  hipLaunchKernelGGL((lk5_dgrad_kernel<DT>), dim3(grid), dim3(256), lds, st, a, nb, segs, seg_rows, (int)units,
+                     (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2));
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int DT> static int lk5_fwd_launch(const srk_conv_args& a, hipStream_t st) {
   constexpr int lds = 25 * 8 * 16 * 16 + 2 * 20 * 20 * 128;
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
@@ -1358,6 +1525,8 @@ int srk_conv_lk_launch(const srk_conv_args& a, hipStream_t st) {
   static const bool no_rows = [] { const char* e = srk_dbg_getenv("SRK_NO_LK_ROWS"); return e && e[0] == '1'; }();      // A/B knob
   if (!no_rows && a.out_mode == SRK_OUT_NHWC && a.Cin == 64 && a.cout_real > 0 && a.cout_real <= 4 && a.cout_real * a.KW <= 32 && a.Cout == 16 && !a.relu && !a.res && a.scale == 1.f)
     return a.dtype == SRK_BF16 ? lk_rows_launch<SRK_BF16>(a, st) : lk_rows_launch<SRK_F16>(a, st);
+  static const bool no_lk5_dgrad = [] { const char* e = srk_dbg_getenv("SRK_NO_LK5_DGRAD"); return e && e[0] == '1'; }();      // A/B knob
+  if (!no_lk5 && !no_lk5_dgrad && lk5_dgrad_ok(a)) return a.dtype == SRK_BF16 ? lk5_dgrad_launch<SRK_BF16>(a, st) : lk5_dgrad_launch<SRK_F16>(a, st);
   if (a.Cin == 16) return a.dtype == SRK_BF16 ? lk_launch<SRK_BF16, 2, 2>(a, st) : lk_launch<SRK_F16, 2, 2>(a, st);
   return a.dtype == SRK_BF16 ? lk_launch<SRK_BF16, 8, 1>(a, st) : lk_launch<SRK_F16, 8, 1>(a, st);
 }

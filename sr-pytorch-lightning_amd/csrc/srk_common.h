@@ -265,3 +265,50 @@ int srk_wgrad_lk_launch(const srk_wgrad_args& a, hipStream_t st);
 bool srk_conv1x1_ok(const srk_conv_args& a);
 int srk_conv1x1_launch(const srk_conv_args& a, hipStream_t st);
 
+
+// ---------------------------------------------------------------------------------------------
+// 4 x 4 transpose of 16-byte pieces inside every quad of lanes (quad-transposed stores: lane j of a quad then holds piece j of the
+// quad's four pixels, so the four lanes of a store instruction cover 64 contiguous bytes of ONE pixel instead of 16 bytes of four).
+// The same transpose for TWO register quartets at once with v_cndmask_b32_dpp: on gfx9 the DPP lane permutation is a modifier of the
+// select's first source (VOP2 encoding, lane mask in VCC), so one instruction per register and stage does what the form above needs
+// two for (select + v_mov_dpp + two selects per register pair): 16 vector instructions per 8 registers instead of 32.  The epilogue
+// phase is bound by vector-instruction ISSUE beside the other group's MFMA wave, and the chip is power-limited under this kernel, so
+// every instruction not issued counts twice.  The lane masks are constants (qi = lane & 3): b0 = odd lanes, b1 = lanes 2, 3 of a quad.
+// v_cndmask_b32: D = VCC ? src1 : dpp(src0).  Hazards (inline asm is invisible to the compiler's hazard recogniser): a DPP read needs two
+// wait states behind the VALU write of its source -- `s_nop 1` covers the inputs, the instruction order below covers the temporaries
+// (every stage-2 DPP source is written at least two instructions earlier).
+SRK_DEV void quad_transpose8_dpp(uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3,
+                                 uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3) {
+  const unsigned long long mb0 = 0xaaaaaaaaaaaaaaaaull, mn0 = 0x5555555555555555ull;
+  const unsigned long long mb1 = 0xccccccccccccccccull, mn1 = 0x3333333333333333ull;
+  uint32_t t0, t1, t2, t3, u0, u1, u2, u3, oa0, oa1, oa2, oa3, oc0, oc1, oc2, oc3;
+  asm("s_nop 1\n\t"
+      "s_mov_b64 vcc, %[mn0]\n\t"                                         // even lanes keep r0 / r2, odd lanes take the neighbour's r1 / r3
+      "v_cndmask_b32_dpp %[t0], %[a1], %[a0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[t2], %[a3], %[a2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[u0], %[c1], %[c0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[u2], %[c3], %[c2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[mb0]\n\t"                                         // odd lanes keep r1 / r3, even lanes take the neighbour's r0 / r2
+      "v_cndmask_b32_dpp %[t1], %[a0], %[a1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[t3], %[a2], %[a3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[u1], %[c0], %[c1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[u3], %[c2], %[c3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[mn1]\n\t"                                         // lanes 0, 1 keep r0 / r1, lanes 2, 3 take r2 / r3 from two lanes over
+      "v_cndmask_b32_dpp %[oa0], %[t2], %[t0], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oa1], %[t3], %[t1], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oc0], %[u2], %[u0], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oc1], %[u3], %[u1], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[mb1]\n\t"
+      "v_cndmask_b32_dpp %[oa2], %[t0], %[t2], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oa3], %[t1], %[t3], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oc2], %[u0], %[u2], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[oc3], %[u1], %[u3], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3),
+        [oa0] "=&v"(oa0), [oa1] "=&v"(oa1), [oa2] "=&v"(oa2), [oa3] "=&v"(oa3), [oc0] "=&v"(oc0), [oc1] "=&v"(oc1), [oc2] "=&v"(oc2), [oc3] "=&v"(oc3)
+      : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3),
+        [mb0] "s"(mb0), [mn0] "s"(mn0), [mb1] "s"(mb1), [mn1] "s"(mn1)
+      : "vcc");
+  a0 = oa0; a1 = oa1; a2 = oa2; a3 = oa3;
+  c0 = oc0; c1 = oc1; c2 = oc2; c3 = oc3;
+}
+

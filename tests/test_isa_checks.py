@@ -91,7 +91,11 @@ def test_conv_ks_hidden_loads_are_not_touched_before_their_wait(listing_ks):
     ("proj.hip", {"proj_down_kernelILi0E": 16, "proj_down_kernelILi1E": 16, "proj_up_kernelILi0E": 32, "proj_up_kernelILi1E": 96,       # (a few spilled pointers; the fp16 conversions cost the fused-PReLU epilogue more)
                   "proj_wgrad_kernelILi0E": 0, "proj_wgrad_kernelILi1E": 0}),
     ("conv_lk.hip", {"lk_wgrad_allrows_kernelILi0ELi9E": 0, "lk_wgrad_packed_kernelILi0ELi9E": 0, "lk_conv_rows_kernelILi0ELi9E": 0,
-                     "lk_wgrad_allrows_kernelILi1ELi9E": 0, "lk_conv_rows_kernelILi1ELi9E": 0}),
+                     "lk_wgrad_allrows_kernelILi1ELi9E": 0, "lk_conv_rows_kernelILi1ELi9E": 0,
+                     # the collapsed HR stage's 5x5 kernels: weights stationary in 160 / 200 registers AND hand-counted vmcnt waits behind hidden
+                     # LDS-DMA -- a spill there is a scratch access the counts do not include (a correctness problem, not only a slow-down)
+                     "lk5_rows_fwd_kernelILi0E": 0, "lk5_rows_fwd_kernelILi1E": 0, "lk5_dgrad_kernelILi0E": 0, "lk5_dgrad_kernelILi1E": 0,
+                     "lk5_fwd_kernelILi0E": 0, "lk5_fwd_kernelILi1E": 0, "lk5_wgrad_kernelILi0E": 0, "lk5_wgrad_kernelILi1E": 0}),
 ])
 def test_register_resident_kernels_do_not_spill(tmp_path, src, limits):
     if not os.path.exists(HIPCC):
