@@ -416,10 +416,10 @@ def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5):
             opt.zero_grad(set_to_none=True)
             loss = model._calculate_losses(img_sr=model(batch_t["lr"]), img_hr=batch_t["hr"])["loss"]
             if scaler is None:
-                loss.backward()
+                A.ops.backward(loss)          # (loss.backward() with a cached seed gradient instead of a per-pass fill launch)
                 opt.step()
             else:
-                scaler.scale(loss).backward()
+                A.ops.backward(scaler.scale(loss))
                 opt.step(grad_scaler=scaler)
             return loss
         for _ in range(3):
@@ -520,7 +520,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         sr = net(batch["lr"])
         loss = model._calculate_losses(img_sr=sr, img_hr=batch["hr"])["loss"]
-        (loss if scaler is None else scaler.scale(loss)).backward()
+        A.ops.backward(loss if scaler is None else scaler.scale(loss))
         return loss
 
     def train_step():

@@ -240,7 +240,7 @@ def _eager_fwd_bwd_reduce(model, net, optimizer, gsync, scaler, batch):
     ops.discard_wgrads()
     optimizer.zero_grad(set_to_none=True)
     loss = model._calculate_losses(img_sr=net(batch["lr"]), img_hr=batch["hr"])["loss"]
-    (loss if (scaler is None or not hasattr(scaler, "state")) else scaler.scale(loss)).backward()
+    ops.backward(loss if (scaler is None or not hasattr(scaler, "state")) else scaler.scale(loss))
     ops.flush_wgrads()
     if gsync is not None:
         gsync.sync()
@@ -255,7 +255,7 @@ def _eager_step(model, net, optimizer, gsync, scaler, batch):
     img_sr = net(batch["lr"])
     loss = model._calculate_losses(img_sr=img_sr, img_hr=batch["hr"])["loss"]
     if scaler is not None and hasattr(scaler, "state"):      # optim.DeviceGradScaler: check / skip / unscale inside the optimizer's launch
-        scaler.scale(loss).backward()
+        ops.backward(scaler.scale(loss))
         ops.flush_wgrads()
         if gsync is not None:
             gsync.sync()
@@ -268,7 +268,7 @@ def _eager_step(model, net, optimizer, gsync, scaler, batch):
         scaler.step(optimizer)
         scaler.update()
     else:
-        loss.backward()
+        ops.backward(loss)
         ops.flush_wgrads()               # normally a no-op: the engine's final callback already ran
         if gsync is not None:
             gsync.sync()
@@ -316,7 +316,8 @@ class GraphedStep:
         self.opt.zero_grad(set_to_none=True)
         sr = self.net(self.static["lr"])
         loss = self.model._calculate_losses(img_sr=sr, img_hr=self.static["hr"])["loss"]
-        (loss if self.scaler is None else self.scaler.scale(loss)).backward()
+        from . import ops
+        ops.backward(loss if self.scaler is None else self.scaler.scale(loss))
         return loss
 
     def _opt_step(self):
