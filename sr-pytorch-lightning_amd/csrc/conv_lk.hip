@@ -1461,8 +1461,9 @@ template <int DT> static int lk5_rows_fwd_launch(const srk_conv_args& a, hipStre
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_rows_fwd_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) { srk_set_error("srk_conv2d: cannot reserve LDS for the 5x5 image conv"); return (int)attr; }
   const int nb = (a.W + 27) / 28;
-  // row segments per band: enough units for every CU at small batches (a segment re-reads four halo rows), at least 8 rows each
-  int segs = (int)((cus + (long long)a.N * nb - 1) / ((long long)a.N * nb));
+  // row segments per band: as many units as there are CUs at small batches, but not more (a second round of units doubles the launch;
+  // a segment re-reads four halo rows), at least 8 rows each
+  int segs = (int)(cus / ((long long)a.N * nb));
   const int max_segs = (a.H + 7) / 8;
   if (segs > max_segs) segs = max_segs;
   if (segs < 1) segs = 1;
@@ -1486,7 +1487,7 @@ template <int DT> static int lk5_dgrad_launch(const srk_conv_args& a, hipStream_
   constexpr int lds = 16 * 36 * 32;
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
   const int nb = (a.W + 31) / 32;
-  int segs = (int)((cus + (long long)a.N * nb - 1) / ((long long)a.N * nb));
+  int segs = (int)(cus / ((long long)a.N * nb));      // (as in lk5_rows_fwd_launch)
   const int max_segs = (a.H + 7) / 8;
   if (segs > max_segs) segs = max_segs;
   if (segs < 1) segs = 1;
