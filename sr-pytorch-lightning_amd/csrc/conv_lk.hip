@@ -904,10 +904,13 @@ __global__ __launch_bounds__(256) void lk5_fwd_kernel(const srk_conv_args a, int
 // step (one per wave), over a 16-row ring of the swizzled 128-byte image (srk_common.h) fed by hidden LDS-DMA two steps ahead: every input row
 // is read once per band (x 32 / 28 for the column halo).  The epilogue of step s - 1 (scratch, shifted sums, PixelShuffle(2) store) is
 // issued BETWEEN the MFMAs of step s.
-template <int DT>
-__global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a, int nb, int segs, int seg_rows, int units, unsigned x_bytes) {
+// NW waves = NW output rows per step.  NW = 4 (one wave per SIMD, rows requested two steps ahead: a 16-row ring) or NW = 8 (two waves per
+// SIMD -- one wave's scratch traffic, address arithmetic and waits under the other's MFMAs; rows one step ahead: a 20-row ring).
+template <int DT, int NW>
+__global__ __launch_bounds__(NW * 64) void lk5_rows_fwd_kernel(const srk_conv_args a, int nb, int segs, int seg_rows, int units, unsigned x_bytes) {
   typedef DTraits<DT> Tr;
-  constexpr int RING = 16, ROWB = 32 * 128, SP = 68, SCR = 32 * SP * 4;      // ring row 4,096 B; scratch [column][row], pitch 68 floats: 8,704 B per wave
+  constexpr int AHEAD = NW == 4 ? 2 : 1, PRO = NW + 4 + (AHEAD - 1) * NW, RING = PRO + NW;
+  constexpr int ROWB = 32 * 128, SP = 68, SCR = 32 * SP * 4;      // ring row 4,096 B; scratch [column][row], pitch 68 floats: 8,704 B per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a
     const int sgm = u % segs, bb = (u / segs) % nb, n = u / (segs * nb);
     const int x0 = bb * 28, ys = sgm * seg_rows;
     const int ye = min(H, ys + seg_rows), nx = min(28, W - x0);
-    const int steps = (ye - ys + 3) >> 2, qmax = (ye - ys) + 4;      // input rows q = 0 .. qmax - 1 <-> image rows ys - 2 + q
+    const int steps = (ye - ys + NW - 1) / NW, qmax = (ye - ys) + 4;      // input rows q = 0 .. qmax - 1 <-> image rows ys - 2 + q
     auto dma_row = [&](int q) {                                       // wave-uniform q; ALWAYS four operations (the counted waits rely on it):
       const int gy = ys - 2 + q;                                      // rows behind the segment's last land as zeros in a free slot
       const bool rok = (unsigned)gy < (unsigned)H && q < qmax;
@@ -976,9 +979,7 @@ __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a
     // the previous unit's last MFMAs have read the ring and its last (zero) rows have landed -- LDS-DMA of different waves is not ordered --
     // before the first rows of this unit are requested
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    dma_row(wave);
-    dma_row(4 + wave);
-    dma_row(8 + wave);
+    for (int q = wave; q < PRO; q += NW) dma_row(q);
 
     f32x16 accp[2];                                      // the step whose epilogue is still owed
     int gyp = 0;
@@ -1014,15 +1015,17 @@ __global__ __launch_bounds__(256) void lk5_rows_fwd_kernel(const srk_conv_args a
     };
     auto step = [&](int s, auto epi_tag) {
       constexpr bool EPI = decltype(epi_tag)::value;
-      // rows q < 4 s + 8 have landed.  Issue order per wave: P (rows 0 .. 11), then per step s: D_s (row 4 s + 12 + wave: four pieces) and,
-      // from step 1 on, E_s (the three image stores of step s - 1's epilogue).  Step s needs D_(s-2): behind it sit E_(s-2), D_(s-1), E_(s-1).
+      // rows q < NW s + NW + 4 have landed.  Issue order per wave: P (the first PRO rows), then per step s: D_s (one row: four pieces) and,
+      // from step 1 on, E_s (the three image stores of step s - 1's epilogue).  Step s needs D_(s-AHEAD): behind it sit E_(s-AHEAD) and the
+      // D, E of the steps between.
       if (!EPI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (AHEAD == 1) { if (s == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
       else if (s == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else if (s == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      dma_row(4 * s + 12 + wave);
-      const int q0 = 4 * s + wave;
+      dma_row(NW * s + PRO + wave);
+      const int q0 = NW * s + wave;
       const char* rowp[5];
 #pragma unroll
       for (int kh = 0; kh < 5; ++kh) rowp[kh] = smem + ((q0 + kh) % RING) * ROWB + r * 128;
@@ -1455,10 +1458,10 @@ template <int DT> static int lk_rows_launch(const srk_conv_args& a, hipStream_t 
   }
 }
 
-template <int DT> static int lk5_rows_fwd_launch(const srk_conv_args& a, hipStream_t st) {
-  constexpr int lds = 16 * 32 * 128 + 4 * 32 * 68 * 4;
+template <int DT, int NW> static int lk5_rows_fwd_launch_w(const srk_conv_args& a, hipStream_t st) {
+  constexpr int PRO = NW + 4 + (NW == 4 ? NW : 0), lds = (PRO + NW) * 32 * 128 + NW * 32 * 68 * 4;
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_rows_fwd_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_rows_fwd_kernel<DT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) { srk_set_error("srk_conv2d: cannot reserve LDS for the 5x5 image conv"); return (int)attr; }
   const int nb = (a.W + 27) / 28;
   // row segments per band: as many units as there are CUs at small batches, but not more (a second round of units doubles the launch;
@@ -1467,16 +1470,19 @@ template <int DT> static int lk5_rows_fwd_launch(const srk_conv_args& a, hipStre
   const int max_segs = (a.H + 7) / 8;
   if (segs > max_segs) segs = max_segs;
   if (segs < 1) segs = 1;
-  const int seg_rows = (((a.H + segs - 1) / segs) + 3) & ~3;
+  const int seg_rows = (((a.H + segs - 1) / segs) + NW - 1) / NW * NW;
   segs = (a.H + seg_rows - 1) / seg_rows;
   const long long units = (long long)a.N * nb * segs;
   SRK_CHECK_ARG(units <= 0x7fffffffLL, "srk_conv2d: %lld units", units);
   const int grid = (int)(units < cus ? units : cus);
-  hipLaunchKernelGGL((lk5_rows_fwd_kernel<DT>), dim3(grid), dim3(256), lds, st, a, nb, segs, seg_rows, (int)units,
+  hipLaunchKernelGGL((lk5_rows_fwd_kernel<DT, NW>), dim3(grid), dim3(NW * 64), lds, st, a, nb, segs, seg_rows, (int)units,
                      (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2));
   SRK_LAUNCH_CHECK();
   return 0;
 }
+// (NW = 8 -- two waves per SIMD -- needs 160 weight + 64 accumulator + 24 fragment registers of a wave's 256: hipcc spills 83 of them, and a
+// scratch access is a vector-memory operation the hand-counted waits do not include.  One wave per SIMD it is.)
+template <int DT> static int lk5_rows_fwd_launch(const srk_conv_args& a, hipStream_t st) { return lk5_rows_fwd_launch_w<DT, 4>(a, st); }
 
 // the data gradient of the collapsed HR stage: 5x5, 16 stored channels -> 64, plain NHWC store
 static bool lk5_dgrad_ok(const srk_conv_args& a) {

@@ -27,9 +27,9 @@ tools/pmc_kernel.sh ${TAG}_conv_ws_plain_n256 conv_ws_kernel tools/microbench_va
 tools/pmc_kernel.sh ${TAG}_conv_ws_residual_n256 conv_ws_kernel tools/microbench_variants.py --n 256 --variant residual --iters 5 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_conv_ws_mask_n256 conv_ws_kernel tools/microbench_variants.py --n 256 --variant mask --iters 5 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_wgrad_group_n256 conv_wgrad_ws_group_kernel tools/microbench_variants.py --n 256 --variant wgrad --iters 4 > /dev/null 2>&1
-tools/pmc_kernel.sh ${TAG}_lk5_fwd_n256 lk5_fwd_kernel tools/microbench_hrtail.py --n 256 --iters 3 > /dev/null 2>&1
+tools/pmc_kernel.sh ${TAG}_lk5_fwd_n256 lk5_rows_fwd_kernel tools/microbench_hrtail.py --n 256 --iters 3 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_lk5_wgrad_n256 lk5_wgrad_kernel tools/microbench_hrtail.py --n 256 --iters 3 > /dev/null 2>&1
-tools/pmc_kernel.sh ${TAG}_lk5_dgrad_n256 lk_conv_kernel tools/microbench_hrtail.py --n 256 --iters 3 > /dev/null 2>&1
+tools/pmc_kernel.sh ${TAG}_lk5_dgrad_n256 lk5_dgrad_kernel tools/microbench_hrtail.py --n 256 --iters 3 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_conv_pair_n16 conv_pair_kernel tools/microbench_pair.py 16 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_pw_wgrad_n256 pw_wgrad_kernel tools/microbench_pw.py --n 256 --only wgrad --iters 5 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_pw_wgrad_n16 pw_wgrad_kernel tools/microbench_pw.py --n 16 --only wgrad --iters 5 > /dev/null 2>&1
