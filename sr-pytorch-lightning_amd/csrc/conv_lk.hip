@@ -264,9 +264,9 @@ __global__ __launch_bounds__(256) void lk_wgrad_kernel(const srk_wgrad_args a, i
   // (channels 16 .. 31) does not exist: those lanes read the zero piece behind the tile
 #pragma unroll
   for (int rd = 0; rd < 2; ++rd) {
-    const int Gl = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
-    const int col = 8 * (Gl >> 1) + 4 * rd + q;
-    boff[rd] = (Gl & 1) ? (16 * 16 * 32 + pq * 8) : (col * 32 + pq * 8);
+    const int G = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const int col = 8 * (G >> 1) + 4 * rd + q;
+    boff[rd] = (G & 1) ? (16 * 16 * 32 + pq * 8) : (col * 32 + pq * 8);
   }
 
   const bool do_bias = a.dbp != nullptr && kh == 0 && wave == 0;     // db = sum of the gradient: from the fragments wave 0 fetches anyway
@@ -1222,40 +1222,33 @@ SRK_DEV void lk5_pair(int t, int& fyA, int& fxA, int& fyB, int& fxB, bool& hasB)
   else { fyA = 2; fxA = t - 12; fyB = 2; fxB = t - 12; hasB = false; }
 }
 
-constexpr int LK5_WG = 2;      // wave groups per workgroup of lk5_wgrad_kernel
-// G wave groups of four share the tiles in LDS: group g takes the tile rows (= K steps) [16 g / G, 16 (g + 1) / G) and keeps its OWN
-// accumulators and slab (partial sums of a workgroup are only written once, at the end of the launch: a second slab per workgroup costs the
-// finalize kernel a little).  G = 2 puts two waves on every SIMD: alone on its SIMD a wave issues an MFMA every ~38 cycles and overlaps
-// neither its 16 transposing LDS reads per K step nor its waits with them (section 3.13).
-template <int DT, int G>
-__global__ __launch_bounds__(256 * G) void lk5_wgrad_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int tq, int trem,
-                                                            unsigned x_bytes, unsigned dy_bytes) {
+template <int DT>
+__global__ __launch_bounds__(256) void lk5_wgrad_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int tq, int trem,
+                                                        unsigned x_bytes, unsigned dy_bytes) {
   typedef DTraits<DT> Tr;
-  constexpr int NT = 256 * G, XK = 2048 / NT, DJ = (800 + NT - 1) / NT;
   constexpr int XB = 16 * 16 * 128, DP = 20, DB = 13 * 1024, BUF = XB + DB;      // gradient halo: 20 x 20 x 32 B = 12,800 (+ DMA slack)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, w4 = wave & 3;
   const int slot = blockIdx.x;
   const int H = a.H, W = a.W;
   const int t0 = slot * tq + min(slot, trem), nt = tq + (slot < trem ? 1 : 0);
   const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
   const unsigned lds0 = lds_addr_of(smem);
 
-  // per-lane DMA constants.  x piece i = tid + NT k: chunk slot i & 7 of tile pixel i >> 3 (the image IS piece order);
-  // gradient piece i = tid + NT j (< 800): chunk i & 1 of halo pixel i >> 1
-  int xconst[XK], xyx[XK];
+  // per-lane DMA constants.  x piece i = tid + 256 k: chunk slot i & 7 of tile pixel i >> 3 (the image IS piece order);
+  // gradient piece i = tid + 256 j (< 800): chunk i & 1 of halo pixel i >> 1
+  int xconst[8], xyx[8];
 #pragma unroll
-  for (int k = 0; k < XK; ++k) {
-    const int i = tid + NT * k, sl = i & 7, p = i >> 3, iy = p >> 4, ix = p & 15, c = sl ^ swz(ix);
+  for (int k = 0; k < 8; ++k) {
+    const int i = tid + 256 * k, sl = i & 7, p = i >> 3, iy = p >> 4, ix = p & 15, c = sl ^ swz(ix);
     xconst[k] = ((iy * W + ix) * a.x_pitch + a.x_coff + c * 8) * 2;
     xyx[k] = iy | (ix << 8);
   }
-  int dconst[DJ], dyx[DJ];
+  int dconst[4], dyx[4];
 #pragma unroll
-  for (int j = 0; j < DJ; ++j) {
-    const int i = tid + NT * j, c = i & 1, pp = i >> 1, iy = pp / DP, ix = pp - iy * DP;
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 256 * j, c = i & 1, pp = i >> 1, iy = pp / DP, ix = pp - iy * DP;
     dconst[j] = (((iy - 2) * W + (ix - 2)) * a.dy_pitch + a.dy_coff + c * 8) * 2;
     dyx[j] = i < 2 * DP * DP ? (((iy - 2) & 0xffff) | ((ix - 2) << 16)) : (int)0x7fff7fff;      // never inside
   }
@@ -1268,22 +1261,22 @@ __global__ __launch_bounds__(256 * G) void lk5_wgrad_kernel(const srk_wgrad_args
     const int y0 = tY * 16, x0 = tX * 16;
     const int xbase = ((n * H + y0) * W + x0) * a.x_pitch * 2, dbase = ((n * H + y0) * W + x0) * a.dy_pitch * 2;
 #pragma unroll
-    for (int k = 0; k < XK; ++k) {
+    for (int k = 0; k < 8; ++k) {
       const bool ok = y0 + (xyx[k] & 255) < H && x0 + (xyx[k] >> 8) < W;
       dma16_hidden(xrs, ok ? (unsigned)(xbase + xconst[k]) : 0x80000000u,
-                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * BUF + ((k * NT + wave * 64) << 4))));
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * BUF + ((k * 256 + wave * 64) << 4))));
     }
 #pragma unroll
-    for (int j = 0; j < DJ; ++j) {
-      if (j * NT + wave * 64 >= 2 * DP * DP) continue;        // wave-uniform: nothing of this piece row is inside the halo image
+    for (int j = 0; j < 4; ++j) {
+      if (j * 256 + wave * 64 >= 2 * DP * DP) continue;        // wave-uniform: nothing of this piece row is inside the halo image
       const int gy = y0 + (int)(short)(dyx[j] & 0xffff), gx = x0 + (dyx[j] >> 16);
       const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
       dma16_hidden(drs, ok ? (unsigned)(dbase + dconst[j]) : 0x80000000u,
-                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * BUF + XB + ((j * NT + wave * 64) << 4))));
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + b * BUF + XB + ((j * 256 + wave * 64) << 4))));
     }
   };
 
-  const int rb = w4 & 1, half = w4 >> 1;
+  const int rb = wave & 1, half = wave >> 1;
   f32x16 acc[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j)
@@ -1293,36 +1286,32 @@ __global__ __launch_bounds__(256 * G) void lk5_wgrad_kernel(const srk_wgrad_args
 #pragma unroll
   for (int rd = 0; rd < 2; ++rd) aoff[rd] = tr_lane_off(0, rd, rb, lane);
   {
-    const int Gl = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const int G = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       int fyA, fxA, fyB, fxB; bool hasB;
       lk5_pair(half * 7 + j, fyA, fxA, fyB, fxB, hasB);
-      const int fy = (Gl & 1) ? fyB : fyA, fx = (Gl & 1) ? fxB : fxA;      // (a lone tap: its columns 16-31 repeat tap A and are not stored)
+      const int fy = (G & 1) ? fyB : fyA, fx = (G & 1) ? fxB : fxA;      // (a lone tap: its columns 16-31 repeat tap A and are not stored)
 #pragma unroll
       for (int rd = 0; rd < 2; ++rd) {
-        const int col = 8 * (Gl >> 1) + 4 * rd + q;
+        const int col = 8 * (G >> 1) + 4 * rd + q;
         boff[j][rd] = ((2 - fy) * DP + (col - fx + 2)) * 32 + pq * 8;
       }
     }
   }
-  const bool do_bias = a.dbp != nullptr && w4 == 2;      // wave 2's first pair is (0,0) & (1,0): its group-0 lanes see the unshifted gradient
+  const bool do_bias = a.dbp != nullptr && wave == 2;      // wave 2's first pair is (0,0) & (1,0): its group-0 lanes see the unshifted gradient
   float dbz = 0.f;
 
   // THREE buffers, the DMA two tiles ahead: a tile's 45 KB need 3-5k cycles to land under load, its MFMAs take 3.6k -- one tile ahead
   // every tile waited for its data (6.6k cycles per tile).  Per tile and wave 8 + 3 or 4 DMA pieces (pieces_of: wave-uniform).
-  // operations per tile and wave: XK + the gradient piece rows j with j NT + 64 wave < 800  (G = 1: 8 + 4 for wave 0, 8 + 3; G = 2: 4 + 2 for waves 0-4, 4 + 1)
-  const int pieces_of = XK + (G == 1 ? (wave == 0 ? 4 : 3) : (wave < 5 ? 2 : 1));
+  const int pieces_of = 8 + (wave == 0 ? 4 : 3);      // gradient piece rows j = 0..2 all waves, j = 3 (pieces 768..799): wave 0 only
   if (nt > 0) dma_tile(t0, 0);
   if (nt > 1) dma_tile(t0 + 1, 1);
   for (int it = 0; it < nt; ++it) {
     const char* const X = smem + (it % 3) * BUF;
     const char* const D = X + XB;
     // tile `it` landed (tile it + 1 may still be in flight: the younger pieces_of operations)
-    if (it + 1 < nt) {
-      if (G == 1) { if (pieces_of == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
-      else { if (pieces_of == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
-    }
+    if (it + 1 < nt) { if (pieces_of == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... for every wave; buffer (it + 2) % 3 (tile it - 1's) is free
     if (it + 2 < nt) dma_tile(t0 + it + 2, (it + 2) % 3);
@@ -1332,16 +1321,14 @@ __global__ __launch_bounds__(256 * G) void lk5_wgrad_kernel(const srk_wgrad_args
 #pragma unroll
       for (int j = 0; j < 7; ++j) bfn[j] = tr_read2(D + y * (DP * 32) + boff[j][0], D + y * (DP * 32) + boff[j][1]);
     };
-    constexpr int YR = 16 / G;
-    const int yb = grp * YR;
-    fetch(yb);
-#pragma unroll 1
-    for (int y = yb; y < yb + YR; ++y) {
+    fetch(0);
+#pragma unroll 2
+    for (int y = 0; y < 16; ++y) {
       const i32x4 af = afn;
       i32x4 bf[7];
 #pragma unroll
       for (int j = 0; j < 7; ++j) bf[j] = bfn[j];
-      if (y + 1 < yb + YR) fetch(y + 1);
+      if (y + 1 < 16) fetch(y + 1);
       if (do_bias) {
         const int qw[4] = {bf[0].x, bf[0].y, bf[0].z, bf[0].w};
 #pragma unroll
@@ -1358,11 +1345,11 @@ __global__ __launch_bounds__(256 * G) void lk5_wgrad_kernel(const srk_wgrad_args
 
   if (do_bias) {
     dbz += __shfl_xor(dbz, 32, 64);                              // the two K halves of a read
-    if (lane < 16) a.dbp[((size_t)slot * G + grp) * 16 + lane] = dbz;
+    if (lane < 16) a.dbp[(size_t)slot * 16 + lane] = dbz;
   }
   {
     const int hq = lane >> 5, n = lane & 31, co = n & 15;
-    float* const sl = a.dwp + ((size_t)slot * G + grp) * (25 * 64 * 16);
+    float* const sl = a.dwp + (size_t)slot * (25 * 64 * 16);
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       int fyA, fxA, fyB, fxB; bool hasB;
@@ -1396,7 +1383,7 @@ int lk_wgrad_slabs_for(const srk_wgrad_args& a) {
     return (int)(nt8 < cus ? nt8 : cus);
   }
   const long long ntiles = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
-  if (lk5_wgrad_ok(a)) return LK5_WG * (int)(ntiles < cus ? ntiles : cus);      // one slab per wave group of a workgroup, all 25 taps inside
+  if (lk5_wgrad_ok(a)) return (int)(ntiles < cus ? ntiles : cus);      // one workgroup per slab, all 25 taps inside
   long long s = cus / a.KH;
   if (s < 1) s = 1;
   if (s > ntiles) s = ntiles;
@@ -1584,11 +1571,9 @@ template <int DT, int K> static int lk_wgrad_launch_k(const srk_wgrad_args& a, h
   if constexpr (K == 5) {
     if (lk5_wgrad_ok(a)) {
       constexpr int l5 = 3 * (16 * 16 * 128 + 13 * 1024);
-      static const hipError_t a5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_wgrad_kernel<DT, LK5_WG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      static const hipError_t a5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&lk5_wgrad_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (a5 != hipSuccess) { srk_set_error("srk_conv2d_wgrad: cannot reserve LDS"); return (int)a5; }
-      SRK_CHECK_ARG(slabs % LK5_WG == 0, "srk_conv2d_wgrad: %d slabs", slabs);
-      const int wgs = slabs / LK5_WG;
-      hipLaunchKernelGGL((lk5_wgrad_kernel<DT, LK5_WG>), dim3(wgs), dim3(256 * LK5_WG), l5, st, a, tilesX, tilesY, (int)(ntiles / wgs), (int)(ntiles % wgs), xb, db);
+      hipLaunchKernelGGL((lk5_wgrad_kernel<DT>), dim3(slabs), dim3(256), l5, st, a, tilesX, tilesY, (int)(ntiles / slabs), (int)(ntiles % slabs), xb, db);
       SRK_LAUNCH_CHECK();
       return 0;
     }
