@@ -1307,14 +1307,24 @@ __global__ __launch_bounds__(256) void lk5_wgrad_kernel(const srk_wgrad_args a, 
   const int pieces_of = 8 + (wave == 0 ? 4 : 3);      // gradient piece rows j = 0..2 all waves, j = 3 (pieces 768..799): wave 0 only
   if (nt > 0) dma_tile(t0, 0);
   if (nt > 1) dma_tile(t0 + 1, 1);
+#if SRK_LK5_STAMPS
+  unsigned long long* const wstamp = (blockIdx.x == 0 && tid == 0 && a.dbp) ? reinterpret_cast<unsigned long long*>(a.dbp) + (size_t)a.nslabs * 8 : nullptr;
+#define SRK_WSTAMP(i) do { if (wstamp && it < 24) wstamp[it * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SRK_WSTAMP(i) do { } while (0)
+#endif
   for (int it = 0; it < nt; ++it) {
+    SRK_WSTAMP(0);
     const char* const X = smem + (it % 3) * BUF;
     const char* const D = X + XB;
     // tile `it` landed (tile it + 1 may still be in flight: the younger pieces_of operations)
     if (it + 1 < nt) { if (pieces_of == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SRK_WSTAMP(1);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... for every wave; buffer (it + 2) % 3 (tile it - 1's) is free
+    SRK_WSTAMP(2);
     if (it + 2 < nt) dma_tile(t0 + it + 2, (it + 2) % 3);
+    SRK_WSTAMP(3);
     i32x4 afn, bfn[7];
     auto fetch = [&](int y) {
       afn = tr_read2(X + y * 2048 + aoff[0], X + y * 2048 + aoff[1]);
@@ -1341,6 +1351,7 @@ __global__ __launch_bounds__(256) void lk5_wgrad_kernel(const srk_wgrad_args a, 
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc[j] = Tr::mma(af, bf[j], acc[j]);
     }
+    SRK_WSTAMP(4);
   }
 
   if (do_bias) {
