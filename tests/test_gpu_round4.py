@@ -292,3 +292,27 @@ def test_relu_sign_bits_equal_the_activation_mask(A, dt, shape):
     assert torch.equal(y1, y2) and torch.equal(gx1, gx2)
     for u, v in zip(gp1, gp2):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("O,n,h,w", [(3, 2, 96, 96), (3, 3, 37, 61), (3, 1, 5, 29), (2, 2, 16, 28), (1, 1, 9, 57), (3, 17, 48, 48), (4, 2, 20, 33)])
+def test_collapsed_stage_forward_kernel_per_element(A, dt, O, n, h, w):
+    """lk5_rows_fwd_kernel ((kernel column, channel) pairs on the MFMA rows, weights in registers, column taps summed through a per-wave
+    scratch; O = 4: the tap-per-MFMA kernel) against float64 conv2d + pixel_shuffle on the SAME 16-bit inputs: the image is stored in
+    fp32, so what is left is the order of fp32 sums -- a slip in the row / column bookkeeping (band edges, row segments, the ring) is O(1)."""
+    import torch.nn.functional as F
+    from sr_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(5 + O + h + w)
+    x = (torch.rand(n, 64, h, w, generator=g) * 2 - 1).to(dt)
+    wt = (((torch.rand(4 * O, 64, 5, 5, generator=g) * 2 - 1) / np.sqrt(64 * 25)).to(dt)).float()
+    b = (torch.rand(4 * O, generator=g) * 2 - 1) * 0.1
+    post = torch.rand(O, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    pk = ops.pack_conv(wt.cuda(), b.cuda(), dt, cache=False)
+    out = torch.full((n, O, 2 * h, 2 * w), float("nan"), device="cuda")
+    ops.conv_raw(xd, pk, N=n, H=h, W=w, Cin=64, Cout=4 * O, out=out, out_mode=L.OUT_PLANAR, ps_r=2, post_add=post.cuda())
+    torch.cuda.synchronize()
+    ref = F.pixel_shuffle(F.conv2d(x.double(), wt.double(), b.double(), padding=2), 2) + post.double().view(1, O, 1, 1)
+    got = out.cpu().double()
+    assert bool(torch.isfinite(got).all()), "pixels the kernel never wrote"
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
