@@ -36,5 +36,11 @@ tools/pmc_kernel.sh ${TAG}_pw_wgrad_n16 pw_wgrad_kernel tools/microbench_pw.py -
 for f in $O/${TAG}_*_pmc.txt; do echo "== $f"; grep -E "^void|MFMA pipe|HBM-side|BANK_CONFLICT" $f | cut -c1-140; done
 python tools/microbench_hrtail.py --n 256 > $O/${TAG}_hrtail_microbench.txt 2>/dev/null; python tools/microbench_hrtail.py --n 256 --layerwise >> $O/${TAG}_hrtail_microbench.txt 2>/dev/null
 python tools/microbench_hrtail.py --n 16 --hw 96 >> $O/${TAG}_hrtail_microbench.txt 2>/dev/null; python tools/microbench_hrtail.py --n 16 --layerwise >> $O/${TAG}_hrtail_microbench.txt 2>/dev/null; cat $O/${TAG}_hrtail_microbench.txt
+# in-kernel s_memtime anatomy (diagnostics build tools/ubench/libsrk_stamp.so = `make -C sr-pytorch-lightning_amd/csrc stamp`, built here, travels with the snapshot)
+if [ -f tools/ubench/libsrk_stamp.so ]; then
+  { for m in 0 2 1; do echo "== conv_pair_kernel, 16 x 48 x 48, STAMP_CA=$m (0: ResBlock; 2 / 1: RCAB forward / backward with the channel attention of the neighbouring block)"; STAMP_CA=$m python tools/stamp_pair.py 16 2>/dev/null | cut -c1-700; done
+    echo "== lk5_dgrad_kernel, 256 x 96 x 96"; python tools/stamp_lk5.py 256 2>/dev/null | head -10
+    echo "== lk5_wgrad_kernel, 256 x 96 x 96"; python tools/stamp_lk5w.py 256 2>/dev/null | head -10; } > $O/${TAG}_stamps.txt
+fi
 tools/ab_ddp.sh > $O/${TAG}_ab_ddp.txt 2>&1; cat $O/${TAG}_ab_ddp.txt
 tools/sweep.sh "16 64 256" > /dev/null 2>&1; cp $O/sweep.txt $O/${TAG}_sweep.txt; cat $O/${TAG}_sweep.txt

@@ -183,7 +183,8 @@ def block(tag):
             best = max(secs, key=lambda c: c["n"])
             kern, busy, hbm, conf = best["kern"], best["busy"], best["hbm"], best["conf"]
             out.append(f"| `{f}` | {kern} | {busy} | {hbm} | {conf} |")
-    for nm, title in ((f"{tag}_hrtail_microbench.txt", "The HR stage alone, forward + backward, eager launches (`tools/microbench_hrtail.py`)"),
+    for nm, title in ((f"{tag}_stamps.txt", "In-kernel `s_memtime` stamps of workgroup 0 (diagnostics build, `tools/stamp_*.py`; ticks ~ cycles)"),
+                      (f"{tag}_hrtail_microbench.txt", "The HR stage alone, forward + backward, eager launches (`tools/microbench_hrtail.py`)"),
                       (f"{tag}_ab_ddp.txt", "Single process against a forced 1-rank RCCL group, same box (`tools/ab_ddp.sh`: value, ms per step, sustained value, graph form, gradient sync)")):
         t = _text(nm)
         if t:
