@@ -18,11 +18,11 @@ torch.cuda.synchronize(); stamps.zero_(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); A.ops.conv_raw(g12, pkd, **kw); e1.record(); torch.cuda.synchronize()
 st = stamps.cpu().numpy().reshape(32, 8)
-print(f"launch {e0.elapsed_time(e1) * 1e3:.1f} us; s_memtime ticks (100 MHz = 10 ns) relative to step 0's first stamp")
+print(f"launch {e0.elapsed_time(e1) * 1e3:.1f} us; s_memtime ticks (~ core cycles) relative to step 0's first stamp")
 t0 = st[0, 0]
-print("step   start  waited barrier  mfma-done stores-issued | step length")
+print("step   start  waited barrier  mfma-loop-done | step length      (the epilogue of step s - 1 is issued inside the MFMA loop of step s)")
 for s in range(24):
     if st[s, 0] == 0: break
     r = st[s] - t0
     nxt = (st[s + 1, 0] - st[s, 0]) if s + 1 < 24 and st[s + 1, 0] else 0
-    print(f"{s:4d} {r[0]:7d} {r[1]:7d} {r[2]:7d} {r[3]:10d} {r[4]:13d} | {nxt}")
+    print(f"{s:4d} {r[0]:7d} {r[1]:7d} {r[2]:7d} {r[3]:15d} | {nxt}")
