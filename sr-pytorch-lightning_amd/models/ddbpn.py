@@ -4,8 +4,8 @@ The up / down projection units use nn.ConvTranspose2d / nn.Conv2d with kernel 6/
 (ddbpn.py:10-24).  Scale 4 (kernel 8, stride 4) in 16-bit runs on the DIRECT projection kernels (csrc/proj.hip through ops.proj_prelu /
 ops.conv_general / ops.conv_transpose_general: no column tensor, the PReLU behind every projection fused into the launch); scales 2 and 8
 and fp32 keep the NHWC im2col / col2im forms (strided conv = unfold + 1x1 MFMA conv, transposed conv = 1x1 MFMA conv + fold).  The
-dense concatenations and the two elementwise ops of a projection unit (`b_0.sub(x)`, `a_0.add(a_1)`, ddbpn.py:57-62) stay torch
-ops on NHWC tensors."""
+dense concatenations are channel slices of two buffers (ops.SliceBuffer: no copies, gradients accumulated in place); `b_0.sub(x)`
+(ddbpn.py:57) stays a torch op on NHWC tensors."""
 from typing import Any
 
 import torch
@@ -54,6 +54,11 @@ class DenseProjection(nn.Module):
         """`dest`: (ops.SliceBuffer, index) -- the slot of a concatenation buffer the unit's output is written to."""
         if self.bottleneck is not None:
             x = ops.prelu(ops.conv(x, self.bottleneck[0].weight, self.bottleneck[0].bias), self.bottleneck[1].weight)
+        else:
+            # x has TWO consumers here (conv_1 and `b_0.sub(x)`): autograd must sum their gradients itself.  A concatenation's
+            # "add your data gradient into the shared buffer" marker (ops.concat_slices) is for a single consumer: a 1x1 conv behind it
+            # (the transposed projection's GEMM at scales 2 / 8) would add in place AND be summed again.
+            x.__dict__.pop("_srk_gacc", None)
         a_0 = _proj(self.conv_1, x)
         b_0 = _proj(self.conv_2, a_0)
         e = b_0.sub(x)
@@ -102,11 +107,14 @@ class DDBPN(SRModel):
             n, h, w, _ = x.shape
             r = self._scale_factor
             hbuf = ops.SliceBuffer(self.depth, accumulate_grads=True).alloc(n, h * r, w * r, x.shape[3], x.dtype, x.device)
+            # ... and the LR feature maps of the down units likewise (`torch.cat(l_list)`, ddbpn.py:118,131: five copies forward and the
+            # slice / add launches of their gradients, ~40 small torch launches per step at the reference's batch)
+            lbuf = ops.SliceBuffer(self.depth - 1, accumulate_grads=True).alloc(n, h, w, x.shape[3], x.dtype, x.device)
             h_list, l_list = [], []
             for i in range(self.depth - 1):
-                l = x if i == 0 else torch.cat(l_list, dim=3)
+                l = x if i == 0 else ops.concat_slices(lbuf, l_list)
                 h_list.append(self.upmodules[i].nhwc(l, (hbuf, i)))
-                l_list.append(self.downmodules[i].nhwc(ops.concat_slices(hbuf, h_list)))
-            h_list.append(self.upmodules[-1].nhwc(torch.cat(l_list, dim=3), (hbuf, self.depth - 1)))
+                l_list.append(self.downmodules[i].nhwc(ops.concat_slices(hbuf, h_list), (lbuf, i)))
+            h_list.append(self.upmodules[-1].nhwc(ops.concat_slices(lbuf, l_list), (hbuf, self.depth - 1)))
             rec = self.reconstruction[0]
             return ops.tail_conv(ops.concat_slices(hbuf, h_list), rec.weight, rec.bias, post_add=self.add_mean.shift() if rgb else None)
