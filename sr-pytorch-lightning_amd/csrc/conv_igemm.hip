@@ -1487,7 +1487,12 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
       if (a.CoutP % 64 == 0 && conv_fast_ok(a, 2)) {
         if (rin == 1 && a.Cin == 64) return launch_ws<DT, 2, 4, true>(a, st);
         if (rin == 1 && a.Cin == 16) return launch_ws<DT, 2, 1, true>(a, st);          // e.g. dgrad of the 3-channel tail conv
-        if (rin > 1 && a.Cin == 64 * rin * rin && !a.relu && a.out_mode == SRK_OUT_NHWC) return launch_ws<DT, 2, 4, true>(a, st);
+        // the data gradient of a 64-feature upsampler conv (256 gradient channels read through the PixelShuffle): ONE launch of the
+        // many-input-channel kernel (conv_ks.hip: K blocks streamed, fp32 partial sums stay in registers) instead of four weight-stationary
+        // passes that add their 16-bit partial results through `res` -- 4 x 10.3 us of launch latency at batch 16 (+2.0 % on the EDSR-baseline
+        // step, neutral at batch 256) and three roundings of the sum less.  SRK_PS_DGRAD_WS=1 (under SRK_DEBUG=1): the four passes.
+        static const bool ps_ws = [] { const char* e = srk_dbg_getenv("SRK_PS_DGRAD_WS"); return e && e[0] == '1'; }();      // A/B knob
+        if (rin > 1 && a.Cin == 64 * rin * rin && !a.relu && a.out_mode == SRK_OUT_NHWC && (ps_ws || !srk_conv_ks_ok(a))) return launch_ws<DT, 2, 4, true>(a, st);
       }
       if (a.CoutP == 32 && rin == 1 && a.Cin == 64) return launch_ws<DT, 1, 4, false>(a, st);   // e.g. the 64->3 tail conv
     }
