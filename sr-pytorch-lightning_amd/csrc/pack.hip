@@ -184,8 +184,17 @@ constexpr int PT_CO = 16, PT_CI = 64, PT_PITCH = PT_CI * 9 + 1;
 __host__ __device__ inline bool pack_tiled_ok(const srk_pack_args& a) {
   return a.KH * a.KW <= 9 && a.dtype != SRK_F32 && !(a.dgrad && a.ps_r > 1) && (long long)a.Cout * a.Cin <= 128LL * 128;
 }
+// workgroups of pack_body for an entry the tile form does not take: one (row, 8-channel chunk) item of a 3x3 layout -- 72 strided loads --
+// per thread (EDSR-large's 256 -> 256 layers: 8,192 items; with 16 workgroups per entry every thread walked two of them, one behind the
+// other: the launch moved its 344 MB at 1.2 TB/s), 16 otherwise
+__host__ __device__ inline int pack_body_blocks(const srk_pack_args& a) {
+  if (a.KH * a.KW > 9 || a.dtype == SRK_F32) return 16;
+  const long long items = (long long)a.CoutP * (a.KinP / 8);
+  const long long b = (items + 255) / 256;
+  return (int)(b < 16 ? 16 : (b > 64 ? 64 : b));
+}
 __host__ __device__ inline int pack_tiles_of(const srk_pack_args& a) {
-  return pack_tiled_ok(a) ? ((a.Cout + PT_CO - 1) / PT_CO) * ((a.Cin + PT_CI - 1) / PT_CI) : 16;
+  return pack_tiled_ok(a) ? ((a.Cout + PT_CO - 1) / PT_CO) * ((a.Cin + PT_CI - 1) / PT_CI) : pack_body_blocks(a);
 }
 // MFMA row of stored channel `chan` inside its blk-row block: the inverse of row_to_chan (srk_common.h)
 __device__ __forceinline__ int chan_to_row(int chan, int blk) {
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(256) void pack_group_tiled_kernel(const srk_pack_ar
     return;
   }
   const long long total = (long long)a.KH * a.KW * a.KinP * a.CoutP;
-  const long long first = (long long)t * blockDim.x + threadIdx.x, stride = 16LL * blockDim.x;
+  const long long first = (long long)t * blockDim.x + threadIdx.x, stride = (long long)pack_body_blocks(a) * blockDim.x;
   switch (a.dtype) {
     case SRK_BF16: pack_body<SRK_BF16>(a, total, first, stride); break;
     case SRK_F16: pack_body<SRK_F16>(a, total, first, stride); break;
