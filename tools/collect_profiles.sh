@@ -39,6 +39,8 @@ python tools/microbench_hrtail.py --n 16 --hw 96 >> $O/${TAG}_hrtail_microbench.
 # in-kernel s_memtime anatomy (diagnostics build tools/ubench/libsrk_stamp.so = `make -C sr-pytorch-lightning_amd/csrc stamp`, built here, travels with the snapshot)
 if [ -f tools/ubench/libsrk_stamp.so ]; then
   { for m in 0 2 1; do echo "== conv_pair_kernel, 16 x 48 x 48, STAMP_CA=$m (0: ResBlock; 2 / 1: RCAB forward / backward with the channel attention of the neighbouring block)"; STAMP_CA=$m python tools/stamp_pair.py 16 2>/dev/null | cut -c1-700; done
+    echo "== conv_ws_kernel, 256 x 48 x 48, conv + ReLU"; python tools/stamp_ws.py 256 2>/dev/null | cut -c1-300
+    echo "== conv_ws_kernel, 256 x 48 x 48, * scale + residual (prefetch variant)"; STAMP_RES=1 python tools/stamp_ws.py 256 2>/dev/null | cut -c1-300
     echo "== lk5_dgrad_kernel, 256 x 96 x 96"; python tools/stamp_lk5.py 256 2>/dev/null | head -10
     echo "== lk5_wgrad_kernel, 256 x 96 x 96"; python tools/stamp_lk5w.py 256 2>/dev/null | head -10; } > $O/${TAG}_stamps.txt
 fi
