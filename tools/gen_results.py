@@ -39,8 +39,8 @@ def _stage_of(kernel):
         return "channel attention (stand-alone launches)"
     if k.startswith("conv_wgrad_ws_group") or k.startswith("wgrad_finalize_group") or k.startswith("upload_kernel"):
         return "grouped 3x3 weight gradients (body + first upsampler stage)"
-    if k.startswith("conv_ws_kernel"):
-        return "conv_ws forward / data-gradient launches (body, first upsampler stage; layer by layer: the HR stage too)"
+    if k.startswith("conv_ws_kernel") or k.startswith("conv_ks_kernel"):
+        return "conv_ws / conv_ks forward / data-gradient launches (body, first upsampler stage; layer by layer: the HR stage too)"
     if k.startswith("l1_") or "FillFunctor" in k:
         return "L1 loss"
     if k.startswith("adam_") or "copyBuffer" in k:
