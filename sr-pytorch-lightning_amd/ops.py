@@ -704,6 +704,11 @@ def backward(loss):
     key = (loss.device, loss.dtype)
     one = _ONES.get(key)
     if one is None:
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a tensor made inside a capture lives in that graph's pool and is only FILLED when the graph replays: not something to cache
+            # for eager passes and other graphs -- this pass pays the fill, the next eager pass creates the cached one
+            loss.backward()
+            return
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
     loss.backward(gradient=one if loss.dim() == 0 else one.expand_as(loss))
 
