@@ -272,26 +272,13 @@ template <int DT> __device__ void pack_tile(const srk_pack_args& a, int t, float
 
 __global__ __launch_bounds__(256) void pack_group_tiled_kernel(const srk_pack_args* __restrict__ table, const int* __restrict__ tile_begin, int n) {
   extern __shared__ float pack_tile_lds[];
-  // the entry whose tile range holds this block.  The prefix table goes to LDS with ONE round of coalesced loads and is searched there:
-  // a binary search in global memory is log2(n) DEPENDENT round trips (7 for EDSR's 76 entries, 11 for RCAN's 1,660) in front of every
-  // block's first useful load -- most of the 26 us this launch took at batch 16.
-  __shared__ int tb_lds[2048];
-  int lo = 0, hi = n;
-  if (n + 1 <= 2048) {
-    for (int i = threadIdx.x; i <= n; i += blockDim.x) tb_lds[i] = tile_begin[i];
-    __syncthreads();
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (tb_lds[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
-    }
-  } else {
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (tile_begin[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
-    }
+  int lo = 0, hi = n;                                            // the entry whose tile range holds this block
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_begin[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
   }
   const srk_pack_args a = table[lo];
-  const int t = (int)blockIdx.x - (n + 1 <= 2048 ? tb_lds[lo] : tile_begin[lo]);
+  const int t = (int)blockIdx.x - tile_begin[lo];
   if (pack_tiled_ok(a)) {
     if (a.dtype == SRK_BF16) pack_tile<SRK_BF16>(a, t, pack_tile_lds); else pack_tile<SRK_F16>(a, t, pack_tile_lds);
     return;
