@@ -588,17 +588,7 @@ SRK_DEV void quad_early_wait(QuadRegs& e0, QuadRegs& e1) {
 // and the phase it bounds is vector-ISSUE-bound (~4 cycles per instruction beside the other group's MFMA wave).  Now: flags are
 // template parameters or ONE uniform branch per pixel block, the mask is applied to the PACKED 16-bit results with packed integer
 // ops (2 instead of 3 instructions per element, no unpack), the transposes take one instruction per register and stage.
-// P (two packed 16-bit results) keeps the lanes whose mask element m is > 0 as a float (sign clear, magnitude non-zero; a NaN passes),
-// the others become +0: three packed-integer instructions per TWO elements (max with 0: negatives and -0.0 -> 0; min with 1: 0 / 1;
-// multiply).  Inline asm: from the vector builtins hipcc builds compares, selects and v_perm instead (6 instructions per dword).
-SRK_DEV void mask_apply_pk16(uint32_t& P, uint32_t m) {
-  uint32_t t;
-  asm("v_pk_max_i16 %0, %2, 0\n\t"
-      "v_pk_min_u16 %0, %0, %3\n\t"
-      "v_pk_mul_lo_u16 %1, %1, %0"
-      : "=&v"(t), "+v"(P) : "v"(m), "s"(0x00010001u));
-}
-
+// (mask_apply_pk16: srk_common.h)
 template <int DT, int EM, bool SC, bool RL>
 SRK_DEV void quad_compute_t(float scale, f32x16 (&acc)[2][2], int pb, const QuadRegs& e, bool use_mask_lo, bool use_mask_hi, QuadRegs& out) {
   static_assert(DTraits<DT>::IS16, "16-bit types only");

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   const int r = lane & 31, h = lane >> 5;
   const int H = a.H, W = a.W;
 #if SRK_PAIR_STAMPS
-  unsigned long long* const stamp = (blockIdx.x == 0 && (tid & 255) == 0) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.b2)) + (wave >> 2) * 32 : nullptr;
+  unsigned long long* const stamp = (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && (tid & 255) == 0) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.b2)) + (wave >> 2) * 32 : nullptr;
 #define SRK_PSTAMP(i) do { if (stamp) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
   const float* const bias2 = nullptr;
 #else
@@ -74,11 +74,10 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
 #endif
   SRK_PSTAMP(0);
 
-  int pt = blockIdx.x;
-  const int tX = pt % tilesX;
-  pt /= tilesX;
-  const int tY = pt % tilesY;
-  const int n = pt / tilesY;
+  // grid = (tilesX, tilesY, N): no integer division on the way to the first DMA (two scalar divisions cost ~0.8k cycles of the
+  // ~1.6k a wave spent before its first transfer, tools/stamp_pair.py)
+  const int tX = blockIdx.x, tY = blockIdx.y, n = blockIdx.z;
+  const int bid = (n * tilesY + tY) * tilesX + tX;        // linear tile index (pool rows)
   const int y0 = tY * C::TO, x0 = tX * C::TO;            // output tile origin; intermediate origin (y0-1, x0-1); input (y0-2, x0-2)
 
   const elem* const xg = reinterpret_cast<const elem*>(a.x);
@@ -86,26 +85,9 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   const i32x4 w1rsrc = make_rsrc4(a.w1, 9 * 8 * 64 * 16), w2rsrc = make_rsrc4(a.w2, 9 * 8 * 64 * 16);
   const unsigned xs_lds = lds_addr_of(Xs), wr_lds = lds_addr_of(Wr);
 
-  // ---- prologue: input tile + slabs a0 a1 a2 ---------------------------------------------------------------------------
-  const bool ca = a.ca_mode != 0;                          // the input is transformed on its way in (below): not by DMA
-  if (!ca) {
-#pragma unroll
-    for (int k = 0; k < C::XK; ++k) {
-      const int i = tid + k * C::NT;
-      if (k * C::NT + wave * 64 < C::XPIECES) {             // wave-uniform
-        const int sl = i & 7, p = i >> 3;
-        const int iy = p / C::XT, ix = p - iy * C::XT;
-        const int c = sl ^ swz(ix);
-        const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
-        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * Tr::CH) * (int)sizeof(elem)) : 0x80000000u;
-        // the last 1 KB piece is half tile: its upper lanes are switched off (EXEC), they would land on the intermediate tile
-        if (i < C::XPIECES)
-          dma16_hidden(xrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + ((k * C::NT + wave * 64) << 4))));
-      }
-    }
-  }
-  // slab g (0..5): taps 3*(g%3)..+2 of conv (g/3); 24 pieces of 1 KB, 3 per wave; a straight copy of the packed layout
+  // ---- prologue: slab a0, input tile, slabs a1 a2 -------------------------------------------------------------------------
+  // slab g (0..5): taps 3*(g%3)..+2 of conv (g/3); 24 pieces of 1 KB; a straight copy of the packed layout.
+  // Prologue form: 3 pieces per wave, all 8 waves (the fastest way to get 72 pieces out).
   auto dma_slab = [&](int g) {
     const i32x4 rs = g < 3 ? w1rsrc : w2rsrc;
     const int gg = g < 3 ? g : g - 3;
@@ -117,11 +99,48 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
                    (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));
     }
   };
-  SRK_PSTAMP(1);
+  // In-loop form: 6 pieces per wave, waves 4..7 only -- the compute waves issue NO transfer between their MFMAs (a piece costs
+  // the issuing wave ~60 cycles next to MFMAs; 7 of them per hand-over stretched conv 1 to 41 cycles per MFMA against conv 2's 37)
+  auto dma_slab_dw = [&](int g) {
+    const i32x4 rs = g < 3 ? w1rsrc : w2rsrc;
+    const int gg = g < 3 ? g : g - 3;
+    const unsigned dst = wr_lds + (unsigned)((g % 3) * C::WG_BYTES);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int piece = (wave - 4) * 6 + k;
+      dma16_hidden(rs, (unsigned)(gg * C::WG_BYTES + piece * 1024 + lane * 16),
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + piece * 1024)));
+    }
+  };
+  const bool ca = a.ca_mode != 0;                          // the input is transformed on its way in (below): not by DMA
+  // a0 first: it needs nothing but the weight pointer, so it flies while the tile's addresses are computed.  The CU takes one
+  // 1 KB piece per ~16 cycles whoever asks (64 B/clk), so ORDER is what the first MFMA waits for: a0 and the tile (65 pieces) by
+  // all eight waves, a1 a2 (48 pieces, not needed before K-step 10) by the DMA waves alone, behind their share of the tile --
+  // with a1 a2 issued by every wave right behind its tile pieces, the last tile pieces queued behind 40 slab pieces
+  // (tools/stamp_pair.py: barrier passed at 3.6k cycles with the tile's last piece issued at 2.7k).
   if (!ca) {
     dma_slab(0);
-    dma_slab(1);
-    dma_slab(2);
+    SRK_PSTAMP(1);
+    unsigned xoff[C::XK];
+#pragma unroll
+    for (int k = 0; k < C::XK; ++k) {
+      const int i = tid + k * C::NT;
+      const int sl = i & 7, p = i >> 3;
+      const int iy = p / C::XT, ix = p - iy * C::XT;
+      const int c = sl ^ swz(ix);
+      const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      xoff[k] = ok ? (unsigned)((((n * H + gy) * W + gx) * a.x_pitch + a.x_coff + c * Tr::CH) * (int)sizeof(elem)) : 0x80000000u;
+    }
+#pragma unroll
+    for (int k = 0; k < C::XK; ++k) {
+      if (k * C::NT + wave * 64 < C::XPIECES) {             // wave-uniform
+        // the last 1 KB piece is half tile: its upper lanes are switched off (EXEC), they would land on the intermediate tile
+        if (tid + k * C::NT < C::XPIECES)
+          dma16_hidden(xrsrc, xoff[k], (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + ((k * C::NT + wave * 64) << 4))));
+      }
+    }
+    if (wave >= 4) dma_slab_dw(1);                          // a2: behind the barrier below (its issue would only delay it)
   }
   SRK_PSTAMP(2);
 
@@ -204,6 +223,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       *reinterpret_cast<f32x4*>(rawS + 4 * f) = vs[u];
     }
     lds_barrier();
+    SRK_PSTAMP(19);
     // slabs a0 a1 a2 (72 pieces) by waves 1..7 only, AFTER the staging barrier: wave 0 carries the MLP below, the longest chain
     // of this prologue, and must not wait for their issue (~1.3k cycles); the transfers land well before the tile transform ends
     if (wave) {
@@ -239,6 +259,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     if (wave == 0) {
       const float mean_c = pooled(rawS, rs, lane) * invHW;
       cmean[lane] = mean_c;
+      SRK_PSTAMP(20);
       if (bwd) {
         const float u = pooled(rawG, rg, lane);
         const float d2 = u * (sg_in * (1.f - sg_in));
@@ -272,6 +293,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         cA[lane] = sg;
         cB[lane] = 0.f;
       }
+      SRK_PSTAMP(21);
     }
     lds_barrier();
     if (slot_owner) {                                        // per-sample results: one workgroup per sample
@@ -300,21 +322,28 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         const int c = sl ^ swz(ix);
         const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
         const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        // packed pairs: v * s + b as v_pk_mul_f32, v_pk_add_f32 (separate roundings, like the stand-alone kernels).  Forward: the
+        // out-of-image pieces were loaded as zeros from both tensors and 0 * s + 0 = 0 needs no select; backward: dmean != 0 there.
         const f32x4 A0 = *reinterpret_cast<const f32x4*>(cA + 8 * c), A1 = *reinterpret_cast<const f32x4*>(cA + 8 * c + 4);
-        const f32x4 B0 = *reinterpret_cast<const f32x4*>(cB + 8 * c), B1 = *reinterpret_cast<const f32x4*>(cB + 8 * c + 4);
-        const float Av[8] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w};
-        const float Bv[8] = {B0.x, B0.y, B0.z, B0.w, B1.x, B1.y, B1.z, B1.w};
+        const f32x2 Av[4] = {{A0.x, A0.y}, {A0.z, A0.w}, {A1.x, A1.y}, {A1.z, A1.w}};
+        f32x2 Bv[4] = {};
+        if (bwd) {
+          const f32x4 B0 = *reinterpret_cast<const f32x4*>(cB + 8 * c), B1 = *reinterpret_cast<const f32x4*>(cB + 8 * c + 4);
+          Bv[0] = f32x2{B0.x, B0.y}; Bv[1] = f32x2{B0.z, B0.w}; Bv[2] = f32x2{B1.x, B1.y}; Bv[3] = f32x2{B1.z, B1.w};
+        }
         const uint32_t w4[4] = {xin[k].x, xin[k].y, xin[k].z, xin[k].w};
         const uint32_t r4[4] = {x2in[k].x, x2in[k].y, x2in[k].z, x2in[k].w};
         uint32_t o4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v0, v1, b0 = Bv[2 * e], b1v = Bv[2 * e + 1];
-          unpack2<DT>(w4[e], v0, v1);
-          if (!bwd) unpack2<DT>(r4[e], b0, b1v);
-          v0 = v0 * Av[2 * e] + b0;
-          v1 = v1 * Av[2 * e + 1] + b1v;
-          o4[e] = ok ? pack2<DT>(v0, v1) : 0u;
+          float t0, t1, q0, q1;
+          unpack2<DT>(w4[e], t0, t1);
+          f32x2 v = {t0, t1}, b = Bv[e];
+          if (!bwd) { unpack2<DT>(r4[e], q0, q1); b = f32x2{q0, q1}; }
+          v = v * Av[e];
+          v = v + b;
+          const uint32_t pk = pack2<DT>(v.x, v.y);
+          o4[e] = (!bwd || ok) ? pk : 0u;
         }
         lds_write16(Xs + (i << 4), i32x4{(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]});
       }
@@ -343,6 +372,13 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     xl[pb] = Xs + ((prow[pb] * C::XP + px) << 7);
     ml[pb] = Ms + ((prow[pb] * C::MP + px) << 7);
   }
+
+  // copies between an LDS tile and HBM (8 lanes = one 128-byte pixel, consecutive lane octets = consecutive pixels): pixels 2 and 3
+  // of every four swap places.  A ds_read_b128 is served in lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: pixel
+  // octets 0 and 2 (same 128-byte half of the bank row) then ask for chunks 0-3 and 4-7 ^ swizzle, which collide whenever the
+  // swizzles differ in bit 2 -- always, two columns apart.  Swapped, octets 0 and 3 / 1 and 2 meet instead (opposite halves).
+  // tools/lds_conflicts_pair.py: 206 -> 34 conflict cycles per workgroup in the copy loops.
+  auto pswap = [](int p) { return p ^ ((p >> 1) & 1); };
 
   f32x16 acc[2][2];                                       // [channel block][pixel block]
   auto init_acc = [&](const float* bias) {
@@ -400,14 +436,14 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   }
   // ReLU-backward mask: its 16x16 tile goes by LDS-DMA to WHERE THE INTERMEDIATE WILL BE WRITTEN -- each lane reads its own
   // mask chunks right before it overwrites them.  (Per-lane 16-byte loads of one pixel each occupy the address path for
-  // ~64 cycles apiece: eight of them cost more than the tile transfer.)  32 pieces of 8 pixels, 4 per wave.
+  // ~64 cycles apiece: eight of them cost more than the tile transfer.)  32 pieces of 8 pixels, 8 per DMA wave (4..7).
   const unsigned ms_lds = lds_addr_of(Ms);
   auto dma_mask = [&]() {
     if (a.mask) {
       const i32x4 mrsrc = make_rsrc4(a.mask, 0x7fffffffu);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int blk = wave + 8 * k;
+      for (int k = 0; k < 8; ++k) {
+        const int blk = (wave - 4) + 4 * k;
         const int iy = blk >> 1, ix = (blk & 1) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ swz(ix);
         const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
@@ -417,36 +453,44 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       }
     }
   };
-  // Only the input tile and kernel row 0 of conv 1 (66 of the 115 KB) are waited for here; rows 1 and 2 (slabs a1, a2: the
-  // 6 youngest transfers of every wave) land under the first MFMAs.
+  // Only the input tile and kernel row 0 of conv 1 (66 of the 115 KB) are waited for here; row 1 (slab a1: the 6 youngest
+  // transfers of every DMA wave) lands under the first MFMAs, row 2 is requested behind the barrier.
   SRK_PSTAMP(3);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if (wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   SRK_PSTAMP(4);
   __builtin_amdgcn_s_barrier();
   SRK_PSTAMP(5);
+  if (!ca && wave >= 4) dma_slab_dw(2);                     // needed from K-step 22 on (~3k cycles from here)
 
   // ---- conv 1 on the 16x16 intermediate pixels ------------------------------------------------------------------------------
   // Hand-over at K-step 10 / 22 (fragments are read two steps ahead, so the reads of kernel row 0 / 1 have all been issued
-  // and, after the drain, returned): kernel row 1 / 2 has landed (own pieces by the counted wait, the others' by the
-  // barrier) and ring slot 0 / 1 is free for conv 2's slab b0 / b1.  The mask tile is requested at the first hand-over,
-  // ahead of b0, so that the second one's count covers it.
-  auto hand1 = [&]() { asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); dma_mask(); dma_slab(3); };
-  auto hand2 = [&]() { asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); dma_slab(4); };
+  // and, after the drain, returned): kernel row 1 / 2 has landed (own prologue pieces by the counted wait, the others' by the
+  // barrier) and ring slot 0 / 1 is free for conv 2's slab b0 / b1, which the DMA waves (4..7) then request.  The mask tile
+  // is requested at the first hand-over, ahead of b0, so that the DMA waves' second wait (all but b0's six pieces) covers it.
+  // vector-memory operations in flight, per wave, oldest first --
+  //   compute waves: none after the prologue
+  //   DMA waves:     [a1 a2 | 6 + 6] [mask 8] [b0 6] [b1 6]       hand 1: vmcnt(6)   hand 2: vmcnt(6) = a2 and the mask have landed
+  // (channel-attention modes: nothing is in flight when conv 1 starts, the counts are merely stricter than needed)
+  auto hand1_cw = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto hand2_cw = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto hand1_dw = [&]() { asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); dma_mask(); dma_slab_dw(3); };
+  auto hand2_dw = [&]() { asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); dma_slab_dw(4); };
   if (cw) {
     conv_loop(0, xl, C::XP, [&](int s) {
-      if (s == 10) hand1();
-      if (s == 22) hand2();
+      if (s == 10) hand1_cw();
+      if (s == 22) hand2_cw();
     });
   } else {
-    hand1();
-    hand2();
+    hand1_dw();
+    hand2_dw();
     // transformed input: this workgroup's 14x14 to HBM, whole 128-byte pixels (the input tile stays until conv 1 is done)
     if (ca && a.xo) {
       const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.xo);
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const int i = (tid - 256) + 256 * k;
-        const int p = i >> 3, c = i & 7;
+        const int p = pswap(i >> 3), c = i & 7;
         const int row = p / C::TO, col = p - row * C::TO;
         const int gy = y0 + row, gx = x0 + col;
         const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
@@ -484,26 +528,24 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
           for (int d = 0; d < 16; ++d) v[d] = f32x2{fmaxf(v[d].x, 0.f), fmaxf(v[d].y, 0.f)};
         }
 #pragma unroll
-        for (int d = 0; d < 16; ++d) v[d] = v[d] * sm2;
+        for (int d = 0; d < 16; ++d) { const f32x2 t = v[d] * sm2; P[d] = pack2<DT>(t.x, t.y); }
         if (a.mask) {
+          // on the PACKED results, three packed-integer instructions per two elements (mask_apply_pk16, the form the
+          // weight-stationary kernel's data gradient uses; unpack + float compare + select was 7 per element pair)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const i32x4 m = lds_read16(mp + (((4 * h + j) ^ g) << 4));
-            const int mw[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float q0, q1;
-              unpack2<DT>((uint32_t)mw[e], q0, q1);
-              v[4 * j + e] = f32x2{q0 > 0.f ? v[4 * j + e].x : 0.f, q1 > 0.f ? v[4 * j + e].y : 0.f};
-            }
+            mask_apply_pk16(P[4 * j + 0], (uint32_t)m.x);
+            mask_apply_pk16(P[4 * j + 1], (uint32_t)m.y);
+            mask_apply_pk16(P[4 * j + 2], (uint32_t)m.z);
+            mask_apply_pk16(P[4 * j + 3], (uint32_t)m.w);
           }
         }
-#pragma unroll
-        for (int d = 0; d < 16; ++d) P[d] = pack2<DT>(v[d].x, v[d].y);
       }
-      if (!m_in[pb]) {
+      // pixels outside the image: conv 2 pads the IMAGE with zeros.  Interior tiles (most) have none: one uniform test
+      if (__builtin_amdgcn_ballot_w64(!m_in[pb]) != 0) {
 #pragma unroll
-        for (int d = 0; d < 16; ++d) P[d] = 0u;
+        for (int d = 0; d < 16; ++d) P[d] = m_in[pb] ? P[d] : 0u;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -511,37 +553,53 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     }
   }
   SRK_PSTAMP(7);
-  drain_barrier();                                        // intermediate tile written; input tile and ring slot 2 are free
+  // ONE barrier between the convs.  Behind it: the intermediate tile is written, the input tile and ring slot 2 are free, and
+  // slabs b0 b1 have landed -- the DMA waves asked for them 5k and 2.5k cycles ago and wait for everything they have in flight
+  // (also their copy of the transformed input) before they arrive.  They then request b2 (+ an external residual tile, in the
+  // input tile's place), which conv 2 needs from K-step 22 on, while the compute waves are already in conv 2.
+  if (!cw) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  drain_barrier();
   SRK_PSTAMP(8);
-  dma_slab(5);
   // a residual that is not the input: its tile replaces the input tile (28 pieces of 8 pixels: rows 2..15, columns 2..17)
-  const unsigned xs_res = a.res && !a.res_from_x;
-  if (xs_res) {
-    const i32x4 rrsrc = make_rsrc4(a.res, 0x7fffffffu);
+  const bool xs_res = a.res && !a.res_from_x;
+  if (!cw) {
+    dma_slab_dw(5);
+    if (xs_res) {
+      const i32x4 rrsrc = make_rsrc4(a.res, 0x7fffffffu);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int blk = wave + 8 * k;                        // 28..31: rows 16, 17 of the tile, never read
-      const int iy = 2 + (blk >> 1), ix = 2 + (blk & 1) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ swz(ix);
-      const int gy = y0 + iy - 2, gx = x0 + ix - 2;
-      const bool ok = blk < 28 && gy < H && gx < W;
-      const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.res_pitch + a.res_coff + c * Tr::CH) * 2) : 0x80000000u;
-      dma16_hidden(rrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + ((iy * C::XP + 2 + (blk & 1) * 8) << 7))));
+      for (int k = 0; k < 7; ++k) {
+        const int blk = (wave - 4) + 4 * k;                  // 0..27
+        const int iy = 2 + (blk >> 1), ix = 2 + (blk & 1) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz(ix);
+        const int gy = y0 + iy - 2, gx = x0 + ix - 2;
+        const bool ok = gy < H && gx < W;
+        const unsigned voff = ok ? (unsigned)((((n * H + gy) * W + gx) * a.res_pitch + a.res_coff + c * Tr::CH) * 2) : 0x80000000u;
+        dma16_hidden(rrsrc, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + ((iy * C::XP + 2 + (blk & 1) * 8) << 7))));
+      }
     }
   }
-  // slab b0 (ring slot 0) was requested two slabs ago: at most slab b2's three pieces (and nothing older than slab b1's) may
-  // still be in flight.  The counts below assume no residual transfer; with it they are merely stricter.
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
 
   // ---- conv 2 on the 14x14 output tile: rows 0..13 x 16 column slots (14 used).  Wave 3's second pixel block is rows
   // 14, 15: computed (it reads past the intermediate tile into the weight ring, inside the allocation) and dropped. ----------
   SRK_PSTAMP(9);
   init_acc(bias2);
-  // slab b1 is needed from step 10 on (fragments are read two steps ahead), b2 from step 22: this wave's pieces by the
-  // counted wait, every other wave's by the barrier
+  // slabs b0 b1 have landed (barrier above); b2 and an external residual tile are needed from step 22 on (fragments are read two
+  // steps ahead): the DMA waves wait for them, the barrier tells the compute waves
   // pooling with a second factor (pool_aux): this lane's four 16-byte pieces of it, requested once nothing else is in
   // flight (conv-2 hand-over at step 22) and used when the output tile leaves
+  // the output tile's way out (after conv 2): lane `tid` copies pieces i = tid + 512 k: chunk c = tid & 7 of pixels pswap((tid >> 3)
+  // + 64 k) -- the same 8 channels each time.  Addresses now, while this wave waits at a barrier anyway, not in the kernel's tail.
+  unsigned out_lds[4], out_off[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + C::NT * k;
+    const int p = pswap(i >> 3), c = i & 7;
+    const int row = p / C::TO, col = p - row * C::TO;
+    const int gy = y0 + row, gx = x0 + col;
+    const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
+    out_lds[k] = (unsigned)((((row + 2) * C::XP + col + 2) << 7) + ((c ^ swz(col + 2)) << 4));
+    out_off[k] = ok ? (unsigned)((((n * H + gy) * W + gx) * a.out_pitch + a.out_coff + c * Tr::CH) * 2) : 0x80000000u;
+  }
   u32x4_t au[4] = {};
   auto load_aux = [&]() {
     if (a.pool && a.pool_aux) {
@@ -549,7 +607,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int i = tid + C::NT * k;
-        const int p = i >> 3, c = i & 7;
+        const int p = pswap(i >> 3), c = i & 7;
         const int row = p / C::TO, col = p - row * C::TO;
         const int gy = y0 + row, gx = x0 + col;
         const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
@@ -560,12 +618,9 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   };
   if (cw) {
     conv_loop(3, ml, C::MP, [&](int s) {
-      if (s == 10) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-      if (s == 22) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); load_aux(); }
+      if (s == 22) { __builtin_amdgcn_s_barrier(); load_aux(); }
     });
   } else {
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
     // the idle waves copy this workgroup's 14x14 of the intermediate to HBM while conv 2 runs: whole 128-byte pixels,
     // 8 lanes each, neighbouring pixels of a row contiguous
     if (a.mid) {
@@ -573,7 +628,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const int i = (tid - 256) + 256 * k;
-        const int p = i >> 3, c = i & 7;
+        const int p = pswap(i >> 3), c = i & 7;
         const int row = p / C::TO, col = p - row * C::TO;
         const int gy = y0 + row, gx = x0 + col;
         const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
@@ -582,6 +637,8 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // b2 (+ residual tile) landed, the copy above has left
+    __builtin_amdgcn_s_barrier();
     load_aux();
   }
 
@@ -624,19 +681,13 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   }
   drain_barrier();
   {
-    // lane `tid` copies pieces i = tid + 512 k: chunk c = tid & 7 of pixels (tid >> 3) + 64 k -- the same 8 channels each time
     const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.out);
     float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int i = tid + C::NT * k;
-      const int p = i >> 3, c = i & 7;
-      const int row = p / C::TO, col = p - row * C::TO;
-      const int gy = y0 + row, gx = x0 + col;
-      const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
-      const i32x4 q = lds_read16(Xs + (((row + 2) * C::XP + col + 2) << 7) + ((c ^ swz(col + 2)) << 4));
-      const unsigned vo = ok ? (unsigned)((((n * H + gy) * W + gx) * a.out_pitch + a.out_coff + c * Tr::CH) * 2) : 0x80000000u;
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
+      const bool ok = out_off[k] != 0x80000000u;
+      const i32x4 q = lds_read16(Xs + out_lds[k]);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, out_off[k], 0, 0);
       if (a.pool && ok) {
         const int qw[4] = {q.x, q.y, q.z, q.w};
         const uint32_t aw[4] = {au[k].x, au[k].y, au[k].z, au[k].w};
@@ -651,17 +702,36 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       }
     }
     if (a.pool) {
-      // per-lane partials -> LDS (the intermediate tile's place), then thread ch sums its channel over the 64 lanes that
-      // carry it, in lane order: bitwise reproducible
+      // per-lane partials -> LDS (the intermediate tile's place), summed per channel over the 64 lanes that carry it in two
+      // steps of eight, each in a fixed order (bitwise reproducible).  Row pitch NT + 4 words: the 32 lanes of a ds_read_b32
+      // group (chunks 0..3 or 4..7 x 8 elements) then hit 32 different banks (pitch NT: 8-way conflicts, and ONE wave walked
+      // all 64 terms behind a barrier that also waited for the tile's stores: ~2k cycles at the end of every RCAB launch).
+      constexpr int PP = C::NT + 4;
       float* const P = reinterpret_cast<float*>(Ms);
+      float* const P2 = P + 8 * PP;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) P[e * C::NT + tid] = ps[e];
-      __syncthreads();
+      for (int e = 0; e < 8; ++e) P[e * PP + tid] = ps[e];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the stores above stay in flight
+      {
+        const int ch = tid & 63, part = tid >> 6;            // channel = chunk ch >> 3, element ch & 7; lanes 8 (8 part + j) + chunk
+        const float* const src = P + (ch & 7) * PP + (ch >> 3) + 64 * part;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[8 * j];
+        float u = v[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) u += v[j];
+        P2[part * 64 + ch] = u;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (tid < 64) {
-        const int c = tid >> 3, e = tid & 7;
-        float u = 0.f;
-        for (int j = 0; j < C::NT / 8; ++j) u += P[e * C::NT + c + 8 * j];
-        a.pool[(size_t)blockIdx.x * 64 + tid] = u;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = P2[j * 64 + tid];
+        float u = v[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) u += v[j];
+        a.pool[(size_t)bid * 64 + tid] = u;
       }
     }
   }
@@ -728,8 +798,10 @@ extern "C" int srk_conv_pair(const srk_conv_pair_args* a, srk_stream_t stream) {
   SRK_CHECK_ARG(nb <= 0x7fffffffLL, "srk_conv_pair: %lld tiles", nb);
   const unsigned xb = (unsigned)(px * a->x_pitch * 2);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->dtype == SRK_BF16) hipLaunchKernelGGL((conv_pair_kernel<SRK_BF16>), dim3((unsigned)nb), dim3(C::NT), C::LDS_BYTES, st, *a, tilesX, tilesY, xb);
-  else hipLaunchKernelGGL((conv_pair_kernel<SRK_F16>), dim3((unsigned)nb), dim3(C::NT), C::LDS_BYTES, st, *a, tilesX, tilesY, xb);
+  SRK_CHECK_ARG(tilesY <= 65535 && a->N <= 65535, "srk_conv_pair: grid (%d, %d, %d)", tilesX, tilesY, a->N);
+  const dim3 grid((unsigned)tilesX, (unsigned)tilesY, (unsigned)a->N);
+  if (a->dtype == SRK_BF16) hipLaunchKernelGGL((conv_pair_kernel<SRK_BF16>), grid, dim3(C::NT), C::LDS_BYTES, st, *a, tilesX, tilesY, xb);
+  else hipLaunchKernelGGL((conv_pair_kernel<SRK_F16>), grid, dim3(C::NT), C::LDS_BYTES, st, *a, tilesX, tilesY, xb);
   SRK_LAUNCH_CHECK();
   return 0;
 }

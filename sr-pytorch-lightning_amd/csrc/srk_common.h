@@ -201,6 +201,18 @@ SRK_DEV uint32_t relu_pk16(uint32_t w) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, z));
 }
 
+// ReLU-backward mask on PACKED 16-bit results (conv_igemm.hip's prefetch variant, conv_pair.hip's intermediate epilogue).
+// P (two packed 16-bit results) keeps the lanes whose mask element m is > 0 as a float (sign clear, magnitude non-zero; a NaN passes),
+// the others become +0: three packed-integer instructions per TWO elements (max with 0: negatives and -0.0 -> 0; min with 1: 0 / 1;
+// multiply).  Inline asm: from the vector builtins hipcc builds compares, selects and v_perm instead (6 instructions per dword).
+SRK_DEV void mask_apply_pk16(uint32_t& P, uint32_t m) {
+  uint32_t t;
+  asm("v_pk_max_i16 %0, %2, 0\n\t"
+      "v_pk_min_u16 %0, %0, %3\n\t"
+      "v_pk_mul_lo_u16 %1, %1, %0"
+      : "=&v"(t), "+v"(P) : "v"(m), "s"(0x00010001u));
+}
+
 // element <-> float helpers on 4-element groups (8 B for 16-bit types, 16 B for fp32)
 template <int DT> SRK_DEV void load4(const typename DTraits<DT>::elem* p, float v[4]) {
   typedef DTraits<DT> Tr;

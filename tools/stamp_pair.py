@@ -37,10 +37,10 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
 print(f"{e0.elapsed_time(e1)*1e3/20:.2f} us per launch")
 st = stamps.cpu().numpy()
-names = ["entry", "x tile issued", "slabs issued", "mask requested", "own DMA landed", "barrier", "conv1 done", "mid epilogue done",
+names = ["entry", "a0 issued", "tile, a1, a2 issued", "mask requested", "own DMA landed", "barrier", "conv1 done", "mid epilogue done",
          "drain barrier", "b0 barrier", "conv2 done", "stores issued", "stores done"]
 for w in (0, 1):
     t = st[w * 32:(w + 1) * 32]
     print(("compute wave 0: " if w == 0 else "DMA wave 4:     ") + "; ".join(f"{nm} {t[i]-t[0]}" for i, nm in enumerate(names)))
     if t[13]:
-        print("      channel-attention block: " + "; ".join(f"{nm} {t[13+i]-t[0]}" for i, nm in enumerate(["input pieces requested", "MLP operands requested", "first operand arrived", "MLP done", "tile transformed", "all landed"])))
+        print("      channel-attention block: " + "; ".join(f"{nm} {t[13+i]-t[0]}" for i, nm in enumerate(["input pieces requested", "MLP operands requested", "first operand arrived", "MLP done", "tile transformed", "all landed", "staging barrier", "pooled mean done (wave 0)", "MLP loop done (wave 0)"])))
