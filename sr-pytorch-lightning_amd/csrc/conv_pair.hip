@@ -22,6 +22,7 @@
 // slabs ahead of the MFMAs).  8 waves: wave w owns pixel block w (2 tile rows x 16 columns = 32 pixels) x all 64
 // channels (2 accumulator tiles): per K-step 2 weight fragments + 1 pixel fragment -> 2 MFMAs.
 #include "srk_common.h"
+#include <type_traits>
 
 // diagnostics build only (make stamp, tools/stamp_pair.py): s_memtime stamps of workgroup 0 through `b2` (conv 2 then runs
 // without bias)
@@ -74,6 +75,12 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
 #endif
   SRK_PSTAMP(0);
 
+  // both biases: one early load by waves 0 / 1, parked in LDS ahead of the first barrier -- the accumulators are initialised from
+  // there (as global loads in front of each conv they were ~0.5k exposed cycles each in the channel-attention modes and before conv 2)
+  __shared__ __attribute__((aligned(16))) float sbias[128];
+  float bias_in = 0.f;
+  if (tid < 64) { if (a.b1) bias_in = a.b1[tid]; }
+  else if (tid < 128) { if (bias2) bias_in = bias2[tid - 64]; }
   // grid = (tilesX, tilesY, N): no integer division on the way to the first DMA (two scalar divisions cost ~0.8k cycles of the
   // ~1.6k a wave spent before its first transfer, tools/stamp_pair.py)
   const int tX = blockIdx.x, tY = blockIdx.y, n = blockIdx.z;
@@ -114,10 +121,10 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   };
   const bool ca = a.ca_mode != 0;                          // the input is transformed on its way in (below): not by DMA
   // a0 first: it needs nothing but the weight pointer, so it flies while the tile's addresses are computed.  The CU takes one
-  // 1 KB piece per ~16 cycles whoever asks (64 B/clk), so ORDER is what the first MFMA waits for: a0 and the tile (65 pieces) by
-  // all eight waves, a1 a2 (48 pieces, not needed before K-step 10) by the DMA waves alone, behind their share of the tile --
-  // with a1 a2 issued by every wave right behind its tile pieces, the last tile pieces queued behind 40 slab pieces
-  // (tools/stamp_pair.py: barrier passed at 3.6k cycles with the tile's last piece issued at 2.7k).
+  // 1 KB piece per ~16-24 cycles whoever asks (64 B/clk), so what is issued AHEAD of the first barrier is what the first MFMA
+  // waits for: a0 and the tile (65 pieces) by all eight waves; a1 a2 (48 pieces, not needed before K-step 10) by the DMA waves
+  // behind that barrier (tools/stamp_pair.py: with a1 a2 issued by every wave right behind its tile pieces the barrier was
+  // passed at 3.6k cycles, the tile's last piece issued at 2.7k).
   if (!ca) {
     dma_slab(0);
     SRK_PSTAMP(1);
@@ -140,21 +147,50 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
           dma16_hidden(xrsrc, xoff[k], (unsigned)__builtin_amdgcn_readfirstlane((int)(xs_lds + ((k * C::NT + wave * 64) << 4))));
       }
     }
-    if (wave >= 4) dma_slab_dw(1);                          // a2: behind the barrier below (its issue would only delay it)
   }
   SRK_PSTAMP(2);
 
-  // ---- channel attention on the way in (RCAN at small batches; CALayer models/rcan.py:10-29) ------------------------------
-  // ca_mode 1, backward: x' = x * s[n][c] + dmean[n][c] (zero outside the image), s and dmean from the squeeze/excite MLP's
-  // backward on this sample's pooled vectors -- what srk_ca_bwd_apply computes as its own launch.
-  // ca_mode 2, forward: x' = x * s[n][c] + x2, the PREVIOUS block's `t * s + residual` (rcan.py:52-54), s from the MLP on that
-  // block's pooled sums -- what srk_ca_apply computes as its own launch.  Same arithmetic in the same ORDER, both: results are
-  // bit-identical to the stand-alone launches.
-  // Laid out for latency (a launch spends ~4k cycles in its prologue without this): every global operand is requested at
-  // once and waited for once, BEFORE the weight slabs' LDS-DMA is issued -- the vector-memory counter retires in order, so
-  // any later compiler-inserted wait would sit behind those 74 KB; the slabs then fly while the MLP and the tile
-  // transform run out of LDS and registers.  The 64 x Cr products of a matrix-vector step are formed in parallel, their
-  // sums (serial, for the order) read all operands first.
+  // ---- per-lane constants -----------------------------------------------------------------------------------------------
+  // Waves 0..3 compute (one per SIMD), each a 64-channel x 64-pixel tile = pixel blocks 2w, 2w+1 (tile rows 4w .. 4w+3):
+  // 2 weight + 2 pixel fragments per K-step feed 4 MFMAs, the 1:1 read:MFMA ratio at which the CU's 128 B/clk of LDS
+  // keeps up (32-pixel wave tiles on all 8 waves need 1.5 reads per MFMA and ran LDS-bound).  Waves 4..7 only issue DMA.
+  const bool cw = wave < 4;
+  const int px = r & 15;
+  int gsw[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) gsw[kw] = swz(px + kw);
+  const char* const wlane = Wr + ((h * 64 + r) << 4);
+  int prow[2];
+  const char* xl[2];
+  const char* ml[2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    prow[pb] = 4 * (wave & 3) + 2 * pb + (r >> 4);
+    xl[pb] = Xs + ((prow[pb] * C::XP + px) << 7);
+    ml[pb] = Ms + ((prow[pb] * C::MP + px) << 7);
+  }
+
+  // copies between an LDS tile and HBM (8 lanes = one 128-byte pixel, consecutive lane octets = consecutive pixels): pixels 2 and 3
+  // of every four swap places.  A ds_read_b128 is served in lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: pixel
+  // octets 0 and 2 (same 128-byte half of the bank row) then ask for chunks 0-3 and 4-7 ^ swizzle, which collide whenever the
+  // swizzles differ in bit 2 -- always, two columns apart.  Swapped, octets 0 and 3 / 1 and 2 meet instead (opposite halves).
+  // tools/lds_conflicts_pair.py: 206 -> 34 conflict cycles per workgroup in the copy loops.
+  auto pswap = [](int p) { return p ^ ((p >> 1) & 1); };
+
+  f32x16 acc[2][2];                                       // [channel block][pixel block]
+  auto init_acc = [&](int which) {                       // 0: conv 1, 1: conv 2
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + which * 64 + 4 * h + cb * 32 + 8 * i);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          acc[cb][pb][4 * i + 0] = b.x; acc[cb][pb][4 * i + 1] = b.y; acc[cb][pb][4 * i + 2] = b.z; acc[cb][pb][4 * i + 3] = b.w;
+        }
+      }
+  };
+  if (!ca && tid < 128) sbias[tid] = bias_in;
   if (ca) {
     __shared__ __attribute__((aligned(16))) float cW1[512], cW2[512], cA[64], cB[64], cmean[64], cd2[64], cz[8], cd1[8];
     const bool bwd = a.ca_mode == 1;
@@ -163,23 +199,28 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     const int Cr = a.ca_cr;                                  // <= 8 (launcher)
     const float invHW = 1.f / (float)(H * W);
     const bool slot_owner = tX == 0 && tY == 0;             // one workgroup per sample writes the per-sample results
-    // input pieces (and, forward, the second operand) through registers: coalesced 16-byte pieces in the tile's LDS order
+    // input pieces (and, forward, the second operand) through registers.  Lane `tid` carries CHUNK tid & 7 of pixels (tid >> 3) +
+    // 64 k (eight lanes = one 128-byte pixel, in order) and writes it to the swizzled slot: the eight scale / shift values of a
+    // lane are then the same for all its pieces (round 4 mapped lanes to SLOTS: four LDS reads of s / dmean per piece).
     u32x4_t xin[C::XK], x2in[C::XK] = {};
+    unsigned xdst[C::XK];
+    unsigned okbits = 0;
+    const int cch = tid & 7;
     {
       const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x);
       const __amdgpu_buffer_rsrc_t r2 = rsrc_of(bwd ? a.x : a.ca_x2);
 #pragma unroll
       for (int k = 0; k < C::XK; ++k) {
-        const int i = tid + k * C::NT;
-        const int sl = i & 7, p = i >> 3;
+        const int p = (tid >> 3) + 64 * k;
         const int iy = p / C::XT, ix = p - iy * C::XT;
-        const int c = sl ^ swz(ix);
         const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
-        const bool ok = i < C::XPIECES && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const bool ok = p < C::XT * C::XT && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         const int pix = (n * H + gy) * W + gx;
-        xin[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)((pix * a.x_pitch + a.x_coff + c * Tr::CH) * 2) : 0x80000000u, 0, 0);
+        okbits |= ok ? (1u << k) : 0u;
+        xdst[k] = (unsigned)((p << 7) + ((cch ^ swz(ix)) << 4));
+        xin[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)((pix * a.x_pitch + a.x_coff + cch * Tr::CH) * 2) : 0x80000000u, 0, 0);
         if (!bwd)
-          x2in[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, ok ? (unsigned)((pix * a.ca_x2_pitch + a.ca_x2_coff + c * Tr::CH) * 2) : 0x80000000u, 0, 0);
+          x2in[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, ok ? (unsigned)((pix * a.ca_x2_pitch + a.ca_x2_coff + cch * Tr::CH) * 2) : 0x80000000u, 0, 0);
       }
     }
     SRK_PSTAMP(13);
@@ -216,6 +257,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     // no per-element branch: a +-0 term leaves a sum as it is)
     cW1[tid] = w1r;
     cW2[tid] = w2r;
+    if (tid < 128) sbias[tid] = bias_in;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int f = tid + C::NT * u;
@@ -255,45 +297,65 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     };
     // The MLP itself on wave 0 alone (LDS operations of one wave execute in order, so its stages need no workgroup barrier):
     // lane = channel; the 64-term sums are wave butterflies (wave_sum64, srk_common.h: the order of the stand-alone kernels
-    // for 64 channels), their results uniform over the wave, so the hidden units live in registers of every lane.
-    if (wave == 0) {
+    // for 64 channels), their results uniform over the wave, so the hidden units live in registers of every lane.  The NJ
+    // butterflies are INDEPENDENT chains in one basic block (no per-unit branch): their DPP stages interleave instead of
+    // each waiting out its own read-after-write distance.  Units beyond Cr have zero weights and biases: z = 0, +0.0 terms.
+    auto mlp = [&](auto njc) {
+      constexpr int NJ = decltype(njc)::value;
+      // column `lane` of W1 [Cr][64], row `lane` of W2 [64][Cr] into registers, all reads issued at once (round 4 read one element
+      // per hidden unit inside the dependent chain: ~500 cycles per unit)
+      float w1c[NJ], w2c[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { w1c[j] = j < Cr ? cW1[j * 64 + lane] : 0.f; w2c[j] = j < Cr ? cW2[lane * Cr + j] : 0.f; }
       const float mean_c = pooled(rawS, rs, lane) * invHW;
       cmean[lane] = mean_c;
       SRK_PSTAMP(20);
+      float zz[8] = {}, dd[8] = {};
       if (bwd) {
         const float u = pooled(rawG, rg, lane);
         const float d2 = u * (sg_in * (1.f - sg_in));
         cA[lane] = sg_in;
         cd2[lane] = d2;
         // dz[j] = sum_c W2[c][j] dpre2[c], dpre1 = relu'(z) dz; dmean[c] = sum_j W1[j][c] dpre1[j] (j ascending)
+        float pr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) pr[j] = w2c[j] * d2;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) pr[j] = wave_sum64(pr[j]);
         float dm = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (j < Cr) {
-            const float dz = wave_sum64(cW2[lane * Cr + j] * d2);
-            const float zj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_in), j));
-            const float d1 = zj > 0.f ? dz : 0.f;
-            dm += cW1[j * 64 + lane] * d1;
-            if (lane == 0) { cz[j] = zj; cd1[j] = d1; }
-          } else if (lane == 0) { cz[j] = 0.f; cd1[j] = 0.f; }
+        for (int j = 0; j < NJ; ++j) {
+          zz[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z_in), j));
+          dd[j] = zz[j] > 0.f ? pr[j] : 0.f;
+          if (j < Cr) dm += w1c[j] * dd[j];
         }
         cB[lane] = dm / (float)(H * W);
       } else {
         // forward: z = relu(b1 + W1 mean), s = sigmoid(b2 + W2 z) (j ascending)
+        float pr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) pr[j] = w1c[j] * mean_c;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) pr[j] = wave_sum64(pr[j]);
         float sg = b2_in;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (j < Cr) {
-            const float zj = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1_in), j)) + wave_sum64(cW1[j * 64 + lane] * mean_c), 0.f);
-            sg += cW2[lane * Cr + j] * zj;
-            if (lane == 0) cz[j] = zj;
-          } else if (lane == 0) cz[j] = 0.f;
+        for (int j = 0; j < NJ; ++j) {
+          zz[j] = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1_in), j)) + pr[j], 0.f);
+          if (j < Cr) sg += w2c[j] * zz[j];
         }
         sg = 1.f / (1.f + expf(-sg));
         cA[lane] = sg;
         cB[lane] = 0.f;
       }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cz[j] = zz[j]; cd1[j] = dd[j]; }
+      }
       SRK_PSTAMP(21);
+    };
+    if (wave == 0) {
+      if (Cr <= 4) mlp(std::integral_constant<int, 4>());
+      else mlp(std::integral_constant<int, 8>());
     }
     lds_barrier();
     if (slot_owner) {                                        // per-sample results: one workgroup per sample
@@ -313,39 +375,36 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       }
     }
     SRK_PSTAMP(16);
+    {
+      // packed pairs: v * s + b as v_pk_mul_f32, v_pk_add_f32 (separate roundings, like the stand-alone kernels).  Forward: the
+      // out-of-image pieces were loaded as zeros from both tensors and 0 * s + 0 = 0 needs no select; backward: dmean != 0 there.
+      const f32x4 A0 = *reinterpret_cast<const f32x4*>(cA + 8 * cch), A1 = *reinterpret_cast<const f32x4*>(cA + 8 * cch + 4);
+      const f32x2 Av[4] = {{A0.x, A0.y}, {A0.z, A0.w}, {A1.x, A1.y}, {A1.z, A1.w}};
+      f32x2 Bv[4] = {};
+      if (bwd) {
+        const f32x4 B0 = *reinterpret_cast<const f32x4*>(cB + 8 * cch), B1 = *reinterpret_cast<const f32x4*>(cB + 8 * cch + 4);
+        Bv[0] = f32x2{B0.x, B0.y}; Bv[1] = f32x2{B0.z, B0.w}; Bv[2] = f32x2{B1.x, B1.y}; Bv[3] = f32x2{B1.z, B1.w};
+      }
 #pragma unroll
-    for (int k = 0; k < C::XK; ++k) {
-      const int i = tid + k * C::NT;
-      if (i < C::XPIECES) {
-        const int sl = i & 7, p = i >> 3;
-        const int iy = p / C::XT, ix = p - iy * C::XT;
-        const int c = sl ^ swz(ix);
-        const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
-        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        // packed pairs: v * s + b as v_pk_mul_f32, v_pk_add_f32 (separate roundings, like the stand-alone kernels).  Forward: the
-        // out-of-image pieces were loaded as zeros from both tensors and 0 * s + 0 = 0 needs no select; backward: dmean != 0 there.
-        const f32x4 A0 = *reinterpret_cast<const f32x4*>(cA + 8 * c), A1 = *reinterpret_cast<const f32x4*>(cA + 8 * c + 4);
-        const f32x2 Av[4] = {{A0.x, A0.y}, {A0.z, A0.w}, {A1.x, A1.y}, {A1.z, A1.w}};
-        f32x2 Bv[4] = {};
-        if (bwd) {
-          const f32x4 B0 = *reinterpret_cast<const f32x4*>(cB + 8 * c), B1 = *reinterpret_cast<const f32x4*>(cB + 8 * c + 4);
-          Bv[0] = f32x2{B0.x, B0.y}; Bv[1] = f32x2{B0.z, B0.w}; Bv[2] = f32x2{B1.x, B1.y}; Bv[3] = f32x2{B1.z, B1.w};
-        }
-        const uint32_t w4[4] = {xin[k].x, xin[k].y, xin[k].z, xin[k].w};
-        const uint32_t r4[4] = {x2in[k].x, x2in[k].y, x2in[k].z, x2in[k].w};
-        uint32_t o4[4];
+      for (int k = 0; k < C::XK; ++k) {
+        if ((tid >> 3) + 64 * k < C::XT * C::XT) {
+          const bool ok = (okbits >> k) & 1;
+          const uint32_t w4[4] = {xin[k].x, xin[k].y, xin[k].z, xin[k].w};
+          const uint32_t r4[4] = {x2in[k].x, x2in[k].y, x2in[k].z, x2in[k].w};
+          uint32_t o4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t0, t1, q0, q1;
-          unpack2<DT>(w4[e], t0, t1);
-          f32x2 v = {t0, t1}, b = Bv[e];
-          if (!bwd) { unpack2<DT>(r4[e], q0, q1); b = f32x2{q0, q1}; }
-          v = v * Av[e];
-          v = v + b;
-          const uint32_t pk = pack2<DT>(v.x, v.y);
-          o4[e] = (!bwd || ok) ? pk : 0u;
+          for (int e = 0; e < 4; ++e) {
+            float t0, t1, q0, q1;
+            unpack2<DT>(w4[e], t0, t1);
+            f32x2 v = {t0, t1}, b = Bv[e];
+            if (!bwd) { unpack2<DT>(r4[e], q0, q1); b = f32x2{q0, q1}; }
+            v = v * Av[e];
+            v = v + b;
+            const uint32_t pk = pack2<DT>(v.x, v.y);
+            o4[e] = (!bwd || ok) ? pk : 0u;
+          }
+          lds_write16(Xs + xdst[k], i32x4{(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]});
         }
-        lds_write16(Xs + (i << 4), i32x4{(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]});
       }
     }
     SRK_PSTAMP(17);
@@ -353,46 +412,6 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     SRK_PSTAMP(18);
   }
 
-  // ---- per-lane constants -----------------------------------------------------------------------------------------------
-  // Waves 0..3 compute (one per SIMD), each a 64-channel x 64-pixel tile = pixel blocks 2w, 2w+1 (tile rows 4w .. 4w+3):
-  // 2 weight + 2 pixel fragments per K-step feed 4 MFMAs, the 1:1 read:MFMA ratio at which the CU's 128 B/clk of LDS
-  // keeps up (32-pixel wave tiles on all 8 waves need 1.5 reads per MFMA and ran LDS-bound).  Waves 4..7 only issue DMA.
-  const bool cw = wave < 4;
-  const int px = r & 15;
-  int gsw[3];
-#pragma unroll
-  for (int kw = 0; kw < 3; ++kw) gsw[kw] = swz(px + kw);
-  const char* const wlane = Wr + ((h * 64 + r) << 4);
-  int prow[2];
-  const char* xl[2];
-  const char* ml[2];
-#pragma unroll
-  for (int pb = 0; pb < 2; ++pb) {
-    prow[pb] = 4 * (wave & 3) + 2 * pb + (r >> 4);
-    xl[pb] = Xs + ((prow[pb] * C::XP + px) << 7);
-    ml[pb] = Ms + ((prow[pb] * C::MP + px) << 7);
-  }
-
-  // copies between an LDS tile and HBM (8 lanes = one 128-byte pixel, consecutive lane octets = consecutive pixels): pixels 2 and 3
-  // of every four swap places.  A ds_read_b128 is served in lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: pixel
-  // octets 0 and 2 (same 128-byte half of the bank row) then ask for chunks 0-3 and 4-7 ^ swizzle, which collide whenever the
-  // swizzles differ in bit 2 -- always, two columns apart.  Swapped, octets 0 and 3 / 1 and 2 meet instead (opposite halves).
-  // tools/lds_conflicts_pair.py: 206 -> 34 conflict cycles per workgroup in the copy loops.
-  auto pswap = [](int p) { return p ^ ((p >> 1) & 1); };
-
-  f32x16 acc[2][2];                                       // [channel block][pixel block]
-  auto init_acc = [&](const float* bias) {
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-          acc[cb][pb][4 * i + 0] = b.x; acc[cb][pb][4 * i + 1] = b.y; acc[cb][pb][4 * i + 2] = b.z; acc[cb][pb][4 * i + 3] = b.w;
-        }
-      }
-  };
   // One conv = 36 K-steps (slab = kernel row kh = s / 12, tap column kw, K-step ks), 4 MFMAs each; the fragments of
   // step s+2 are read during step s, one ds_read_b128 per MFMA gap (a burst of four per gap oversubscribes the LDS
   // array while the four waves run in step).  `at_step(s)` runs the slab hand-over (barriers, waits, DMA) between steps.
@@ -425,7 +444,6 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   // every LDS read of this wave has returned, then the workgroup barrier: the ring slot / tile behind it may be rewritten
   auto drain_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  init_acc(a.b1);
   int mpix[2];
   bool m_in[2];
 #pragma unroll
@@ -453,15 +471,16 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       }
     }
   };
-  // Only the input tile and kernel row 0 of conv 1 (66 of the 115 KB) are waited for here; row 1 (slab a1: the 6 youngest
-  // transfers of every DMA wave) lands under the first MFMAs, row 2 is requested behind the barrier.
+  // Only the input tile and kernel row 0 of conv 1 (66 of the 115 KB) are requested and waited for before the first MFMA.
   SRK_PSTAMP(3);
-  if (wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   SRK_PSTAMP(4);
   __builtin_amdgcn_s_barrier();
   SRK_PSTAMP(5);
-  if (!ca && wave >= 4) dma_slab_dw(2);                     // needed from K-step 22 on (~3k cycles from here)
+  if (cw) init_acc(0);
+  // a1 is needed from K-step 10 on (~1.5k cycles from here), a2 from K-step 22: requested NOW, not in the prologue, where every
+  // piece issued ahead of the barrier delays it by the ~24 cycles the CU needs per piece
+  if (!ca && wave >= 4) { dma_slab_dw(1); dma_slab_dw(2); }
 
   // ---- conv 1 on the 16x16 intermediate pixels ------------------------------------------------------------------------------
   // Hand-over at K-step 10 / 22 (fragments are read two steps ahead, so the reads of kernel row 0 / 1 have all been issued
@@ -582,7 +601,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   // ---- conv 2 on the 14x14 output tile: rows 0..13 x 16 column slots (14 used).  Wave 3's second pixel block is rows
   // 14, 15: computed (it reads past the intermediate tile into the weight ring, inside the allocation) and dropped. ----------
   SRK_PSTAMP(9);
-  init_acc(bias2);
+  init_acc(1);
   // slabs b0 b1 have landed (barrier above); b2 and an external residual tile are needed from step 22 on (fragments are read two
   // steps ahead): the DMA waves wait for them, the barrier tells the compute waves
   // pooling with a second factor (pool_aux): this lane's four 16-byte pieces of it, requested once nothing else is in
@@ -637,7 +656,10 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // b2 (+ residual tile) landed, the copy above has left
+    // b2 (+ residual tile) have landed; the copy's seven stores (the youngest operations) may still be on their way -- waiting for
+    // them too made the compute waves wait at K-step 22 (conv 2 at 40 cycles per MFMA against conv 1's 37.6)
+    if (a.mid) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     load_aux();
   }
