@@ -415,12 +415,30 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   // One conv = 36 K-steps (slab = kernel row kh = s / 12, tap column kw, K-step ks), 4 MFMAs each; the fragments of
   // step s+2 are read during step s, one ds_read_b128 per MFMA gap (a burst of four per gap oversubscribes the LDS
   // array while the four waves run in step).  `at_step(s)` runs the slab hand-over (barriers, waits, DMA) between steps.
-  auto conv_loop = [&](int g0, const char* const (&pix)[2], int pitch, auto&& at_step) {
+  // SPLIT (round 5): the LAST kernel row (K-steps 24..35) runs pixel block 0 first (pass A: 24 MFMAs), then pixel block 1
+  // (pass B: 24 MFMAs), and `epi(piece)`, piece 0..23, is issued behind the MFMAs of pass B: the epilogue of pixel block 0 --
+  // pack, ReLU / mask, residual, the LDS stores: ~0.6k cycles of vector instructions per conv that used to follow the loop --
+  // rides in the shadow of the matrix pipe.  Every accumulator still sees its K-steps in the same order (bit-identical
+  // results); the last row reads its weight fragments twice (1.5 LDS reads per MFMA there instead of 1).
+  auto conv_loop = [&](auto split_c, int g0, const char* const (&pix)[2], int pitch, auto&& at_step, auto&& epi) {
+    constexpr bool SPLIT = decltype(split_c)::value;
+    constexpr int NV = SPLIT ? 48 : 36;                    // virtual steps: 0..23 | pass A 24..35 | pass B 36..47 (K-steps 24..35 again)
     i32x4 fa[3][2], fb[3][2];
-    auto frag1 = [&](int s, int q, i32x4 (&af)[2], i32x4 (&bf)[2]) {
+    auto needed = [&](int v, int q) { return v < NV && (!SPLIT || v < 24 || (v < 36 ? q != 3 : q != 2)); };
+    auto frag1 = [&](int v, int q, i32x4 (&af)[2], i32x4 (&bf)[2]) {
+      const int s = v < 36 ? v : v - 12;
       const int kh = s / 12, kw = (s % 12) / 4, ks = s % 4;
       if (q < 2) af[q] = lds_read16(wlane + ((g0 + kh) % 3) * C::WG_BYTES + (((kw * 8 + 2 * ks) * 64 + q * 32) << 4));
       else bf[q - 2] = lds_read16(pix[q - 2] + ((kh * pitch + kw) << 7) + (((2 * ks + h) ^ gsw[kw]) << 4));
+    };
+    // the MFMA gap of step v in which fragment q of step v + 2 is read: one per gap in a 4-MFMA step; in a 2-MFMA step the
+    // (at most three) fragments of step v + 2 go two into the first gap, one into the second
+    auto gap_of = [&](int v, int q) {
+      if (!needed(v + 2, q)) return -1;
+      if (!SPLIT || v < 24) return q;
+      int idx = 0;
+      for (int qq = 0; qq < q; ++qq) idx += needed(v + 2, qq) ? 1 : 0;
+      return idx >> 1;
     };
 #pragma unroll
     for (int q = 0; q < 4; ++q) frag1(0, q, fa[0], fb[0]);
@@ -428,15 +446,30 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     for (int q = 0; q < 4; ++q) frag1(1, q, fa[1], fb[1]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int s = 0; s < 36; ++s) {
-      at_step(s);
-      const int c0 = s % 3, c2 = (s + 2) % 3;
+    for (int v = 0; v < NV; ++v) {
+      if (v < 36) at_step(v);
+      const int c0 = v % 3, c2 = (v + 2) % 3;
+      if (!SPLIT || v < 24) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        if (s + 2 < 36) frag1(s + 2, m, fa[c2], fb[c2]);
-        const int cb = m >> 1, pb = m & 1;
-        acc[cb][pb] = Tr::mma(fa[c0][cb], fb[c0][pb], acc[cb][pb]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (gap_of(v, q) == m) frag1(v + 2, q, fa[c2], fb[c2]);
+          const int cb = m >> 1, pb = m & 1;
+          acc[cb][pb] = Tr::mma(fa[c0][cb], fb[c0][pb], acc[cb][pb]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        const int pb = v < 36 ? 0 : 1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (gap_of(v, q) == m) frag1(v + 2, q, fa[c2], fb[c2]);
+          acc[m][pb] = Tr::mma(fa[c0][m], fb[c0][pb], acc[m][pb]);
+          if (v >= 36) epi(2 * (v - 36) + m);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -495,11 +528,105 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   auto hand2_cw = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   auto hand1_dw = [&]() { asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); dma_mask(); dma_slab_dw(3); };
   auto hand2_dw = [&]() { asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); dma_slab_dw(4); };
+  // intermediate epilogue: [ReLU | mask], * scale_mid, zero outside the image (conv 2 pads the IMAGE with zeros), into the
+  // LDS tile in the image format (this lane: 32 contiguous channels 32h .. 32h+31 of its pixel = chunks 4h .. 4h+3).
+  // Pixel block 0's epilogue rides behind the MFMAs of pixel block 1's last kernel row (conv_loop, SPLIT) in the two common
+  // flavours -- forward (ReLU, no scale, no mask) and backward (mask, scale) --, as 24 pieces of at most 6 vector instructions.
+  const float sm = a.scale_mid;
+  const f32x2 sm2 = {sm, sm};
+  const int gmid = swz(px);
+  auto mid_full = [&](int pb) {
+    char* const mp = const_cast<char*>(ml[pb]);
+    uint32_t P[16];
+    if (a.relu_mid && sm == 1.f) {                         // forward: ReLU on the packed pairs (the form srk_conv2d uses)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) P[8 * cb + d] = relu_pk16(pack2<DT>(acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]));
+    } else {
+      f32x2 v[16];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) v[8 * cb + d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]};
+      if (a.relu_mid) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) v[d] = f32x2{fmaxf(v[d].x, 0.f), fmaxf(v[d].y, 0.f)};
+      }
+#pragma unroll
+      for (int d = 0; d < 16; ++d) { const f32x2 t = v[d] * sm2; P[d] = pack2<DT>(t.x, t.y); }
+    }
+    if (a.mask) {
+      // on the PACKED results, three packed-integer instructions per two elements (mask_apply_pk16, the form the
+      // weight-stationary kernel's data gradient uses; unpack + float compare + select was 7 per element pair)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const i32x4 m = lds_read16(mp + (((4 * h + j) ^ gmid) << 4));
+        mask_apply_pk16(P[4 * j + 0], (uint32_t)m.x);
+        mask_apply_pk16(P[4 * j + 1], (uint32_t)m.y);
+        mask_apply_pk16(P[4 * j + 2], (uint32_t)m.z);
+        mask_apply_pk16(P[4 * j + 3], (uint32_t)m.w);
+      }
+    }
+    // pixels outside the image: conv 2 pads the IMAGE with zeros.  Interior tiles (most) have none: one uniform test
+    if (__builtin_amdgcn_ballot_w64(!m_in[pb]) != 0) {
+#pragma unroll
+      for (int d = 0; d < 16; ++d) P[d] = m_in[pb] ? P[d] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      lds_write16(mp + (((4 * h + j) ^ gmid) << 4), i32x4{(int)P[4 * j], (int)P[4 * j + 1], (int)P[4 * j + 2], (int)P[4 * j + 3]});
+  };
+  // the same arithmetic for pixel block 0, cut into the pieces conv_loop places behind pass B's MFMAs
+  uint32_t P0[16];
+  i32x4 mreg[4];
+  char* const mp0 = const_cast<char*>(ml[0]);
+  auto mid_piece_relu = [&](int p) {                       // 16 x (pack, ReLU, zero outside the image), 4 stores
+    if (p < 16) {
+      const int cb = p >> 3, d = p & 7;
+      const uint32_t w = relu_pk16(pack2<DT>(acc[cb][0][2 * d], acc[cb][0][2 * d + 1]));
+      P0[p] = m_in[0] ? w : 0u;
+    } else if (p < 20) {
+      const int j = p - 16;
+      lds_write16(mp0 + (((4 * h + j) ^ gmid) << 4), i32x4{(int)P0[4 * j], (int)P0[4 * j + 1], (int)P0[4 * j + 2], (int)P0[4 * j + 3]});
+    }
+  };
+  auto mid_piece_mask = [&](int p) {                       // 4 mask chunks, 16 x (scale, pack, mask, zero outside), 4 stores
+    if (p < 4) {
+      mreg[p] = lds_read16(mp0 + (((4 * h + p) ^ gmid) << 4));
+    } else if (p < 20) {
+      const int e = p - 4, cb = e >> 3, d = e & 7;
+      const f32x2 t = f32x2{acc[cb][0][2 * d], acc[cb][0][2 * d + 1]} * sm2;
+      uint32_t w = pack2<DT>(t.x, t.y);
+      const i32x4 m = mreg[e >> 2];
+      mask_apply_pk16(w, (uint32_t)((e & 3) == 0 ? m.x : (e & 3) == 1 ? m.y : (e & 3) == 2 ? m.z : m.w));
+      P0[e] = m_in[0] ? w : 0u;
+    } else {
+      const int j = p - 20;
+      lds_write16(mp0 + (((4 * h + j) ^ gmid) << 4), i32x4{(int)P0[4 * j], (int)P0[4 * j + 1], (int)P0[4 * j + 2], (int)P0[4 * j + 3]});
+    }
+  };
+  auto hand_cw = [&](int s) {
+    if (s == 10) hand1_cw();
+    if (s == 22) hand2_cw();
+  };
+  const std::integral_constant<bool, true> split_on;
+  const std::integral_constant<bool, false> split_off;
   if (cw) {
-    conv_loop(0, xl, C::XP, [&](int s) {
-      if (s == 10) hand1_cw();
-      if (s == 22) hand2_cw();
-    });
+    if (a.relu_mid && sm == 1.f && !a.mask) {
+      conv_loop(split_on, 0, xl, C::XP, hand_cw, mid_piece_relu);
+      SRK_PSTAMP(6);
+      mid_full(1);
+    } else if (a.mask && !a.relu_mid) {
+      conv_loop(split_on, 0, xl, C::XP, hand_cw, mid_piece_mask);
+      SRK_PSTAMP(6);
+      mid_full(1);
+    } else {
+      conv_loop(split_off, 0, xl, C::XP, hand_cw, [](int) {});
+      SRK_PSTAMP(6);
+      mid_full(0);
+      mid_full(1);
+    }
   } else {
     hand1_dw();
     hand2_dw();
@@ -520,57 +647,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     }
   }
 
-  SRK_PSTAMP(6);
-  // intermediate epilogue: [ReLU | mask], * scale_mid, zero outside the image (conv 2 pads the IMAGE with zeros), into the
-  // LDS tile in the image format (this lane: 32 contiguous channels 32h .. 32h+31 of its pixel = chunks 4h .. 4h+3)
-  if (cw) {
-    const float sm = a.scale_mid;
-    const f32x2 sm2 = {sm, sm};
-    const int g = swz(px);
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-      char* const mp = const_cast<char*>(ml[pb]);
-      uint32_t P[16];
-      if (a.relu_mid && sm == 1.f) {                       // forward: ReLU on the packed pairs (the form srk_conv2d uses)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int d = 0; d < 8; ++d) P[8 * cb + d] = relu_pk16(pack2<DT>(acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]));
-      } else {
-        f32x2 v[16];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int d = 0; d < 8; ++d) v[8 * cb + d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]};
-        if (a.relu_mid) {
-#pragma unroll
-          for (int d = 0; d < 16; ++d) v[d] = f32x2{fmaxf(v[d].x, 0.f), fmaxf(v[d].y, 0.f)};
-        }
-#pragma unroll
-        for (int d = 0; d < 16; ++d) { const f32x2 t = v[d] * sm2; P[d] = pack2<DT>(t.x, t.y); }
-        if (a.mask) {
-          // on the PACKED results, three packed-integer instructions per two elements (mask_apply_pk16, the form the
-          // weight-stationary kernel's data gradient uses; unpack + float compare + select was 7 per element pair)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const i32x4 m = lds_read16(mp + (((4 * h + j) ^ g) << 4));
-            mask_apply_pk16(P[4 * j + 0], (uint32_t)m.x);
-            mask_apply_pk16(P[4 * j + 1], (uint32_t)m.y);
-            mask_apply_pk16(P[4 * j + 2], (uint32_t)m.z);
-            mask_apply_pk16(P[4 * j + 3], (uint32_t)m.w);
-          }
-        }
-      }
-      // pixels outside the image: conv 2 pads the IMAGE with zeros.  Interior tiles (most) have none: one uniform test
-      if (__builtin_amdgcn_ballot_w64(!m_in[pb]) != 0) {
-#pragma unroll
-        for (int d = 0; d < 16; ++d) P[d] = m_in[pb] ? P[d] : 0u;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        lds_write16(mp + (((4 * h + j) ^ g) << 4), i32x4{(int)P[4 * j], (int)P[4 * j + 1], (int)P[4 * j + 2], (int)P[4 * j + 3]});
-    }
-  }
+  if (!cw) SRK_PSTAMP(6);
   SRK_PSTAMP(7);
   // ONE barrier between the convs.  Behind it: the intermediate tile is written, the input tile and ring slot 2 are free, and
   // slabs b0 b1 have landed -- the DMA waves asked for them 5k and 2.5k cycles ago and wait for everything they have in flight
@@ -635,10 +712,76 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       }
     }
   };
+  // ---- output epilogue: * scale_out, + residual (in the input tile's place either way), the result written back over the
+  // residual it used; pixel block 0's part behind the MFMAs of pixel block 1's last kernel row (conv_loop, SPLIT) ----------
+  const float so = a.scale_out;
+  const f32x2 so2 = {so, so};
+  const int gout = swz(px + 2);
+  auto out_full = [&](int pb) {
+    f32x2 v[16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int d = 0; d < 8; ++d) v[8 * cb + d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]} * so2;
+    char* const xr = Xs + (((prow[pb] + 2) * C::XP + px + 2) << 7);
+    if (a.res) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const i32x4 q = lds_read16(xr + (((4 * h + j) ^ gout) << 4));
+        const int qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float f0, f1;
+          unpack2<DT>((uint32_t)qw[e], f0, f1);
+          v[4 * j + e] = v[4 * j + e] + f32x2{f0, f1};
+        }
+      }
+    }
+    if (prow[pb] < C::TO && px < C::TO) {                  // rows 14, 15 / columns 14, 15 are not part of the tile
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        lds_write16(xr + (((4 * h + j) ^ gout) << 4),
+                    i32x4{(int)pack2<DT>(v[4 * j].x, v[4 * j].y), (int)pack2<DT>(v[4 * j + 1].x, v[4 * j + 1].y),
+                          (int)pack2<DT>(v[4 * j + 2].x, v[4 * j + 2].y), (int)pack2<DT>(v[4 * j + 3].x, v[4 * j + 3].y)});
+    }
+  };
+  uint32_t Q0[16];
+  i32x4 rreg[4];
+  char* const xr0 = Xs + (((prow[0] + 2) * C::XP + px + 2) << 7);
+  const bool keep0 = prow[0] < C::TO && px < C::TO;
+  auto out_piece_res = [&](int p) {                        // 4 residual chunks, 16 x (scale, + residual, pack), 4 stores
+    if (p < 4) {
+      rreg[p] = lds_read16(xr0 + (((4 * h + p) ^ gout) << 4));
+    } else if (p < 20) {
+      const int e = p - 4, cb = e >> 3, d = e & 7;
+      const i32x4 q = rreg[e >> 2];
+      float f0, f1;
+      unpack2<DT>((uint32_t)((e & 3) == 0 ? q.x : (e & 3) == 1 ? q.y : (e & 3) == 2 ? q.z : q.w), f0, f1);
+      const f32x2 t = f32x2{acc[cb][0][2 * d], acc[cb][0][2 * d + 1]} * so2 + f32x2{f0, f1};
+      Q0[e] = pack2<DT>(t.x, t.y);
+    } else if (keep0) {
+      const int j = p - 20;
+      lds_write16(xr0 + (((4 * h + j) ^ gout) << 4), i32x4{(int)Q0[4 * j], (int)Q0[4 * j + 1], (int)Q0[4 * j + 2], (int)Q0[4 * j + 3]});
+    }
+  };
+  auto out_piece_plain = [&](int p) {                      // 16 x (scale, pack), 4 stores
+    if (p < 16) {
+      const int cb = p >> 3, d = p & 7;
+      const f32x2 t = f32x2{acc[cb][0][2 * d], acc[cb][0][2 * d + 1]} * so2;
+      Q0[p] = pack2<DT>(t.x, t.y);
+    } else if (p < 20 && keep0) {
+      const int j = p - 16;
+      lds_write16(xr0 + (((4 * h + j) ^ gout) << 4), i32x4{(int)Q0[4 * j], (int)Q0[4 * j + 1], (int)Q0[4 * j + 2], (int)Q0[4 * j + 3]});
+    }
+  };
+  auto hand_c2 = [&](int s) {
+    if (s == 22) { __builtin_amdgcn_s_barrier(); load_aux(); }
+  };
   if (cw) {
-    conv_loop(3, ml, C::MP, [&](int s) {
-      if (s == 22) { __builtin_amdgcn_s_barrier(); load_aux(); }
-    });
+    if (a.res) conv_loop(split_on, 3, ml, C::MP, hand_c2, out_piece_res);
+    else conv_loop(split_on, 3, ml, C::MP, hand_c2, out_piece_plain);
+    SRK_PSTAMP(10);
+    out_full(1);
   } else {
     // the idle waves copy this workgroup's 14x14 of the intermediate to HBM while conv 2 runs: whole 128-byte pixels,
     // 8 lanes each, neighbouring pixels of a row contiguous
@@ -664,43 +807,8 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     load_aux();
   }
 
-  SRK_PSTAMP(10);
-  // ---- output epilogue: * scale_out, + residual (in the input tile's place either way), the result written back over the
-  // residual it used; then all eight waves copy the 14x14 tile to HBM in whole pixels -------------------------------------
-  if (cw) {
-    const float so = a.scale_out;
-    const f32x2 so2 = {so, so};
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-      f32x2 v[16];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int d = 0; d < 8; ++d) v[8 * cb + d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]} * so2;
-      char* const xr = Xs + (((prow[pb] + 2) * C::XP + px + 2) << 7);
-      const int g = swz(px + 2);
-      if (a.res) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const i32x4 q = lds_read16(xr + (((4 * h + j) ^ g) << 4));
-          const int qw[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float f0, f1;
-            unpack2<DT>((uint32_t)qw[e], f0, f1);
-            v[4 * j + e] = v[4 * j + e] + f32x2{f0, f1};
-          }
-        }
-      }
-      if (prow[pb] < C::TO && px < C::TO) {                // rows 14, 15 / columns 14, 15 are not part of the tile
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          lds_write16(xr + (((4 * h + j) ^ g) << 4),
-                      i32x4{(int)pack2<DT>(v[4 * j].x, v[4 * j].y), (int)pack2<DT>(v[4 * j + 1].x, v[4 * j + 1].y),
-                            (int)pack2<DT>(v[4 * j + 2].x, v[4 * j + 2].y), (int)pack2<DT>(v[4 * j + 3].x, v[4 * j + 3].y)});
-      }
-    }
-  }
+  if (!cw) SRK_PSTAMP(10);
+  // all eight waves copy the 14x14 tile to HBM in whole pixels
   drain_barrier();
   {
     const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.out);
