@@ -116,7 +116,16 @@ def cpu_baseline(model_name, scale, patch, seconds=15.0, max_steps=8, model=None
         step()
         k += 1
     dt = time.perf_counter() - t0
-    out = {"value": round(n * k / dt, 3), "unit": "LR patches/s", "cores": cores, "kind": "port",
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    out = {"value": round(n * k / dt, 3), "unit": "LR patches/s", "cores": cores, "cores_available": avail, "cpu_model": cpu_model, "kind": "port",
            "sample": f"{k} training steps of batch {n} ({cls} fp32, torch {torch.__version__} CPU, {cores} threads), {dt:.1f} s"}
     if model is not None and lr is not None:
         try:
@@ -333,7 +342,105 @@ def _flavours(A, model_name, batch, patch, feats, dtype):
     return f"{kern} 3x3 {feats}->{feats}, fwd = dgrad kernel", fl
 
 
-def dominant_kernel_roofline(A, model_name, batch, patch, feats, dtype, iters=100, sustain_s=1.0):
+def _replay_us(capture, sustain_s):
+    """`capture()` issues launches; they are captured into ONE hipGraph, replayed back to back for `sustain_s` seconds, and the
+    second half of the replays is timed by HIP events on the launch stream.  Returns microseconds per replay."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            capture()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        capture()
+    for _ in range(2):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    one = max(e0.elapsed_time(e1) * 1e3, 1.0)
+    nrep = max(4, int(sustain_s * 1e6 / one))
+    for _ in range(nrep // 2):
+        g.replay()
+    e0.record()
+    for _ in range(nrep - nrep // 2):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (nrep - nrep // 2)
+    del g
+    return us
+
+
+def in_step_body(A, model, batch, patch, dtype, sustain_s=0.6):
+    """The dominant kernel family WHERE IT LIVES: the residual trunk of the benched model -- `model.body_nhwc`,
+    the code its forward runs -- as it runs inside a training step: autograd recording (the conv + ReLU launches store their sign
+    bits, every layer writes its own activation buffer: 33 x 75 MB at batch 256, nothing is re-read from the Infinity Cache the way
+    an isolated launch re-reads its one input), the flavours alternating in dependency order, the data gradients behind them in
+    the backward pass's order, sustained clocks.  Three graphs, replayed back to back and timed by HIP events on the launch stream:
+        F   = weight packing + trunk forward                       (n convs)
+        FB  = F + backward with the weight gradients left queued   (+ n data-gradient launches)
+        FBW = F + backward + the grouped weight-gradient launch and its finalize
+    and P = the packing launch alone.  in-step time per launch of the family = (FB - P) / 2n; algorithmic FLOPs = 2 x 64 x 64 x 9
+    per pixel and launch.  (The reference has no counterpart: cuDNN picks its kernels.)  Returns None for models without `body_nhwc`."""
+    if not hasattr(model, "body_nhwc") or dtype == "f32":
+        return None
+    ops = A.ops
+    n_conv, feats = model.body_conv_launches()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dt = TDT[dtype]
+    f0 = (torch.rand(batch, patch, patch, feats, device=dev) - 0.5).to(dt)
+    g0 = ((torch.rand(batch, patch, patch, feats, device=dev) - 0.5) * 1e-3).to(dt)
+    params = [p for p in model.body.parameters() if p.requires_grad]
+
+    def pack_only():
+        with ops.forward_scope(model._pack_group()):
+            pass
+
+    def fwd():
+        with ops.forward_scope(model._pack_group()):
+            f = f0.detach().requires_grad_(True)
+            return f, model.body_nhwc(f)
+
+    def fwd_only():
+        fwd()
+
+    def fwd_bwd(flush):
+        for p in params:
+            p.grad = None
+        f, r = fwd()
+        if flush:
+            torch.autograd.backward(r, g0)
+        else:
+            with ops.hold_wgrads_discard():
+                torch.autograd.backward(r, g0)
+
+    t_p = _replay_us(pack_only, 0.05)
+    t_f = _replay_us(fwd_only, sustain_s)
+    t_fb = _replay_us(lambda: fwd_bwd(False), sustain_s)
+    t_fbw = _replay_us(lambda: fwd_bwd(True), sustain_s)
+    for p in params:
+        p.grad = None
+    px = batch * patch * patch
+    flops = 2.0 * px * feats * feats * 9
+    fam_us = (t_fb - t_p) / (2 * n_conv)
+    return {"launches": 2 * n_conv, "us_per_launch": round(fam_us, 2), "flops_per_launch": flops,
+            "fwd_us_per_launch": round((t_f - t_p) / n_conv, 2), "dgrad_us_per_launch": round((t_fb - t_f) / n_conv, 2),
+            "wgrad_us_per_layer": round((t_fbw - t_fb) / n_conv, 2),
+            "graph_us": {"pack": round(t_p, 1), "fwd": round(t_f, 1), "fwd_bwd": round(t_fb, 1), "fwd_bwd_wgrad": round(t_fbw, 1)},
+            "frac": round(flops / (fam_us * 1e-6) / 1e12 / PEAK_TFLOPS[dtype], 4),
+            "frac_with_wgrad": round(3 * n_conv * flops / ((t_fbw - t_p) * 1e-6) / 1e12 / PEAK_TFLOPS[dtype], 4),
+            "method": "the model's own trunk (body_nhwc) captured as hipGraphs in training mode (autograd on, one buffer per layer), replayed "
+                      f"for {sustain_s:g} s each, second half timed by HIP events on the launch stream; FB = forward + data gradients "
+                      "(weight gradients queued, not launched), minus the weight-packing launch"}
+
+
+def dominant_kernel_roofline(A, model_name, batch, patch, feats, dtype, iters=100, sustain_s=1.0, in_step=None):
     """The kernel(s) that carry the model's residual blocks AT THIS BATCH (`_flavours`), each flavour a training step issues timed
     by HIP events on the launch stream: a burst (one graph of `iters` launches right after a warm-up replay) and SUSTAINED
     (>= `sustain_s` seconds of back-to-back replays, the second half timed: the clock has dropped by then, which is what a
@@ -367,20 +474,30 @@ def dominant_kernel_roofline(A, model_name, batch, patch, feats, dtype, iters=10
     ach = f0["flops"] / (us * 1e-6) / 1e12
     px = batch * patch * patch
     alg_bytes = 2.0 * px * feats * esz                              # one read + one write of the block's activation
-    r = {"bound": "mfma", "kernel": f"{kernel} @{patch}x{patch} x{batch} ({dtype}); quoted flavour: {f0['name']}",
-         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-         "frac_burst": round(f0["flops"] / (burst[f0["name"]] * 1e-6) / 1e12 / peak, 4),
-         "us_per_launch": round(us, 2), "flops_per_launch": f0["flops"],
-         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": round(alg_bytes / (us * 1e-6) / 1e9, 1),
-         "traffic": pmc_traffic(f"{f0['name']}:{model_name}:{feats}x{patch}x{batch}x{dtype}"),
-         "variants_us": {k: round(v, 2) for k, v in sust.items()},
-         "variants_us_burst": {k: round(v, 2) for k, v in burst.items()},
-         "timing": f"HIP events around hipGraph replays; sustained = second half of {sustain_s:g} s of replays per flavour"}
+    iso = {"quoted_flavour": f0["name"], "us_per_launch": round(us, 2), "achieved": round(ach, 2), "frac": round(ach / peak, 4),
+           "frac_burst": round(f0["flops"] / (burst[f0["name"]] * 1e-6) / 1e12 / peak, 4),
+           "variants_us": {k: round(v, 2) for k, v in sust.items()},
+           "variants_us_burst": {k: round(v, 2) for k, v in burst.items()},
+           "timing": f"each flavour ALONE on the chip, re-reading its own buffers: HIP events around hipGraph replays; sustained = second half of {sustain_s:g} s of replays"}
     if len(fl) > 1:
         tot = sum(f["count"] * f["flops"] for f in fl)
-        r["step_weighted_frac"] = round(tot / (sum(f["count"] * sust[f["name"]] for f in fl) * 1e-6) / 1e12 / peak, 4)
-        r["step_weighted_frac_burst"] = round(tot / (sum(f["count"] * burst[f["name"]] for f in fl) * 1e-6) / 1e12 / peak, 4)
-        r["launches_per_block"] = {f["name"]: f["count"] for f in fl}
+        iso["step_weighted_frac"] = round(tot / (sum(f["count"] * sust[f["name"]] for f in fl) * 1e-6) / 1e12 / peak, 4)
+        iso["step_weighted_frac_burst"] = round(tot / (sum(f["count"] * burst[f["name"]] for f in fl) * 1e-6) / 1e12 / peak, 4)
+        iso["launches_per_block"] = {f["name"]: f["count"] for f in fl}
+    r = {"bound": "mfma", "kernel": f"{kernel} @{patch}x{patch} x{batch} ({dtype})",
+         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+         "us_per_launch": round(us, 2), "flops_per_launch": f0["flops"], "where": f"isolated launches of {f0['name']} (no in-step measurement for this model)",
+         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": round(alg_bytes / (us * 1e-6) / 1e9, 1),
+         "traffic": pmc_traffic(f"{f0['name']}:{model_name}:{feats}x{patch}x{batch}x{dtype}"),
+         "isolated": iso}
+    if in_step is not None:
+        # the ONE fraction of the line: the family's launches inside the step (in_step_body), executed = algorithmic FLOPs per launch
+        ach = in_step["flops_per_launch"] / (in_step["us_per_launch"] * 1e-6) / 1e12
+        r.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "us_per_launch": in_step["us_per_launch"],
+                  "flops_per_launch": in_step["flops_per_launch"], "algorithmic_GBps": round(alg_bytes / (in_step["us_per_launch"] * 1e-6) / 1e9, 1),
+                  "where": f"IN THE STEP: average over the {in_step['launches']} forward + data-gradient launches of the trunk in a training step's "
+                           "order, buffers and autograd mode (`in_step`); `isolated` = each flavour alone on the chip",
+                  "in_step": in_step})
     return r
 
 
@@ -398,7 +515,7 @@ def executed_gflop_fwd(model_name, gflop_fwd, patch, scale, dtype, collapsed):
     return g
 
 
-def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5):
+def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5, keep_model=False):
     """One more BASELINE config in this process (after the timed region): the training step of `name` at `batch` as one
     hipGraph, replayed for >= `seconds`; returns patches/s and the model-level MFMA fraction."""
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -448,7 +565,13 @@ def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5):
            "model_mfma_frac_executed": round(value * flop_x / 1e3 / PEAK_TFLOPS[dtype], 4), "loss": float(loss.detach().float())}
     if scaler is not None:
         out["loss_scale"] = {"scale": scaler.get_scale(), "skipped_steps": scaler.skipped_steps}
-    del g, model, opt, batch_t
+    del g, opt, batch_t
+    if keep_model:
+        for p_ in model.parameters():
+            p_.grad = None
+        torch.cuda.empty_cache()
+        return out, model
+    del model
     torch.cuda.empty_cache()
     return out
 
@@ -699,7 +822,8 @@ def main():
             out["sustained_value"] = round(a.batch * world / sustained, 2)
         if not a.no_roofline:
             try:
-                out["roofline"] = dominant_kernel_roofline(A, a.model, a.batch, a.patch, feats, a.dtype)
+                ins = None if a.inference else in_step_body(A, model, a.batch, a.patch, a.dtype)
+                out["roofline"] = dominant_kernel_roofline(A, a.model, a.batch, a.patch, feats, a.dtype, in_step=ins)
             except Exception as e:  # noqa: BLE001
                 out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_other_configs and not a.inference and a.model == "edsr_baseline" and a.batch == 256:
@@ -709,10 +833,16 @@ def main():
             torch.cuda.empty_cache()
             for name in ("edsr_baseline", "rcan", "edsr_large", "wdsr_b", "rdn_b", "srresnet", "ddbpn"):
                 try:
-                    e_ = quick_train_rate(A, T, name, 16, a.patch, a.scale, a.dtype)
-                    try:      # the dominant kernel of THAT model at THAT batch against its roofline (short sustained window)
-                        r_ = dominant_kernel_roofline(A, name, 16, a.patch, MODELS[name][3], a.dtype, iters=60, sustain_s=0.25)
-                        e_["roofline"] = {k: r_[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "us_per_launch", "step_weighted_frac") if k in r_}
+                    e_, m_ = quick_train_rate(A, T, name, 16, a.patch, a.scale, a.dtype, keep_model=True)
+                    try:      # the dominant kernel of THAT model at THAT batch against its roofline (short sustained window), in the step where the model has a trunk
+                        ins_ = in_step_body(A, m_, 16, a.patch, a.dtype, sustain_s=0.25)
+                        del m_
+                        r_ = dominant_kernel_roofline(A, name, 16, a.patch, MODELS[name][3], a.dtype, iters=60, sustain_s=0.25, in_step=ins_)
+                        e_["roofline"] = {k: r_[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "us_per_launch", "where") if k in r_}
+                        if ins_ is not None:
+                            e_["roofline"]["in_step"] = {k: ins_[k] for k in ("launches", "fwd_us_per_launch", "dgrad_us_per_launch", "wgrad_us_per_layer")}
+                        iso_ = r_.get("isolated") or {}
+                        e_["roofline"]["isolated"] = {k: iso_[k] for k in ("frac", "variants_us", "step_weighted_frac") if k in iso_}
                     except Exception as e:  # noqa: BLE001
                         e_["roofline"] = {"error": f"{type(e).__name__}: {e}"}
                     oc.append(e_)

@@ -692,6 +692,11 @@ int srk_adam_step(const srk_adam_args* a, srk_stream_t stream);
  *   srk_loss_scale_update: once per step behind the last parameter group: found_inf ? scale *= backoff, tracker = 0
  *                          : (++tracker == interval ? scale *= growth, tracker = 0);  found_inf = 0     (GradScaler.update)      */
 int srk_adam_step_scaled(const srk_adam_args* a, float* scaler_state, srk_stream_t stream);
+/* the two halves of srk_adam_step_scaled for optimizers with SEVERAL parameter groups: GradScaler.step checks every group's
+ * gradients before it updates any (torch/amp/grad_scaler.py: `found_inf` over all groups, then optimizer.step or nothing), so
+ * call srk_adam_check_scaled for every group first, then srk_adam_update_scaled for every group, then srk_loss_scale_update */
+int srk_adam_check_scaled(const srk_adam_args* a, float* scaler_state, srk_stream_t stream);
+int srk_adam_update_scaled(const srk_adam_args* a, const float* scaler_state, srk_stream_t stream);
 int srk_loss_scale_update(float* scaler_state, srk_stream_t stream);
 
 /* ---- misc ------------------------------------------------------------------------------------------ */

@@ -1508,6 +1508,8 @@ template <int DT> int dispatch_tc(const srk_conv_args& a, hipStream_t st) {
 static bool conv_bits_ok(const srk_conv_args& a) {
   static const bool no_ws = srk_dbg_getenv("SRK_NO_WS") != nullptr;
   if (no_ws || a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3 || a.Cin != 64 || a.CoutP != 64 || a.Cout != 64 || a.x_ps > 1 || a.out_mode != SRK_OUT_NHWC) return false;
+  // the bit words are indexed by the conv's own output pixel: no shuffled store (ps_r) and no planar-only post_add on this path
+  if (a.ps_r > 1 || a.post_add) return false;
   if (!conv_fast_ok(a, 2) || ((long long)a.N * a.H * a.W * a.x_pitch) * 2 >= 0x7fffffffLL || (long long)a.N * a.H * a.W * 8 >= 0x7fffffffLL) return false;
   if (a.relu_bits && !(a.relu && !a.res && !a.mask && a.scale == 1.f)) return false;
   if (a.mask_bits && (a.res || a.mask)) return false;

@@ -149,6 +149,28 @@ extern "C" int srk_adam_step_scaled(const srk_adam_args* a, float* scaler_state,
   return 0;
 }
 
+/* Several parameter groups: GradScaler.step unscales and checks EVERY group before any is updated -- an inf in group 1
+ * must not leave group 0 already stepped.  srk_adam_check_scaled over all groups first, then srk_adam_update_scaled per group. */
+extern "C" int srk_adam_check_scaled(const srk_adam_args* a, float* scaler_state, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->slots && a->blocks && scaler_state, "srk_adam_check_scaled: null pointer");
+  SRK_CHECK_ARG(a->nblocks > 0 && a->nslots > 0, "srk_adam_check_scaled: %d blocks, %d tensors", a->nblocks, a->nslots);
+  hipLaunchKernelGGL(adam_check_kernel, dim3((unsigned)a->nblocks), dim3(ADAM_NT), 0, reinterpret_cast<hipStream_t>(stream), *a, scaler_state);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int srk_adam_update_scaled(const srk_adam_args* a, const float* scaler_state, srk_stream_t stream) {
+  SRK_CHECK_ARG(a && a->slots && a->blocks && a->m && a->v && a->steps && scaler_state, "srk_adam_update_scaled: null pointer");
+  SRK_CHECK_ARG(a->nblocks > 0 && a->nslots > 0, "srk_adam_update_scaled: %d blocks, %d tensors", a->nblocks, a->nslots);
+  SRK_CHECK_ARG(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps >= 0.f && a->lr >= 0.f,
+                "srk_adam_update_scaled: lr=%g betas=(%g, %g) eps=%g", a->lr, a->beta1, a->beta2, a->eps);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(adam_group_kernel<true>, dim3((unsigned)a->nblocks), dim3(ADAM_NT), 0, st, *a, scaler_state);
+  hipLaunchKernelGGL(adam_bump_kernel, dim3((unsigned)((a->nslots + ADAM_NT - 1) / ADAM_NT)), dim3(ADAM_NT), 0, st, *a, scaler_state);
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
+
 /* after the LAST parameter group's srk_adam_step_scaled of a step: the scale / growth-tracker update (one thread) */
 extern "C" int srk_loss_scale_update(float* scaler_state, srk_stream_t stream) {
   SRK_CHECK_ARG(scaler_state, "srk_loss_scale_update: null pointer");

@@ -24,6 +24,18 @@ class EDSR(SRModel):
         self.body = nn.Sequential(*m_body)
         self.tail = nn.Sequential(*m_tail)
 
+    def body_nhwc(self, f):
+        """The residual trunk on NHWC features (edsr.py:44-47): `res = body(x); res += x`.  Its own method so that bench.py can time the
+        trunk's launches in the order, with the buffers and in the autograd mode of a training step (`roofline.in_step`)."""
+        r = f
+        for blk in list(self.body)[:-1]:
+            r = ops.cut(blk.nhwc(r))
+        return self.body[-1].nhwc(r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
+
+    def body_conv_launches(self):
+        """(3x3 F -> F convolutions of the trunk per forward pass, F)"""
+        return 2 * (len(self.body) - 1) + 1, self.body[-1].out_channels
+
     def forward(self, x):
         """NCHW float in [0,1] -> NCHW fp32, x scale_factor (edsr.py:40-54)."""
         with ops.forward_scope(self._pack_group()):
@@ -31,10 +43,7 @@ class EDSR(SRModel):
             f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, self.sub_mean.neg_shift() if rgb else None,
                               self.compute_dtype)
             f = ops.cut(f, keep=True)                            # (segment boundaries: identity unless ops.record_segments is active)
-            r = f
-            for blk in list(self.body)[:-1]:
-                r = ops.cut(blk.nhwc(r))
-            r = self.body[-1].nhwc(r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
+            r = self.body_nhwc(f)
             # upsampler (PixelShuffle = the conv's store addressing) + tail conv + add_mean; the last stage and the tail conv as ONE
             # collapsed 5x5 convolution on the 16-bit path (common.upscale_tail)
             up = list(self.tail[0])

@@ -88,6 +88,18 @@ class RCAN(SRModel):
         if self._channels == 3:
             self.add_mean = MeanShift(sign=1)
 
+    def body_nhwc(self, f):
+        """The residual-in-residual trunk on NHWC features (rcan.py:119-122); see EDSR.body_nhwc."""
+        r = f
+        for grp in list(self.body)[:-1]:
+            r = ops.cut(grp.nhwc(r))
+        return self.body[-1].nhwc(r, res=f)
+
+    def body_conv_launches(self):
+        """(3x3 F -> F convolutions of the trunk per forward pass, F)"""
+        groups = list(self.body)[:-1]
+        return sum(2 * (len(g.body) - 1) + 1 for g in groups) + 1, self.body[-1].out_channels
+
     def forward(self, x):
         """rcan.py:115-129"""
         with ops.forward_scope(self._pack_group()):
@@ -95,10 +107,7 @@ class RCAN(SRModel):
             f = ops.head_conv(x, self.head[0].weight, self.head[0].bias, self.sub_mean.neg_shift() if rgb else None,
                               self.compute_dtype)
             f = ops.cut(f, keep=True)
-            r = f
-            for grp in list(self.body)[:-1]:
-                r = ops.cut(grp.nhwc(r))
-            r = self.body[-1].nhwc(r, res=f)
+            r = self.body_nhwc(f)
             up = list(self.tail[0])
             return upscale_tail(r, [(c, p.upscale_factor) for c, p in zip(up[0::2], up[1::2])], self.tail[1],
                                 post_add=self.add_mean.shift() if rgb else None)

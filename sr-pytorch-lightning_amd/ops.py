@@ -360,7 +360,8 @@ def conv_raw(x, pk, *, N, H, W, Cin, Cout, out, out_mode=L.OUT_NHWC, ps_r=0, rel
     passes both: `mask` is the fallback when the kernel cannot take bits)."""
     _need_gpu(x)
     if relu_bits is not None or mask_bits is not None:
-        ok = _SIGN_BITS and _batch_chunks(N, x, out, res, mask) == 1 and mask_from == 0 and out_mode == L.OUT_NHWC
+        # (a pixel-shuffled or post_add launch is not a bits launch: the bit words are indexed by the conv's own output pixel)
+        ok = _SIGN_BITS and _batch_chunks(N, x, out, res, mask) == 1 and mask_from == 0 and out_mode == L.OUT_NHWC and int(ps_r) <= 1 and post_add is None
         bits_t = None
         if ok:
             bits_t = mask_bits if mask_bits is not None else torch.empty((N * H * W, 2), dtype=torch.int32, device=x.device)
@@ -563,6 +564,19 @@ class hold_wgrads:
         _WQ.armed = self.prev
         if not self.prev and exc[0] is None:
             flush_wgrads()
+
+
+class hold_wgrads_discard:
+    """Like `hold_wgrads`, but the queued jobs are DROPPED on exit: a backward pass without its weight-gradient launches (bench.py times
+    a trunk's data-gradient launches this way; the parameters' .grad then hold unfilled buffers -- never use them)."""
+
+    def __enter__(self):
+        self.prev, _WQ.armed = _WQ.armed, True
+        return self
+
+    def __exit__(self, *exc):
+        discard_wgrads()
+        _WQ.armed = self.prev
 
 
 def set_defer_wgrad(enabled):

@@ -254,12 +254,12 @@ class Adam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        launches = []
         for gi, group in enumerate(self.param_groups):
             plan = self._plan(gi, group)
             if plan is None:
                 continue
             with torch.cuda.device(plan.m.device):
-                stream = torch.cuda.current_stream().cuda_stream
                 t = self._table(plan, group)
                 if t.nblocks == 0:
                     continue
@@ -270,8 +270,21 @@ class Adam(torch.optim.Adam):
                                lr=float(group["lr"]), beta1=float(b1), beta2=float(b2), eps=float(group["eps"]),
                                weight_decay=float(group["weight_decay"]), maximize=int(bool(group["maximize"])),
                                one_minus_beta1=1.0 - float(b1), one_minus_beta2=1.0 - float(b2))
+                launches.append((plan, t, a))
+        # torch.amp.GradScaler.step looks at EVERY group's gradients before it steps any: with several groups all checks come first
+        # (an inf in group 1 used to leave group 0 updated); one group keeps the combined entry point (same three launches)
+        split = grad_scaler is not None and len(launches) > 1
+        if split:
+            for plan, t, a in launches:
+                with torch.cuda.device(plan.m.device):
+                    L.check(L.load().srk_adam_check_scaled(C.byref(a), grad_scaler.state.data_ptr(), torch.cuda.current_stream().cuda_stream), "srk_adam_check_scaled")
+        for plan, t, a in launches:
+            with torch.cuda.device(plan.m.device):
+                stream = torch.cuda.current_stream().cuda_stream
                 if grad_scaler is None:
                     L.call("srk_adam_step", a, stream)
+                elif split:
+                    L.check(L.load().srk_adam_update_scaled(C.byref(a), grad_scaler.state.data_ptr(), stream), "srk_adam_update_scaled")
                 else:
                     L.check(L.load().srk_adam_step_scaled(C.byref(a), grad_scaler.state.data_ptr(), stream), "srk_adam_step_scaled")
                 # the kernel wrote through raw pointers: tell autograd (and the packed-weight cache, which keys on it) that

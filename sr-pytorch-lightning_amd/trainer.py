@@ -287,7 +287,10 @@ class GraphedStep:
     step is CAPTURED (capturing records launches, it does not execute them) and then replayed for it and every later batch of
     the same shape.  One process: one graph (forward, loss, backward, Adam).  Several ranks: forward + backward + gradient
     packing are one graph, the bucketed all-reduce (RCCL) and the optimizer step (three launches) are issued eagerly behind it --
-    no collective is ever inside a capture.  A batch of another shape (a short last batch) runs eagerly.  If a capture fails
+    no collective is ever inside a capture.  Round 4's form of it: ONE graph = [the update of the PREVIOUS step] + forward + backward +
+    packing, so between two calls the parameters LAG one update; `flush()` applies it (call it before anything reads the parameters:
+    validation, checkpoints; `finish()` at the end of training), always with the hyper-parameters its gradients were produced under.
+    A batch of another shape (a short last batch) runs eagerly.  If a capture fails
     the loop stays eager (and says so once).  Callers must not keep a loss WITH its autograd graph from an earlier eager step
     alive across the capture (`_eager_step` returns it detached for that reason)."""
 
@@ -304,6 +307,7 @@ class GraphedStep:
         self.loss = None
         self.failed = False
         self.hyper = None
+        self.pending_hyper = None            # the hyper-parameters that were live when the pending gradients were produced
 
     def _hyper(self):
         """The optimizer's hyper-parameters travel BY VALUE in the captured launch (srk_adam_args): a scheduler or a manual
@@ -311,6 +315,42 @@ class GraphedStep:
         keys = ("lr", "betas", "eps", "weight_decay", "maximize", "momentum", "alpha")
         return tuple(tuple((k, tuple(g[k]) if isinstance(g[k], (tuple, list)) else float(g[k])) for k in keys if k in g)
                      for g in self.opt.param_groups)
+
+    def _set_hyper(self, snap):
+        for g, vals in zip(self.opt.param_groups, snap):
+            for k, v in vals:
+                g[k] = tuple(v) if isinstance(v, tuple) else v
+
+    def _mark_pending(self):
+        self.pending, self.pending_hyper = True, self._hyper()
+
+    def flush(self):
+        """Apply the update that is still pending (several ranks, optimizer-first graph form: step k's update normally opens replay
+        k + 1, so between two calls the parameters LAG one update).  Call before reading the parameters -- validation, a checkpoint,
+        `state_dict()` -- and when training ends (`finish()` = this).  The update uses the hyper-parameters that were live when its
+        gradients were produced: the reference's order is `optimizer.step()`, then `scheduler.step()`, so a learning rate changed
+        after step k must not scale step k's update."""
+        if not self.pending:
+            return
+        cur = self._hyper()
+        if self.pending_hyper is not None and self.pending_hyper != cur:
+            self._set_hyper(self.pending_hyper)
+            try:
+                self._opt_step()
+            finally:
+                self._set_hyper(cur)
+        else:
+            self._opt_step()
+        self.pending, self.pending_hyper = False, None
+
+    def shifted_eager_step(self, batch):
+        """What ONE replay of the optimizer-first graph does, launch by launch: [the update the previous step left pending] forward,
+        losses, backward, gradient average -- and this step's update stays pending.  Used for batches the graph does not fit (a short
+        last batch) and by tests/test_ddp_gloo.py, which drives the shifted order on two CPU ranks."""
+        self.flush()
+        loss = _eager_fwd_bwd_reduce(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
+        self._mark_pending()
+        return loss
 
     def _fwd_bwd(self):
         self.opt.zero_grad(set_to_none=True)
@@ -347,10 +387,11 @@ class GraphedStep:
             # bucket all-reduces are issued eagerly between two replays (round 3 also issued the optimizer step's three launches
             # eagerly: host-paced, half of the structure's overhead at batch 16).  Same arithmetic, shifted by one replay: the
             # caller's batch trains eagerly up to the reduce (its update opens the first replay), `finish()` applies the last one.
-            if self.pending:                 # (a re-capture after a hyper-parameter change: the previous replay's update first)
-                self._opt_step()
+            self.flush()                     # (a re-capture after a hyper-parameter change: the previous replay's update first, with ITS values)
+            self.primed = None
             now = _eager_fwd_bwd_reduce(self.model, self.net, self.opt, self.gsync, self.scaler, self.static)
-            self.pending = True
+            self._mark_pending()
+            self.primed = now                # this batch has trained up to its reduce: a capture failure below must not train it again
             if hasattr(self.opt, "reserve_capture_tables"):
                 self.opt.reserve_capture_tables()
             torch.cuda.synchronize()
@@ -361,14 +402,13 @@ class GraphedStep:
                 self.loss = self._fwd_bwd()
                 self.gsync.pack()
             self.graphs = (ga, "opt_first")
+            self.primed = None
             return now
         return None
 
     def finish(self):
         """Call when training ends: the update of the last replayed step (multi-rank graph form) is still pending."""
-        if self.pending:
-            self._opt_step()
-            self.pending = False
+        self.flush()
 
     def __call__(self, batch):
         self.seen += 1
@@ -377,11 +417,11 @@ class GraphedStep:
             if self.ogs is not None and self.ogs.gsync is not None:
                 return self.ogs.eager_step(batch)          # (the buckets were re-cut along the segments: its own eager form)
             if self.pending:                               # optimizer-first graph form: keep "reduced gradients, update pending" invariant
-                self._opt_step()
-                return _eager_fwd_bwd_reduce(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
+                return self.shifted_eager_step(batch)
             return _eager_step(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
         if self.graphs is not None and self._hyper() != self.hyper:
-            # lr / betas / ... changed: capture again with the new values (the old graphs go first, then the tables they read)
+            # lr / betas / ... changed: capture again with the new values (the old graphs go first, then the tables they read).  The
+            # update still pending belongs to the OLD values (`flush`, called by `_capture`)
             self.graphs = None
             if self.ogs is not None:
                 self.ogs.graphs = None
@@ -397,7 +437,7 @@ class GraphedStep:
                     loss = ogs.prepare(batch)
                     self.ogs = ogs
                     return loss
-                except Exception as e:  # noqa: BLE001  (a model whose graph cannot be cut: every rank fails the same way, before any update)
+                except SegmentationUnavailable as e:     # every rank raises it together (prepare() agrees on the outcome before any collective)
                     import sys
                     from . import ops
                     ops.discard_wgrads()
@@ -431,9 +471,10 @@ class GraphedStep:
                 print(f"[trainer] hipGraph capture failed ({type(e).__name__}: {e}); training continues eagerly", file=sys.stderr)
                 self.failed, self.graphs, self.static = True, None, None
                 torch.cuda.synchronize()
-                if self.pending:
-                    self._opt_step()
-                    self.pending = False
+                primed, self.primed = getattr(self, "primed", None), None
+                self.flush()
+                if primed is not None:       # the batch already trained eagerly up to its reduce inside _capture: its update was the flush
+                    return primed
                 return _eager_step(self.model, self.net, self.opt, self.gsync, self.scaler, batch)
             if now is not None:              # several ranks: this batch trained eagerly up to the reduce; its update opens the first replay
                 return now
@@ -443,7 +484,13 @@ class GraphedStep:
         self.graphs[0].replay()
         if len(self.graphs) == 2:            # [pending update] forward, backward, packing were the graph; the collective is eager
             self.gsync.reduce()
+            self.pending_hyper = self.hyper  # (the replay applied the previous update with the captured values and left a new one pending)
         return self.loss.detach()
+
+
+class SegmentationUnavailable(RuntimeError):
+    """Raised by `OverlappedGraphStep.prepare` on EVERY rank when the segmented backward pass failed on any of them (the ranks
+    agree through one MIN all-reduce before any gradient collective), so that all of them take the same fallback."""
 
 
 class OverlappedGraphStep:
@@ -510,9 +557,24 @@ class OverlappedGraphStep:
                     first[id(p)] = k
             have = [p for p in params if p.grad is not None]
             sums.append((have, torch.stack([p.grad.detach().double().sum() for p in have]) if have else None))
-        self.opt.zero_grad(set_to_none=True)
-        loss, rec = self._forward(batch, self.every)
-        ops.backward_segments(loss, rec.cuts, after=collect)
+        # The local part may fail on ONE rank only (out of memory, a HIP error): the ranks agree on the outcome BEFORE the gradient
+        # collective below -- a rank that fell back alone would issue bucketed all-reduces against the others' single flat one
+        # (mismatched collectives hang or corrupt the gradients).
+        err = None
+        try:
+            self.opt.zero_grad(set_to_none=True)
+            loss, rec = self._forward(batch, self.every)
+            ops.backward_segments(loss, rec.cuts, after=collect)
+        except RuntimeError as e:              # autograd's "backward through the graph a second time", HIP / allocation errors
+            err = e
+            ops.discard_wgrads()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            flag = torch.tensor([0.0 if err is not None else 1.0], device=next(self.model.parameters()).device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) == 0.0:
+                raise SegmentationUnavailable(str(err) if err is not None else "the segmented backward pass failed on another rank")
+        elif err is not None:
+            raise SegmentationUnavailable(str(err))
         # a parameter used on both sides of a cut (a shared module) keeps changing after its first segment: its bucket may only be
         # reduced behind the LAST segment that touches it (one host read for all checksums)
         last = dict(first)

@@ -141,3 +141,77 @@ def test_segmented_backward_two_ranks_equals_single_process(tmp_path):
     tr.fit(m, [T.synthetic_batch(4, 3, 16, 2, 100 + s, "cpu") for s in range(3)])
     for k, v in m.state_dict().items():
         assert torch.allclose(v, a[k], rtol=1e-5, atol=1e-7), k
+
+
+def _worker_shifted(rank, world, port, out):
+    """The multi-rank hipGraph step's update ORDER on CPU: `GraphedStep.shifted_eager_step` is one replay of the optimizer-first
+    graph launch by launch -- step k's update is applied at the start of step k + 1, `finish()` applies the last one -- with the
+    learning rate changed between two steps the way a scheduler does (after `optimizer.step()` in the reference's order)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import sr_amd
+    from sr_amd import trainer as T
+    T.init_distributed("cpu")
+    torch.manual_seed(0)
+    m = sr_amd.SRCNN(scale_factor=2, optimizer="SGD")
+    opt = m.configure_optimizers()[0]
+    gsync = T.GradSync(m, overlap=False, bucket_bytes=4096)
+    gsync.broadcast()
+    gs = T.GraphedStep(m, m, opt, gsync, warm_steps=0)
+    full = [T.synthetic_batch(4, 3, 16, 2, 200 + s, "cpu") for s in range(5)]
+    for k, b in enumerate(full):
+        sh = {"lr": b["lr"][rank * 2:(rank + 1) * 2], "hr": b["hr"][rank * 2:(rank + 1) * 2]}
+        if k == 3:                                   # "scheduler.step()" after the third optimizer step
+            for g in opt.param_groups:
+                g["lr"] *= 0.1
+        gs.shifted_eager_step(sh)
+        assert gs.pending
+    gs.finish()
+    assert not gs.pending
+    gsync.detach()
+    torch.save({k: v.clone() for k, v in m.state_dict().items()}, os.path.join(out, f"s{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_shifted_update_order_two_ranks_equals_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_shifted, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"replicas diverged at {k}"
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(v, None)
+    import sr_amd
+    from sr_amd import trainer as T
+    torch.manual_seed(0)
+    m = sr_amd.SRCNN(scale_factor=2, optimizer="SGD")
+    opt = m.configure_optimizers()[0]
+    for k in range(5):
+        bt = T.synthetic_batch(4, 3, 16, 2, 200 + k, "cpu")
+        if k == 3:
+            for g in opt.param_groups:
+                g["lr"] *= 0.1
+        opt.zero_grad()
+        m._calculate_losses(img_sr=m(bt["lr"]), img_hr=bt["hr"])["loss"].backward()
+        opt.step()
+    for k, v in m.state_dict().items():
+        assert torch.allclose(v, a[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_pending_update_uses_the_hyper_parameters_of_its_gradients():
+    """after an lr change the pending update (step k's) must use the OLD lr; flush() restores the new one."""
+    sys.path.insert(0, ROOT)
+    from sr_amd import trainer as T
+    w = torch.nn.Parameter(torch.ones(4))
+    opt = torch.optim.SGD([w], lr=0.5)
+    gs = T.GraphedStep(torch.nn.Module(), None, opt, None)
+    w.grad = torch.full((4,), 2.0)
+    gs._mark_pending()
+    opt.param_groups[0]["lr"] = 0.01
+    gs.flush()
+    assert torch.allclose(w.detach(), torch.full((4,), 1.0 - 0.5 * 2.0))
+    assert opt.param_groups[0]["lr"] == 0.01 and not gs.pending
+    gs.flush()                                         # nothing pending: no second update
+    assert torch.allclose(w.detach(), torch.full((4,), 0.0))

@@ -1,0 +1,89 @@
+"""GPU tests added in round 5 (ADVICE r4 / VERDICT r4): the device-resident loss scaler with several parameter groups, the
+gradient-target alias guard across backward segments, conv_bits_ok's refusals, conv_pair's split epilogue flavours."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import sr_amd
+    assert torch.cuda.is_available()
+    sr_amd._lib.load()
+    return sr_amd
+
+
+def _params(seed, shapes):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter((torch.rand(*s, generator=g) - 0.5).cuda()) for s in shapes]
+
+
+def test_device_grad_scaler_checks_every_group_before_any_update(A):
+    """with TWO parameter groups an inf in group 1 must leave group 0 untouched too (torch.amp.GradScaler unscales and
+    checks every group, then steps or skips the whole optimizer); the per-group launcher used to update group 0 first."""
+    shapes0, shapes1 = [(5,), (33, 7)], [(4097,), (8, 3, 3, 3)]
+    p0, p1 = _params(1, shapes0), _params(2, shapes1)
+    r0, r1 = _params(1, shapes0), _params(2, shapes1)
+    opt = A.optim.Adam([{"params": p0, "lr": 1e-2}, {"params": p1, "lr": 3e-3}])
+    ropt = torch.optim.Adam([{"params": r0, "lr": 1e-2}, {"params": r1, "lr": 3e-3}])
+    sc = A.optim.DeviceGradScaler("cuda", init_scale=256.0, growth_interval=100)
+    rsc = torch.amp.GradScaler("cuda", init_scale=256.0, growth_interval=100)
+    rsc.scale(torch.zeros(1, device="cuda"))
+    for step in range(5):
+        s_now = sc.get_scale()
+        assert s_now == rsc.get_scale()
+        g = torch.Generator().manual_seed(50 + step)
+        for p, r in zip(p0 + p1, r0 + r1):
+            gr = ((torch.rand(*p.shape, generator=g) - 0.5) * s_now).cuda()
+            p.grad, r.grad = gr.clone(), gr.clone()
+        if step == 2:                                        # the LAST group carries the inf
+            p1[0].grad[77] = float("inf")
+            r1[0].grad[77] = float("inf")
+        before = [p.detach().clone() for p in p0 + p1]
+        steps_before = [float(opt.state[p]["step"]) if "step" in opt.state[p] else 0.0 for p in p0 + p1]
+        opt.step(grad_scaler=sc)
+        rsc.unscale_(ropt)
+        rsc.step(ropt)
+        rsc.update()
+        torch.cuda.synchronize()
+        if step == 2:
+            for p, b in zip(p0 + p1, before):
+                assert torch.equal(p.detach(), b), "a skipped step changed a parameter"
+            assert [float(opt.state[p]["step"]) for p in p0 + p1] == steps_before
+            assert sc.skipped_steps == 1
+        for p, r in zip(p0 + p1, r0 + r1):
+            assert float((p.detach() - r.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max())), (step, p.shape)
+    assert sc.get_scale() == rsc.get_scale()
+
+
+def test_conv_bits_ok_refuses_pixel_shuffle_and_post_add(A):
+    """the sign-bit store indexes its [N*H*W][2] buffer by the OUTPUT pixel: a pixel-shuffled store (ps_r > 1) or a planar
+    epilogue with post_add is not a bits launch -- srk_conv_bits_ok is the gate the C ABI advertises and must say so."""
+    L = A._lib
+    lib = L.load()
+    n, hw = 2, 16
+    x = torch.zeros(n, hw, hw, 64, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty_like(x)
+    w = torch.nn.Parameter(torch.zeros(64, 64, 3, 3, device="cuda"))
+    pk = A.ops.pack_conv(w, None, torch.bfloat16)
+    bits = torch.empty(n * hw * hw, 2, dtype=torch.int32, device="cuda")
+
+    def args(**kw):
+        a = L.ConvArgs(x=x.data_ptr(), x_pitch=64, x_coff=0, N=n, H=hw, W=hw, Cin=64, wpk=pk.wpk.data_ptr(), bias=0, CoutP=64, Cout=64, KH=3, KW=3,
+                       relu=1, scale=1.0, res=0, mask=0, out=out.data_ptr(), out_pitch=64, out_coff=0, out_mode=L.OUT_NHWC, ps_r=0, post_add=0,
+                       dtype=L.SRK_BF16, relu_bits=bits.data_ptr(), mask_bits=0)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+    import ctypes as C
+    assert lib.srk_conv_bits_ok(C.byref(args())) == 1
+    assert lib.srk_conv_bits_ok(C.byref(args(ps_r=2, out_mode=L.OUT_NHWC_PS))) == 0
+    assert lib.srk_conv_bits_ok(C.byref(args(ps_r=2))) == 0
+    assert lib.srk_conv_bits_ok(C.byref(args(post_add=bits.data_ptr()))) == 0

@@ -14,7 +14,7 @@ python bench.py --inference --no-cpu-baseline --no-other-configs --no-roofline >
 tools/variants_trace.sh 256 $TAG > /dev/null 2>&1; cat $O/${TAG}_variants_n256.txt
 for m in edsr_baseline rcan edsr_large wdsr_b rdn_b ddbpn srresnet; do
   python bench.py --model $m --batch 16 --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 > $O/${TAG}_bench_b16_$m.json
-  python3 -c "import json,sys; d=json.load(open('$O/${TAG}_bench_b16_$m.json')); print('$m b16', d['value'], d['roofline']['variants_us'], d['roofline'].get('step_weighted_frac'))"
+  python3 -c "import json,sys; d=json.load(open('$O/${TAG}_bench_b16_$m.json')); print('$m b16', d['value'], d['roofline'].get('isolated', d['roofline']).get('variants_us'), d['roofline'].get('step_weighted_frac'))"
 done
 tools/profile_bench.sh ${TAG}final --no-roofline --sustain-seconds 0 > /dev/null 2>&1; cp $O/prof_${TAG}final/kernel_stats_summary.txt $O/${TAG}_kernel_stats_default.txt; head -14 $O/${TAG}_kernel_stats_default.txt | cut -c1-150
 # one step in dispatch order (body / upsampler / HR stage / weight gradients are separable although the persistent kernels share a grid size)
