@@ -255,6 +255,11 @@ typedef struct {
 } srk_pw_wgrad_args;
 int srk_pw_wgrad_ranges(long long P, int Chid);
 int srk_pw_wgrad(const srk_pw_wgrad_args* a, srk_stream_t stream);
+/* the same in two steps, so that a backward pass with many pointwise pairs (WDSR-B: 16 blocks) finishes them with ONE launch:
+ * srk_pw_wgrad_partial fills the slabs only; srk_pw_wgrad_finalize_group sums the slabs of `njobs` such calls (their argument
+ * structs as a device table, e.g. written by srk_upload_small) into dw1 / db1 / dw2 / db2, `blocks_per_job` workgroups each */
+int srk_pw_wgrad_partial(const srk_pw_wgrad_args* a, srk_stream_t stream);
+int srk_pw_wgrad_finalize_group(const srk_pw_wgrad_args* jobs_dev, int njobs, int blocks_per_job, srk_stream_t stream);
 
 /* ---- weight / bias gradient -------------------------------------------------------------------
  * Replaces autograd's conv weight-gradient for the convs above:

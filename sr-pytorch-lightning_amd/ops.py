@@ -538,6 +538,7 @@ class _WgradQueue:
     def __init__(self):
         self.jobs = []          # dicts, see wgrad()
         self.rjobs = []         # row-sum jobs (channel-attention parameter gradients), see defer_rowsum()
+        self.pwjobs = []        # finalize steps of pointwise-pair weight gradients (WDSR _Block_B), see pw_wgrad_raw()
         self.armed = False      # somebody will flush (final callback queued, or inside hold_wgrads)
         self.enabled = True
         self.targets = {}       # address of a dw buffer -> number of jobs queued on it (weight sharing -> rounds)
@@ -667,6 +668,21 @@ def _launch_rowsums(rjobs, st):
     L.check(L.load().srk_rowsum_group(table.data_ptr(), n, max(j["k"] for j in rjobs), st), "srk_rowsum_group")
 
 
+def _launch_pw_finalize(pwjobs, st):
+    """ONE launch sums the slabs of every queued pointwise-pair weight gradient (srk_pw_wgrad_finalize_group)."""
+    import ctypes as C
+    n = len(pwjobs)
+    host = (L.PwWgradArgs * n)(*[j["a"] for j in pwjobs])
+    nbytes = C.sizeof(L.PwWgradArgs) * n
+    table = torch.empty(_roundup(nbytes, 16), dtype=torch.uint8, device=pwjobs[0]["keep"][0].device)
+    L.check(L.load().srk_upload_small(table.data_ptr(), C.addressof(host), nbytes, st), "srk_upload_small")
+    items = max((j["a"].Chid * (j["a"].Cin + j["a"].CoutP)) // 4 + j["a"].Chid + j["a"].CoutP for j in pwjobs)
+    bpj = max(1, min((items + 255) // 256, 256))           # one item per thread: the launch is a 30 MB-per-job read, latency-bound with fewer blocks
+    L.check(L.load().srk_pw_wgrad_finalize_group(table.data_ptr(), n, bpj, st), "srk_pw_wgrad_finalize_group")
+    for j in pwjobs:
+        j["keep"].append(table)
+
+
 def defer_rowsum(per, params, shapes_offsets):
     """Sum `per` [n][K] over n into a fresh [K] buffer whose slices become the gradients of `params` -- deferred to the end of
     the backward pass, where ONE launch serves every queued job (an RCAN backward has 200 of them).
@@ -731,7 +747,7 @@ def discard_wgrads():
     """Drop whatever a backward pass that did NOT end normally left queued (an exception inside backward, a failed hipGraph
     capture: the engine's final callback may never have run, so `armed` would stay set and later passes would queue jobs
     nobody flushes).  Call before starting a fresh step."""
-    _WQ.jobs, _WQ.rjobs, _WQ.armed, _WQ.targets = [], [], False, {}
+    _WQ.jobs, _WQ.rjobs, _WQ.pwjobs, _WQ.armed, _WQ.targets = [], [], [], False, {}
     _WQ.gen += 1
 
 
@@ -740,8 +756,9 @@ def flush_wgrads():
     import ctypes as C
     jobs, _WQ.jobs, _WQ.armed, _WQ.targets = _WQ.jobs, [], False, {}
     rjobs, _WQ.rjobs = _WQ.rjobs, []
+    pwjobs, _WQ.pwjobs = _WQ.pwjobs, []
     _WQ.gen += 1
-    if not jobs and not rjobs:
+    if not jobs and not rjobs and not pwjobs:
         return
     lib = L.load()
     stream = _WQ.stream if _WQ.stream is not None else torch.cuda.current_stream()
@@ -749,6 +766,8 @@ def flush_wgrads():
         st = stream.cuda_stream
         if rjobs:
             _launch_rowsums(rjobs, st)
+        if pwjobs:
+            _launch_pw_finalize(pwjobs, st)
         for dt in sorted({j["a"].dtype for j in jobs}):
             grp = [j for j in jobs if j["a"].dtype == dt]
             n = len(grp)
@@ -1570,7 +1589,7 @@ def pw_backward_raw(x, gz, pk, gx, *, res=None, h_out=None, gh_out=None):
     return gx
 
 
-def pw_wgrad_raw(x, gz, pk, w1_shape, w2_shape, want_b1=True, want_b2=True):
+def pw_wgrad_raw(x, gz, pk, w1_shape, w2_shape, want_b1=True, want_b2=True, defer=False):
     """dW1, db1, dW2, db2 of the pointwise pair from x and gz alone (srk_pw_wgrad: h and gh are re-computed tile by tile)."""
     n, h, wd, _ = x.shape
     P = n * h * wd
@@ -1584,15 +1603,25 @@ def pw_wgrad_raw(x, gz, pk, w1_shape, w2_shape, want_b1=True, want_b2=True):
     o2 = nr * pk.chid * pk.cin
     o3 = o2 + nr * pk.chid * pk.coutp
     o4 = o3 + nr * pk.chid
-    L.call("srk_pw_wgrad", L.PwWgradArgs(
+    a = L.PwWgradArgs(
         x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, gz=gz.data_ptr(), gz_pitch=_pitch(gz), gz_coff=0, Cz=gz.shape[3], P=P,
         Cin=pk.cin, Chid=pk.chid, Cmid=pk.cmid, CoutP=pk.coutp, wpk=pk.bwd.data_ptr(),
         dw1p=scratch.data_ptr(), dw2p=scratch.data_ptr() + 4 * o2, db1p=scratch.data_ptr() + 4 * o3,
         db2p=(scratch.data_ptr() + 4 * o4) if want_b2 else 0, nranges=nr,
-        dw1=dw1.data_ptr(), db1=_ptr(db1), dw2=dw2.data_ptr(), db2=_ptr(db2), dtype=_DT[x.dtype]), _stream())
+        dw1=dw1.data_ptr(), db1=_ptr(db1), dw2=dw2.data_ptr(), db2=_ptr(db2), dtype=_DT[x.dtype])
+    if defer and _WQ.enabled and not _PW_FIN_EACH and _arm_flush():
+        # inside a backward pass: the slabs now, their sums with every other pointwise pair's in ONE launch when the pass's deferred
+        # weight gradients are flushed (the results are read no earlier: WeightNormGroup's node flushes first)
+        L.call("srk_pw_wgrad_partial", a, _stream())
+        # (the STORAGES, not the tensors: AccumulateGrad adopts a gradient nobody else references, and clones -- now, unfilled -- one that is)
+        _WQ.pwjobs.append(dict(a=a, keep=[scratch] + [t.untyped_storage() for t in (dw1, db1, dw2, db2) if t is not None]))
+        _WQ.stream = torch.cuda.current_stream()
+    else:
+        L.call("srk_pw_wgrad", a, _stream())
     return dw1, db1, dw2, db2
 
 
+_PW_FIN_EACH = _knob("SRK_NO_PW_GROUP_FIN", "0") == "1"   # A/B knob: every pointwise pair finalizes its weight gradients with its own launch (round 4)
 _PW_WG_OFF = _knob("SRK_NO_PW_WGRAD", "0") == "1"      # A/B knob: h / gh through HBM + the two 1x1 weight-gradient GEMMs
 
 
@@ -1646,7 +1675,10 @@ class WdsrBlockBFn(torch.autograd.Function):
                              want_bias=b1 is not None)
             return gx, None, gw1, gb1, gw2, gb2, gw3, gb3
         pw_backward_raw(x, gz, pk, gx, res=g)
-        gw1, gb1, gw2, gb2 = pw_wgrad_raw(x, gz, pk, tuple(w1.shape), tuple(w2.shape), want_b1=b1 is not None, want_b2=b2 is not None)
+        # deferred finalize only where autograd will ADOPT the (still unfilled) results: no existing .grad to accumulate into, no hooks
+        can_defer = all((sl := _grad_slot(p_, sh_)) is not None and sl[0] == "new"
+                        for p_, sh_ in ((ctx.wb[0], tuple(w1.shape)), (b1, (w1.shape[0],)), (ctx.wb[2], tuple(w2.shape)), (b2, (w2.shape[0],))))
+        gw1, gb1, gw2, gb2 = pw_wgrad_raw(x, gz, pk, tuple(w1.shape), tuple(w2.shape), want_b1=b1 is not None, want_b2=b2 is not None, defer=can_defer)
         return gx, None, gw1, gb1, gw2, gb2, gw3, gb3
 
 

@@ -87,3 +87,40 @@ def test_conv_bits_ok_refuses_pixel_shuffle_and_post_add(A):
     assert lib.srk_conv_bits_ok(C.byref(args(ps_r=2, out_mode=L.OUT_NHWC_PS))) == 0
     assert lib.srk_conv_bits_ok(C.byref(args(ps_r=2))) == 0
     assert lib.srk_conv_bits_ok(C.byref(args(post_add=bits.data_ptr()))) == 0
+
+
+def test_wdsr_b_finalizes_all_pointwise_pairs_with_one_launch(A, monkeypatch):
+    """WDSR-B's 16 blocks issued 16 pw_wgrad_finalize launches (6.8 % of the batch-16 step).  Now every block's
+    srk_pw_wgrad_partial fills its slabs and ONE srk_pw_wgrad_finalize_group sums them all when the pass's deferred gradients are
+    flushed; the gradients are the same bits as with a finalize per pair."""
+    L = A._lib
+    kw = dict(type="B", n_feats=128, n_resblocks=3, scale_factor=2)
+
+    def grads(each):
+        prev = A.ops._PW_FIN_EACH
+        A.ops._PW_FIN_EACH = each
+        try:
+            torch.manual_seed(0)
+            m = A.WDSR(precision="bf16", **kw).cuda()
+            g = torch.Generator().manual_seed(3)
+            lr, hr = torch.rand(2, 3, 24, 24, generator=g).cuda(), torch.rand(2, 3, 48, 48, generator=g).cuda()
+            loss = m._calculate_losses(img_sr=m(lr), img_hr=hr)["loss"]
+            loss.backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        finally:
+            A.ops._PW_FIN_EACH = prev
+
+    calls = []
+    real, real_check = L.call, L.check
+    monkeypatch.setattr(L, "call", lambda name, *a, **k: (calls.append(name), real(name, *a, **k))[1])
+    monkeypatch.setattr(L, "check", lambda rc, name="": (calls.append(name), real_check(rc, name))[1])
+    ga = grads(False)
+    assert calls.count("srk_pw_wgrad_partial") == 3 and calls.count("srk_pw_wgrad_finalize_group") == 1 and calls.count("srk_pw_wgrad") == 0, \
+        [c for c in calls if "pw_wgrad" in c]
+    calls.clear()
+    gb = grads(True)
+    assert calls.count("srk_pw_wgrad") == 3 and calls.count("srk_pw_wgrad_partial") == 0
+    assert ga.keys() == gb.keys() and len(ga) > 10
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
