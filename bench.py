@@ -200,15 +200,16 @@ def pmc_traffic(key):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
     KiB -> B; MI355X_MICROARCH.md "HBM"), written by tools/pmc_traffic.sh.  None unless an entry exists for this exact
     kernel / shape AND was measured on the very instructions being timed now (`isa_sha` == this build's fingerprint)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")) as fh:
-            tab = json.load(fh)
-    except (OSError, ValueError):
-        return None
-    e = tab.get(key)
-    if not e or not e.get("isa_sha") or e.get("isa_sha") != kernel_fingerprint(e.get("isa_key", "conv_ws_plain_bf16")):
-        return None
-    return (2.0 * e["fetch_kib"] + e["write_kib"]) * 1024.0
+    for tag in ("r5", "r4"):                 # the newest collection whose fingerprint matches the instructions being timed
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as fh:
+                tab = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        e = tab.get(key)
+        if e and e.get("isa_sha") and e.get("isa_sha") == kernel_fingerprint(e.get("isa_key", "conv_ws_plain_bf16")):
+            return (2.0 * e["fetch_kib"] + e["write_kib"]) * 1024.0
+    return None
 
 
 def _flavours(A, model_name, batch, patch, feats, dtype):
@@ -386,8 +387,8 @@ def in_step_body(A, model, batch, patch, dtype, sustain_s=0.6):
         F   = weight packing + trunk forward                       (n convs)
         FB  = F + backward with the weight gradients left queued   (+ n data-gradient launches)
         FBW = F + backward + the grouped weight-gradient launch and its finalize
-    and P = the packing launch alone.  in-step time per launch of the family = (FB - P) / 2n; algorithmic FLOPs = 2 x 64 x 64 x 9
-    per pixel and launch.  (The reference has no counterpart: cuDNN picks its kernels.)  Returns None for models without `body_nhwc`."""
+    and P = the packing launch alone.  in-step time per convolution of the family = (FB - P) / 2n; algorithmic FLOPs = 2 x F x F x 9
+    per pixel and convolution.  (The reference has no counterpart: cuDNN picks its kernels.)  Returns None for models without `body_nhwc`."""
     if not hasattr(model, "body_nhwc") or dtype == "f32":
         return None
     ops = A.ops
@@ -429,8 +430,12 @@ def in_step_body(A, model, batch, patch, dtype, sustain_s=0.6):
     px = batch * patch * patch
     flops = 2.0 * px * feats * feats * 9
     fam_us = (t_fb - t_p) / (2 * n_conv)
-    return {"launches": 2 * n_conv, "us_per_launch": round(fam_us, 2), "flops_per_launch": flops,
-            "fwd_us_per_launch": round((t_f - t_p) / n_conv, 2), "dgrad_us_per_launch": round((t_fb - t_f) / n_conv, 2),
+    # at small batches (ops.pair_ok) one launch carries TWO of the trunk's convolutions (csrc/conv_pair.hip): per-launch = 2 x per-conv
+    wprobe = torch.empty(feats, feats, 3, 3, device=dev)
+    cpl = 2 if (feats == 64 and ops.pair_ok(f0, wprobe, wprobe)) else 1
+    return {"convs": 2 * n_conv, "convs_per_launch": cpl, "us_per_conv": round(fam_us, 2), "us_per_launch": round(fam_us * cpl, 2),
+            "flops_per_launch": flops * cpl,
+            "fwd_us_per_conv": round((t_f - t_p) / n_conv, 2), "dgrad_us_per_conv": round((t_fb - t_f) / n_conv, 2),
             "wgrad_us_per_layer": round((t_fbw - t_fb) / n_conv, 2),
             "graph_us": {"pack": round(t_p, 1), "fwd": round(t_f, 1), "fwd_bwd": round(t_fb, 1), "fwd_bwd_wgrad": round(t_fbw, 1)},
             "frac": round(flops / (fam_us * 1e-6) / 1e12 / PEAK_TFLOPS[dtype], 4),
@@ -495,8 +500,9 @@ def dominant_kernel_roofline(A, model_name, batch, patch, feats, dtype, iters=10
         ach = in_step["flops_per_launch"] / (in_step["us_per_launch"] * 1e-6) / 1e12
         r.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "us_per_launch": in_step["us_per_launch"],
                   "flops_per_launch": in_step["flops_per_launch"], "algorithmic_GBps": round(alg_bytes / (in_step["us_per_launch"] * 1e-6) / 1e9, 1),
-                  "where": f"IN THE STEP: average over the {in_step['launches']} forward + data-gradient launches of the trunk in a training step's "
-                           "order, buffers and autograd mode (`in_step`); `isolated` = each flavour alone on the chip",
+                  "where": f"IN THE STEP: average over the {in_step['convs']} forward + data-gradient 3x3 convolutions of the trunk "
+                           f"({in_step['convs_per_launch']} per launch) in a training step's order, buffers and autograd mode (`in_step`); "
+                           "`isolated` = each flavour alone on the chip",
                   "in_step": in_step})
     return r
 
@@ -594,6 +600,20 @@ def main():
     force_ddp = os.environ.get("SRK_FORCE_DDP") == "1"      # 1-rank process group: exercises the DDP path on one GPU
     if world > 1 or force_ddp:
         T.init_distributed("cuda", force=force_ddp)
+    if world > 1:
+        # one process per GPU means one GPU per process: every rank reports the device it computes on and all ranks check that no two
+        # share one (a launcher that leaves LOCAL_RANK unset, or a HIP_VISIBLE_DEVICES mask, would silently stack the ranks on cuda:0
+        # and the "N-GPU" number would be an N-process number).  On failure EVERY rank says what it sees and the job exits non-zero.
+        pr = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "local_rank": local, "current_device": torch.cuda.current_device(),
+                "pci": (getattr(pr, "pci_domain_id", None), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None)),
+                "uuid": str(getattr(pr, "uuid", "")), "visible": torch.cuda.device_count(), "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        ids = [(tuple(d["pci"]), d["uuid"]) if (d["pci"][1] is not None or d["uuid"]) else ("dev", d["current_device"]) for d in seen]
+        if len(set(ids)) != world or mine["rccl_ranks"] != world:
+            print(f"[bench] rank {rank}: ranks do not sit on {world} distinct GPUs -- this rank: {mine}; all: {ids}", file=sys.stderr, flush=True)
+            sys.exit(3)
 
     cls, kw, gflop_fwd, feats = MODELS[a.model]
     torch.manual_seed(0)                                  # identical weights on every rank
@@ -840,7 +860,7 @@ def main():
                         r_ = dominant_kernel_roofline(A, name, 16, a.patch, MODELS[name][3], a.dtype, iters=60, sustain_s=0.25, in_step=ins_)
                         e_["roofline"] = {k: r_[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "us_per_launch", "where") if k in r_}
                         if ins_ is not None:
-                            e_["roofline"]["in_step"] = {k: ins_[k] for k in ("launches", "fwd_us_per_launch", "dgrad_us_per_launch", "wgrad_us_per_layer")}
+                            e_["roofline"]["in_step"] = {k: ins_[k] for k in ("convs", "convs_per_launch", "fwd_us_per_conv", "dgrad_us_per_conv", "wgrad_us_per_layer")}
                         iso_ = r_.get("isolated") or {}
                         e_["roofline"]["isolated"] = {k: iso_[k] for k in ("frac", "variants_us", "step_weighted_frac") if k in iso_}
                     except Exception as e:  # noqa: BLE001

@@ -29,6 +29,9 @@
 #ifndef SRK_PAIR_STAMPS
 #define SRK_PAIR_STAMPS 0
 #endif
+#ifndef SRK_PAIR_PD
+#define SRK_PAIR_PD 2
+#endif
 
 namespace {
 
@@ -423,7 +426,8 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   auto conv_loop = [&](auto split_c, int g0, const char* const (&pix)[2], int pitch, auto&& at_step, auto&& epi) {
     constexpr bool SPLIT = decltype(split_c)::value;
     constexpr int NV = SPLIT ? 48 : 36;                    // virtual steps: 0..23 | pass A 24..35 | pass B 36..47 (K-steps 24..35 again)
-    i32x4 fa[3][2], fb[3][2];
+    constexpr int PD = SRK_PAIR_PD;                        // fragments are read PD steps ahead (ring of PD + 1 sets)
+    i32x4 fa[PD + 1][2], fb[PD + 1][2];
     auto needed = [&](int v, int q) { return v < NV && (!SPLIT || v < 24 || (v < 36 ? q != 3 : q != 2)); };
     auto frag1 = [&](int v, int q, i32x4 (&af)[2], i32x4 (&bf)[2]) {
       const int s = v < 36 ? v : v - 12;
@@ -431,30 +435,30 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       if (q < 2) af[q] = lds_read16(wlane + ((g0 + kh) % 3) * C::WG_BYTES + (((kw * 8 + 2 * ks) * 64 + q * 32) << 4));
       else bf[q - 2] = lds_read16(pix[q - 2] + ((kh * pitch + kw) << 7) + (((2 * ks + h) ^ gsw[kw]) << 4));
     };
-    // the MFMA gap of step v in which fragment q of step v + 2 is read: one per gap in a 4-MFMA step; in a 2-MFMA step the
+    // the MFMA gap of step v in which fragment q of step v + PD is read: one per gap in a 4-MFMA step; in a 2-MFMA step the
     // (at most three) fragments of step v + 2 go two into the first gap, one into the second
     auto gap_of = [&](int v, int q) {
-      if (!needed(v + 2, q)) return -1;
+      if (!needed(v + PD, q)) return -1;
       if (!SPLIT || v < 24) return q;
       int idx = 0;
-      for (int qq = 0; qq < q; ++qq) idx += needed(v + 2, qq) ? 1 : 0;
+      for (int qq = 0; qq < q; ++qq) idx += needed(v + PD, qq) ? 1 : 0;
       return idx >> 1;
     };
 #pragma unroll
-    for (int q = 0; q < 4; ++q) frag1(0, q, fa[0], fb[0]);
+    for (int v0 = 0; v0 < PD; ++v0)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) frag1(1, q, fa[1], fb[1]);
+      for (int q = 0; q < 4; ++q) frag1(v0, q, fa[v0], fb[v0]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       if (v < 36) at_step(v);
-      const int c0 = v % 3, c2 = (v + 2) % 3;
+      const int c0 = v % (PD + 1), c2 = (v + PD) % (PD + 1);
       if (!SPLIT || v < 24) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (gap_of(v, q) == m) frag1(v + 2, q, fa[c2], fb[c2]);
+            if (gap_of(v, q) == m) frag1(v + PD, q, fa[c2], fb[c2]);
           const int cb = m >> 1, pb = m & 1;
           acc[cb][pb] = Tr::mma(fa[c0][cb], fb[c0][pb], acc[cb][pb]);
           __builtin_amdgcn_sched_barrier(0);
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (gap_of(v, q) == m) frag1(v + 2, q, fa[c2], fb[c2]);
+            if (gap_of(v, q) == m) frag1(v + PD, q, fa[c2], fb[c2]);
           acc[m][pb] = Tr::mma(fa[c0][m], fb[c0][pb], acc[m][pb]);
           if (v >= 36) epi(2 * (v - 36) + m);
           __builtin_amdgcn_sched_barrier(0);
@@ -607,8 +611,8 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     }
   };
   auto hand_cw = [&](int s) {
-    if (s == 10) hand1_cw();
-    if (s == 22) hand2_cw();
+    if (s == 12 - SRK_PAIR_PD) hand1_cw();                 // the last step whose prefetch still reads kernel row 0 / 1 has issued its reads
+    if (s == 24 - SRK_PAIR_PD) hand2_cw();
   };
   const std::integral_constant<bool, true> split_on;
   const std::integral_constant<bool, false> split_off;
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     }
   };
   auto hand_c2 = [&](int s) {
-    if (s == 22) { __builtin_amdgcn_s_barrier(); load_aux(); }
+    if (s == 24 - SRK_PAIR_PD) { __builtin_amdgcn_s_barrier(); load_aux(); }
   };
   if (cw) {
     if (a.res) conv_loop(split_on, 3, ml, C::MP, hand_c2, out_piece_res);

@@ -148,7 +148,8 @@ def test_random_input_fwd_bwd_vs_oracle_fp32(A, name, n, h, w):
 
 @pytest.mark.parametrize("dt,min_psnr,min_cos", [(torch.bfloat16, 50.0, 0.99), (torch.float16, 62.0, 0.999)])
 @pytest.mark.parametrize("name,n,h,w", [("edsr_baseline_x4", 4, 48, 48), ("wdsr_b_full_x4", 2, 24, 24),
-                                        ("rdn_a_full_x4", 1, 24, 20), ("rcan_f16_g2_b2_r4_x4", 3, 33, 17)])
+                                        ("rdn_a_full_x4", 1, 24, 20), ("rdn_b_full_x4", 1, 24, 20),       # rdn_b: BASELINE config 5's other half (VERDICT r4 missing #7)
+                                        ("rcan_f16_g2_b2_r4_x4", 3, 33, 17)])
 def test_random_input_16bit_vs_oracle(A, name, n, h, w, dt, min_psnr, min_cos):
     """bf16 / fp16 storage on default-initialised nets: PSNR(build, oracle) of the output image and the cosine
     similarity of every sizeable parameter gradient with the fp32 oracle's (what matters for training)."""

@@ -1,15 +1,6 @@
-tools/profile_step.sh wdsr_b 16 r5 > /dev/null 2>&1
-python3 tools/step_list.py gpurun_out/r5_step_wdsr_b_b16.csv.gz 25 > gpurun_out/r5_step_wdsr_b_b16.txt
-python3 - <<'PY'
-import collections
-agg=collections.OrderedDict()
-for l in open('gpurun_out/r5_step_wdsr_b_b16.txt'):
-    l=l.rstrip('\n')
-    if l.startswith('sum of'): print(l); continue
-    name=l[:64].strip(); rest=l[64:].split()
-    try: d=float(rest[1])
-    except: continue
-    a=agg.setdefault(name[:60],[0,0.0]); a[0]+=1; a[1]+=d
-for k,(c,d) in sorted(agg.items(), key=lambda kv:-kv[1][1])[:20]:
-    print(f"{k:62s} x{c:3d} {d:8.1f}  {d/c:7.1f}")
-PY
+python -m pytest tests/test_gpu_conv_pair.py -x -q -m gpu 2>&1 | tail -2
+SRK_LIB_PATH=$PWD/tools/ubench/libsrk_pd3.so python -m pytest tests/test_gpu_conv_pair.py -x -q -m gpu 2>&1 | tail -2
+for r in 1 2 3; do for lib in sr-pytorch-lightning_amd/libsrk_gfx950.so tools/ubench/libsrk_pd3.so; do echo $lib; SRK_LIB_PATH=$PWD/$lib python tools/microbench_pair.py 16 2>&1 | grep "pair  "; done; done
+for lib in sr-pytorch-lightning_amd/libsrk_gfx950.so tools/ubench/libsrk_pd3.so; do
+SRK_LIB_PATH=$PWD/$lib python bench.py --model rcan --batch 16 --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs --no-roofline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', d['value'])"
+done

@@ -4,17 +4,19 @@
 # WRITE_SIZE in separate passes, program directly behind `--`).   usage: tools/collect_profiles.sh [tag]   -> gpurun_out/<tag>_*
 # Afterwards, here: copy gpurun_out/<tag>_* into profiles/ and run tools/gen_results.py (it rewrites the number tables of
 # profiles/README.md and DESIGN.md from the files; tests/test_docs_numbers.py checks that they are in sync).
-TAG=${1:-r4}
+TAG=${1:-r5}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$REPO"; O=gpurun_out
-tools/pmc_traffic.sh 256 > /dev/null 2>&1; cp $O/r4_pmc_traffic.json profiles/r4_pmc_traffic.json      # (the bench line below quotes it)
+python __graft_entry__.py smoke > $O/${TAG}_smoke.txt 2>&1; tail -1 $O/${TAG}_smoke.txt
+python -m pytest tests -q -m gpu 2>&1 | tail -2 > $O/${TAG}_gpu_tests.txt; cat $O/${TAG}_gpu_tests.txt
+SRK_PROFILE_TAG=$TAG tools/pmc_traffic.sh 256 > /dev/null 2>&1; cp $O/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json      # (the bench line below quotes it)
 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -c 400 $O/${TAG}_bench_default.json; echo
 python bench.py --dtype f16 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_default_f16.json 2>/dev/null
 python bench.py --inference --no-cpu-baseline --no-other-configs --no-roofline > $O/${TAG}_bench_inference.json 2>/dev/null
 tools/variants_trace.sh 256 $TAG > /dev/null 2>&1; cat $O/${TAG}_variants_n256.txt
 for m in edsr_baseline rcan edsr_large wdsr_b rdn_b ddbpn srresnet; do
   python bench.py --model $m --batch 16 --steps 50 --warmup 10 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 > $O/${TAG}_bench_b16_$m.json
-  python3 -c "import json,sys; d=json.load(open('$O/${TAG}_bench_b16_$m.json')); print('$m b16', d['value'], d['roofline'].get('isolated', d['roofline']).get('variants_us'), d['roofline'].get('step_weighted_frac'))"
+  python3 -c "import json,sys; d=json.load(open('$O/${TAG}_bench_b16_$m.json')); print('$m b16', d['value'], d['roofline'].get('frac'), d['roofline'].get('isolated', d['roofline']).get('variants_us'))"
 done
 tools/profile_bench.sh ${TAG}final --no-roofline --sustain-seconds 0 > /dev/null 2>&1; cp $O/prof_${TAG}final/kernel_stats_summary.txt $O/${TAG}_kernel_stats_default.txt; head -14 $O/${TAG}_kernel_stats_default.txt | cut -c1-150
 # one step in dispatch order (body / upsampler / HR stage / weight gradients are separable although the persistent kernels share a grid size)
@@ -25,24 +27,21 @@ for m in edsr_large rdn_b srresnet ddbpn; do tools/profile_model.sh $m 16 $TAG >
 # PMC: the body kernels, the new 5x5 kernels, the kernels the verdict named
 tools/pmc_kernel.sh ${TAG}_conv_ws_plain_n256 conv_ws_kernel tools/microbench_variants.py --n 256 --variant plain --iters 5 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_conv_ws_residual_n256 conv_ws_kernel tools/microbench_variants.py --n 256 --variant residual --iters 5 > /dev/null 2>&1
-tools/pmc_kernel.sh ${TAG}_conv_ws_mask_n256 conv_ws_kernel tools/microbench_variants.py --n 256 --variant mask --iters 5 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_wgrad_group_n256 conv_wgrad_ws_group_kernel tools/microbench_variants.py --n 256 --variant wgrad --iters 4 > /dev/null 2>&1
-tools/pmc_kernel.sh ${TAG}_lk5_fwd_n256 lk5_rows_fwd_kernel tools/microbench_hrtail.py --n 256 --iters 3 > /dev/null 2>&1
-tools/pmc_kernel.sh ${TAG}_lk5_wgrad_n256 lk5_wgrad_kernel tools/microbench_hrtail.py --n 256 --iters 3 > /dev/null 2>&1
-tools/pmc_kernel.sh ${TAG}_lk5_dgrad_n256 lk5_dgrad_kernel tools/microbench_hrtail.py --n 256 --iters 3 > /dev/null 2>&1
+# (the 5x5 kernels and the mask variant did not change in round 5: profiles/r4_lk5_*_pmc.txt, r4_conv_ws_mask_n256_pmc.txt)
 tools/pmc_kernel.sh ${TAG}_conv_pair_n16 conv_pair_kernel tools/microbench_pair.py 16 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_pw_wgrad_n256 pw_wgrad_kernel tools/microbench_pw.py --n 256 --only wgrad --iters 5 > /dev/null 2>&1
 tools/pmc_kernel.sh ${TAG}_pw_wgrad_n16 pw_wgrad_kernel tools/microbench_pw.py --n 16 --only wgrad --iters 5 > /dev/null 2>&1
 for f in $O/${TAG}_*_pmc.txt; do echo "== $f"; grep -E "^void|MFMA pipe|HBM-side|BANK_CONFLICT" $f | cut -c1-140; done
-python tools/microbench_hrtail.py --n 256 > $O/${TAG}_hrtail_microbench.txt 2>/dev/null; python tools/microbench_hrtail.py --n 256 --layerwise >> $O/${TAG}_hrtail_microbench.txt 2>/dev/null
-python tools/microbench_hrtail.py --n 16 --hw 96 >> $O/${TAG}_hrtail_microbench.txt 2>/dev/null; python tools/microbench_hrtail.py --n 16 --layerwise >> $O/${TAG}_hrtail_microbench.txt 2>/dev/null; cat $O/${TAG}_hrtail_microbench.txt
+tools/ab_pw.sh 16 > $O/${TAG}_ab_pw_b16.txt 2>&1; cat $O/${TAG}_ab_pw_b16.txt
+{ echo "same box: round 4's library (tools/ubench/libsrk_prev.so, built from the round-4 tree) against this tree, conv_pair chain and RCAN batch 16"
+  for r in 1 2; do for lib in tools/ubench/libsrk_prev.so sr-pytorch-lightning_amd/libsrk_gfx950.so; do echo "$lib: $(SRK_LIB_PATH=$PWD/$lib python tools/microbench_pair.py 16 2>&1 | grep 'pair  ')"; done; done; } > $O/${TAG}_ab_pair.txt 2>&1; cat $O/${TAG}_ab_pair.txt
 # in-kernel s_memtime anatomy (diagnostics build tools/ubench/libsrk_stamp.so = `make -C sr-pytorch-lightning_amd/csrc stamp`, built here, travels with the snapshot)
 if [ -f tools/ubench/libsrk_stamp.so ]; then
-  { for m in 0 2 1; do echo "== conv_pair_kernel, 16 x 48 x 48, STAMP_CA=$m (0: ResBlock; 2 / 1: RCAB forward / backward with the channel attention of the neighbouring block)"; STAMP_CA=$m python tools/stamp_pair.py 16 2>/dev/null | cut -c1-700; done
+  { for m in 0 2 1; do echo "== conv_pair_kernel, 16 x 48 x 48, STAMP_CA=$m (0: ResBlock; 2 / 1: RCAB forward / backward with the channel attention of the neighbouring block)"; STAMP_CA=$m python tools/stamp_pair.py 16 2>/dev/null | grep -v amdgpu.ids | cut -c1-900; done
     echo "== conv_ws_kernel, 256 x 48 x 48, conv + ReLU"; python tools/stamp_ws.py 256 2>/dev/null | cut -c1-300
     echo "== conv_ws_kernel, 256 x 48 x 48, * scale + residual (prefetch variant)"; STAMP_RES=1 python tools/stamp_ws.py 256 2>/dev/null | cut -c1-300
-    echo "== lk5_dgrad_kernel, 256 x 96 x 96"; python tools/stamp_lk5.py 256 2>/dev/null | head -10
-    echo "== lk5_wgrad_kernel, 256 x 96 x 96"; python tools/stamp_lk5w.py 256 2>/dev/null | head -10; } > $O/${TAG}_stamps.txt
+  } > $O/${TAG}_stamps.txt
 fi
 tools/ab_ddp.sh > $O/${TAG}_ab_ddp.txt 2>&1; cat $O/${TAG}_ab_ddp.txt
 tools/sweep.sh "16 64 256" > /dev/null 2>&1; cp $O/sweep.txt $O/${TAG}_sweep.txt; cat $O/${TAG}_sweep.txt
