@@ -279,6 +279,22 @@ def load():
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path.")
     lib = C.CDLL(LIB_PATH)
+    # A/B timing against an OLDER build of this library (tools/ab_lib.sh: SRK_LIB_PATH=tools/ubench/libsrk_prev.so): entry points that
+    # build does not have yet are left unbound (calling one raises).  The product library (no SRK_LIB_PATH) must export everything.
+    older = bool(os.environ.get("SRK_LIB_PATH"))
+
+    class _Absent:
+        def __init__(self, name):
+            self.name = name
+            self.argtypes = self.restype = None
+
+        def __call__(self, *a, **k):
+            raise RuntimeError(f"{self.name} is not exported by {LIB_PATH} (an older build loaded through SRK_LIB_PATH)")
+
+    if older:
+        for name in list(LAUNCHERS) + list(OTHER_SYMBOLS):
+            if not hasattr(lib, name):
+                setattr(lib, name, _Absent(name))
     for name, st in LAUNCHERS.items():
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(st), C.c_void_p]

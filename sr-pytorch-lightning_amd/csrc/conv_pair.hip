@@ -202,6 +202,33 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     const int Cr = a.ca_cr;                                  // <= 8 (launcher)
     const float invHW = 1.f / (float)(H * W);
     const bool slot_owner = tX == 0 && tY == 0;             // one workgroup per sample writes the per-sample results
+    // The MLP's operands FIRST: they head the longest chain of this prologue (operands -> staging -> pooled means -> squeeze / excite ->
+    // scale -> tile transform); the tile's own loads follow and stay in flight behind the staging barrier (requested ahead of the
+    // operands, their 12 vector-memory instructions per wave delayed the chain by ~0.7k cycles).
+    // The per-block partial sums of the pooled vectors ([rows <= 64][64] floats each): 16-byte loads spread over the whole
+    // workgroup -- a CU issues roughly one vector-memory instruction per 16 cycles whoever asks, so their NUMBER is what
+    // costs -- staged raw in the (still unused) intermediate tile's LDS
+    const bool want_s = !bwd || slot_owner;
+    const int rg = bwd ? a.ca_gsum_rows : 0, rs = want_s ? a.ca_sums_rows : 0;
+    float* const rawG = reinterpret_cast<float*>(Ms);
+    float* const rawS = rawG + 64 * 64;
+    f32x4 vg[2], vs[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f = tid + C::NT * u;                         // float4 index: row f >> 4, channels 4 (f & 15) ..
+      vg[u] = f < rg * 16 ? *reinterpret_cast<const f32x4*>(a.ca_gsum + (size_t)n * rg * 64 + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
+      vs[u] = f < rs * 16 ? *reinterpret_cast<const f32x4*>(a.ca_sums + (size_t)n * rs * 64 + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float w1r = 0.f, w2r = 0.f, sg_in = 0.f, z_in = 0.f, b1_in = 0.f, b2_in = 0.f;
+    if (tid < 64 * Cr) { w1r = a.ca_w1[tid]; w2r = a.ca_w2[tid]; }
+    if (bwd) {
+      if (tid < 64) sg_in = a.ca_s[(size_t)n * 64 + tid];
+      if (tid < Cr) z_in = a.ca_z[(size_t)n * Cr + tid];
+    } else {
+      if (tid < Cr) b1_in = a.ca_b1[tid];
+      if (tid < 64) b2_in = a.ca_b2[tid];
+    }
+    SRK_PSTAMP(13);
     // input pieces (and, forward, the second operand) through registers.  Lane `tid` carries CHUNK tid & 7 of pixels (tid >> 3) +
     // 64 k (eight lanes = one 128-byte pixel, in order) and writes it to the swizzled slot: the eight scale / shift values of a
     // lane are then the same for all its pieces (round 4 mapped lanes to SLOTS: four LDS reads of s / dmean per piece).
@@ -226,35 +253,10 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
           x2in[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, ok ? (unsigned)((pix * a.ca_x2_pitch + a.ca_x2_coff + cch * Tr::CH) * 2) : 0x80000000u, 0, 0);
       }
     }
-    SRK_PSTAMP(13);
-    // the per-block partial sums of the pooled vectors ([rows <= 64][64] floats each): 16-byte loads spread over the whole
-    // workgroup -- a CU issues roughly one vector-memory instruction per 16 cycles whoever asks, so their NUMBER is what
-    // costs -- staged raw in the (still unused) intermediate tile's LDS
-    const bool want_s = !bwd || slot_owner;
-    const int rg = bwd ? a.ca_gsum_rows : 0, rs = want_s ? a.ca_sums_rows : 0;
-    float* const rawG = reinterpret_cast<float*>(Ms);
-    float* const rawS = rawG + 64 * 64;
-    f32x4 vg[2], vs[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f = tid + C::NT * u;                         // float4 index: row f >> 4, channels 4 (f & 15) ..
-      vg[u] = f < rg * 16 ? *reinterpret_cast<const f32x4*>(a.ca_gsum + (size_t)n * rg * 64 + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
-      vs[u] = f < rs * 16 ? *reinterpret_cast<const f32x4*>(a.ca_sums + (size_t)n * rs * 64 + 4 * f) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    float w1r = 0.f, w2r = 0.f, sg_in = 0.f, z_in = 0.f, b1_in = 0.f, b2_in = 0.f;
-    if (tid < 64 * Cr) { w1r = a.ca_w1[tid]; w2r = a.ca_w2[tid]; }
-    if (bwd) {
-      if (tid < 64) sg_in = a.ca_s[(size_t)n * 64 + tid];
-      if (tid < Cr) z_in = a.ca_z[(size_t)n * Cr + tid];
-    } else {
-      if (tid < Cr) b1_in = a.ca_b1[tid];
-      if (tid < 64) b2_in = a.ca_b2[tid];
-    }
     SRK_PSTAMP(14);
-    // everything requested so far is used (= waited for) HERE, then the weight slabs' DMA starts
-#pragma unroll
-    for (int k = 0; k < C::XK; ++k) asm volatile("" : "+v"(xin[k]), "+v"(x2in[k]));
-    asm volatile("" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vs[0]), "+v"(vs[1]), "+v"(w1r), "+v"(w2r), "+v"(sg_in), "+v"(z_in), "+v"(b1_in), "+v"(b2_in));
+    // the MLP's operands are used (= waited for) HERE; the tile's pieces, requested after them, keep flying (the counter retires in
+    // order: their wait at the transform also covers the weight slabs waves 1..7 request below, which have landed by then)
+    asm volatile("" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vs[0]), "+v"(vs[1]), "+v"(w1r), "+v"(w2r), "+v"(sg_in), "+v"(z_in), "+v"(b1_in), "+v"(b2_in), "+v"(bias_in));
     SRK_PSTAMP(15);
     // (everything beyond the real rows / hidden units is staged as ZERO, so that the sums below run over fixed ranges with
     // no per-element branch: a +-0 term leaves a sum as it is)
@@ -357,8 +359,10 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
       SRK_PSTAMP(21);
     };
     if (wave == 0) {
+      __builtin_amdgcn_s_setprio(3);                         // the chain everyone waits for: first pick over its SIMD partner (a DMA wave issuing slab pieces)
       if (Cr <= 4) mlp(std::integral_constant<int, 4>());
       else mlp(std::integral_constant<int, 8>());
+      __builtin_amdgcn_s_setprio(0);
     }
     lds_barrier();
     if (slot_owner) {                                        // per-sample results: one workgroup per sample

@@ -1621,7 +1621,11 @@ def pw_wgrad_raw(x, gz, pk, w1_shape, w2_shape, want_b1=True, want_b2=True, defe
     return dw1, db1, dw2, db2
 
 
-_PW_FIN_EACH = _knob("SRK_NO_PW_GROUP_FIN", "0") == "1"   # A/B knob: every pointwise pair finalizes its weight gradients with its own launch (round 4)
+# One finalize launch for ALL pointwise pairs of a backward pass (srk_pw_wgrad_finalize_group) is OFF by default: measured on two boxes
+# (tools/ab_pw.sh, profiles/r5_ab_pw_b16.txt) it is -1 % ... +0.5 % against a finalize per pair -- each pair's 31.5 MB of slabs are still in the
+# Infinity Cache when its own finalize reads them right behind the kernel that wrote them; all sixteen read at the end of the pass (504 MB) come
+# from HBM.  SRK_DEBUG=1 SRK_PW_GROUP_FIN=1 selects the grouped form.
+_PW_FIN_EACH = _knob("SRK_PW_GROUP_FIN", "0") != "1"
 _PW_WG_OFF = _knob("SRK_NO_PW_WGRAD", "0") == "1"      # A/B knob: h / gh through HBM + the two 1x1 weight-gradient GEMMs
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes the NUMBER tables of profiles/README.md and DESIGN.md (section 7c) from the files under profiles/ -- nothing in those two
+"""Writes the NUMBER tables of profiles/README.md and DESIGN.md (section 7; rounds before 5: profiles/HISTORY.md) from the files under profiles/ -- nothing in those two
 blocks is typed by hand (three documents quoted three sets of numbers for one profile file).
 usage: tools/gen_results.py [tag]            rewrite the blocks between `<!-- results:<tag>:begin -->` / `<!-- results:<tag>:end -->`
        tools/gen_results.py [tag] --check    exit 1 if a block differs from what the files give (tests/test_docs_numbers.py)"""
@@ -82,7 +82,25 @@ def block(tag):
         if lw and "value" in lw:
             out.append(f"Same process, same step with the HR stage layer by layer (`layerwise_hr_stage`): {lw['value']:,.0f} patches/s, {lw['ms_per_step']:.3f} ms per step "
                        f"(`model_mfma_frac` {lw['model_mfma_frac']:.4f}): the collapsed form is {d['value'] / lw['value']:.2f}x.")
-        if r and "variants_us" in r:
+        if r and "isolated" in r:                       # round 5: ONE fraction, measured in the step; the isolated flavours in a sub-object
+            iso, ins = r["isolated"], r.get("in_step")
+            out.append("")
+            out.append(f"`roofline` ({r['kernel']}): **{r['us_per_launch']} us per launch = {r['achieved']} TFLOP/s = {r['frac']:.4f} of 2.5 PFLOP/s** -- {r.get('where')}; "
+                       f"HBM-side traffic per launch {('%.1f MB' % (r['traffic'] / 1e6)) if r.get('traffic') else 'null'} against {r['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic.")
+            if ins:
+                g = ins["graph_us"]
+                out.append(f"`in_step`: {ins['convs']} convolutions ({ins['convs_per_launch']} per launch); forward {ins['fwd_us_per_conv']} us, data gradient {ins['dgrad_us_per_conv']} us, "
+                           f"grouped weight gradient {ins['wgrad_us_per_layer']} us per layer; with the weight gradients the trunk runs at {ins['frac_with_wgrad']} of the peak "
+                           f"(graphs: packing {g['pack']} us, forward {g['fwd']}, + data gradients {g['fwd_bwd']}, + weight gradients {g['fwd_bwd_wgrad']}).")
+            v, vb = iso["variants_us"], iso.get("variants_us_burst", {})
+            out.append(f"`isolated` (each flavour alone on the chip, re-reading its own buffers): {iso['quoted_flavour']} {iso['us_per_launch']} us = {iso['frac']} (burst {iso.get('frac_burst')}); "
+                       f"step-weighted over a block's launches {iso.get('step_weighted_frac')} (burst {iso.get('step_weighted_frac_burst')}).")
+            out.append("")
+            out.append("| flavour (HIP events, isolated) | sustained us | burst us | launches per block |")
+            out.append("|---|---|---|---|")
+            for k in v:
+                out.append(f"| {k} | {v[k]} | {vb.get(k)} | {iso.get('launches_per_block', {}).get(k)} |")
+        elif r and "variants_us" in r:
             v, vb = r["variants_us"], r.get("variants_us_burst", {})
             out.append("")
             out.append(f"`roofline` ({r['kernel']}): sustained {r['us_per_launch']} us per launch = {r['achieved']} TFLOP/s = **{r['frac']:.4f}** of 2.5 PFLOP/s "
@@ -96,19 +114,23 @@ def block(tag):
         cb = d.get("cpu_baseline")
         if cb and "value" in cb:
             out.append("")
+            if cb.get("cpu_model"):
+                out.append(f"`cpu_baseline` host: {cb['cpu_model']}, {cb.get('cores_available')} cores available, {cb['cores']} threads used.")
             out.append(f"`cpu_baseline`: {cb['value']} patches/s ({cb['sample']}); parity of the build on the bench's own weights: PSNR(build, oracle) {cb.get('parity', {}).get('psnr_build_vs_oracle_db')} dB, max |err| {cb.get('parity', {}).get('max_abs_err')}.")
         oc = d.get("other_configs")
         if oc:
             out.append("")
-            out.append("| `other_configs` (batch 16, training step as one hipGraph) | patches/s | ms / step | model_mfma_frac (reference graph / executed) | dominant kernel frac (sustained) | step-weighted |")
+            out.append("| `other_configs` (batch 16, training step as one hipGraph) | patches/s | ms / step | model_mfma_frac (reference graph / executed) | dominant kernel frac (in the step where the model has a trunk) | isolated frac / step-weighted |")
             out.append("|---|---|---|---|---|---|")
             for e in oc:
                 if "value" not in e:
                     out.append(f"| {e.get('model')} {e.get('dtype', '')} | error: {e.get('error')} | | | | |")
                     continue
                 rr = e.get("roofline") or {}
+                iso = rr.get("isolated") or {}
                 out.append(f"| {e['model']}{' fp16' if e.get('dtype') == 'f16' else ''} | {e['value']:,.0f} | {e['ms_per_step']} | {e['model_mfma_frac']} / {e.get('model_mfma_frac_executed')} | "
-                           f"{rr.get('frac', '')} {('(' + rr.get('unit', '') + ')') if rr else ''} | {rr.get('step_weighted_frac', '')} |")
+                           f"{rr.get('frac', '')} {('(' + rr.get('unit', '') + (', in step' if 'in_step' in rr else ', isolated') + ')') if rr else ''} | "
+                           f"{iso.get('frac', rr.get('frac', ''))} / {iso.get('step_weighted_frac', rr.get('step_weighted_frac', ''))} |")
     for nm, what in ((f"{tag}_bench_default_f16.json", "fp16 (`--dtype f16`, device-resident dynamic loss scaling, the step still ONE hipGraph)"),
                      (f"{tag}_bench_inference.json", "forward only (`--inference`)")):
         e = _load(nm)
@@ -183,7 +205,9 @@ def block(tag):
             best = max(secs, key=lambda c: c["n"])
             kern, busy, hbm, conf = best["kern"], best["busy"], best["hbm"], best["conf"]
             out.append(f"| `{f}` | {kern} | {busy} | {hbm} | {conf} |")
-    for nm, title in ((f"{tag}_stamps.txt", "In-kernel `s_memtime` stamps of workgroup 0 (diagnostics build, `tools/stamp_*.py`; ticks ~ cycles)"),
+    for nm, title in ((f"{tag}_ab_pair.txt", "conv_pair, same box, round 4's library against this tree (`tools/microbench_pair.py 16`: a dependent chain of 32 ResBlock pairs)"),
+                      (f"{tag}_ab_pw_b16.txt", "WDSR-B at batch 16, same box, round 5's two changes switched off and on (`tools/ab_pw.sh 16`: patches/s, ms per step)"),
+                      (f"{tag}_stamps.txt", "In-kernel `s_memtime` stamps of workgroup 0 (diagnostics build, `tools/stamp_*.py`; ticks ~ cycles)"),
                       (f"{tag}_hrtail_microbench.txt", "The HR stage alone, forward + backward, eager launches (`tools/microbench_hrtail.py`)"),
                       (f"{tag}_ab_ddp.txt", "Single process against a forced 1-rank RCCL group, same box (`tools/ab_ddp.sh`: value, ms per step, sustained value, graph form, gradient sync)")):
         t = _text(nm)
@@ -199,12 +223,13 @@ def block(tag):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = args[0] if args else "r4"
+    tag = args[0] if args else "r5"
     check = "--check" in sys.argv
     body = block(tag)
     b, e = f"<!-- results:{tag}:begin -->\n", f"<!-- results:{tag}:end -->"
     bad = 0
-    for path in (os.path.join(ROOT, "DESIGN.md"), os.path.join(P, "README.md")):
+    first = os.path.join(ROOT, "DESIGN.md") if tag == "r5" else os.path.join(P, "HISTORY.md")      # earlier rounds' results live in profiles/HISTORY.md
+    for path in (first, os.path.join(P, "README.md")):
         s = open(path).read()
         if b not in s or e not in s:
             print(f"{path}: markers for {tag} not found")

@@ -43,4 +43,4 @@ for w in (0, 1):
     t = st[w * 32:(w + 1) * 32]
     print(("compute wave 0: " if w == 0 else "DMA wave 4:     ") + "; ".join(f"{nm} {t[i]-t[0]}" for i, nm in enumerate(names)))
     if t[13]:
-        print("      channel-attention block: " + "; ".join(f"{nm} {t[13+i]-t[0]}" for i, nm in enumerate(["input pieces requested", "MLP operands requested", "first operand arrived", "MLP done", "tile transformed", "all landed", "staging barrier", "pooled mean done (wave 0)", "MLP loop done (wave 0)"])))
+        print("      channel-attention block: " + "; ".join(f"{nm} {t[13+i]-t[0]}" for i, nm in enumerate(["MLP operands requested", "input pieces requested", "MLP operands arrived", "MLP done", "tile transformed", "all landed", "staging barrier", "pooled mean done (wave 0)", "MLP loop done (wave 0)"])))
