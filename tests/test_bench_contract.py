@@ -55,19 +55,21 @@ def test_round5_line_quotes_the_in_step_roofline():
     assert set(iso["variants_us"]) == set(iso["variants_us_burst"]) == set(iso["launches_per_block"])
     c = line["cpu_baseline"]
     assert c["cpu_model"] and c["cores"] >= 1 and c["cores_available"] >= c["cores"]
-    # the same kernel family in the committed rocprofv3 step trace: within 5 % (VERDICT r4 item 3's criterion)
-    us, n = 0.0, 0
+    # the same kernel family in the committed rocprofv3 step trace of the same box: within 5 % (VERDICT r4 item 3's criterion).  The trunk's
+    # 66 launches are the conv_ws launches below 100 us (the one above is the first upsampler stage, 64 -> 256)
+    durs = []
     for ln in open(os.path.join(ROOT, "profiles", "r5_step_edsr_baseline_b256.txt")):
-        if not ln.startswith("conv_ws_kernel<0, 2, 4"):
+        if not ln.startswith("conv_ws_kernel"):
             continue
         parts = ln[64:].split()
         if parts[0].startswith("x"):
-            n += int(parts[0][1:]); us += float(parts[1])
-        elif int(parts[0]) == 131072:                                                   # 64 -> 64 launches (the 64 -> 256 upsampler launches have other grids? same grid: filtered by duration below)
-            n += 1; us += float(parts[1])
-    assert n >= 66
-    trace_frac = ins["flops_per_launch"] / (us / n * 1e-6) / 1e12 / r["peak"]
-    assert abs(trace_frac - r["frac"]) / trace_frac < 0.08, (trace_frac, r["frac"])
+            durs += [float(parts[1]) / int(parts[0][1:])] * int(parts[0][1:])
+        else:
+            durs.append(float(parts[1]))
+    durs = [d for d in durs if d < 100.0]
+    assert len(durs) == ins["convs"]
+    trace_frac = ins["flops_per_launch"] / (sum(durs) / len(durs) * 1e-6) / 1e12 / r["peak"]
+    assert abs(trace_frac - r["frac"]) / trace_frac < 0.05, (trace_frac, r["frac"])
 
 
 def test_refuses_to_run_without_a_gpu():

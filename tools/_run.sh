@@ -1,4 +1,4 @@
-python -m pytest tests/test_gpu_conv_pair.py tests/test_gpu_round5.py -x -q -m gpu 2>&1 | tail -2
-python -m pytest tests/test_gpu_round3.py -x -q -m gpu -k "rcan_64_feature" 2>&1 | tail -2
-bash tools/ab_lib.sh
-for m in 2 1; do echo "== STAMP_CA=$m"; STAMP_CA=$m python tools/stamp_pair.py 16 2>&1 | grep -v amdgpu.ids | cut -c1-900; done
+python -m pytest tests/test_gpu_conv_pair.py -x -q -m gpu 2>&1 | tail -1
+for r in 1 2; do for lib in tools/ubench/libsrk_prev.so tools/ubench/libsrk_headA.so sr-pytorch-lightning_amd/libsrk_gfx950.so tools/ubench/libsrk_st1.so tools/ubench/libsrk_st2.so; do
+SRK_LIB_PATH=$PWD/$lib python bench.py --model rcan --batch 16 --steps 60 --warmup 10 --no-cpu-baseline --no-other-configs --no-roofline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', d['value'], d['ms_per_step'])"
+done; done
