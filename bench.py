@@ -610,7 +610,9 @@ def main():
                 "uuid": str(getattr(pr, "uuid", "")), "visible": torch.cuda.device_count(), "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
         seen = [None] * world
         dist.all_gather_object(seen, mine)
-        ids = [(tuple(d["pci"]), d["uuid"]) if (d["pci"][1] is not None or d["uuid"]) else ("dev", d["current_device"]) for d in seen]
+        # two ranks share a GPU only if EVERYTHING they report about it is equal (device index in the process's visible set, PCI address,
+        # uuid): attributes a driver build leaves empty or equal for all devices can then never turn N good ranks into a false alarm
+        ids = [(d["current_device"], d["visible"], tuple(d["pci"]), d["uuid"]) for d in seen]
         if len(set(ids)) != world or mine["rccl_ranks"] != world:
             print(f"[bench] rank {rank}: ranks do not sit on {world} distinct GPUs -- this rank: {mine}; all: {ids}", file=sys.stderr, flush=True)
             sys.exit(3)
