@@ -844,7 +844,9 @@ def main():
             out["sustained_value"] = round(a.batch * world / sustained, 2)
         if not a.no_roofline:
             try:
-                ins = None if a.inference else in_step_body(A, model, a.batch, a.patch, a.dtype)
+                # (several ranks: rank 0 alone must not run a backward pass through a model whose gradient hooks / flat buffer belong to the
+                # process group -- a hook-launched all-reduce on one rank would wait for the others forever; the N = 1 line carries `in_step`)
+                ins = None if (a.inference or ddp) else in_step_body(A, model, a.batch, a.patch, a.dtype)
                 out["roofline"] = dominant_kernel_roofline(A, a.model, a.batch, a.patch, feats, a.dtype, in_step=ins)
             except Exception as e:  # noqa: BLE001
                 out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
