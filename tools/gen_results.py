@@ -70,7 +70,9 @@ def step_anatomy(name):
     return agg, total
 
 
-def block(tag):
+def block(tag, short=False):
+    """short: DESIGN.md's block (the lines, the tables of the default step and of all models); everything else -- rocprofv3 flavours, PMC
+    passes, stamps, A/B files -- only in profiles/README.md's block."""
     out = []
     d = _load(f"{tag}_bench_default.json")
     if d:
@@ -141,7 +143,7 @@ def block(tag):
                 extra = f"; loss scale {ls['scale']:g}, {ls['skipped_steps']} skipped steps"
             out.append("")
             out.append(f"{what}: **{e['value']:,.0f} patches/s**, {e['ms_per_step']:.3f} ms per step (`profiles/{nm}`{extra}).")
-    t = _text(f"{tag}_variants_n256.txt")
+    t = None if short else _text(f"{tag}_variants_n256.txt")
     if t:
         out.append("")
         out.append(f"The same flavours under rocprofv3 (`profiles/{tag}_variants_n256.txt`: isolated launches replayed for 1.5 s, second half of the dispatches averaged):")
@@ -152,7 +154,7 @@ def block(tag):
     for nm, title in ((f"{tag}_step_edsr_baseline_b256.txt", "Where the default step goes (one step of the rocprofv3 kernel trace in dispatch order, grouped by stage)"),
                       (f"{tag}_step_edsr_baseline_b256_layerwise.txt", "The same with the HR stage layer by layer (`SRK_DEBUG=1 SRK_NO_HR_COLLAPSE=1`)"),
                       (f"{tag}_step_edsr_baseline_b16.txt", "EDSR-baseline at the reference's batch of 16"), (f"{tag}_step_rcan_b16.txt", "RCAN at batch 16")):
-        sa = step_anatomy(nm)
+        sa = None if (short and "layerwise" in nm) else step_anatomy(nm)
         if sa:
             agg, total = sa
             out.append("")
@@ -170,6 +172,10 @@ def block(tag):
         out.append("```")
         out += t.strip().splitlines()
         out.append("```")
+    if short:
+        out.append("")
+        out.append(f"rocprofv3 timings of the isolated flavours, PMC passes, in-kernel stamps and the same-box A/B files: `profiles/README.md` (generated from the same files).")
+        return "\n".join(out) + "\n"
     pm = sorted(f for f in os.listdir(P) if f.startswith(tag + "_") and f.endswith("_pmc.txt")) if os.path.isdir(P) else []
     if pm:
         out.append("")
@@ -225,11 +231,11 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     tag = args[0] if args else "r5"
     check = "--check" in sys.argv
-    body = block(tag)
     b, e = f"<!-- results:{tag}:begin -->\n", f"<!-- results:{tag}:end -->"
     bad = 0
     first = os.path.join(ROOT, "DESIGN.md") if tag == "r5" else os.path.join(P, "HISTORY.md")      # earlier rounds' results live in profiles/HISTORY.md
     for path in (first, os.path.join(P, "README.md")):
+        body = block(tag, short=(path.endswith("DESIGN.md")))
         s = open(path).read()
         if b not in s or e not in s:
             print(f"{path}: markers for {tag} not found")
