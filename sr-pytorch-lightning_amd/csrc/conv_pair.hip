@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   };
   // Only the input tile and kernel row 0 of conv 1 (66 of the 115 KB) are requested and waited for before the first MFMA.
   SRK_PSTAMP(3);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tile and a0 have landed; this wave's LDS stores (the biases) have completed
   SRK_PSTAMP(4);
   __builtin_amdgcn_s_barrier();
   SRK_PSTAMP(5);
