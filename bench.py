@@ -433,7 +433,22 @@ def in_step_body(A, model, batch, patch, dtype, sustain_s=0.6):
     # at small batches (ops.pair_ok) one launch carries TWO of the trunk's convolutions (csrc/conv_pair.hip): per-launch = 2 x per-conv
     wprobe = torch.empty(feats, feats, 3, 3, device=dev)
     cpl = 2 if (feats == 64 and ops.pair_ok(f0, wprobe, wprobe)) else 1
-    return {"convs": 2 * n_conv, "convs_per_launch": cpl, "us_per_conv": round(fam_us, 2), "us_per_launch": round(fam_us * cpl, 2),
+    # the same launches against the OTHER roofline: a 64 -> 64 3x3 convolution on bf16 sits at the ridge (2 x 64 x 64 x 9 FLOP over 2 x 64 x 2
+    # bytes per pixel = 288 FLOP/B against 2.5 PFLOP/s / 8 TB/s = 312), and the flavours that also read a residual (every second forward
+    # launch, every second data gradient) below it: 192 FLOP/B.  EDSR's trunk: per ResBlock forward 2 + 3 activation tensors, backward
+    # 2 (+ the sign bits, 1/16) + 3, the trunk's last convolution 3 forward (long skip) and 2 backward.
+    hbm = None
+    if type(model).__name__ == "EDSR" and cpl == 1:
+        T = px * feats * 2.0
+        nb = (n_conv - 1) // 2
+        tot_b = (nb * 5 + 3) * T + (nb * (5 + 1.0 / 16) + 2) * T
+        per = tot_b / (2 * n_conv)
+        hbm = {"algorithmic_bytes_per_conv": round(per), "achieved_GBps": round(per / (fam_us * 1e-6) / 1e9, 1), "peak_GBps": 8000.0,
+               "frac": round(per / (fam_us * 1e-6) / 1e9 / 8000.0, 4), "flop_per_byte": round(flops / per, 1), "ridge_flop_per_byte": 312.5,
+               "note": "activation tensors each launch must read and write once (input, output, residual where the flavour has one, sign bits), "
+                       "averaged over the trunk's forward + data-gradient launches; below the ridge, so by the roofline model these launches are "
+                       "bound by HBM, not by the matrix pipes"}
+    return {"convs": 2 * n_conv, "convs_per_launch": cpl, "us_per_conv": round(fam_us, 2), "us_per_launch": round(fam_us * cpl, 2), "hbm_view": hbm,
             "flops_per_launch": flops * cpl,
             "fwd_us_per_conv": round((t_f - t_p) / n_conv, 2), "dgrad_us_per_conv": round((t_fb - t_f) / n_conv, 2),
             "wgrad_us_per_layer": round((t_fbw - t_fb) / n_conv, 2),

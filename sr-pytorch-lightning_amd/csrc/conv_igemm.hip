@@ -16,7 +16,9 @@
 #include <stdlib.h>
 #include "srk_common.h"
 
-// timing-experiment knob (separate builds only; measured: sc1 / nt stores do not beat plain stores here)
+// timing-experiment knob (separate builds only; measured again in round 5 with all-workgroup stamps: sc1 stores shorten the dead time
+// between two dependent launches from 3.8 to 1.8 us (no write-back at the kernel's end) and one flavour ALONE by 2 %, but a training
+// step, whose launches are bound by memory throughput, by nothing: plain stores stay)
 #ifndef SRK_WS_STAMPS
 #define SRK_WS_STAMPS 0
 #endif
@@ -919,6 +921,15 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   constexpr int dbg = SRK_WS_ABLATE;      // compile-time: a run-time knob costs registers and branches in the hot loops
 #if SRK_WS_STAMPS
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+  // every workgroup: entry / exit on the constant 100 MHz clock (comparable across XCDs), [256 + (launch & 1) * 1024 + 2 * block + {0, 1}];
+  // the launch index from an arrival counter at [255]
+  unsigned long long* const wgst = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.post_add));
+  unsigned long long* wg_slot = nullptr;
+  if (threadIdx.x == 0 && gridDim.x <= 512) {
+    const unsigned long long c = atomicAdd(wgst + 255, 1ull);
+    wg_slot = wgst + 256 + ((c / gridDim.x) & 1) * 1024 + 2 * blockIdx.x;
+    wg_slot[0] = __builtin_amdgcn_s_memrealtime();
+  }
 #endif
 
   const int tid = threadIdx.x;
@@ -951,16 +962,20 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   const i32x4 xrsrc = make_rsrc4(xg, x_bytes), wrsrc = make_rsrc4(wg, 0x7fffffffu);
   const __amdgpu_buffer_rsrc_t xrsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem*>(xg), 0, x_bytes, 0x00020000);
   const unsigned xg_lds = lds_addr_of(Xg), wl_lds = lds_addr_of(Wl);
+  // (filled by fill_pieces() BEHIND the first DMA requests of the prologue: 11 divisions by 18 per lane that nothing before
+  // the second halo tile needs -- they used to be ~2k cycles in front of the first request)
   int pconst[NPK], pyx[NPK];
+  auto fill_pieces = [&]() {
 #pragma unroll
-  for (int k = 0; k < NPK; ++k) {
-    const int i = gtid + k * GT;
-    const int sl = i & 7, p = i >> 3;
-    const int iy = p / C::TIN, ix = p - iy * C::TIN;
-    const int c = sl ^ swz(ix);
-    pconst[k] = ((iy - 1) * xs_row + (ix - 1) * xs_col + a.x_coff + c * CH) * (int)sizeof(elem);
-    pyx[k] = (i < C::XPIECES && c < 2 * NKS) ? (((iy - 1) & 0xffff) | ((ix - 1) << 16)) : (int)0x7fff7fff;   // never valid
-  }
+    for (int k = 0; k < NPK; ++k) {
+      const int i = gtid + k * GT;
+      const int sl = i & 7, p = i >> 3;
+      const int iy = p / C::TIN, ix = p - iy * C::TIN;
+      const int c = sl ^ swz(ix);
+      pconst[k] = ((iy - 1) * xs_row + (ix - 1) * xs_col + a.x_coff + c * CH) * (int)sizeof(elem);
+      pyx[k] = (i < C::XPIECES && c < 2 * NKS) ? (((iy - 1) & 0xffff) | ((ix - 1) << 16)) : (int)0x7fff7fff;   // never valid
+    }
+  };
   auto tile_of = [&](int j, int& n, int& y0, int& x0) {
     const int pt = t0 + 2 * j + grp;
     const int tX = pt % tilesX;
@@ -993,18 +1008,20 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   static_assert(EARLY ? (EM >= 1 && EM <= 3) : EM == 0, "EM: what the prefetch variant prefetches (1 = residual, 2 = ReLU-backward mask, 3 = its sign bits)");
   f32x16 bias16[EARLY ? 1 : CBW];
   float* const Bl = reinterpret_cast<float*>(smem + WPIECES * 16 + 2 * C::XS_BYTES);
-  if constexpr (EARLY) {
-    if (tid < TCW) Bl[tid] = a.bias ? a.bias[ctile * TCW + tid] : 0.f;
-  } else {
+  float bias_lane = 0.f;                                   // EARLY: this lane's bias value on its way to LDS
+  auto load_bias = [&]() {                                 // requested behind the prologue's weight DMA, before a group's halo pieces
+    if constexpr (EARLY) {
+      if (tid < TCW && a.bias) bias_lane = a.bias[ctile * TCW + tid];
+    } else {
 #pragma unroll
-    for (int cb = 0; cb < CBW; ++cb)
+      for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ctile * TCW + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bias16[cb][4 * i + 0] = b.x; bias16[cb][4 * i + 1] = b.y; bias16[cb][4 * i + 2] = b.z; bias16[cb][4 * i + 3] = b.w;
-      }
-  }
-  asm volatile("" ::: "memory");
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ctile * TCW + 4 * h + cb * 32 + 8 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+          bias16[cb][4 * i + 0] = b.x; bias16[cb][4 * i + 1] = b.y; bias16[cb][4 * i + 2] = b.z; bias16[cb][4 * i + 3] = b.w;
+        }
+    }
+  };
   // ---- prologue: all 9 taps of this channel tile (both groups), then each group's first halo tile ---------------
   // every workgroup needs the SAME weight bytes at the same moment: walking them in the same order would send all
   // CUs of an XCD to one L2 channel at a time, so each workgroup starts at its own 1-KB block (SRK_WS_ABLATE bit 16: off;
@@ -1062,6 +1079,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
       if (blk < NBLK) dma_wblock(blk);
     }
   }
+  __builtin_amdgcn_sched_barrier(0);                        // the requests above first, the set-up below behind them
+  fill_pieces();
+  load_bias();
+  asm volatile("" ::: "memory");
   if (!STAGED && nj > 0) dma_x(0);
 #if SRK_WS_STAMPS
   const unsigned long long tB = __builtin_amdgcn_s_memtime();
@@ -1111,6 +1132,10 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
 #if SRK_WS_STAMPS
   const unsigned long long tC = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (EARLY) {                                   // (lanes 0..63 = wave 0 of group 0: its vmcnt(0) above covers the load)
+    if (tid < TCW) Bl[tid] = bias_lane;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
 #if SRK_WS_STAMPS
   const unsigned long long tD = __builtin_amdgcn_s_memtime();
@@ -1349,6 +1374,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     else __builtin_amdgcn_s_barrier();
   }
 #if SRK_WS_STAMPS
+  if (wg_slot) wg_slot[1] = __builtin_amdgcn_s_memrealtime();
   if (stamp) {                       // [100] entry of the FIRST stamped launch, [101] entry / [102] exit of the last one
     if (stamp[100] == 0) stamp[100] = t_entry;
     stamp[101] = t_entry;

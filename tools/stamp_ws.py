@@ -17,15 +17,28 @@ out = torch.empty(n, COUT, HW, HW, device=dev) if PLANAR else torch.empty(n, HW,
 RES = torch.zeros_like(out) if os.environ.get('STAMP_RES') else None
 MASK = torch.ones_like(out) if os.environ.get('STAMP_MASK') else None
 KW = dict(res=RES, mask=MASK, N=n, H=HW, W=HW, Cin=64, Cout=COUT, out=out, relu=(not PLANAR) and RES is None and MASK is None, out_mode=A._lib.OUT_PLANAR if PLANAR else A._lib.OUT_NHWC)
-stamps = torch.zeros(256, dtype=torch.int64, device=dev)
+stamps = torch.zeros(256 + 2048, dtype=torch.int64, device=dev)
 NL = int(os.environ.get('STAMP_NL', '20'))
 A.ops.conv_raw(x, pk, post_add=stamps.view(torch.float32), **KW)
 stamps.zero_()
 torch.cuda.synchronize()
+CHAIN = os.environ.get('STAMP_CHAIN')       # "fwd": the trunk's forward order on its own buffers (conv+ReLU, conv*s+residual per block); STAMP_ODD=1: one more launch (the stamped pair is then residual -> plain)
+if CHAIN:
+    bufs = [x] + [torch.empty_like(x) for _ in range(NL + 1)]
+    def chain():
+        k = 0
+        for i in range(NL):
+            if i % 2 == 0:
+                A.ops.conv_raw(bufs[i], pk, post_add=stamps.view(torch.float32), N=n, H=HW, W=HW, Cin=64, Cout=64, out=bufs[i + 1], relu=True, out_mode=A._lib.OUT_NHWC)
+            else:
+                A.ops.conv_raw(bufs[i], pk, post_add=stamps.view(torch.float32), N=n, H=HW, W=HW, Cin=64, Cout=64, out=bufs[i + 1], res=bufs[i - 1], scale=0.1, out_mode=A._lib.OUT_NHWC)
+    if os.environ.get('STAMP_ODD'): NL += 1; bufs.append(torch.empty_like(x))
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
-    for _ in range(NL):
-        A.ops.conv_raw(x, pk, post_add=stamps.view(torch.float32), **KW)
+    if CHAIN: chain()
+    else:
+        for _ in range(NL):
+            A.ops.conv_raw(x, pk, post_add=stamps.view(torch.float32), **KW)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(int(os.environ.get('STAMP_WARM', '0'))): g.replay()
 torch.cuda.synchronize(); stamps.zero_(); torch.cuda.synchronize()
@@ -59,3 +72,26 @@ if t[40]:
     b = t[4]
     print(f"group 0, phase 2 (MFMA) sub-stamps, ticks from phase start: first fragments requested {t[40]-b}; K-step 1 reached {t[41]-b}; last K-step reached {t[42]-b} "
           f"({(t[42]-t[41])/ (4*34):.2f} cycles per MFMA over steps 1..34); loop left {t[43]-b}")
+
+# every workgroup's entry / exit on the 100 MHz clock, the last two launches (stamp build only)
+import numpy as np
+nl_total = int(st[255])
+if nl_total:
+    grid = nl_total // (NL)
+    if grid * NL == nl_total and grid <= 512:
+        last = ((NL - 1) & 1); prev = last ^ 1
+        def reg(k):
+            r = st[256 + k * 1024: 256 + k * 1024 + 2 * grid].reshape(grid, 2).astype(np.int64)
+            return r[:, 0], r[:, 1]
+        e1_, x1_ = reg(last); e0_, x0_ = reg(prev)
+        t0 = e0_.min()
+        f = lambda v: f"{(v - t0) / 100.0:.2f}"
+        print(f"all {grid} workgroups, us from the first entry of the launch before the last (100 MHz clock):")
+        print(f"  launch A: entries {f(e0_.min())} .. {f(e0_.max())} (median {f(np.median(e0_))}); exits {f(x0_.min())} .. {f(x0_.max())} (median {f(np.median(x0_))})")
+        print(f"  launch B: entries {f(e1_.min())} .. {f(e1_.max())} (median {f(np.median(e1_))}); exits {f(x1_.min())} .. {f(x1_.max())} (median {f(np.median(x1_))})")
+        print(f"  last exit of A -> first entry of B: {(e1_.min() - x0_.max()) / 100.0:.2f} us; workgroup residence: median {np.median(x0_ - e0_) / 100.0:.2f} us, max {(x0_ - e0_).max() / 100.0:.2f} us")
+        if os.environ.get('STAMP_WGDIST'):
+            ra, rb = (x0_ - e0_) / 100.0, (x1_ - e1_) / 100.0
+            print("  residence by XCD (block % 8), us, launch A | B: " + "; ".join(f"{k}: {np.median(ra[k::8]):.1f} [{ra[k::8].min():.1f}-{ra[k::8].max():.1f}] | {np.median(rb[k::8]):.1f} [{rb[k::8].min():.1f}-{rb[k::8].max():.1f}]" for k in range(8)))
+            print(f"  correlation of a workgroup's residence in A and in B: {np.corrcoef(ra, rb)[0, 1]:.2f}; deciles A: {np.percentile(ra, [0,10,25,50,75,90,100]).round(1).tolist()}; deciles B: {np.percentile(rb, [0,10,25,50,75,90,100]).round(1).tolist()}")
+            print(f"  entry by XCD, us after the launch's first entry (A): " + "; ".join(f"{k}: {np.median(e0_[k::8] - e0_.min())/100.0:.2f}" for k in range(8)))
