@@ -612,6 +612,107 @@ __global__ __launch_bounds__(256, 1) void wgrad1x1_ws_kernel(const srk_wgrad_arg
   }
 }
 
+// ---- at most 64 x 64 channels (the unfolded 3-channel head conv: 27 (32) x 64; RCAN / RDN never get here with fewer than 128) ---------
+// The kernel above moves 12 KB of real operands per 64-pixel tile there (6 of its 8 planes lie beyond the channel counts) and keeps ONE tile
+// in flight: 256 CUs x 12 KB per ~2 us of memory latency = 1.7 TB/s, 65.5 us for the head conv of a 256 x 48 x 48 batch (rocprofv3, round 5).
+// Same tiles, same planes, same MFMA order (bit-identical slabs), but ONE 64 x 64 block pair and a ring of NBUF tile buffers of 16 KB:
+// NBUF - 1 tiles in flight.  Every iteration requests exactly NPK pieces (tiles beyond the slot's range as out-of-range offsets: zeros
+// into a buffer nobody reads), so the counted wait in front of a tile is a constant.
+template <int DT, int NBUF>
+__global__ __launch_bounds__(256, 1) void wgrad1x1_small_kernel(const srk_wgrad_args a, int ntiles, unsigned x_bytes, unsigned dy_bytes,
+                                                                 int tq, int trem) {
+  typedef DTraits<DT> Tr;
+  constexpr int CH = Tr::CH, ESZ = 2;
+  constexpr int PLANE = 64 * 128, BUF_BYTES = 2 * PLANE, NPK = 4;
+  static_assert(Tr::IS16, "16-bit types only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = wave >> 1, cbk = wave & 1;
+  const int slot = blockIdx.x;
+  const long long P = (long long)a.N * a.H * a.W;
+  const int nch_x = a.Cin / CH, nch_d = a.Cout / CH;
+  const int t0 = slot * tq + min(slot, trem);
+  const int nt = tq + (slot < trem ? 1 : 0);
+  const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+  const int px0 = tid >> 3, sl = tid & 7;
+  const int cchunk = sl ^ swz(px0 & 15);
+  auto dma_tile = [&](int j) {                          // the slot's tile j (none: j >= nt) into ring buffer j % NBUF
+    const unsigned buf = lds0 + (unsigned)(j % NBUF) * BUF_BYTES;
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) {
+      const int plane = k >> 1;
+      const long long p = (long long)(t0 + j) * 64 + px0 + 32 * (k & 1);
+      const bool isx = plane == 0;
+      const bool ok = j < nt && p < P && cchunk < (isx ? nch_x : nch_d);
+      const unsigned voff = ok ? (unsigned)((p * (isx ? a.x_pitch : a.dy_pitch) + (isx ? a.x_coff : a.dy_coff) + cchunk * CH) * ESZ) : 0x80000000u;
+      dma16_hidden(isx ? xrs : drs, voff, (unsigned)__builtin_amdgcn_readfirstlane((int)(buf + plane * PLANE + (((k & 1) * 256 + wave * 64) << 4))));
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = a.dbp != nullptr;
+  const int aoff0 = tr_lane_off(0, 0, rb, lane), aoff1 = tr_lane_off(0, 1, rb, lane);
+  const int boff0 = tr_lane_off(0, 0, cbk, lane), boff1 = tr_lane_off(0, 1, cbk, lane);
+#pragma unroll
+  for (int j = 0; j < NBUF - 1; ++j) dma_tile(j);
+#pragma unroll 1
+  for (int it = 0; it < nt; ++it) {
+    const char* const B0 = smem + (it % NBUF) * BUF_BYTES;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * NPK) : "memory");     // tile `it` landed (the NBUF - 2 younger tiles may be on their way)
+    __builtin_amdgcn_s_barrier();                                                // ... for every wave; tile it - 1's buffer is free
+    dma_tile(it + NBUF - 1);
+    if (do_bias) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const i32x4 raw = lds_read16(B0 + PLANE + ((tid + 256 * hf) << 4));
+        const uint32_t w4[4] = {(uint32_t)raw.x, (uint32_t)raw.y, (uint32_t)raw.z, (uint32_t)raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bsum[2 * i] += Tr::to_f32((uint16_t)(w4[i] & 0xffff));
+          bsum[2 * i + 1] += Tr::to_f32((uint16_t)(w4[i] >> 16));
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const i32x4 af = tr_read2(B0 + r * 2048 + aoff0, B0 + r * 2048 + aoff1);
+      const i32x4 bf = tr_read2(B0 + PLANE + r * 2048 + boff0, B0 + PLANE + r * 2048 + boff1);
+      acc = Tr::mma(af, bf, acc);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the ring's trailing (empty) requests, before the LDS is reused below
+  {
+    const int hq = lane >> 5;
+    const size_t slab_elems = (size_t)a.Cin * a.Cout;
+    const __amdgpu_buffer_rsrc_t srs =
+        __builtin_amdgcn_make_buffer_rsrc(a.dwp + (size_t)slot * slab_elems, 0, (unsigned)(slab_elems * 4), 0x00020000);
+    const int ci0 = rb * 32 + 4 * hq, co = cbk * 32 + (lane & 31);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ci = ci0 + (e & 3) + 8 * (e >> 2);
+      const unsigned voff = (ci < a.Cin && co < a.Cout) ? (unsigned)((ci * a.Cout + co) * 4) : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[e]), srs, voff, 0, 0);
+    }
+  }
+  if (do_bias) {
+    float* const bred = reinterpret_cast<float*>(smem);      // [256][8]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bred[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 64) {
+      const int ch = tid >> 3, e = tid & 7;
+      float t = 0.f;
+      for (int p0 = 0; p0 < 32; ++p0) t += bred[((p0 << 3) + (ch ^ swz(p0 & 15))) * 8 + e];
+      if (tid < a.Cout) a.dbp[(size_t)slot * a.Cout + tid] = t;
+    }
+  }
+}
+
 // pixel slabs used by the slab-mode kernel for these arguments (0: atomic-mode kernel)
 // 1x1 slab kernel: tile shape (ci blocks x co blocks of 64) and slab count
 static void wgrad1x1_shape(const srk_wgrad_args& a, int& cib, int& cob) {
@@ -689,7 +790,24 @@ template <int DT, int CIB, int COB> int launch_1x1(const srk_wgrad_args& a, hipS
   SRK_LAUNCH_CHECK();
   return 0;
 }
+template <int DT> int launch_1x1_small(const srk_wgrad_args& a, hipStream_t st, int slabs) {
+  constexpr int NBUF = 8, LDS = NBUF * 2 * 64 * 128;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_small_kernel<DT, NBUF>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr != hipSuccess) {
+    srk_set_error("srk_conv2d_wgrad(1x1 small): cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
+    return (int)attr;
+  }
+  const long long P = (long long)a.N * a.H * a.W;
+  const long long ntiles = (P + 63) / 64;
+  hipLaunchKernelGGL((wgrad1x1_small_kernel<DT, NBUF>), dim3(slabs), dim3(256), LDS, st, a, (int)ntiles,
+                     (unsigned)(P * a.x_pitch * 2), (unsigned)(P * a.dy_pitch * 2), (int)(ntiles / slabs), (int)(ntiles % slabs));
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
 template <int DT> int launch_1x1_any(const srk_wgrad_args& a, hipStream_t st, int slabs) {
+  static const bool no_small = srk_dbg_getenv("SRK_NO_WGRAD1X1_SMALL") != nullptr;      // A/B knob, read once
+  if (a.Cin <= 64 && a.Cout <= 64 && !no_small) return launch_1x1_small<DT>(a, st, slabs);
   int cib, cob;
   wgrad1x1_shape(a, cib, cob);
   return cib == 2 ? launch_1x1<DT, 2, 4>(a, st, slabs) : launch_1x1<DT, 4, 2>(a, st, slabs);
