@@ -160,8 +160,9 @@ def _time_replays(fn, iters, sustain_s=0.0):
         fn()
     torch.cuda.current_stream().wait_stream(st)
     torch.cuda.synchronize()
+    import sr_amd as A
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with A.ops.graph_capture(g):
         for _ in range(iters):
             fn()
     g.replay()
@@ -353,8 +354,9 @@ def _replay_us(capture, sustain_s):
             capture()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    import sr_amd as A
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    with A.ops.graph_capture(g, stream=side):
         capture()
     for _ in range(2):
         g.replay()
@@ -565,7 +567,7 @@ def quick_train_rate(A, T, name, batch, patch, scale, dtype, seconds=1.5, keep_m
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    with A.ops.graph_capture(g, stream=side):
         loss = step()
     for _ in range(3):
         g.replay()
@@ -732,7 +734,7 @@ def main():
             cem = "thread_local" if ddp else "global"     # RCCL's watchdog thread polls events while this thread captures
             if mode == "full":
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side, capture_error_mode=cem):
+                with A.ops.graph_capture(g, stream=side, capture_error_mode=cem):
                     last["out"] = step()
                 graphs = (g,)
             else:
@@ -749,7 +751,7 @@ def main():
                 if hasattr(opt, "reserve_capture_tables"):
                     opt.reserve_capture_tables()
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, stream=side, capture_error_mode=cem):
+                with A.ops.graph_capture(ga, stream=side, capture_error_mode=cem):
                     opt_step()
                     last["out"] = fwd_bwd()
                     gsync.pack()

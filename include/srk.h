@@ -323,6 +323,12 @@ int srk_wgrad_finalize_group(const srk_wgrad_fin_args* table_dev, int n, int blo
 /* Copies a small HOST table (<= 4 MiB) to 16-byte-aligned DEVICE memory through kernel arguments: capturable into a
  * hipGraph (a replay rewrites the same bytes), no pinned staging buffer.                                          */
 int srk_upload_small(void* dst_dev, const void* src_host, long long nbytes, srk_stream_t stream);
+/* The same upload for a table that a hipGraph UNDER CAPTURE will own and whose memory the capture site keeps alive as long as the graph
+ * (ops.static_tables): the bytes are written once, now, on a stream of the library's own (no graph nodes); srk_upload_fence() -- after the
+ * capture has ended, before the first replay -- waits for them.  srk_upload_prepare() creates that stream and must run outside any capture. */
+int srk_upload_prepare(void);
+int srk_upload_eager(void* dst_dev, const void* src_host, long long nbytes);
+int srk_upload_fence(void);
 
 /* ---- input unfold (model boundary) -----------------------------------------------------------------
  * Head convs 3->F (edsr.py:21-22, rcan.py:92-93, rdn.py:57-58, wdsr.py:69-71) and WDSR's 5x5 skip conv

@@ -261,7 +261,7 @@ LAUNCHERS = {
 }
 OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_cus", "srk_wgrad_slabs",
                  "srk_pack_conv_weights_group", "srk_l1_blocks", "srk_wgrad_group_ok", "srk_wgrad_group_job_bytes",
-                 "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_ca_splits", "srk_chan_stats_blocks",
+                 "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_upload_prepare", "srk_upload_eager", "srk_upload_fence", "srk_ca_splits", "srk_chan_stats_blocks",
                  "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges", "srk_l1_loss_mean", "srk_chan_stats_finalize", "srk_pack_group_tiles", "srk_pack_conv_weights_group_tiled",
                  "srk_proj_pack", "srk_proj_pack_bytes", "srk_proj_wgrad_scratch_floats", "srk_proj_pack_group", "srk_wgrad_slab_cout",
                  "srk_hrtail_scratch_floats", "srk_pw_wgrad_finalize_group", "srk_adam_step_scaled", "srk_adam_check_scaled", "srk_adam_update_scaled", "srk_loss_scale_update", "srk_conv_bits_ok")
@@ -327,6 +327,13 @@ def load():
     lib.srk_rowsum_group.restype = C.c_int
     lib.srk_upload_small.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
     lib.srk_upload_small.restype = C.c_int
+    if not isinstance(getattr(lib, "srk_upload_eager", None), _Absent):
+        lib.srk_upload_prepare.argtypes = []
+        lib.srk_upload_prepare.restype = C.c_int
+        lib.srk_upload_eager.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+        lib.srk_upload_eager.restype = C.c_int
+        lib.srk_upload_fence.argtypes = []
+        lib.srk_upload_fence.restype = C.c_int
     lib.srk_chan_stats_finalize.argtypes = [C.POINTER(ChanStatsArgs), C.POINTER(ChanFinalizeArgs), C.c_void_p, C.c_void_p]
     lib.srk_chan_stats_finalize.restype = C.c_int
     lib.srk_chan_stats_blocks.argtypes = [C.c_longlong]

@@ -667,6 +667,30 @@ extern "C" int srk_upload_small(void* dst_dev, const void* src_host, long long n
   return 0;
 }
 
+// ---- the same upload, ONCE, for a table that a hipGraph under capture will own (round 5) ---------------------------------------------
+// Inside a graph the tables never change (every address a replay sees is the capture's), yet the chunks above are replayed with it: 3 launches
+// per EDSR step, 30 per RCAN step (135 us of 8.7 ms at batch 16).  A capture site that keeps the table's memory alive as long as its graph
+// (ops.static_tables) uploads through these instead: the chunks run NOW on a stream of the library's own -- not the capturing one, so they
+// do not become graph nodes --, and srk_upload_fence(), called after the capture has ended and before the first replay, waits for them.
+static hipStream_t g_upload_stream = nullptr;
+extern "C" int srk_upload_prepare(void) {            // outside any capture: creates the stream
+  if (!g_upload_stream) {
+    const hipError_t e = hipStreamCreateWithFlags(&g_upload_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_upload_stream = nullptr; srk_set_error("srk_upload_prepare: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  return 0;
+}
+extern "C" int srk_upload_eager(void* dst_dev, const void* src_host, long long nbytes) {
+  SRK_CHECK_ARG(g_upload_stream != nullptr, "srk_upload_eager: call srk_upload_prepare() first (outside the capture)");
+  return srk_upload_small(dst_dev, src_host, nbytes, reinterpret_cast<srk_stream_t>(g_upload_stream));
+}
+extern "C" int srk_upload_fence(void) {
+  if (!g_upload_stream) return 0;
+  const hipError_t e = hipStreamSynchronize(g_upload_stream);
+  if (e != hipSuccess) { srk_set_error("srk_upload_fence: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
 extern "C" int srk_wgrad_finalize_group(const srk_wgrad_fin_args* table_dev, int n, int blocks_per_job, srk_stream_t stream) {
   SRK_CHECK_ARG(table_dev && n > 0 && n <= 65535, "srk_wgrad_finalize_group: bad table (%d entries)", n);
   const int bx = blocks_per_job < 1 ? 1 : (blocks_per_job > 2048 ? 2048 : blocks_per_job);

@@ -11,6 +11,7 @@ cached per parameter version.
 Nothing here falls back to PyTorch arithmetic: every op raises if the tensors are
 not on a GPU or the HIP library is missing.
 """
+import contextlib
 import os
 
 import torch
@@ -656,6 +657,87 @@ def _arm_flush():
     return True
 
 
+class TableHolder:
+    """Owns the device tables (job descriptors of the grouped launches) of hipGraphs captured under `static_tables`: keep it alive as
+    long as the graphs, call `fence()` after the capture(s) and before the first replay."""
+
+    ARENA_BYTES = 1 << 20
+
+    def __init__(self):
+        self.tables = []
+        self.arena = None          # allocated by static_tables() OUTSIDE the capture: see take()
+        self.used = 0
+
+    def take(self, nbytes):
+        """`nbytes` of the arena (16-byte aligned), or None when it is full.  NOT memory of the graph's own pool: an allocation made
+        during the capture may reuse the address of an earlier temporary of the same graph, whose writer node would overwrite the
+        table in every replay (the in-graph upload sits behind that writer; a table written once does not)."""
+        n = (int(nbytes) + 15) // 16 * 16
+        if self.arena is None or self.used + n > self.arena.numel():
+            return None
+        t = self.arena[self.used:self.used + n]
+        self.used += n
+        self.tables.append(t)
+        return t
+
+    def fence(self):
+        if self.tables:
+            L.check(L.load().srk_upload_fence(), "srk_upload_fence")
+
+
+class _StaticTables:
+    holder = None
+
+
+@contextlib.contextmanager
+def static_tables(holder):
+    """Capture sites that own their graphs wrap the capture in this: the descriptor tables of the grouped launches (weight gradients,
+    finalizes, row sums, weight normalisation) are then written ONCE, at capture time, instead of by upload launches inside the graph
+    (3 per EDSR step, 30 per RCAN step at batch 16: include/srk.h, srk_upload_eager).  Valid because every address a replay sees is the
+    capture's; the holder keeps the tables' memory from being reused inside the graph's pool.  Foreign captures (a user's own
+    torch.cuda.graph around a step) keep the in-graph uploads."""
+    ok = _STATIC_TABLES
+    if ok:
+        try:
+            L.check(L.load().srk_upload_prepare(), "srk_upload_prepare")
+        except RuntimeError:          # an older library loaded through SRK_LIB_PATH (A/B runs)
+            ok = False
+    if ok and holder.arena is None and not torch.cuda.is_current_stream_capturing():
+        holder.arena = torch.empty(holder.ARENA_BYTES, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+    prev, _StaticTables.holder = _StaticTables.holder, (holder if ok else None)
+    try:
+        yield holder
+    finally:
+        _StaticTables.holder = prev
+
+
+@contextlib.contextmanager
+def graph_capture(g, **kw):
+    """`torch.cuda.graph(g, **kw)` for a graph whose owner is this package: the grouped launches' tables are static (static_tables),
+    kept alive by the graph object itself."""
+    holder = TableHolder()
+    try:
+        with static_tables(holder):
+            with torch.cuda.graph(g, **kw):
+                yield holder
+    finally:
+        holder.fence()
+    g._srk_tables = holder
+
+
+def _upload_table(host_addr, nbytes, alloc, dev, st):
+    """Host bytes -> a fresh device table of `alloc` bytes on stream `st` (see static_tables)."""
+    h = _StaticTables.holder
+    if h is not None and h.arena is not None and h.arena.device == torch.device(dev) and torch.cuda.is_current_stream_capturing():
+        table = h.take(alloc)
+        if table is not None:
+            L.check(L.load().srk_upload_eager(table.data_ptr(), host_addr, nbytes), "srk_upload_eager")
+            return table
+    table = torch.empty(alloc, dtype=torch.uint8, device=dev)
+    L.check(L.load().srk_upload_small(table.data_ptr(), host_addr, nbytes, st), "srk_upload_small")
+    return table
+
+
 def _launch_rowsums(rjobs, st):
     import ctypes as C
     n = len(rjobs)
@@ -663,8 +745,7 @@ def _launch_rowsums(rjobs, st):
     for i, j in enumerate(rjobs):
         host[i].src, host[i].dst, host[i].n, host[i].k = j["src"].data_ptr(), j["dst"], j["n"], j["k"]
     nbytes = C.sizeof(L.RowsumJob) * n
-    table = torch.empty(_roundup(nbytes, 16), dtype=torch.uint8, device=rjobs[0]["src"].device)
-    L.check(L.load().srk_upload_small(table.data_ptr(), C.addressof(host), nbytes, st), "srk_upload_small")
+    table = _upload_table(C.addressof(host), nbytes, _roundup(nbytes, 16), rjobs[0]["src"].device, st)
     L.check(L.load().srk_rowsum_group(table.data_ptr(), n, max(j["k"] for j in rjobs), st), "srk_rowsum_group")
 
 
@@ -674,8 +755,7 @@ def _launch_pw_finalize(pwjobs, st):
     n = len(pwjobs)
     host = (L.PwWgradArgs * n)(*[j["a"] for j in pwjobs])
     nbytes = C.sizeof(L.PwWgradArgs) * n
-    table = torch.empty(_roundup(nbytes, 16), dtype=torch.uint8, device=pwjobs[0]["keep"][0].device)
-    L.check(L.load().srk_upload_small(table.data_ptr(), C.addressof(host), nbytes, st), "srk_upload_small")
+    table = _upload_table(C.addressof(host), nbytes, _roundup(nbytes, 16), pwjobs[0]["keep"][0].device, st)
     items = max((j["a"].Chid * (j["a"].Cin + j["a"].CoutP)) // 4 + j["a"].Chid + j["a"].CoutP for j in pwjobs)
     bpj = max(1, min((items + 255) // 256, 256))           # one item per thread: the launch is a 30 MB-per-job read, latency-bound with fewer blocks
     L.check(L.load().srk_pw_wgrad_finalize_group(table.data_ptr(), n, bpj, st), "srk_pw_wgrad_finalize_group")
@@ -794,8 +874,7 @@ def flush_wgrads():
                                     KH=3, KW=3, CinP=a.Cin, CoutP=a.Cout, ps_r=f["ps_r"], scale=f["scale"], accumulate=f["acc"])
                 C.memmove(base + off_fin + pos * fin_sz, C.addressof(fa), fin_sz)
                 rounds.setdefault(f["round"], [pos, 0])[1] += 1
-            table = torch.empty(total, dtype=torch.uint8, device=dev)
-            L.check(lib.srk_upload_small(table.data_ptr(), base, total, st), "srk_upload_small")
+            table = _upload_table(base, total, total, dev, st)
             L.check(lib.srk_conv2d_wgrad_group(table.data_ptr(), table.data_ptr() + off_bj, nblocks.value, dt, st), "srk_conv2d_wgrad_group")
             # workgroups per job: one per (2 input channels x 64 output channels) tile of the largest job, 32..256
             tiles = max(((a_.Cin + 1) // 2) * ((a_.Cout + 63) // 64) for a_ in arr)
@@ -962,6 +1041,7 @@ def _f32c(t):
 # autograd Functions
 # --------------------------------------------------------------------------------------------
 _RES_LINK = _knob("SRK_NO_RES_LINK", "0") != "1"        # A/B knob
+_STATIC_TABLES = _knob("SRK_NO_STATIC_TABLES", "0") != "1"      # A/B knob: descriptor tables written once per captured graph (static_tables)
 
 
 class ResLink:
@@ -1502,9 +1582,8 @@ class WeightNormGroup:
             if backward:
                 j.dw, j.dv, j.dg = dws[i].data_ptr(), dv.data_ptr() + 4 * off, dg.data_ptr() + 4 * r0
         nbytes = C.sizeof(L.WnJob) * n
-        table = torch.empty(_roundup(nbytes, 16), dtype=torch.uint8, device=params[0].device)
         st = _stream()
-        L.check(L.load().srk_upload_small(table.data_ptr(), C.addressof(host), nbytes, st), "srk_upload_small")
+        table = _upload_table(C.addressof(host), nbytes, _roundup(nbytes, 16), params[0].device, st)
         L.check(L.load().srk_weight_norm_group(table.data_ptr(), n, self.rows, 1 if backward else 0, st), "srk_weight_norm_group")
 
     def weights(self):

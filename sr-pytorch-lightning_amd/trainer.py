@@ -367,6 +367,7 @@ class GraphedStep:
             self.opt.step(grad_scaler=self.scaler)
 
     def _capture(self, batch):
+        from . import ops
         self.static = {"lr": batch["lr"].clone(), "hr": batch["hr"].clone()}
         self.hyper = self._hyper()
         if hasattr(self.opt, "reserve_capture_tables"):
@@ -378,7 +379,7 @@ class GraphedStep:
         cem = "thread_local" if self.gsync is not None else "global"      # RCCL's watchdog polls events while this thread captures
         if self.gsync is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, capture_error_mode=cem):
+            with ops.graph_capture(g, stream=side, capture_error_mode=cem):
                 self.loss = self._fwd_bwd()
                 self._opt_step()
             self.graphs = (g,)
@@ -397,7 +398,7 @@ class GraphedStep:
             torch.cuda.synchronize()
             side.wait_stream(torch.cuda.current_stream())
             ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, stream=side, capture_error_mode=cem):
+            with ops.graph_capture(ga, stream=side, capture_error_mode=cem):
                 self._opt_step()
                 self.loss = self._fwd_bwd()
                 self.gsync.pack()
@@ -644,7 +645,7 @@ class OverlappedGraphStep:
         side.wait_stream(torch.cuda.current_stream())
         self.opt.zero_grad(set_to_none=True)
         gf = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gf, stream=side, capture_error_mode=capture_error_mode):
+        with ops.graph_capture(gf, stream=side, capture_error_mode=capture_error_mode):
             loss, rec = self._forward(self.static, self.every)
         pool = gf.pool()
         graphs = [gf]
@@ -652,7 +653,7 @@ class OverlappedGraphStep:
         nseg = len(cuts) + 1
         for k in range(nseg):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, pool=pool, capture_error_mode=capture_error_mode):
+            with ops.graph_capture(g, stream=side, pool=pool, capture_error_mode=capture_error_mode):
                 if k == 0:
                     loss.backward()
                 else:
