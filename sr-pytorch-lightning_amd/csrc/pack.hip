@@ -178,11 +178,15 @@ __global__ void pack_group_kernel(const srk_pack_args* __restrict__ table) {
 // attempt at LDS staging gave every block of a (tiles x entries) grid a whole CU's LDS and lost).  Entries the tile form does not
 // cover (more than 9 taps, fp32, a pixel-shuffle permutation on a dgrad layout) get 16 blocks of pack_body.
 constexpr int PT_CO = 16, PT_CI = 64, PT_PITCH = PT_CI * 9 + 1;
+#ifndef SRK_PACK_TILED_MAX
+#define SRK_PACK_TILED_MAX (1024LL * 1024)
+#endif
 
-// (layers beyond 128 x 128 channels keep pack_body too: its 4,096 threads per entry are busy there, and measured the tile form
-// LOSES on them -- EDSR-large 1,376 -> 1,353 patches/s with every layer tiled; RCAN's 829 small layouts gain: 1,647 -> 1,689)
+// (round 3 kept layers beyond 128 x 128 channels on pack_body -- measured then, the tile form LOST on them (EDSR-large 1,376 -> 1,353 patches/s).
+// What lost was the tile form's gather loop, one load in flight per thread; with nine (pack_tile) the tile form wins there too: EDSR-large's
+// launch 214 -> 186 us, RDN's 112 -> 106 us on one box (tools/microbench_packgroup.py), so every 16-bit layout of at most 9 taps is tiled now)
 __host__ __device__ inline bool pack_tiled_ok(const srk_pack_args& a) {
-  return a.KH * a.KW <= 9 && a.dtype != SRK_F32 && !(a.dgrad && a.ps_r > 1) && (long long)a.Cout * a.Cin <= 128LL * 128;
+  return a.KH * a.KW <= 9 && a.dtype != SRK_F32 && !(a.dgrad && a.ps_r > 1) && (long long)a.Cout * a.Cin <= SRK_PACK_TILED_MAX;
 }
 // workgroups of pack_body for an entry the tile form does not take: one (row, 8-channel chunk) item of a 3x3 layout -- 72 strided loads --
 // per thread (EDSR-large's 256 -> 256 layers: 8,192 items; with 16 workgroups per entry every thread walked two of them, one behind the
@@ -211,9 +215,17 @@ template <int DT> __device__ void pack_tile(const srk_pack_args& a, int t, float
   const int co0 = cog * PT_CO, ci0 = cig * PT_CI;
   const int nco = min(PT_CO, a.Cout - co0), nci = min(PT_CI, a.Cin - ci0);
   const int run = nci * taps;                                    // contiguous floats per output channel
-  for (int i = threadIdx.x; i < nco * run; i += blockDim.x) {
-    const int r16 = i / run, j = i - r16 * run;
-    tile[r16 * PT_PITCH + j] = a.w[((size_t)(co0 + r16) * a.Cin + ci0) * taps + j];
+  // one wave per output channel at a time, NINE loads in flight per lane before the first LDS store (round 5: the loop this replaces had a
+  // division per element and, with its run-time trip count, one load in flight per thread -- 36 memory latencies in a row per tile)
+  for (int r16 = threadIdx.x >> 6; r16 < nco; r16 += 4) {
+    const float* const src = a.w + ((size_t)(co0 + r16) * a.Cin + ci0) * taps;
+    const int j0 = threadIdx.x & 63;
+    float tmp[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tmp[k] = j0 + 64 * k < run ? src[j0 + 64 * k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      if (j0 + 64 * k < run) tile[r16 * PT_PITCH + j0 + 64 * k] = tmp[k];
   }
   __syncthreads();
   const int nch = a.KinP / 8;
