@@ -67,7 +67,21 @@ SRK_DEV float collapse_w(const Wts& p, int sub, int o, int a, int b, int ci, int
       if (ex < -1 || ex > 1) continue;
       const float* wt = p.wt + (size_t)o * p.C * 9 + (dy + 1) * 3 + (dx + 1);
       const float* wu = p.wu + ((size_t)(i * 2 + j) * p.Ci + ci) * 9 + (ey + 1) * 3 + (ex + 1);
-      for (int c = sub; c < p.C; c += 16) acc += wt[(size_t)c * 9] * wu[(size_t)c * 4 * p.Ci * 9];
+      // (same order of additions as `for (c = sub; c < C; c += 16) acc += wt[..] * wu[..]`, but the eight loads of four channels are
+      // requested together: with the run-time trip count one pair was in flight at a time, and the kernel was ~36 L2 latencies long)
+      for (int c0 = sub; c0 < p.C; c0 += 64) {
+        float x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = c0 + 16 * k;
+          const bool ok = c < p.C;
+          x[k] = ok ? wt[(size_t)c * 9] : 0.f;
+          y[k] = ok ? wu[(size_t)c * 4 * p.Ci * 9] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (c0 + 16 * k < p.C) acc += x[k] * y[k];
+      }
     }
   }
   return sum16(acc);
