@@ -127,7 +127,7 @@ def test_wdsr_b_finalizes_all_pointwise_pairs_with_one_launch(A, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", [(2, 3, 48, 48), (3, 3, 17, 23), (1, 3, 1, 5)])
+@pytest.mark.parametrize("shape", [(90, 3, 48, 48), (2, 3, 48, 48), (29, 3, 83, 85), (1, 3, 1, 5)])    # >= 200k pixels: the per-pixel kernel
 def test_head_unfold_one_thread_per_pixel_is_exact(A, dtype, shape):
     """The 3-channel 3x3 im2col of the head conv (edsr.py:41-44 with sub_mean, common.py:58-71) has its own kernel (one thread per pixel, 64
     bytes per store group): the values are (x - mean) rounded once to the storage type, zeros outside the image and in channels 27..31, in
