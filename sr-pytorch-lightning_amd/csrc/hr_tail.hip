@@ -181,25 +181,55 @@ SRK_DEV EdgeGeo edge_geo(int ty, int H, int W) {
   e.fix_hr = ty == 0 ? 0 : ty == 1 ? 2 * H - 1 : ty == 2 ? 0 : 2 * W - 1;
   return e;
 }
+// n floats from global memory to LDS by a 256-thread workgroup, EIGHT loads in flight per thread (the plain strided loop keeps one: its
+// trip count is a run-time value; 1,920 edge weights were 8 memory latencies in a row at the head of every edge kernel)
+SRK_DEV void stage_copy256(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  int i = threadIdx.x;
+  for (; i + 256 * 7 < n; i += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[i + 256 * k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[i + 256 * k] = v[k];
+  }
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = i + 256 * k < n ? src[i + 256 * k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (i + 256 * k < n) dst[i + 256 * k] = v[k];
+}
 // stage the line of X: Xl[(s + 2) * pitch + ci], s = -2 .. len + 1 (zeros outside); 16-byte loads (8 channels) where the layout allows
 template <int DT>
 SRK_DEV void stage_line(const srk_hrtail_args& a, const EdgeGeo& e, int n, float* Xl, int pitch) {
   typedef DTraits<DT> Tr;
   const int Ci = a.Ci;
   if ((Ci & 7) == 0 && (a.x_pitch & 7) == 0) {
-    const int nch = Ci >> 3;
-    for (int i = threadIdx.x; i < (e.len + 4) * nch; i += 256) {
-      const int sp = i / nch, c8 = i - sp * nch, s = sp - 2;
-      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (s >= 0 && s < e.len) {
-        const int yy = e.row ? e.fix_lr : s, xx = e.row ? s : e.fix_lr;
-        const i32x4 raw = gload16(reinterpret_cast<const typename Tr::elem*>(a.x) + ((size_t)(n * a.H + yy) * a.W + xx) * a.x_pitch + c8 * 8);
-        const int w4[4] = {raw.x, raw.y, raw.z, raw.w};
+    const int nch = Ci >> 3, total = (e.len + 4) * nch;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 4) {          // four 16-byte loads in flight per thread
+      i32x4 raw[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) unpack2<DT>((uint32_t)w4[k], v[2 * k], v[2 * k + 1]);
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        const int sp = i / nch, c8 = i - sp * nch, s = sp - 2;
+        raw[u] = i32x4{0, 0, 0, 0};
+        if (i < total && s >= 0 && s < e.len) {
+          const int yy = e.row ? e.fix_lr : s, xx = e.row ? s : e.fix_lr;
+          raw[u] = gload16(reinterpret_cast<const typename Tr::elem*>(a.x) + ((size_t)(n * a.H + yy) * a.W + xx) * a.x_pitch + c8 * 8);
+        }
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) Xl[sp * pitch + c8 * 8 + k] = v[k];
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        if (i >= total) continue;
+        const int sp = i / nch, c8 = i - sp * nch;
+        const int w4[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) unpack2<DT>((uint32_t)w4[k], v[2 * k], v[2 * k + 1]);     // (16 zero bits unpack to 0.0 in both 16-bit types)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Xl[sp * pitch + c8 * 8 + k] = v[k];
+      }
     }
     return;
   }
@@ -224,7 +254,7 @@ __global__ __launch_bounds__(256) void hrtail_edge_fwd_kernel(const srk_hrtail_a
   float* const Xl = reinterpret_cast<float*>(smem_raw);           // [len + 4][Ci + 1]
   float* const Wl = Xl + (size_t)(e.len + 4) * pitch;             // [2 O][Ci][5]
   stage_line<DT>(a, e, n, Xl, pitch);
-  for (int i = threadIdx.x; i < 2 * O * Ci * 5; i += 256) Wl[i] = a.wedge[(size_t)e.ty * 2 * O * Ci * 5 + i];
+  stage_copy256(Wl, a.wedge + (size_t)e.ty * 2 * O * Ci * 5, 2 * O * Ci * 5);
   __syncthreads();
   const size_t oplane = (size_t)H2 * W2;
   float* const out = a.out + (size_t)n * O * oplane;
@@ -274,13 +304,21 @@ __global__ __launch_bounds__(256) void hrtail_edge_bwd_x_kernel(const srk_hrtail
   float* const Gl = reinterpret_cast<float*>(smem_raw);           // [2 O][len + 4]: g of sub-pixel row kk along the line, zeros outside
   float* const Wl = Gl + (size_t)2 * O * (e.len + 4);             // [2 O][Ci][5]
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * O * (e.len + 4); i += 256) {
-    const int kk = i / (e.len + 4), s = i % (e.len + 4) - 2, o = kk >> 1, q = kk & 1;
-    float v = 0.f;
-    if (s >= 0 && s < e.len) v = e.row ? g[(size_t)o * gplane + (size_t)e.fix_hr * W2 + 2 * s + q] : g[(size_t)o * gplane + (size_t)(2 * s + q) * W2 + e.fix_hr];
-    Gl[i] = v;
+  for (int i0 = threadIdx.x; i0 < 2 * O * (e.len + 4); i0 += 256 * 4) {      // four loads in flight per thread
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u;
+      const int kk = i / (e.len + 4), s = i % (e.len + 4) - 2, o = kk >> 1, q = kk & 1;
+      v[u] = 0.f;
+      if (i < 2 * O * (e.len + 4) && s >= 0 && s < e.len)
+        v[u] = e.row ? g[(size_t)o * gplane + (size_t)e.fix_hr * W2 + 2 * s + q] : g[(size_t)o * gplane + (size_t)(2 * s + q) * W2 + e.fix_hr];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + 256 * u < 2 * O * (e.len + 4)) Gl[i0 + 256 * u] = v[u];
   }
-  for (int i = threadIdx.x; i < 2 * O * Ci * 5; i += 256) Wl[i] = a.wedge[(size_t)e.ty * 2 * O * Ci * 5 + i];
+  stage_copy256(Wl, a.wedge + (size_t)e.ty * 2 * O * Ci * 5, 2 * O * Ci * 5);
   __syncthreads();
   // one thread = 8 channels of one pixel: ONE 16-byte read-modify-write of dX (2-byte scalar updates were 24 dependent global round
   // trips per thread)
