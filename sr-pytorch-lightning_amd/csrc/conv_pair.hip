@@ -72,6 +72,17 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   unsigned long long* const stamp = (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && (tid & 255) == 0) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.b2)) + (wave >> 2) * 32 : nullptr;
 #define SRK_PSTAMP(i) do { if (stamp) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
   const float* const bias2 = nullptr;
+  // every workgroup: entry / exit on the constant 100 MHz clock, [64 + (launch & 1) * 1024 + 2 * block + {0, 1}], launch index from an arrival counter at [63]
+  unsigned long long* wg_slot = nullptr;
+  {
+    unsigned long long* const wgst = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.b2));
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    if (tid == 0 && nwg <= 512) {
+      const unsigned long long c = atomicAdd(wgst + 63, 1ull);
+      wg_slot = wgst + 64 + ((c / nwg) & 1) * 1024 + 2 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+      wg_slot[0] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
 #else
 #define SRK_PSTAMP(i) do { } while (0)
   const float* const bias2 = a.b2;
@@ -877,6 +888,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   SRK_PSTAMP(11);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   SRK_PSTAMP(12);
+  if (wg_slot) wg_slot[1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
