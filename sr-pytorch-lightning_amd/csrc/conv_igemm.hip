@@ -16,9 +16,10 @@
 #include <stdlib.h>
 #include "srk_common.h"
 
-// timing-experiment knob (separate builds only; measured again in round 5 with all-workgroup stamps: sc1 stores shorten the dead time
-// between two dependent launches from 3.8 to 1.8 us (no write-back at the kernel's end) and one flavour ALONE by 2 %, but a training
-// step, whose launches are bound by memory throughput, by nothing: plain stores stay)
+// store policy of the conv epilogues (16 = sc1, write-through).  Plain stores leave the output dirty in the XCDs' L2s until the kernel's end; the
+// write-back then sits in front of the NEXT launch (all-workgroup stamps: 3.8 -> 1.8 us between two dependent launches).  At batch 256 the step's
+// launches are bound by memory throughput and gain nothing (+0.2 %); a chain of small launches gains what the write-back cost per link: EDSR-baseline
+// batch 64 30.4k -> 32.0k patches/s, RDN batch 16 +1.3 %, same box (conv_pair.hip: RCAN batch 16 +7.6 %).  -DSRK_ST_AUX=0 / 2 (nt) for A/B builds.
 #ifndef SRK_WS_STAMPS
 #define SRK_WS_STAMPS 0
 #endif
@@ -26,7 +27,7 @@
 #define SRK_WS_ABLATE 0        // timing ablations (wrong results): 1 = skip MFMAs, 2 = skip epilogue, 4 = skip halo DMA, 16 = no weight-order rotation
 #endif
 #ifndef SRK_ST_AUX
-#define SRK_ST_AUX 0          // cache policy of the quad epilogue's stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#define SRK_ST_AUX 16         // cache policy of the quad epilogue's stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
 
 namespace {
@@ -211,7 +212,7 @@ template <int DT> SRK_DEV void buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned vo
   if constexpr (Tr::IS16) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, 0);
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, SRK_ST_AUX);
       unpack2<DT>(raw.x, q[8 * t + 0], q[8 * t + 1]);
       unpack2<DT>(raw.y, q[8 * t + 2], q[8 * t + 3]);
       unpack2<DT>(raw.z, q[8 * t + 4], q[8 * t + 5]);
@@ -220,7 +221,7 @@ template <int DT> SRK_DEV void buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned vo
   } else {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, 0);
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, SRK_ST_AUX);
       q[4 * t + 0] = __uint_as_float(raw.x); q[4 * t + 1] = __uint_as_float(raw.y);
       q[4 * t + 2] = __uint_as_float(raw.z); q[4 * t + 3] = __uint_as_float(raw.w);
     }
@@ -238,7 +239,7 @@ template <int DT> SRK_DEV void buf_store16(__amdgpu_buffer_rsrc_t rs, unsigned v
       raw.z = pack2<DT>(v[8 * t + 4], v[8 * t + 5]);
       raw.w = pack2<DT>(v[8 * t + 6], v[8 * t + 7]);
       if (relu_packed) { raw.x = relu_pk16(raw.x); raw.y = relu_pk16(raw.y); raw.z = relu_pk16(raw.z); raw.w = relu_pk16(raw.w); }
-      __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff + imm_bytes + 16 * t, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff + imm_bytes + 16 * t, 0, SRK_ST_AUX);
     }
   } else {
 #pragma unroll
@@ -246,7 +247,7 @@ template <int DT> SRK_DEV void buf_store16(__amdgpu_buffer_rsrc_t rs, unsigned v
       u32x4 raw;
       raw.x = __float_as_uint(v[4 * t + 0]); raw.y = __float_as_uint(v[4 * t + 1]);
       raw.z = __float_as_uint(v[4 * t + 2]); raw.w = __float_as_uint(v[4 * t + 3]);
-      __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff + imm_bytes + 16 * t, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff + imm_bytes + 16 * t, 0, SRK_ST_AUX);
     }
   }
 }
@@ -358,7 +359,7 @@ SRK_DEV void conv_epilogue_planar4(const srk_conv_args& a, f32x16 (&acc)[1][PB_W
       if (relu) v = fmaxf(v, 0.f);
       v = v * scale + q[pb][e];
       v += pa[e];
-      if (e < a.Cout) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vo[pb][e], 0, 0);
+      if (e < a.Cout) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vo[pb][e], 0, SRK_ST_AUX);
     }
 }
 
@@ -438,7 +439,7 @@ SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int
         }
         const bool ok = (okm >> qi) & 1;
         const unsigned off = ok ? (unsigned)(((pbase + qi * pstep) * 2 + hbit) * 4) : SRK_OOB;
-        __builtin_amdgcn_raw_buffer_store_b32(word, big_rsrc(a.relu_bits), off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(word, big_rsrc(a.relu_bits), off, 0, SRK_ST_AUX);
       }
       quad_transpose8_dpp(P[0][0], P[1][0], P[2][0], P[3][0], P[0][1], P[1][1], P[2][1], P[3][1]);
       quad_transpose8_dpp(P[0][2], P[1][2], P[2][2], P[3][2], P[0][3], P[1][3], P[2][3], P[3][3]);

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
         // (fused PixelShuffle(r) store: packed channel co' = (i*r+j)*Cc + c goes to pixel (gy*r+i, gx*r+j), channel c)
         const int opix = orr == 1 ? (n * H + gy) * W + gx : (n * H * orr + gy * orr + osi) * (W * orr) + gx * orr + osj;
         const unsigned vo = ok ? (unsigned)((opix * a.out_pitch + a.out_coff + ocb + c * Tr::CH) * 2) : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, SRK_AUX_WT);
       }
     }
   };

@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void lk5_fwd_kernel(const srk_conv_args a, int
             v.x = __float_as_uint(acc[pb][o * 4 + i * 2] * sc + pa[o]);
             v.y = __float_as_uint(acc[pb][o * 4 + i * 2 + 1] * sc + pa[o]);
             const unsigned off = ok ? (unsigned)((((n * O + o) * H2 + 2 * gy + i) * W2 + 2 * gx) * 4) : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b64(v, orsrc, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(v, orsrc, off, 0, SRK_AUX_WT);
           }
         }
       }
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(NW * 64) void lk5_rows_fwd_kernel(const srk_conv_ar
         v.x = __float_as_uint((ev[o * 2] + bias6[o * 2]) * sc + pa3[o]);
         v.y = __float_as_uint((ev[o * 2 + 1] + bias6[o * 2 + 1]) * sc + pa3[o]);
         const unsigned off = (ok && o < O) ? (unsigned)((((n * O + o) * H2 + 2 * gyp + h) * W2 + 2 * (x0 + r)) * 4) : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b64(v, orsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, orsrc, off, 0, SRK_AUX_WT);
       }
     };
     auto step = [&](int s, auto epi_tag) {
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256) void lk5_dgrad_kernel(const srk_conv_args a, i
       const bool ok = gyp < ye && gxq + j < W;
       const unsigned off = (unsigned)((((n * H + gyp) * W + gxq + j) * a.out_pitch + a.out_coff + 32 * h + 8 * qi) * 2);
       const u32x4_t ov = {P[j][0], P[j][1], P[j][2], P[j][3]};
-      __builtin_amdgcn_raw_buffer_store_b128(ov, orsrc, ok ? off : 0x80000000u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ov, orsrc, ok ? off : 0x80000000u, 0, SRK_AUX_WT);
     };
     auto step = [&](int s, auto epi_tag) {
       constexpr bool EPI = decltype(epi_tag)::value;

@@ -32,6 +32,12 @@
 #ifndef SRK_PAIR_PD
 #define SRK_PAIR_PD 2
 #endif
+#ifndef SRK_PAIR_ST_AUX
+#define SRK_PAIR_ST_AUX 16      // cache policy of the tile stores (gfx940+: 16 = sc1, write-through).  With plain stores the tiles sit dirty in the XCDs' L2s
+                                // and are written back when the kernel ends -- ~1 us in front of the NEXT launch of a chain of dependent launches, which at the
+                                // batch sizes this kernel serves is all the step is (all-workgroup stamps: 3.0 us between last exit and next entry).
+                                // Same box, batch 16: RCAN 2,014 / 2,024 -> 2,168 / 2,176 patches/s, EDSR-baseline 19.25k / 19.29k -> 20.31k / 20.13k.
+#endif
 
 namespace {
 
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
         const i32x4 q = lds_read16(Xs + (((row + 2) * C::XP + col + 2) << 7) + ((c ^ swz(col + 2)) << 4));
         const unsigned vo = ok ? (unsigned)((((n * H + gy) * W + gx) * a.xo_pitch + a.xo_coff + c * Tr::CH) * 2) : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, SRK_PAIR_ST_AUX);
       }
     }
   }
@@ -815,7 +821,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         const bool ok = i < C::TO * C::TO * 8 && gy < H && gx < W;
         const i32x4 q = lds_read16(Ms + (((row + 1) * C::MP + col + 1) << 7) + ((c ^ swz(col + 1)) << 4));
         const unsigned vo = ok ? (unsigned)((((n * H + gy) * W + gx) * a.mid_pitch + a.mid_coff + c * Tr::CH) * 2) : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, vo, 0, SRK_PAIR_ST_AUX);
       }
     }
     // b2 (+ residual tile) have landed; the copy's seven stores (the youngest operations) may still be on their way -- waiting for
@@ -836,7 +842,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
     for (int k = 0; k < 4; ++k) {
       const bool ok = out_off[k] != 0x80000000u;
       const i32x4 q = lds_read16(Xs + out_lds[k]);
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, out_off[k], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w}, ro, out_off[k], 0, SRK_PAIR_ST_AUX);
       if (a.pool && ok) {
         const int qw[4] = {q.x, q.y, q.z, q.w};
         const uint32_t aw[4] = {au[k].x, au[k].y, au[k].z, au[k].w};

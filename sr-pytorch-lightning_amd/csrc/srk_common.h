@@ -127,6 +127,11 @@ SRK_DEV i32x4 make_rsrc4(const void* base, unsigned bytes) {
 SRK_DEV unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
+// Store policy "write-through" (sc1) for the buffer-store builtins' `aux` operand.  A kernel's plain stores leave their lines dirty in the XCDs' L2s;
+// they are written back when the kernel ends, in front of the next launch -- ~1-2 us that a chain of small dependent launches pays per link
+// (round 5: all-workgroup stamps).  The conv kernels hand their activations to the next launch this way.  (Measured and NOT
+// used in pw_chain.hip: WDSR-B 1.5 % slower with it at batch 16 and 256.)
+constexpr int SRK_AUX_WT = 16;          // the same policy for the buffer-store builtins' `aux` operand
 SRK_DEV void dma16_hidden(i32x4 rsrc, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                :: "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory", "m0");
