@@ -44,10 +44,31 @@ def halves_deep():
             block(acts[2 * k][s], acts[2 * k + 1][s], acts[2 * k + 2][s], m)
 
 
-for name, fn in (("whole batch per launch", whole), ("two half-batches per block", halves), ("half A through the trunk, then half B", halves_deep)):
-    fn(); torch.cuda.synchronize()
+S2 = torch.cuda.Stream()
+
+
+def halves_two_streams():
+    """half A's trunk and half B's trunk as two branches of the graph (fork / join by events): two chains of dependent launches that can
+    fill each other's launch boundaries -- a workgroup needs a whole CU's LDS, so B's workgroups take the CUs A's leave"""
+    m = a.n // 2
+    s1 = torch.cuda.current_stream()
+    ev = torch.cuda.Event(); ev.record(s1); S2.wait_event(ev)
+    with torch.cuda.stream(S2):
+        for k in range(a.blocks):
+            block(acts[2 * k][m:], acts[2 * k + 1][m:], acts[2 * k + 2][m:], a.n - m)
+    for k in range(a.blocks):
+        block(acts[2 * k][:m], acts[2 * k + 1][:m], acts[2 * k + 2][:m], m)
+    ev2 = torch.cuda.Event(); ev2.record(S2); s1.wait_event(ev2)
+
+
+for name, fn in (("whole batch per launch", whole), ("two half-batches per block", halves), ("half A through the trunk, then half B", halves_deep),
+                 ("half A and half B as two streams of the graph", halves_two_streams)):
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=side):
         fn()
     for _ in range(3):
         g.replay()
