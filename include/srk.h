@@ -124,6 +124,23 @@ int srk_conv2d(const srk_conv_args* a, srk_stream_t stream);
 /* channel tile (32/64/128) the launcher uses for a given number of output channels */
 int srk_conv_tile(int Cout);
 
+/* ---- a CHAIN of 3x3 64->64 convolutions in ONE launch, image by image (large batches) -------------------------------
+ * Replaces, where the batch fills the chip with whole images (N a multiple of the CU count), the sequence of srk_conv2d launches
+ * of a residual trunk -- the 2 x n_resblocks + 1 convolutions of EDSR's body (models/edsr.py:24-31,44-47; ResBlock:
+ * models/common.py:74-109) in the forward pass and, given data-gradient packs, their data gradients in the backward pass.
+ * A 'same' convolution of an image reads that image only, so the workgroup that owns an image runs the layers on it back
+ * to back with no launch boundary and no synchronisation with other workgroups.
+ *   layers_host[l] : the arguments srk_conv2d would get for layer l (layer l + 1 normally reads layer l's `out`; `res`,
+ *                    `relu_bits`, `mask_bits` may name any buffer written by an EARLIER layer or before the launch);
+ *   table_dev      : the same nlayers structs in device memory (srk_upload_small / srk_upload_eager), read by the kernel.
+ * Every layer: 16-bit, 3x3, Cin = Cout = CoutP = 64, NHWC output, no pixel shuffle, no `mask` (sign bits only), no
+ * post_add; all layers the same N, H, W, dtype and x_pitch.  A layer with KH = KW = 0 is the elementwise `out = x + res` on dense
+ * 64-channel tensors (fp32 add, rounded once: the two gradient contributions of a long skip, models/edsr.py:46-47).
+ * srk_conv_trunk_ok says whether a table qualifies (0: issue the layers as srk_conv2d launches).  Results are bit-identical to
+ * those launches.                                                                                                          */
+int srk_conv_trunk_ok(const srk_conv_args* layers_host, int nlayers);
+int srk_conv_trunk(const srk_conv_args* layers_host, const void* table_dev, int nlayers, srk_stream_t stream);
+
 /* ---- two chained 3x3 64->64 convolutions in one launch (small batches) ---------------------------
  * Replaces, at the reference's batch of 16 where a layer is one tile per CU and launches dominate, the conv pair of
  * ResBlock (models/common.py:74-109: conv, ReLU, conv, `* res_scale`, `res += x`) and of RCAB (models/rcan.py:33-55),

@@ -264,7 +264,8 @@ OTHER_SYMBOLS = ("srk_conv_tile", "srk_last_error", "srk_version", "srk_device_c
                  "srk_wgrad_group_plan", "srk_conv2d_wgrad_group", "srk_wgrad_finalize_group", "srk_upload_small", "srk_upload_prepare", "srk_upload_eager", "srk_upload_fence", "srk_ca_splits", "srk_chan_stats_blocks",
                  "srk_conv_pair_tiles", "srk_rowsum_group", "srk_pw_shape_ok", "srk_pw_pack_bytes", "srk_pw_pack_group", "srk_weight_norm_group", "srk_pw_wgrad_ranges", "srk_l1_loss_mean", "srk_chan_stats_finalize", "srk_pack_group_tiles", "srk_pack_conv_weights_group_tiled",
                  "srk_proj_pack", "srk_proj_pack_bytes", "srk_proj_wgrad_scratch_floats", "srk_proj_pack_group", "srk_wgrad_slab_cout",
-                 "srk_hrtail_scratch_floats", "srk_pw_wgrad_finalize_group", "srk_adam_step_scaled", "srk_adam_check_scaled", "srk_adam_update_scaled", "srk_loss_scale_update", "srk_conv_bits_ok")
+                 "srk_hrtail_scratch_floats", "srk_pw_wgrad_finalize_group", "srk_adam_step_scaled", "srk_adam_check_scaled", "srk_adam_update_scaled", "srk_loss_scale_update", "srk_conv_bits_ok",
+                 "srk_conv_trunk", "srk_conv_trunk_ok")
 
 _lib = None
 
@@ -365,6 +366,10 @@ def load():
     lib.srk_hrtail_scratch_floats.restype = C.c_longlong
     lib.srk_conv_bits_ok.argtypes = [C.POINTER(ConvArgs)]
     lib.srk_conv_bits_ok.restype = C.c_int
+    lib.srk_conv_trunk_ok.argtypes = [C.POINTER(ConvArgs), C.c_int]
+    lib.srk_conv_trunk_ok.restype = C.c_int
+    lib.srk_conv_trunk.argtypes = [C.POINTER(ConvArgs), C.c_void_p, C.c_int, C.c_void_p]
+    lib.srk_conv_trunk.restype = C.c_int
     lib.srk_adam_step_scaled.argtypes = [C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]
     lib.srk_adam_step_scaled.restype = C.c_int
     for fn in (lib.srk_adam_check_scaled, lib.srk_adam_update_scaled):

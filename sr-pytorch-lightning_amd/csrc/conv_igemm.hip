@@ -26,6 +26,12 @@
 #ifndef SRK_WS_ABLATE
 #define SRK_WS_ABLATE 0        // timing ablations (wrong results): 1 = skip MFMAs, 2 = skip epilogue, 4 = skip halo DMA, 16 = no weight-order rotation
 #endif
+#ifndef SRK_WS_PRIO_M
+#define SRK_WS_PRIO_M 1       // s_setprio of a wave in its MFMA phase / its epilogue phase (A/B builds)
+#endif
+#ifndef SRK_WS_PRIO_E
+#define SRK_WS_PRIO_E 0
+#endif
 #ifndef SRK_ST_AUX
 #define SRK_ST_AUX 16         // cache policy of the quad epilogue's stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
@@ -605,16 +611,19 @@ SRK_DEV void quad_compute_t(float scale, f32x16 (&acc)[2][2], int pb, const Quad
 #pragma unroll
       for (int x = 0; x < 8; ++x) v[x] = fmaxf(v[x], 0.f);
     }
+    // scalar v_mul_f32 / v_add_f32 from inline asm: left to hipcc, adjacent elements are SLP-packed into v_pk_mul_f32 / v_pk_add_f32, and a packed
+    // f32 instruction beside the partner wave's MFMAs costs ~13 cycles more than a scalar one (MI355X_MICROARCH.md, constants table: "an
+    // anti-lever beside MFMAs"); same roundings (one multiply, one add).  Residual flavour alone 45.8 -> 43.9 us (profiles/r6_ab_noslp.txt)
     if constexpr (SC) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) v[x] *= scale;
+      for (int x = 0; x < 8; ++x) asm("v_mul_f32_e32 %0, %1, %0" : "+v"(v[x]) : "s"(scale));
     }
     if constexpr (EM == 1) {
       float r8[8];
       unpack2<DT>(e.r[k].x, r8[0], r8[1]); unpack2<DT>(e.r[k].y, r8[2], r8[3]);
       unpack2<DT>(e.r[k].z, r8[4], r8[5]); unpack2<DT>(e.r[k].w, r8[6], r8[7]);
 #pragma unroll
-      for (int x = 0; x < 8; ++x) v[x] += r8[x];
+      for (int x = 0; x < 8; ++x) asm("v_add_f32_e32 %0, %1, %0" : "+v"(v[x]) : "v"(r8[x]));
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) P[k][d] = pack2<DT>(v[2 * d], v[2 * d + 1]);
@@ -895,10 +904,12 @@ SRK_DEV void grp_barrier(unsigned addr, unsigned target, int lane) {
   while (grp_peek(addr) < target) __builtin_amdgcn_s_sleep(1);
 }
 
+// The body of the weight-stationary kernel for ONE contiguous range of tiles [t0, t0 + nt) of channel tile `ctile`: called once per
+// launch by conv_ws_kernel and once per (image, layer) by conv_trunk_kernel (below).  Every wave of the workgroup must call it with the
+// same arguments; on return the last tile's 8 stores per lane may still be in flight.
 template <int DT, int CBW, int NKS, bool FAST, bool EARLY, int EM>
-__global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
-                                                          int nptiles, unsigned x_bytes, int tq, int trem, int /*unused*/,
-                                                          int xs_img, int xs_row, int xs_col, int wtap) {
+SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ctile, int t0, int nt, unsigned x_bytes,
+                          int xs_img, int xs_row, int xs_col, int wtap, const int tid) {
   // wtap: 16-byte chunks per tap in the packed weight buffer (8 for Cin = 64; 8*r*r when this launch handles one
   // 64-channel K-block of a wider reduction, a.wpk then points at that block's first chunk)
   // xs_img / xs_row / xs_col: element strides of the input between images, rows and columns of the conv-space grid
@@ -933,7 +944,6 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   }
 #endif
 
-  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, w4 = wave & 3;
@@ -944,12 +954,6 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
   const elem* const wg = reinterpret_cast<const elem*>(a.wpk);
   char* const Xg = smem + WPIECES * 16 + grp * C::XS_BYTES;
 
-  // (tq, trem) = divmod(nptiles, slots) from the host: slot s owns tq tiles, +1 for the first trem slots
-  const unsigned slot = blockIdx.x / (unsigned)ctiles;
-  const int ctile = (int)(blockIdx.x - slot * (unsigned)ctiles);
-  const int t0 = (int)slot * tq + min((int)slot, trem);
-  const int nt = tq + ((int)slot < trem ? 1 : 0);
-  if (nt <= 0) return;
   const int nj = (nt - grp + 1) >> 1;          // tiles of this group: t0 + 2j + grp
   const int nph = 2 * ((nt + 1) >> 1) + 1;     // phases (group 0 has the most tiles)
 
@@ -1241,7 +1245,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
         frag(1, fa[1], fb0[1], fb1[1]);
         QuadPre pre;
         if constexpr (EARLY) pre = EM == 3 ? quad_early_setup_bits(a, quad_geo(j), qi, h) : quad_early_setup(a, quad_geo(j), qi);     // behind the first LDS reads: overlaps their latency
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(SRK_WS_PRIO_M);
 #if SRK_WS_STAMPS
         if (p == 2) SRK_STAMP(40);
 #endif
@@ -1283,7 +1287,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(SRK_WS_PRIO_E);
 #if SRK_WS_STAMPS
         if (p == 2) SRK_STAMP(43);
 #endif
@@ -1383,6 +1387,72 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
     stamp[104] = tA; stamp[105] = tB; stamp[106] = tC; stamp[107] = tD;
   }
 #endif
+}
+
+template <int DT, int CBW, int NKS, bool FAST, bool EARLY, int EM>
+__global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, int tilesX, int tilesY, int ctiles,
+                                                          int nptiles, unsigned x_bytes, int tq, int trem, int /*unused*/,
+                                                          int xs_img, int xs_row, int xs_col, int wtap) {
+  // (tq, trem) = divmod(nptiles, slots) from the host: slot s owns tq tiles, +1 for the first trem slots
+  const unsigned slot = blockIdx.x / (unsigned)ctiles;
+  const int ctile = (int)(blockIdx.x - slot * (unsigned)ctiles);
+  const int t0 = (int)slot * tq + min((int)slot, trem);
+  const int nt = tq + ((int)slot < trem ? 1 : 0);
+  if (nt <= 0) return;
+  conv_ws_body<DT, CBW, NKS, FAST, EARLY, EM>(a, tilesX, tilesY, ctile, t0, nt, x_bytes, xs_img, xs_row, xs_col, wtap, (int)threadIdx.x);
+}
+
+// ---- image-stationary persistent trunk: a CHAIN of 3x3 64 -> 64 convolutions in ONE launch (srk_conv_trunk, include/srk.h) -------------
+// A 'same' convolution of one image needs that image only, so a workgroup that owns an image can run layer l + 1 on it as soon as it
+// has stored layer l itself: no launch boundary (entry ramp 3.2 us, 3.8 us between the last exit and the next entry, every workgroup
+// waiting for the launch's slowest one: DESIGN.md 3.17) and no synchronisation with any other workgroup.  Workgroup b walks the images
+// b, b + grid, ...; for each image the layers of the table in order, each with the weight-stationary body above (a layer is what one
+// conv_ws_kernel launch does for that image's tiles: same code, same results, bit for bit).  Between two layers: the workgroup's own
+// stores complete (vmcnt(0); they are write-through, sc1) and one workgroup barrier -- the workgroup-scope release / acquire of the gfx942+
+// memory model: an image's bytes are written and read by ONE CU, whose vector L1 is coherent with its own stores.  (No `buffer_inv sc1`:
+// at agent scope it also drops the XCD's L2 lines, 33 times per image: 46.9 instead of 41.2 us per convolution.)  The table lives in
+// device memory; a layer's arguments are scalar loads.  A layer with KH = 0 is `out = x + res` on the image (the long skip's gradient).
+template <int DT>
+__global__ __launch_bounds__(512, 2) void conv_trunk_kernel(const srk_conv_args* __restrict__ tab, int nlayers, int nimages, int tilesX,
+                                                             int tilesY, unsigned x_bytes) {
+  const int tpi = tilesX * tilesY;
+#pragma unroll 1
+  for (int n = (int)blockIdx.x; n < nimages; n += (int)gridDim.x) {
+#pragma unroll 1
+    for (int l = 0; l < nlayers; ++l) {
+      const srk_conv_args a = tab[l];
+      // an opaque copy of the thread index per layer: every per-lane constant of a body derives from it, so none of them is hoisted
+      // out of the layer loop (hoisted, the three bodies' constants are live together: 86 registers spilled)
+      int tid = (int)threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      const int xs_col = a.x_pitch, xs_row = a.W * a.x_pitch, xs_img = a.H * a.W * a.x_pitch;
+      if (a.KH == 0) {
+        // pseudo-layer `out = x + res` on this image (the long skip's gradient: the two contributions to the trunk input's gradient,
+        // models/edsr.py:46-47 backward): fp32 add of the two 16-bit values, rounded once -- what torch's add does
+        const int npc = a.H * a.W * 8;                                   // 16-byte pieces of the image
+        const uint4* const px = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.x) + (size_t)n * npc * 16);
+        const uint4* const pr = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.res) + (size_t)n * npc * 16);
+        uint4* const po = reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out) + (size_t)n * npc * 16);
+        for (int i = tid; i < npc; i += 512) {
+          const uint4 u = px[i], v = pr[i];
+          const uint32_t uu[4] = {u.x, u.y, u.z, u.w}, vv[4] = {v.x, v.y, v.z, v.w};
+          uint32_t oo[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float a0, a1, b0, b1;
+            unpack2<DT>(uu[k], a0, a1);
+            unpack2<DT>(vv[k], b0, b1);
+            oo[k] = pack2<DT>(a0 + b0, a1 + b1);
+          }
+          po[i] = uint4{oo[0], oo[1], oo[2], oo[3]};
+        }
+      } else if (a.mask_bits) conv_ws_body<DT, 2, 4, true, true, 3>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid);
+      else if (a.res) conv_ws_body<DT, 2, 4, true, true, 1>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid);
+      else conv_ws_body<DT, 2, 4, true, false, 0>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
 }
 
 // launcher-side preconditions of conv_epilogue_fast
@@ -1543,6 +1613,57 @@ static bool conv_bits_ok(const srk_conv_args& a) {
   return true;
 }
 extern "C" int srk_conv_bits_ok(const srk_conv_args* a) { return a && conv_bits_ok(*a) ? 1 : 0; }
+
+// one layer of a trunk table: exactly what dispatch_tc sends to launch_ws<DT, 2, 4, true> with one of the three flavours conv_trunk_kernel holds
+static bool conv_trunk_layer_ok(const srk_conv_args& a, const srk_conv_args& a0) {
+  if (a.dtype != a0.dtype || a.N != a0.N || a.H != a0.H || a.W != a0.W) return false;
+  if (a.KH == 0)      // pseudo-layer out = x + res: dense 64-channel tensors
+    return a.KW == 0 && a.x && a.res && a.out && a.x_pitch == 64 && a.res_pitch == 64 && a.out_pitch == 64 && !a.x_coff && !a.res_coff && !a.out_coff &&
+           a.dtype != SRK_F32 && !a.mask && !a.mask_bits && !a.relu_bits && !a.post_add;
+  if (a.dtype == SRK_F32 || a.KH != 3 || a.KW != 3 || a.Cin != 64 || a.CoutP != 64 || a.Cout != 64 || a.x_ps > 1) return false;
+  if (a.out_mode != SRK_OUT_NHWC || a.ps_r > 1 || a.post_add || a.mask || a.x_coff % 8 || a.x_pitch % 8) return false;
+  if (!a.x || !a.wpk || !a.out || !conv_fast_ok(a, 2)) return false;
+  if (((long long)a.N * a.H * a.W * a.x_pitch) * 2 >= 0x7fffffffLL || (long long)a.N * a.H * a.W * 8 >= 0x7fffffffLL) return false;
+  if (a.relu_bits && !(a.relu && !a.res && a.scale == 1.f)) return false;
+  if (a.mask_bits && (a.res || a.relu_bits)) return false;
+  if (a.x_pitch != a0.x_pitch) return false;                      // one buffer size (x_bytes) for the whole chain
+  return true;
+}
+extern "C" int srk_conv_trunk_ok(const srk_conv_args* layers, int nlayers) {
+  if (!layers || nlayers < 1) return 0;
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  static const bool off = srk_dbg_getenv("SRK_NO_TRUNK") != nullptr;      // diagnostics knob, read once
+  if (off) return 0;
+  // every CU one image at a time: worth it when the batch fills the chip in whole rounds (else the per-layer launches balance better)
+  if (layers[0].N < cus || layers[0].N % cus != 0) return 0;
+  for (int l = 0; l < nlayers; ++l)
+    if (!conv_trunk_layer_ok(layers[l], layers[0])) return 0;
+  return 1;
+}
+extern "C" int srk_conv_trunk(const srk_conv_args* layers_host, const void* table_dev, int nlayers, srk_stream_t stream) {
+  SRK_CHECK_ARG(layers_host && table_dev && nlayers >= 1, "srk_conv_trunk: null table / no layers");
+  SRK_CHECK_ARG(srk_conv_trunk_ok(layers_host, nlayers), "srk_conv_trunk: a layer is not a 16-bit 3x3 64 -> 64 NHWC convolution of the chain's shape, "
+                "or the batch is not a multiple of the CU count (srk_conv_trunk_ok)");
+  const srk_conv_args& a = layers_host[0];
+  static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
+  const unsigned xb = (unsigned)(((long long)a.N * a.H * a.W * a.x_pitch) * 2);
+  const unsigned grid = (unsigned)(a.N < cus ? a.N : cus);
+  constexpr int LDS = 9 * 2 * 4 * 64 * 16 + 2 * WsCfg::XS_BYTES + 64 * 4 + 16;      // as launch_ws_one<.., 2, 4, ..>
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const srk_conv_args* tab = reinterpret_cast<const srk_conv_args*>(table_dev);
+  if (a.dtype == SRK_BF16) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_kernel<SRK_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (attr != hipSuccess) { srk_set_error("srk_conv_trunk: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr)); return (int)attr; }
+    hipLaunchKernelGGL((conv_trunk_kernel<SRK_BF16>), dim3(grid), dim3(WsCfg::NT), LDS, st, tab, nlayers, a.N, tilesX, tilesY, xb);
+  } else {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_kernel<SRK_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (attr != hipSuccess) { srk_set_error("srk_conv_trunk: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr)); return (int)attr; }
+    hipLaunchKernelGGL((conv_trunk_kernel<SRK_F16>), dim3(grid), dim3(WsCfg::NT), LDS, st, tab, nlayers, a.N, tilesX, tilesY, xb);
+  }
+  SRK_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int srk_conv_tile(int Cout) {
   if (Cout <= 32) return 32;

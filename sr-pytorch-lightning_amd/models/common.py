@@ -154,6 +154,13 @@ class ResBlock(_NCHWContract, nn.Module):
     def _cout(self):
         return self.body[0].out_channels
 
+    def plain_convs(self):
+        """[(w1, b1), (w2, b2)] when the block is conv -> ReLU -> conv (EDSR's form), else None: what ops.res_trunk takes."""
+        mods = list(self.body)
+        if len(mods) == 3 and isinstance(mods[0], nn.Conv2d) and isinstance(mods[1], nn.ReLU) and isinstance(mods[2], nn.Conv2d):
+            return [(mods[0].weight, mods[0].bias), (mods[2].weight, mods[2].bias)]
+        return None
+
     def nhwc(self, x):
         mods = list(self.body)
         convs = [m for m in mods if isinstance(m, nn.Conv2d)]

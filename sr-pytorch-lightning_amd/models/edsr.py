@@ -27,10 +27,17 @@ class EDSR(SRModel):
     def body_nhwc(self, f):
         """The residual trunk on NHWC features (edsr.py:44-47): `res = body(x); res += x`.  Its own method so that bench.py can time the
         trunk's launches in the order, with the buffers and in the autograd mode of a training step (`roofline.in_step`)."""
+        blocks = list(self.body)[:-1]
+        tail = self.body[-1]
+        specs = [blk.plain_convs() for blk in blocks]
+        if all(sp is not None for sp in specs) and len({blk.res_scale for blk in blocks}) == 1:
+            # a batch that fills the chip with whole images: the whole trunk is ONE launch per direction (ops.ResTrunkFn)
+            if ops.res_trunk_ok(f, specs, (tail.weight, tail.bias)):
+                return ops.res_trunk(f, specs, (tail.weight, tail.bias), scale=blocks[0].res_scale)
         r = f
-        for blk in list(self.body)[:-1]:
+        for blk in blocks:
             r = ops.cut(blk.nhwc(r))
-        return self.body[-1].nhwc(r, res=f)                      # body conv fused with `res += x` (edsr.py:46-47)
+        return tail.nhwc(r, res=f)                               # body conv fused with `res += x` (edsr.py:46-47)
 
     def body_conv_launches(self):
         """(3x3 F -> F convolutions of the trunk per forward pass, F)"""

@@ -1444,6 +1444,152 @@ def conv_chain(x, convs, relus, scale=1.0):
 
 
 # --------------------------------------------------------------------------------------------
+# a whole residual trunk per launch (csrc/conv_igemm.hip: conv_trunk_kernel; include/srk.h: srk_conv_trunk)
+# --------------------------------------------------------------------------------------------
+_TRUNK_OFF = _knob("SRK_NO_TRUNK", "0") == "1"       # A/B knob: the trunk as one srk_conv2d launch per convolution
+
+
+def _trunk_layer(x, pk, out, *, relu=False, scale=1.0, res=None, relu_bits=None, mask_bits=None, use_bias=True):
+    n, h, w, _ = x.shape
+    return L.ConvArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, x_ps=0, N=n, H=h, W=w, Cin=64, wpk=pk.wpk.data_ptr(),
+                      bias=_ptr(pk.bias) if use_bias else 0, CoutP=pk.CoutP, Cout=64, KH=3, KW=3, relu=int(relu), scale=float(scale), res=_ptr(res),
+                      res_pitch=0 if res is None else _pitch(res), res_coff=0, mask=0, mask_pitch=0, mask_coff=0, mask_from=0, out=out.data_ptr(),
+                      out_pitch=_pitch(out), out_coff=0, out_mode=L.OUT_NHWC, ps_r=0, post_add=0, dtype=_DT[x.dtype], cout_real=0,
+                      relu_bits=_ptr(relu_bits), mask_bits=_ptr(mask_bits))
+
+
+def _trunk_add_layer(x, res, out):
+    n, h, w, _ = x.shape
+    return L.ConvArgs(x=x.data_ptr(), x_pitch=64, x_coff=0, x_ps=0, N=n, H=h, W=w, Cin=64, wpk=0, bias=0, CoutP=64, Cout=64, KH=0, KW=0, relu=0, scale=1.0,
+                      res=res.data_ptr(), res_pitch=64, res_coff=0, mask=0, mask_pitch=0, mask_coff=0, mask_from=0, out=out.data_ptr(), out_pitch=64,
+                      out_coff=0, out_mode=L.OUT_NHWC, ps_r=0, post_add=0, dtype=_DT[x.dtype], cout_real=0, relu_bits=0, mask_bits=0)
+
+
+def _trunk_launch(layers, dev):
+    """The table of `layers` (ConvArgs) to the device, one srk_conv_trunk launch.  False (nothing launched) when the table does not qualify."""
+    import ctypes as C
+    nl = len(layers)
+    host = (L.ConvArgs * nl)(*layers)
+    lib = L.load()
+    if not lib.srk_conv_trunk_ok(host, nl):
+        return False
+    st = _stream()
+    nbytes = C.sizeof(L.ConvArgs) * nl
+    table = _upload_table(C.addressof(host), nbytes, _roundup(nbytes, 16), dev, st)
+    L.check(lib.srk_conv_trunk(host, table.data_ptr(), nl, st), "srk_conv_trunk")
+    return True
+
+
+def res_trunk_ok(x, blocks, tail):
+    """EDSR's body -- ResBlocks of two 3x3 F -> F convs with a ReLU between, then one more conv and the long skip -- as ONE launch: 16-bit
+    NHWC features with F = 64, a batch that is a whole number of rounds over the CUs, not while a segmented backward is being recorded
+    (its cuts lie between the blocks)."""
+    if _TRUNK_OFF or not _SIGN_BITS or getattr(_TLS, "seg", None) is not None or not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    if x.dim() != 4 or x.shape[3] != 64 or not x.is_contiguous() or not blocks:
+        return False
+    cus = L.load().srk_device_cus()
+    if cus <= 0 or x.shape[0] < cus or x.shape[0] % cus != 0 or _batch_chunks(x.shape[0], x) != 1:
+        return False
+    ws = [w for blk in blocks for (w, _b) in blk] + [tail[0]]
+    return all(len(blk) == 2 for blk in blocks) and all(tuple(w.shape) == (64, 64, 3, 3) for w in ws)
+
+
+class ResTrunkFn(torch.autograd.Function):
+    """r = conv_f(B_n(... B_1(x))) + x with B_i(t) = t + scale * conv_2(relu(conv_1(t))): EDSR's body (models/edsr.py:24-31,44-47; ResBlock:
+    models/common.py:74-109).  Forward: ONE srk_conv_trunk launch (2 n + 1 layers per image, back to back on the CU that owns the image);
+    backward: ONE launch for the 2 n + 1 data gradients and the long skip's add, the weight gradients queued as usual.  Saved: the block
+    inputs, the post-ReLU activations and their sign bits -- what the per-block ConvChainFn saves.  Bit-identical to the per-layer launches."""
+
+    @staticmethod
+    def forward(ctx, x, scale, nb, *params):
+        _need_gpu(x)
+        dt, dev = x.dtype, x.device
+        n, h, wd, _ = x.shape
+        ws, bs = params[0::2], params[1::2]
+        train = any(ctx.needs_input_grad)
+        xs, hs, bits, layers = [x], [], [], []
+        spare = []                                   # no gradient wanted: three buffers rotate (no layer writes a buffer it reads)
+
+        def take():
+            return spare.pop() if spare else torch.empty_like(x)
+        cur = x
+        for b in range(nb):
+            hb, xo = take(), take()
+            bt = torch.empty((n * h * wd, 2), dtype=torch.int32, device=dev) if train else None
+            layers.append(_trunk_layer(cur, pack_conv(ws[2 * b], bs[2 * b], dt), hb, relu=True, relu_bits=bt))
+            layers.append(_trunk_layer(hb, pack_conv(ws[2 * b + 1], bs[2 * b + 1], dt), xo, scale=scale, res=cur))
+            if train:
+                xs.append(xo)
+                hs.append(hb)
+                bits.append(bt)
+            else:
+                spare.append(hb)
+                if cur is not x:
+                    spare.append(cur)
+            cur = xo
+        out = take()
+        layers.append(_trunk_layer(cur, pack_conv(ws[2 * nb], bs[2 * nb], dt), out, res=x))
+        if not _trunk_launch(layers, dev):
+            raise RuntimeError("ResTrunkFn: srk_conv_trunk_ok refused a table res_trunk_ok had accepted")
+        if train:
+            ctx.save_for_backward(*xs, *hs, *ws)
+            ctx.bits = bits
+            ctx.cfg = (float(scale), int(nb), tuple(b is not None for b in bs))
+            ctx.wb = (tuple(ws), tuple(bs))
+            ctx.pg = _tok()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, nb, has_b = ctx.cfg
+        sv = ctx.saved_tensors
+        xs, hs, ws = sv[:nb + 1], sv[nb + 1:2 * nb + 1], sv[2 * nb + 1:]
+        g = g.contiguous()
+        dt, dev = g.dtype, g.device
+        n, h, wd, _ = g.shape
+        need_x = bool(ctx.needs_input_grad[0])
+
+        def pkd(w):
+            return pack_conv(w, None, dt, dgrad=True, token=ctx.pg)
+        gxs = [None] * (nb + 1)                        # gxs[b]: gradient of block b's input (gxs[nb]: of the last conv's input)
+        ghs = [None] * nb
+        gxs[nb] = torch.empty_like(g)
+        layers = [_trunk_layer(g, pkd(ws[2 * nb]), gxs[nb], use_bias=False)]
+        for b in range(nb - 1, -1, -1):
+            ghs[b] = torch.empty_like(g)
+            layers.append(_trunk_layer(gxs[b + 1], pkd(ws[2 * b + 1]), ghs[b], scale=scale, mask_bits=ctx.bits[b], use_bias=False))
+            if b > 0 or need_x:
+                gxs[b] = torch.empty_like(g)
+                layers.append(_trunk_layer(ghs[b], pkd(ws[2 * b]), gxs[b], res=gxs[b + 1], use_bias=False))
+        gx = None
+        if need_x:
+            gx = torch.empty_like(g)
+            layers.append(_trunk_add_layer(gxs[0], g, gx))          # the long skip: d r / d x = (chain) + identity
+        if not _trunk_launch(layers, dev):
+            raise RuntimeError("ResTrunkFn.backward: srk_conv_trunk_ok refused the data-gradient table")
+        grads = [None] * (2 * (2 * nb + 1))
+        jobs = [(2 * nb, xs[nb], g, 1.0)]
+        for b in range(nb - 1, -1, -1):
+            jobs += [(2 * b + 1, hs[b], gxs[b + 1], scale), (2 * b, xs[b], ghs[b], 1.0)]
+        for i, a_in, dy, sc in jobs:
+            if ctx.needs_input_grad[3 + 2 * i]:
+                grads[2 * i], grads[2 * i + 1] = wgrad(a_in, dy, wparam=ctx.wb[0][i], bparam=ctx.wb[1][i], N=n, H=h, W=wd, Cin=64, Cout=64, k=3,
+                                                       w_shape=(64, 64, 3, 3), scale=sc, want_bias=has_b[i])
+        return (gx, None, None, *grads)
+
+
+def res_trunk(x, blocks, tail, scale=1.0):
+    """blocks: [((w1, b1), (w2, b2)), ...]; tail: (w, b).  Call only when res_trunk_ok(x, blocks, tail)."""
+    flat = []
+    for blk in blocks:
+        for w, b in blk:
+            flat += [w, b]
+    flat += [tail[0], tail[1]]
+    return ResTrunkFn.apply(x, float(scale), len(blocks), *flat)
+
+
+# --------------------------------------------------------------------------------------------
 # backward in SEGMENTS (multi-GPU: a bucket's all-reduce can start while the rest of backward still runs, also when the
 # step is replayed from hipGraphs -- a capture cannot be switched from inside `backward()`, so the cut has to be in the graph)
 # --------------------------------------------------------------------------------------------
