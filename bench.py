@@ -380,6 +380,13 @@ def _replay_us(capture, sustain_s):
     return us
 
 
+def _uses_trunk(ops, model, f0):
+    blocks = list(model.body)[:-1]
+    specs = [blk.plain_convs() if hasattr(blk, "plain_convs") else None for blk in blocks]
+    tail = model.body[-1]
+    return all(sp is not None for sp in specs) and hasattr(ops, "res_trunk_ok") and bool(ops.res_trunk_ok(f0, specs, (tail.weight, tail.bias)))
+
+
 def in_step_body(A, model, batch, patch, dtype, sustain_s=0.6):
     """The dominant kernel family WHERE IT LIVES: the residual trunk of the benched model -- `model.body_nhwc`,
     the code its forward runs -- as it runs inside a training step: autograd recording (the conv + ReLU launches store their sign
@@ -435,12 +442,17 @@ def in_step_body(A, model, batch, patch, dtype, sustain_s=0.6):
     # at small batches (ops.pair_ok) one launch carries TWO of the trunk's convolutions (csrc/conv_pair.hip): per-launch = 2 x per-conv
     wprobe = torch.empty(feats, feats, 3, 3, device=dev)
     cpl = 2 if (feats == 64 and ops.pair_ok(f0, wprobe, wprobe)) else 1
+    # a batch of whole rounds over the CUs (ops.res_trunk_ok): the trunk is ONE image-stationary launch per direction (csrc/conv_igemm.hip,
+    # conv_trunk_kernel: n_conv layers per launch, + the long skip's elementwise add in the backward one) -- F and FB - F are one launch each
+    trunk = type(model).__name__ == "EDSR" and feats == 64 and _uses_trunk(ops, model, f0)
+    if trunk:
+        cpl = n_conv
     # the same launches against the OTHER roofline: a 64 -> 64 3x3 convolution on bf16 sits at the ridge (2 x 64 x 64 x 9 FLOP over 2 x 64 x 2
     # bytes per pixel = 288 FLOP/B against 2.5 PFLOP/s / 8 TB/s = 312), and the flavours that also read a residual (every second forward
     # launch, every second data gradient) below it: 192 FLOP/B.  EDSR's trunk: per ResBlock forward 2 + 3 activation tensors, backward
     # 2 (+ the sign bits, 1/16) + 3, the trunk's last convolution 3 forward (long skip) and 2 backward.
     hbm = None
-    if type(model).__name__ == "EDSR" and cpl == 1:
+    if type(model).__name__ == "EDSR" and (cpl == 1 or trunk):
         T = px * feats * 2.0
         nb = (n_conv - 1) // 2
         tot_b = (nb * 5 + 3) * T + (nb * (5 + 1.0 / 16) + 2) * T
@@ -450,7 +462,7 @@ def in_step_body(A, model, batch, patch, dtype, sustain_s=0.6):
                "note": "activation tensors each launch must read and write once (input, output, residual where the flavour has one, sign bits), "
                        "averaged over the trunk's forward + data-gradient launches; below the ridge, so by the roofline model these launches are "
                        "bound by HBM, not by the matrix pipes"}
-    return {"convs": 2 * n_conv, "convs_per_launch": cpl, "us_per_conv": round(fam_us, 2), "us_per_launch": round(fam_us * cpl, 2), "hbm_view": hbm,
+    return {"convs": 2 * n_conv, "convs_per_launch": cpl, "launch": "conv_trunk_kernel" if trunk else None, "us_per_conv": round(fam_us, 2), "us_per_launch": round(fam_us * cpl, 2), "hbm_view": hbm,
             "flops_per_launch": flops * cpl,
             "fwd_us_per_conv": round((t_f - t_p) / n_conv, 2), "dgrad_us_per_conv": round((t_fb - t_f) / n_conv, 2),
             "wgrad_us_per_layer": round((t_fbw - t_fb) / n_conv, 2),
@@ -515,6 +527,9 @@ def dominant_kernel_roofline(A, model_name, batch, patch, feats, dtype, iters=10
     if in_step is not None:
         # the ONE fraction of the line: the family's launches inside the step (in_step_body), executed = algorithmic FLOPs per launch
         ach = in_step["flops_per_launch"] / (in_step["us_per_launch"] * 1e-6) / 1e12
+        if in_step.get("launch"):
+            r["kernel"] = (f"{in_step['launch']}: the trunk's {in_step['convs_per_launch']} 3x3 {feats}->{feats} convolutions per direction in ONE image-stationary "
+                           f"launch, each layer the body of conv_ws_kernel (csrc/conv_igemm.hip) @{patch}x{patch} x{batch} ({dtype})")
         r.update({"achieved": round(ach, 2), "frac": round(ach / peak, 4), "us_per_launch": in_step["us_per_launch"],
                   "flops_per_launch": in_step["flops_per_launch"], "algorithmic_GBps": round(alg_bytes / (in_step["us_per_launch"] * 1e-6) / 1e9, 1),
                   "where": f"IN THE STEP: average over the {in_step['convs']} forward + data-gradient 3x3 convolutions of the trunk "
@@ -622,14 +637,15 @@ def main():
         # share one (a launcher that leaves LOCAL_RANK unset, or a HIP_VISIBLE_DEVICES mask, would silently stack the ranks on cuda:0
         # and the "N-GPU" number would be an N-process number).  On failure EVERY rank says what it sees and the job exits non-zero.
         pr = torch.cuda.get_device_properties(local)
-        mine = {"rank": rank, "local_rank": local, "current_device": torch.cuda.current_device(),
+        import socket
+        mine = {"rank": rank, "local_rank": local, "host": socket.gethostname(), "current_device": torch.cuda.current_device(),
                 "pci": (getattr(pr, "pci_domain_id", None), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None)),
                 "uuid": str(getattr(pr, "uuid", "")), "visible": torch.cuda.device_count(), "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
         seen = [None] * world
         dist.all_gather_object(seen, mine)
         # two ranks share a GPU only if EVERYTHING they report about it is equal (device index in the process's visible set, PCI address,
         # uuid): attributes a driver build leaves empty or equal for all devices can then never turn N good ranks into a false alarm
-        ids = [(d["current_device"], d["visible"], tuple(d["pci"]), d["uuid"]) for d in seen]
+        ids = [(d["host"], d["current_device"], d["visible"], tuple(d["pci"]), d["uuid"]) for d in seen]      # (only ranks of one host can collide)
         if len(set(ids)) != world or mine["rccl_ranks"] != world:
             print(f"[bench] rank {rank}: ranks do not sit on {world} distinct GPUs -- this rank: {mine}; all: {ids}", file=sys.stderr, flush=True)
             sys.exit(3)

@@ -15,7 +15,8 @@
  *  - Return value: 0 on success, otherwise a hipError_t or a negative SRK_E_* code;
  *    `srk_last_error()` returns a thread-local message.  No exceptions cross the ABI.
  *  - Launchers are re-entrant and hold no mutable global state (autograd calls
- *    backward from another thread).
+ *    backward from another thread).  The one exception is write-once and
+ *    mutex-guarded: the per-device upload stream of srk_upload_prepare / _eager / _fence.
  *  - Activations are NHWC with an explicit pixel pitch and channel offset (both in
  *    elements) so that a conv can read / write a channel slice of a wider buffer
  *    (RDN dense blocks, models/rdn.py:21).  Channel counts seen by the MFMA kernels are
@@ -342,7 +343,9 @@ int srk_wgrad_finalize_group(const srk_wgrad_fin_args* table_dev, int n, int blo
 int srk_upload_small(void* dst_dev, const void* src_host, long long nbytes, srk_stream_t stream);
 /* The same upload for a table that a hipGraph UNDER CAPTURE will own and whose memory the capture site keeps alive as long as the graph
  * (ops.static_tables): the bytes are written once, now, on a stream of the library's own (no graph nodes); srk_upload_fence() -- after the
- * capture has ended, before the first replay -- waits for them.  srk_upload_prepare() creates that stream and must run outside any capture. */
+ * capture has ended, before the first replay -- waits for them.  srk_upload_prepare() creates that stream and must run outside any capture.
+ * The stream belongs to the CURRENT device of the calling thread (one per device, created once under a mutex): all three calls of one table
+ * must be made with the table's device current.                                                                                          */
 int srk_upload_prepare(void);
 int srk_upload_eager(void* dst_dev, const void* src_host, long long nbytes);
 int srk_upload_fence(void);

@@ -218,7 +218,7 @@ template <int DT> SRK_DEV void buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned vo
   if constexpr (Tr::IS16) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, SRK_ST_AUX);
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, 0);      // (SRK_ST_AUX is a STORE policy)
       unpack2<DT>(raw.x, q[8 * t + 0], q[8 * t + 1]);
       unpack2<DT>(raw.y, q[8 * t + 2], q[8 * t + 3]);
       unpack2<DT>(raw.z, q[8 * t + 4], q[8 * t + 5]);
@@ -227,7 +227,7 @@ template <int DT> SRK_DEV void buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned vo
   } else {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, SRK_ST_AUX);
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + imm_bytes + 16 * t, 0, 0);      // (SRK_ST_AUX is a STORE policy)
       q[4 * t + 0] = __uint_as_float(raw.x); q[4 * t + 1] = __uint_as_float(raw.y);
       q[4 * t + 2] = __uint_as_float(raw.z); q[4 * t + 3] = __uint_as_float(raw.w);
     }

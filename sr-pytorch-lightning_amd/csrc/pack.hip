@@ -2,6 +2,7 @@
 // and the library's error/introspection entry points.
 #include <stdarg.h>
 #include <string.h>
+#include <mutex>
 #include "srk_common.h"
 
 static thread_local char g_err[512] = "";
@@ -684,21 +685,42 @@ extern "C" int srk_upload_small(void* dst_dev, const void* src_host, long long n
 // per EDSR step, 30 per RCAN step (135 us of 8.7 ms at batch 16).  A capture site that keeps the table's memory alive as long as its graph
 // (ops.static_tables) uploads through these instead: the chunks run NOW on a stream of the library's own -- not the capturing one, so they
 // do not become graph nodes --, and srk_upload_fence(), called after the capture has ended and before the first replay, waits for them.
-static hipStream_t g_upload_stream = nullptr;
-extern "C" int srk_upload_prepare(void) {            // outside any capture: creates the stream
-  if (!g_upload_stream) {
-    const hipError_t e = hipStreamCreateWithFlags(&g_upload_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { g_upload_stream = nullptr; srk_set_error("srk_upload_prepare: %s", hipGetErrorString(e)); return (int)e; }
+// One stream per DEVICE, created under a mutex (the forward thread and autograd's backward thread can both reach a capture site; a process
+// may capture on several devices): the only process-wide state of the library, and it is write-once per device.
+namespace {
+constexpr int kMaxDev = 64;
+std::mutex g_upload_mu;
+hipStream_t g_upload_stream[kMaxDev] = {};
+int upload_stream_of_current_device(hipStream_t* out, bool create) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDev) { srk_set_error("srk_upload: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev); return e != hipSuccess ? (int)e : SRK_E_BADARG; }
+  std::lock_guard<std::mutex> lock(g_upload_mu);
+  if (!g_upload_stream[dev] && create) {
+    e = hipStreamCreateWithFlags(&g_upload_stream[dev], hipStreamNonBlocking);
+    if (e != hipSuccess) { g_upload_stream[dev] = nullptr; srk_set_error("srk_upload_prepare: %s", hipGetErrorString(e)); return (int)e; }
   }
+  *out = g_upload_stream[dev];
   return 0;
 }
+}  // namespace
+extern "C" int srk_upload_prepare(void) {            // outside any capture: creates the current device's stream
+  hipStream_t st = nullptr;
+  return upload_stream_of_current_device(&st, true);
+}
 extern "C" int srk_upload_eager(void* dst_dev, const void* src_host, long long nbytes) {
-  SRK_CHECK_ARG(g_upload_stream != nullptr, "srk_upload_eager: call srk_upload_prepare() first (outside the capture)");
-  return srk_upload_small(dst_dev, src_host, nbytes, reinterpret_cast<srk_stream_t>(g_upload_stream));
+  hipStream_t st = nullptr;
+  const int rc = upload_stream_of_current_device(&st, false);
+  if (rc != 0) return rc;
+  SRK_CHECK_ARG(st != nullptr, "srk_upload_eager: call srk_upload_prepare() on this device first (outside the capture)");
+  return srk_upload_small(dst_dev, src_host, nbytes, reinterpret_cast<srk_stream_t>(st));
 }
 extern "C" int srk_upload_fence(void) {
-  if (!g_upload_stream) return 0;
-  const hipError_t e = hipStreamSynchronize(g_upload_stream);
+  hipStream_t st = nullptr;
+  const int rc = upload_stream_of_current_device(&st, false);
+  if (rc != 0) return rc;
+  if (!st) return 0;
+  const hipError_t e = hipStreamSynchronize(st);
   if (e != hipSuccess) { srk_set_error("srk_upload_fence: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
 }

@@ -834,7 +834,7 @@ __global__ __launch_bounds__(512) void pw_bwd_kernel(const srk_pw_bwd_args a, un
 // pw_wgrad_finalize_kernel adds the slabs of the pixel ranges.
 // ------------------------------------------------------------------------------------------------------------------------------
 // swizzle of pw_wgrad_kernel's h / gh images: slot = chunk ^ hsw(pixel); a bit permutation of the pixel's low three bits (bit 1 -> bit 2)
-#ifndef SRK_PW_OLD_SWZ          // diagnostics build only (tools/ab_pw_swz.sh): round 4's swizzle of these images, for the same-box A/B
+#ifndef SRK_PW_OLD_SWZ          // diagnostics build only (tools/ab_pw.sh; `make pwold` builds tools/ubench/libsrk_pwold.so): round 4's swizzle of these images, for the same-box A/B
 #define SRK_PW_OLD_SWZ 0
 #endif
 SRK_DEV int hsw(int pl) { return SRK_PW_OLD_SWZ ? swz(pl & 15) : ((pl & 1) | (((pl >> 1) & 1) << 2) | (((pl >> 2) & 1) << 1)); }

@@ -704,6 +704,9 @@ def static_tables(holder):
             ok = False
     if ok and holder.arena is None and not torch.cuda.is_current_stream_capturing():
         holder.arena = torch.empty(holder.ARENA_BYTES, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+        # the arena comes from the caching allocator on the ambient stream and is written from the library's upload stream: whatever that
+        # memory was last used for must have finished first (explicit, not a side effect of torch.cuda.graph's own synchronize)
+        torch.cuda.current_stream().synchronize()
     prev, _StaticTables.holder = _StaticTables.holder, (holder if ok else None)
     try:
         yield holder

@@ -566,8 +566,8 @@ class OverlappedGraphStep:
             self.opt.zero_grad(set_to_none=True)
             loss, rec = self._forward(batch, self.every)
             ops.backward_segments(loss, rec.cuts, after=collect)
-        except RuntimeError as e:              # autograd's "backward through the graph a second time", HIP / allocation errors
-            err = e
+        except Exception as e:                 # autograd's "backward through the graph a second time", HIP / allocation errors -- and ANY other
+            err = e                            # failure of a model or hook: a rank that left here would leave the others in the all-reduce below
             ops.discard_wgrads()
         if dist.is_initialized() and dist.get_world_size() > 1:
             flag = torch.tensor([0.0 if err is not None else 1.0], device=next(self.model.parameters()).device)
