@@ -9,7 +9,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SRK_LIB_PATH: A/B timing of two builds of the same library (tools/); never a different implementation
-LIB_PATH = os.environ.get("SRK_LIB_PATH") or os.path.join(_HERE, "libsrk_gfx950.so")
+# SRK_EXACT_RELU=1: the build of the same sources whose ReLU keeps a NaN like torch.relu (csrc/srk_common.h, `make exact`); default: one
+# instruction per value, a NaN pre-activation becomes 0 (fp32) / keeps its payload only with a clear sign bit (16-bit)
+EXACT_RELU = os.environ.get("SRK_EXACT_RELU") == "1"
+LIB_PATH = os.environ.get("SRK_LIB_PATH") or os.path.join(_HERE, "libsrk_gfx950_exact.so" if EXACT_RELU else "libsrk_gfx950.so")
 
 SRK_BF16, SRK_F16, SRK_F32 = 0, 1, 2
 OUT_NHWC, OUT_NHWC_PS, OUT_PLANAR = 0, 1, 2

@@ -123,7 +123,7 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_apply_kernel(const
     if (tid < 64) {
       const float m = mean[tid];
       for (int j = 0; j < Cr; ++j) {
-        const float z = fmaxf(a.b1[j] + wave_sum64(a.w1[j * 64 + tid] * m), 0.f);
+        const float z = relu_f32(a.b1[j] + wave_sum64(a.w1[j * 64 + tid] * m));
         if (tid == 0) {
           zv[j] = z;
           if (a.z_out && split == 0) a.z_out[(size_t)n * Cr + j] = z;
@@ -133,7 +133,7 @@ template <int DT> __global__ __launch_bounds__(CA_NT) void ca_apply_kernel(const
   } else if (tid < Cr) {
     float z = a.b1[tid];
     for (int c = 0; c < C; ++c) z += a.w1[tid * C + c] * mean[c];
-    z = fmaxf(z, 0.f);
+    z = relu_f32(z);
     zv[tid] = z;
     if (a.z_out && split == 0) a.z_out[(size_t)n * Cr + tid] = z;
   }

@@ -105,7 +105,7 @@ SRK_DEV void conv_epilogue(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W], in
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = acc[g >> 2][pb][4 * (g & 3) + e];
-        if (relu) t = fmaxf(t, 0.f);
+        if (relu) t = relu_f32(t);
         v[g][e] = t * scale;
       }
 
@@ -244,7 +244,7 @@ template <int DT> SRK_DEV void buf_store16(__amdgpu_buffer_rsrc_t rs, unsigned v
       raw.y = pack2<DT>(v[8 * t + 2], v[8 * t + 3]);
       raw.z = pack2<DT>(v[8 * t + 4], v[8 * t + 5]);
       raw.w = pack2<DT>(v[8 * t + 6], v[8 * t + 7]);
-      if (relu_packed) { raw.x = relu_pk16(raw.x); raw.y = relu_pk16(raw.y); raw.z = relu_pk16(raw.z); raw.w = relu_pk16(raw.w); }
+      if (relu_packed) { raw.x = relu_pk16<DT>(raw.x); raw.y = relu_pk16<DT>(raw.y); raw.z = relu_pk16<DT>(raw.z); raw.w = relu_pk16<DT>(raw.w); }
       __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff + imm_bytes + 16 * t, 0, SRK_ST_AUX);
     }
   } else {
@@ -286,7 +286,7 @@ SRK_DEV void conv_epilogue_fast(const srk_conv_args& a, f32x16 (&acc)[CB_W][PB_W
       }
       if (relu) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 16; ++e) v[e] = relu_f32(v[e]);
       }
       if (scale != 1.f) {
 #pragma unroll
@@ -362,7 +362,7 @@ SRK_DEV void conv_epilogue_planar4(const srk_conv_args& a, f32x16 (&acc)[1][PB_W
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float v = acc[0][pb][e];
-      if (relu) v = fmaxf(v, 0.f);
+      if (relu) v = relu_f32(v);
       v = v * scale + q[pb][e];
       v += pa[e];
       if (e < a.Cout) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vo[pb][e], 0, SRK_ST_AUX);
@@ -430,7 +430,7 @@ SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           P[k][d] = pack2<DT>(acc[k >> 1][pb][8 * (k & 1) + 2 * d], acc[k >> 1][pb][8 * (k & 1) + 2 * d + 1]);
-          if (relu) P[k][d] = relu_pk16(P[k][d]);
+          if (relu) P[k][d] = relu_pk16<DT>(P[k][d]);
         }
       if (a.relu_bits) {
         // ReLU sign bits of this lane's pixel (natural layout: pixel qi of the quad, channels 32 h ..): dword i = 4 k + d of the packed
@@ -482,7 +482,7 @@ SRK_DEV void conv_epilogue_quad(const srk_conv_args& a, f32x16 (&acc)[2][2], int
       for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(F[j][e]);
       if (relu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = relu_f32(v[e]);
       }
       if (scale != 1.f) {
 #pragma unroll
@@ -609,7 +609,7 @@ SRK_DEV void quad_compute_t(float scale, f32x16 (&acc)[2][2], int pb, const Quad
     for (int x = 0; x < 8; ++x) v[x] = acc[k >> 1][pb][8 * (k & 1) + x];
     if constexpr (RL) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) v[x] = fmaxf(v[x], 0.f);
+      for (int x = 0; x < 8; ++x) v[x] = relu_f32(v[x]);
     }
     // scalar v_mul_f32 / v_add_f32 from inline asm: left to hipcc, adjacent elements are SLP-packed into v_pk_mul_f32 / v_pk_add_f32, and a packed
     // f32 instruction beside the partner wave's MFMAs costs ~13 cycles more than a scalar one (MI355X_MICROARCH.md, constants table: "an
@@ -907,9 +907,13 @@ SRK_DEV void grp_barrier(unsigned addr, unsigned target, int lane) {
 // The body of the weight-stationary kernel for ONE contiguous range of tiles [t0, t0 + nt) of channel tile `ctile`: called once per
 // launch by conv_ws_kernel and once per (image, layer) by conv_trunk_kernel (below).  Every wave of the workgroup must call it with the
 // same arguments; on return the last tile's 8 stores per lane may still be in flight.
-template <int DT, int CBW, int NKS, bool FAST, bool EARLY, int EM>
+// CHAIN (conv_trunk_kernel only): `w_ready` -- this layer's weight slab is already in LDS, fetched by the previous layer's call --, and
+// `next_wpk` -- the next layer's packed weights (or null): the wave group that is idle while the other one finishes the layer's last tile
+// fetches them into the (then unused) weight region, so the next layer starts with its halo tiles only.
+template <int DT, int CBW, int NKS, bool FAST, bool EARLY, int EM, bool CHAIN = false>
 SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ctile, int t0, int nt, unsigned x_bytes,
-                          int xs_img, int xs_row, int xs_col, int wtap, const int tid) {
+                          int xs_img, int xs_row, int xs_col, int wtap, const int tid, const bool w_ready = false,
+                          const void* const next_wpk = nullptr) {
   // wtap: 16-byte chunks per tap in the packed weight buffer (8 for Cin = 64; 8*r*r when this launch handles one
   // 64-channel K-block of a wider reduction, a.wpk then points at that block's first chunk)
   // xs_img / xs_row / xs_col: element strides of the input between images, rows and columns of the conv-space grid
@@ -1043,8 +1047,10 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
   // through phase 0, fetches taps 3-8 behind it; group 0 meets it at a workgroup barrier just before the first
   // fragment of tap 3 / tap 6 is read (K-steps 10 / 22), then group 1 loads its own first halo tile.
   constexpr bool STAGED = !EARLY && FAST && CBW == 2 && NKS == 4;
+  const bool have_w = CHAIN && w_ready;                // (compile-time false outside the trunk kernel)
+  const bool staged = STAGED && !have_w;
   const int rot = (STAGED || (dbg & 16)) ? 0 : (int)((blockIdx.x * 11u) % (unsigned)NBLK);
-  if constexpr (STAGED) {
+  if (staged) {
     const int pt0 = t0;                                   // group 0's first tile
     const int tX = pt0 % tilesX, q0 = pt0 / tilesX, tY = q0 % tilesY, n0 = q0 / tilesY;
     const int y0 = tY * 16, x0 = tX * 16;
@@ -1074,7 +1080,25 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
     if constexpr (EARLY) dma16(wg + off, Wl + (rb << 10));
     else dma16_hidden(wrsrc, (unsigned)(off * sizeof(elem)), (unsigned)__builtin_amdgcn_readfirstlane((int)(wl_lds + (rb << 10))));
   };
-  if constexpr (STAGED) {
+  auto fetch_next_weights = [&]() {               // this wave GROUP's 4 waves: the whole slab of the next layer, in place
+    if constexpr (CHAIN) {
+      const elem* const wn = reinterpret_cast<const elem*>(next_wpk);
+      const i32x4 wnrsrc = make_rsrc4(wn, 0x7fffffffu);
+#pragma unroll 1
+      for (int kk = 0; kk < NBLK / 4; ++kk) {
+        const int blk = kk * 4 + w4;
+        const int i = blk * 64 + lane;
+        const int co = i % TCW, c = (i / TCW) % (2 * NKS), tap = i / (TCW * 2 * NKS);
+        const size_t off = ((size_t)(tap * wtap + c) * a.CoutP + ctile * TCW + co) * CH;
+        if constexpr (EARLY) dma16(wn + off, Wl + (blk << 10));
+        else dma16_hidden(wnrsrc, (unsigned)(off * sizeof(elem)), (unsigned)__builtin_amdgcn_readfirstlane((int)(wl_lds + (blk << 10))));
+      }
+    }
+  };
+  static_assert(!CHAIN || NBLK % 4 == 0, "the slab splits over a group's 4 waves");
+  if (have_w) {
+    // (the slab is in LDS already: conv_trunk_kernel, fetched during the previous layer's last phase)
+  } else if (staged) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) dma_wblock(k * 8 + wave);          // taps 0-2, all 8 waves; taps 3-8: group 1, below
   } else {
@@ -1088,7 +1112,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
   fill_pieces();
   load_bias();
   asm volatile("" ::: "memory");
-  if (!STAGED && nj > 0) dma_x(0);
+  if (!staged && nj > 0) dma_x(0);
 #if SRK_WS_STAMPS
   const unsigned long long tB = __builtin_amdgcn_s_memtime();
 #endif
@@ -1128,7 +1152,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
   // group 0 needs the weights and its halo tile now; group 1 idles through phase 0, so it only has to have landed its
   // share of the weights here (its 10-11 halo pieces are the youngest operations) and waits for its halo tile at the
   // end of phase 0: 41.5 KB less in the all-CUs-at-once prologue burst (~12-14 B/clk/CU)
-  if constexpr (STAGED) {
+  if (staged) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of group 0's halo tile and of taps 0-2
   } else {
     if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1145,7 +1169,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
 #if SRK_WS_STAMPS
   const unsigned long long tD = __builtin_amdgcn_s_memtime();
 #endif
-  if constexpr (STAGED) {
+  if (staged) {
     // group 1 (idle through phase 0) fetches taps 3-8: 12 blocks per wave, in tap order
     if (grp == 1) {
 #pragma unroll
@@ -1200,6 +1224,11 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
     const int q = FREE ? p : p - grp;            // this group's own phase counter
     const int j = q >> 1;
     SRK_STAMP(2 * p);
+    if constexpr (CHAIN && !FREE) {
+      // phase nt: the layer's last MFMA phase (tile nt - 1, the other group's) ended at the barrier just passed, that group now stores the tile,
+      // this one has nothing left: it fetches the next layer's weight slab (18 blocks per wave)
+      if (next_wpk && p == nt && grp == (nt & 1)) fetch_next_weights();
+    }
     if (q >= 0 && j < nj) {
       if ((q & 1) == 0) {
         if (dbg & 1) {
@@ -1260,7 +1289,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
           // 4 reads per wave in one gap oversubscribes the array while the waves run in step
           if constexpr (STAGED) {
             // first tile only: taps 3-5 / 6-8 are needed from K-steps 12 / 24 on, their fragments two steps earlier
-            if (p == 0 && (s == 10 || s == 22)) __builtin_amdgcn_s_barrier();      // group 1 has landed taps 3-5 / 6-8
+            if (staged && p == 0 && (s == 10 || s == 22)) __builtin_amdgcn_s_barrier();      // group 1 has landed taps 3-5 / 6-8
           }
           int q = 0;
           if constexpr (EARLY) {
@@ -1364,7 +1393,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
         }
       }
     }
-    if constexpr (STAGED) {
+    if (staged) {
       if (q < 0) {                                        // group 1, phase 0: the two staged weight syncs of group 0
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // its 6 blocks of taps 3-5 (taps 6-8 are the 6 younger ones)
         __builtin_amdgcn_s_barrier();
@@ -1377,6 +1406,18 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
     SRK_STAMP(2 * p + 1);
     if constexpr (FREE) grp_barrier(my_ctr, 4 * ++gen, lane);
     else __builtin_amdgcn_s_barrier();
+  }
+  if constexpr (CHAIN && FREE) {
+    // free-running groups: the one that does NOT own the layer's last tile waits until the other one has left its last MFMA phase (its
+    // arrival counter: one barrier per phase, group 1 one more before its first), then fetches the next layer's weight slab
+    if (next_wpk && grp == (nt & 1)) {
+      const int o = 1 - grp;
+      const int nj_o = (nt - o + 1) >> 1;
+      const unsigned target = 4u * (unsigned)(o == 0 ? 2 * nj_o - 1 : 2 * nj_o);
+      const unsigned other = lds_addr_of(sync_ctr + o);
+      while (grp_peek(other) < target) __builtin_amdgcn_s_sleep(1);
+      fetch_next_weights();
+    }
   }
 #if SRK_WS_STAMPS
   if (wg_slot) wg_slot[1] = __builtin_amdgcn_s_memrealtime();
@@ -1418,6 +1459,7 @@ __global__ __launch_bounds__(512, 2) void conv_trunk_kernel(const srk_conv_args*
   const int tpi = tilesX * tilesY;
 #pragma unroll 1
   for (int n = (int)blockIdx.x; n < nimages; n += (int)gridDim.x) {
+    bool w_ready = false;
 #pragma unroll 1
     for (int l = 0; l < nlayers; ++l) {
       const srk_conv_args a = tab[l];
@@ -1426,6 +1468,8 @@ __global__ __launch_bounds__(512, 2) void conv_trunk_kernel(const srk_conv_args*
       int tid = (int)threadIdx.x;
       asm volatile("" : "+v"(tid));
       const int xs_col = a.x_pitch, xs_row = a.W * a.x_pitch, xs_img = a.H * a.W * a.x_pitch;
+      // the next layer's weights are fetched while this layer stores its last tile (conv_ws_body, CHAIN)
+      const void* const next_w = (l + 1 < nlayers && tab[l + 1].KH != 0 && a.KH != 0) ? tab[l + 1].wpk : nullptr;
       if (a.KH == 0) {
         // pseudo-layer `out = x + res` on this image (the long skip's gradient: the two contributions to the trunk input's gradient,
         // models/edsr.py:46-47 backward): fp32 add of the two 16-bit values, rounded once -- what torch's add does
@@ -1446,11 +1490,12 @@ __global__ __launch_bounds__(512, 2) void conv_trunk_kernel(const srk_conv_args*
           }
           po[i] = uint4{oo[0], oo[1], oo[2], oo[3]};
         }
-      } else if (a.mask_bits) conv_ws_body<DT, 2, 4, true, true, 3>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid);
-      else if (a.res) conv_ws_body<DT, 2, 4, true, true, 1>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid);
-      else conv_ws_body<DT, 2, 4, true, false, 0>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid);
+      } else if (a.mask_bits) conv_ws_body<DT, 2, 4, true, true, 3, true>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid, w_ready, next_w);
+      else if (a.res) conv_ws_body<DT, 2, 4, true, true, 1, true>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid, w_ready, next_w);
+      else conv_ws_body<DT, 2, 4, true, false, 0, true>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid, w_ready, next_w);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      w_ready = next_w != nullptr;
     }
   }
 }

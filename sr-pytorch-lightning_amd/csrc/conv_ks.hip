@@ -345,7 +345,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
           for (int d = 0; d < 8; ++d) v[d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]};
           if (a.relu) {
 #pragma unroll
-            for (int d = 0; d < 8; ++d) v[d] = f32x2{fmaxf(v[d].x, 0.f), fmaxf(v[d].y, 0.f)};
+            for (int d = 0; d < 8; ++d) v[d] = f32x2{relu_f32(v[d].x), relu_f32(v[d].y)};
           }
 #pragma unroll
           for (int d = 0; d < 8; ++d) v[d] = v[d] * sc2;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void lk_conv_kernel(const srk_conv_args a, int
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           float u = acc[rb][pb][8 * q + t];
-          if (a.relu) u = fmaxf(u, 0.f);
+          if (a.relu) u = relu_f32(u);
           v[t] = u * sc;
         }
         if (rs) {

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         float sg = b2_in;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          zz[j] = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1_in), j)) + pr[j], 0.f);
+          zz[j] = relu_f32(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1_in), j)) + pr[j]);
           if (j < Cr) sg += w2c[j] * zz[j];
         }
         sg = 1.f / (1.f + expf(-sg));
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int d = 0; d < 8; ++d) P[8 * cb + d] = relu_pk16(pack2<DT>(acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]));
+        for (int d = 0; d < 8; ++d) P[8 * cb + d] = relu_pk16<DT>(pack2<DT>(acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]));
     } else {
       f32x2 v[16];
 #pragma unroll
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
         for (int d = 0; d < 8; ++d) v[8 * cb + d] = f32x2{acc[cb][pb][2 * d], acc[cb][pb][2 * d + 1]};
       if (a.relu_mid) {
 #pragma unroll
-        for (int d = 0; d < 16; ++d) v[d] = f32x2{fmaxf(v[d].x, 0.f), fmaxf(v[d].y, 0.f)};
+        for (int d = 0; d < 16; ++d) v[d] = f32x2{relu_f32(v[d].x), relu_f32(v[d].y)};
       }
 #pragma unroll
       for (int d = 0; d < 16; ++d) { const f32x2 t = v[d] * sm2; P[d] = pack2<DT>(t.x, t.y); }
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const srk_conv_pair_args
   auto mid_piece_relu = [&](int p) {                       // 16 x (pack, ReLU, zero outside the image), 4 stores
     if (p < 16) {
       const int cb = p >> 3, d = p & 7;
-      const uint32_t w = relu_pk16(pack2<DT>(acc[cb][0][2 * d], acc[cb][0][2 * d + 1]));
+      const uint32_t w = relu_pk16<DT>(pack2<DT>(acc[cb][0][2 * d], acc[cb][0][2 * d + 1]));
       P0[p] = m_in[0] ? w : 0u;
     } else if (p < 20) {
       const int j = p - 16;

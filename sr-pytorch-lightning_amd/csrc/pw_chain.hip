@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512) void pw_fwd_kernel(const srk_pw_args a, unsign
   };
   auto pack_piece = [&](int d, i32x4 (&hf)[4]) {                 // dword d of the 16 that hold the slice: block d >> 3, K-step half (d >> 2) & 1
     const int b = d >> 3, m = (d >> 2) & 1, w = d & 3;
-    const int v = (int)relu_pk16(pack2<DT>(acc1[b][8 * m + 2 * w], acc1[b][8 * m + 2 * w + 1]));
+    const int v = (int)relu_pk16<DT>(pack2<DT>(acc1[b][8 * m + 2 * w], acc1[b][8 * m + 2 * w + 1]));
     if (w == 0) hf[2 * b + m].x = v; else if (w == 1) hf[2 * b + m].y = v; else if (w == 2) hf[2 * b + m].z = v; else hf[2 * b + m].w = v;
   };
   // first: first step of the stream (0: conv 1 + conv 2; G1: conv 2 only, the last iteration); w1 / w2: fragment bases of the lane
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void pw_fwd2_kernel(const srk_pw_args a, unsig
   auto pack1 = [&](auto bc, auto dc) __attribute__((always_inline)) {                          // dword d (0..15) of row block b: K-step 2b + (d >> 3), column block (d >> 2) & 1
     constexpr int b = decltype(bc)::value, d = decltype(dc)::value;
     constexpr int mm = d >> 3, c = (d >> 2) & 1, w = d & 3;
-    const int v = (int)relu_pk16(pack2<DT>(acc1[b][c][8 * mm + 2 * w], acc1[b][c][8 * mm + 2 * w + 1]));
+    const int v = (int)relu_pk16<DT>(pack2<DT>(acc1[b][c][8 * mm + 2 * w], acc1[b][c][8 * mm + 2 * w + 1]));
     i32x4& t = hf[2 * b + mm][c];
     if constexpr (w == 0) t.x = v; else if constexpr (w == 1) t.y = v; else if constexpr (w == 2) t.z = v; else t.w = v;
   };
@@ -734,10 +734,10 @@ __global__ __launch_bounds__(512) void pw_bwd_kernel(const srk_pw_bwd_args a, un
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           i32x4 q;
-          q.x = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 0], acc[b][8 * m + 1]));
-          q.y = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 2], acc[b][8 * m + 3]));
-          q.z = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 4], acc[b][8 * m + 5]));
-          q.w = (int)relu_pk16(pack2<DT>(acc[b][8 * m + 6], acc[b][8 * m + 7]));
+          q.x = (int)relu_pk16<DT>(pack2<DT>(acc[b][8 * m + 0], acc[b][8 * m + 1]));
+          q.y = (int)relu_pk16<DT>(pack2<DT>(acc[b][8 * m + 2], acc[b][8 * m + 3]));
+          q.z = (int)relu_pk16<DT>(pack2<DT>(acc[b][8 * m + 4], acc[b][8 * m + 5]));
+          q.w = (int)relu_pk16<DT>(pack2<DT>(acc[b][8 * m + 6], acc[b][8 * m + 7]));
           hf[2 * b + m] = q;
         }
       }

@@ -197,13 +197,36 @@ template <int DT> SRK_DEV void unpack2(uint32_t w, float& lo, float& hi) {
     hi = (float)h.y;
   }
 }
-// ReLU on a packed pair of 16-bit floats: negative <=> sign bit <=> negative as int16 (-0.0 -> +0.0... stays -0.0
-// only for max(-0.0, 0) = 0 as integers: 0x8000 is negative, so it becomes +0.0)
-SRK_DEV uint32_t relu_pk16(uint32_t w) {
+// ---- ReLU (models/common.py:89,99-100: torch.relu) ---------------------------------------------------------------------------------
+// Default build: one instruction per value -- fp32: v_max_f32 with 0 (IEEE maxNum: a NaN becomes 0); packed 16-bit: integer max with 0
+// (negative <=> sign bit <=> negative as int16; -0.0 -> +0.0; a NaN keeps its payload unless its SIGN bit is set, then it becomes 0).
+// torch.relu returns NaN for a NaN of either sign.  -DSRK_EXACT_RELU=1 (`make exact` -> libsrk_gfx950_exact.so, loaded when the process
+// runs with SRK_EXACT_RELU=1) builds the NaN-preserving forms: `v < 0 ? 0 : v` (compare + select) and its packed equivalent.  Finite
+// values: identical bits in both builds.  Cost of the exact build: profiles/r6_exact_relu.txt.
+#ifndef SRK_EXACT_RELU
+#define SRK_EXACT_RELU 0
+#endif
+SRK_DEV float relu_f32(float v) {
+#if SRK_EXACT_RELU
+  return v < 0.f ? 0.f : v;
+#else
+  return fmaxf(v, 0.f);
+#endif
+}
+template <int DT> SRK_DEV uint32_t relu_pk16(uint32_t w) {
   typedef __attribute__((ext_vector_type(2))) short i16x2;
   const i16x2 v = __builtin_bit_cast(i16x2, w);
   const i16x2 z = {0, 0};
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, z));
+  const uint32_t t = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, z));
+#if SRK_EXACT_RELU
+  // a NaN (magnitude bits above the exponent mask) passes whatever its sign: per half n = 1 for a NaN, t | w * n
+  constexpr uint32_t EXP = DT == SRK_BF16 ? 0x7f80u : 0x7c00u;
+  const uint32_t lo = w & 0x7fffu, hi = (w >> 16) & 0x7fffu;
+  const uint32_t keep = (lo > EXP ? 0x0000ffffu : 0u) | (hi > EXP ? 0xffff0000u : 0u);
+  return t | (w & keep);
+#else
+  return t;
+#endif
 }
 
 // ReLU-backward mask on PACKED 16-bit results (conv_igemm.hip's prefetch variant, conv_pair.hip's intermediate epilogue).
