@@ -139,7 +139,7 @@ def cpu_baseline(model_name, scale, patch, seconds=15.0, max_steps=8, model=None
             out["parity"] = {"patches": np_, "psnr_build_vs_oracle_db": round(10.0 * math.log10(1.0 / max(mse, 1e-20)), 2),
                              "max_abs_err": float((y_hip - y_ref).abs().max()),
                              "note": "HIP forward in the bench dtype vs fp32 CPU oracle, the model's current weights, synthetic (uniform) patches; "
-                                     "north_star's 0.01 dB criterion needs a TRAINED net and smooth images: tests/test_gpu_round2.py::"
+                                     "north_star's 0.01 dB criterion needs a TRAINED net and smooth images: tests/test_gpu_fullsize_parity.py::"
                                      "test_psnr_within_0p01_db_of_reference_path"}
         except Exception as e:  # noqa: BLE001
             out["parity"] = {"error": f"{type(e).__name__}: {e}"}

@@ -197,7 +197,7 @@ class SRModel(_Base):
         #: arithmetic type of the HIP path: storage dtype of activations / packed weights (fp32 accumulate)
         self.compute_dtype = _dtype_from_precision(precision)
         #: storage dtype of the validation / predict forward.  bf16 keeps 8 mantissa bits on the residual trunk, which
-        #: costs 0.005-0.013 dB of PSNR on a trained EDSR-baseline (tests/test_gpu_round2.py); fp16 storage runs at the same
+        #: costs 0.005-0.013 dB of PSNR on a trained EDSR-baseline (tests/test_gpu_fullsize_parity.py); fp16 storage runs at the same
         #: speed and stays within 0.0002 dB of the fp32 reference path, so a bf16 model evaluates in fp16 unless told
         #: otherwise (`eval_precision=` 32 / 16 / 'bf16'; non-finite fp16 outputs fall back to the training dtype)
         ep = kwargs.get("eval_precision")
