@@ -88,10 +88,24 @@ FINGERPRINTED = {
     "conv_ws_residual_bf16": kernel_name(0, 4, 1) + "iiiijiiiiiii:",
     "conv_ws_mask_bf16": kernel_name(0, 4, 2) + "iiiijiiiiiii:",
     "conv_ws_maskbits_bf16": kernel_name(0, 4, 3) + "iiiijiiiiiii:",
+    "conv_trunk_bf16": "_ZN12_GLOBAL__N_117conv_trunk_kernelILi0EEEvPK13srk_conv_argsiiiij:",
 }
 
 
-def main(path, fp_out=None):
+# kernels of the OTHER translation units whose PMC figures bench.py quotes for configs 3-5 (tools/pmc_traffic.sh): file stem -> {key: mangled-name prefix}
+FINGERPRINTED_MORE = {
+    "conv_pair": {"conv_pair_bf16": "_ZN12_GLOBAL__N_116conv_pair_kernelILi0EEEv18srk_conv_pair_argsiij:"},
+    "conv_ks": {"conv_ks_bf16": "_ZN12_GLOBAL__N_114conv_ks_kernelILi0ELb0EEEv13srk_conv_argsiiijji:",
+                "conv_ks_psdgrad_bf16": "_ZN12_GLOBAL__N_114conv_ks_kernelILi0ELb1EEEv13srk_conv_argsiiijji:"},
+    "pw_chain": {"pw_fwd_bf16": "_ZN12_GLOBAL__N_113pw_fwd_kernelILi0ELi8ELi4EEEv11srk_pw_argsjji:",
+                 "pw_bwd_bf16": "_ZN12_GLOBAL__N_113pw_bwd_kernelILi0ELi8ELi4ELb0EEEv15srk_pw_bwd_argsjjji:",
+                 "pw_wgrad_bf16": "_ZN12_GLOBAL__N_115pw_wgrad_kernelILi0ELi8ELi4EEEv17srk_pw_wgrad_argsjjiii:"},
+    "proj": {"proj_up_bf16": "_ZN12_GLOBAL__N_114proj_up_kernelILi0EEEv13srk_proj_argsiii:"},
+}
+
+
+def main(path, fp_out=None, more=()):
+    """path: conv_igemm's listing (prefetch gate + fingerprints); more: listings of other translation units (fingerprints only)."""
     asm = open(path).read()
     ok = True
     for dt in (0, 1):
@@ -105,10 +119,17 @@ def main(path, fp_out=None):
                     print(f"check_isa: conv_ws_kernel<dtype {dt}, NKS {nks}, EARLY, EM {em}>: FAILED: {e}", file=sys.stderr)
     if fp_out:
         import json
+        import os
+        tab = {k: isa_fingerprint(asm, v) for k, v in FINGERPRINTED.items()}
+        for m in more:
+            stem = os.path.basename(m).split(".")[0]
+            other = open(m).read()
+            for k, v in FINGERPRINTED_MORE.get(stem, {}).items():
+                tab[k] = isa_fingerprint(other, v)
         with open(fp_out, "w") as fh:
-            json.dump({k: isa_fingerprint(asm, v) for k, v in FINGERPRINTED.items()}, fh, indent=1)
+            json.dump(tab, fh, indent=1)
     return 0 if ok else 1
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None))
+    sys.exit(main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, sys.argv[3:]))

@@ -32,6 +32,12 @@
 #ifndef SRK_WS_PRIO_E
 #define SRK_WS_PRIO_E 0
 #endif
+#ifndef SRK_TRUNK_PREFETCH
+#define SRK_TRUNK_PREFETCH 0  // conv_trunk_kernel: 1 = the wave group that is idle while the other one stores the layer's last tile fetches the NEXT
+                              // layer's weight slab (conv_ws_body<.., CHAIN>).  Built, bit-identical, measured on one box (tools/microbench_trunk.py,
+                              // two runs each): 42.54 / 42.58 us per convolution with it, 42.36 / 42.40 without -- a layer's prologue is not what bounds the
+                              // chain (the memory system is: DESIGN.md 3.20), and the extra live scalars cost 63 more SGPR spills.  Off.
+#endif
 #ifndef SRK_ST_AUX
 #define SRK_ST_AUX 16         // cache policy of the quad epilogue's stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
@@ -1469,7 +1475,7 @@ __global__ __launch_bounds__(512, 2) void conv_trunk_kernel(const srk_conv_args*
       asm volatile("" : "+v"(tid));
       const int xs_col = a.x_pitch, xs_row = a.W * a.x_pitch, xs_img = a.H * a.W * a.x_pitch;
       // the next layer's weights are fetched while this layer stores its last tile (conv_ws_body, CHAIN)
-      const void* const next_w = (l + 1 < nlayers && tab[l + 1].KH != 0 && a.KH != 0) ? tab[l + 1].wpk : nullptr;
+      const void* const next_w = (SRK_TRUNK_PREFETCH && l + 1 < nlayers && tab[l + 1].KH != 0 && a.KH != 0) ? tab[l + 1].wpk : nullptr;
       if (a.KH == 0) {
         // pseudo-layer `out = x + res` on this image (the long skip's gradient: the two contributions to the trunk input's gradient,
         // models/edsr.py:46-47 backward): fp32 add of the two 16-bit values, rounded once -- what torch's add does
