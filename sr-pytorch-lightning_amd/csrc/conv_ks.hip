@@ -74,13 +74,22 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(const srk_conv_args a, int
                                                         // 16-byte chunks per pixel / tap
 
   // PERSISTENT: the workgroup keeps its output-channel block and walks tiles q, q + stride, ... (the workgroups that share a halo
-  // tile -- the ncob blocks of one tile -- have neighbouring indices and run together).  The K-blocks of all its tiles form ONE
+  // tile -- the ncob blocks of one tile -- have neighbouring LOGICAL indices: one XCD, see below).  The K-blocks of all its tiles form ONE
   // stream Gk = 0 .. total - 1 (tile Gk / nkb, channel block Gk % nkb): halo tiles alternate between the two buffers by Gk's
   // parity, weight slabs keep cycling through the ring -- the next tile's first halo tile and slabs arrive during the current
   // tile's last K-block.  (One tile per workgroup, as before round 3's last change: 6k cycles of prologue, a first K-block twice as
   // long as the later ones -- the ring not yet ahead -- and 3.5k of epilogue around 9.2k cycles of MFMA for 112 -> 128 channels.)
-  const int cob = (int)blockIdx.x % ncob;
-  const int q0 = (int)blockIdx.x / ncob, qstride = (int)gridDim.x / ncob;
+  // The hardware hands consecutive block ids to the eight XCDs in turn, each with an L2 of its own: taken as they come, the ncob blocks of one tile
+  // would sit on ncob DIFFERENT XCDs and every one of them would fetch the tile's halo from HBM again (round 6, PMC in the EDSR-large step:
+  // 133 MB per 256 -> 256 launch at batch 16 against 39 MB algorithmic).  Logical index = (XCD, slot in the XCD): the blocks of a tile -- and
+  // neighbouring tiles -- share one L2.  (SRK_KS_XCD_REMAP=0: A/B builds.)
+#ifndef SRK_KS_XCD_REMAP
+#define SRK_KS_XCD_REMAP 1
+#endif
+  unsigned lb = blockIdx.x;
+  if (SRK_KS_XCD_REMAP && (gridDim.x & 7u) == 0 && ((gridDim.x >> 3) % (unsigned)ncob) == 0) lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int cob = (int)(lb % (unsigned)ncob);
+  const int q0 = (int)(lb / (unsigned)ncob), qstride = (int)gridDim.x / ncob;
   const int mytiles = (ntiles - q0 + qstride - 1) / qstride;
   const int total = mytiles * nkb;
   auto tile_origin = [&](int ti, int& n, int& y0, int& x0) __attribute__((always_inline)) {
