@@ -33,6 +33,8 @@ def _stage_of(kernel):
     k = kernel
     if k.startswith("hrtail_") or k.startswith("lk5_") or k.startswith("lk_conv_kernel") or k.startswith("to_nhwc16") or k.startswith("pack_kernel"):
         return "HR stage's own kernels (5x5 conv, border terms, collapse / expand, layout of the image gradient)"
+    if k.startswith("conv_trunk_kernel"):
+        return "conv_trunk: the trunk's 33 convolutions per direction in one image-stationary launch (+ the long skip's add in the backward one)"
     if k.startswith("conv_pair_kernel"):
         return "conv_pair: one launch per ResBlock / RCAB conv pair and direction"
     if k.startswith("ca_") or k.startswith("rowsum_group"):
@@ -118,21 +120,32 @@ def block(tag, short=False):
             out.append("")
             if cb.get("cpu_model"):
                 out.append(f"`cpu_baseline` host: {cb['cpu_model']}, {cb.get('cores_available')} cores available, {cb['cores']} threads used.")
-            out.append(f"`cpu_baseline`: {cb['value']} patches/s ({cb['sample']}); parity of the build on the bench's own weights: PSNR(build, oracle) {cb.get('parity', {}).get('psnr_build_vs_oracle_db')} dB, max |err| {cb.get('parity', {}).get('max_abs_err')}.")
+            par = cb.get("parity", {})
+            bw = par.get("bench_weights", par)
+            out.append(f"`cpu_baseline`: {cb['value']} patches/s ({cb['sample']}); parity of the build on the bench's own weights: PSNR(build, oracle) {bw.get('psnr_build_vs_oracle_db')} dB, max |err| {bw.get('max_abs_err')}.")
+            ac = cb.get("all_cores")
+            if ac:
+                out.append(f"`cpu_baseline.all_cores`: {ac['value']} patches/s ({ac['sample']}).")
+            tn = par.get("trained_net")
+            if tn and "delta_psnr_db" in tn:
+                d_, w_ = tn["delta_psnr_db"], tn.get("worst_image_delta_db", {})
+                out.append(f"`cpu_baseline.parity.trained_net` ({tn['net']}; PSNR of the reference path {tn['psnr_reference_path_db']} dB, criterion {tn['criterion_db']} dB): "
+                           + "; ".join(f"{k} {d_[k]:+.4f} dB (worst image {w_.get(k, 0):+.4f})" for k in d_) + ".")
         oc = d.get("other_configs")
         if oc:
             out.append("")
-            out.append("| `other_configs` (batch 16, training step as one hipGraph) | patches/s | ms / step | model_mfma_frac (reference graph / executed) | dominant kernel frac (in the step where the model has a trunk) | isolated frac / step-weighted |")
-            out.append("|---|---|---|---|---|---|")
+            out.append("| `other_configs` (batch 16, training step as one hipGraph) | patches/s | ms / step | model_mfma_frac (reference graph / executed) | dominant kernel frac (in the step where the model has a trunk) | isolated frac / step-weighted | in-step PMC traffic / algorithmic bytes per launch (kernel) |")
+            out.append("|---|---|---|---|---|---|---|")
             for e in oc:
                 if "value" not in e:
-                    out.append(f"| {e.get('model')} {e.get('dtype', '')} | error: {e.get('error')} | | | | |")
+                    out.append(f"| {e.get('model')} {e.get('dtype', '')} | error: {e.get('error')} | | | | | |")
                     continue
                 rr = e.get("roofline") or {}
                 iso = rr.get("isolated") or {}
                 out.append(f"| {e['model']}{' fp16' if e.get('dtype') == 'f16' else ''} | {e['value']:,.0f} | {e['ms_per_step']} | {e['model_mfma_frac']} / {e.get('model_mfma_frac_executed')} | "
                            f"{rr.get('frac', '')} {('(' + rr.get('unit', '') + (', in step' if 'in_step' in rr else ', isolated') + ')') if rr else ''} | "
-                           f"{iso.get('frac', rr.get('frac', ''))} / {iso.get('step_weighted_frac', rr.get('step_weighted_frac', ''))} |")
+                           f"{iso.get('frac', rr.get('frac', ''))} / {iso.get('step_weighted_frac', rr.get('step_weighted_frac', ''))} | "
+                           + (f"{rr['traffic'] / 1e6:.1f} MB / {rr['algorithmic_bytes_per_launch'] / 1e6:.1f} MB ({rr.get('traffic_kernel')})" if rr.get("traffic") and rr.get("algorithmic_bytes_per_launch") else "") + " |")
     for nm, what in ((f"{tag}_bench_default_f16.json", "fp16 (`--dtype f16`, device-resident dynamic loss scaling, the step still ONE hipGraph)"),
                      (f"{tag}_bench_inference.json", "forward only (`--inference`)")):
         e = _load(nm)
@@ -153,8 +166,10 @@ def block(tag, short=False):
         out.append("```")
     for nm, title in ((f"{tag}_step_edsr_baseline_b256.txt", "Where the default step goes (one step of the rocprofv3 kernel trace in dispatch order, grouped by stage)"),
                       (f"{tag}_step_edsr_baseline_b256_layerwise.txt", "The same with the HR stage layer by layer (`SRK_DEBUG=1 SRK_NO_HR_COLLAPSE=1`)"),
-                      (f"{tag}_step_edsr_baseline_b16.txt", "EDSR-baseline at the reference's batch of 16"), (f"{tag}_step_rcan_b16.txt", "RCAN at batch 16")):
-        sa = None if (short and "layerwise" in nm) else step_anatomy(nm)
+                      (f"{tag}_step_edsr_baseline_b256_per_layer.txt", "The same with the trunk as one launch per convolution (`SRK_DEBUG=1 SRK_NO_TRUNK=1`)"),
+                      (f"{tag}_step_edsr_baseline_b16.txt", "EDSR-baseline at the reference's batch of 16"), (f"{tag}_step_rcan_b16.txt", "RCAN at batch 16"),
+                      (f"{tag}_step_rcan_b64.txt", "RCAN at batch 64"), (f"{tag}_step_rcan_b256.txt", "RCAN at batch 256")):
+        sa = None if (short and ("layerwise" in nm or "rcan_b64" in nm)) else step_anatomy(nm)
         if sa:
             agg, total = sa
             out.append("")
@@ -215,7 +230,10 @@ def block(tag, short=False):
                       (f"{tag}_ab_pw_b16.txt", "WDSR-B at batch 16, same box, round 5's two changes switched off and on (`tools/ab_pw.sh 16`: patches/s, ms per step)"),
                       (f"{tag}_stamps.txt", "In-kernel `s_memtime` stamps of workgroup 0 (diagnostics build, `tools/stamp_*.py`; ticks ~ cycles)"),
                       (f"{tag}_hrtail_microbench.txt", "The HR stage alone, forward + backward, eager launches (`tools/microbench_hrtail.py`)"),
-                      (f"{tag}_ab_ddp.txt", "Single process against a forced 1-rank RCCL group, same box (`tools/ab_ddp.sh`: value, ms per step, sustained value, graph form, gradient sync)")):
+                      (f"{tag}_ab_ddp.txt", "Single process against a forced 1-rank RCCL group, same box (`tools/ab_ddp.sh`: value, ms per step, sustained value, graph form, gradient sync)"),
+                      (f"{tag}_ab_trunk.txt", "The trunk as one image-stationary launch per direction against one launch per convolution, same box (`tools/microbench_trunk.py`; `SRK_NO_TRUNK`)"),
+                      (f"{tag}_exact_relu.txt", "The NaN-preserving-ReLU build against the default build, same box (`tools/ab_exact_relu.sh`: patches/s, ms per step)"),
+                      (f"{tag}_experiments.txt", "Round 6's same-box experiments on the way to the trunk launch")):
         t = _text(nm)
         if t:
             out.append("")
@@ -229,11 +247,11 @@ def block(tag, short=False):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = args[0] if args else "r5"
+    tag = args[0] if args else "r6"
     check = "--check" in sys.argv
     b, e = f"<!-- results:{tag}:begin -->\n", f"<!-- results:{tag}:end -->"
     bad = 0
-    first = os.path.join(ROOT, "DESIGN.md") if tag == "r5" else os.path.join(P, "HISTORY.md")      # earlier rounds' results live in profiles/HISTORY.md
+    first = os.path.join(ROOT, "DESIGN.md") if tag == "r6" else os.path.join(P, "HISTORY.md")      # earlier rounds' results live in profiles/HISTORY.md
     for path in (first, os.path.join(P, "README.md")):
         body = block(tag, short=(path.endswith("DESIGN.md")))
         s = open(path).read()
