@@ -129,13 +129,17 @@ def cpu_baseline(model_name, scale, patch, seconds=15.0, max_steps=8, model=None
            "sample": f"{k} training steps of batch {n} ({cls} fp32, torch {torch.__version__} CPU, {cores} threads), {dt:.1f} s"}
     if avail > cores and os.environ.get("SRK_BENCH_NO_ALLCORES") != "1":
         # SURVEY.md 8(d) defines the baseline on os.cpu_count() threads; the quoted figure uses min(32, cores) because torch's CPU convs collapse
-        # beyond that on this host.  ONE step on every available core, so that the deviation is visible in the line itself.
+        # beyond that on this host (one batch-16 step on 256 threads: 107 s, 0.15 patches/s -- profiles/r6_bench_default_first.json).  ONE step of ONE patch
+        # on every available core, so that the deviation is visible in the line itself without holding the bench for minutes.
         try:
             torch.set_num_threads(avail)
+            one = {"lr": batch["lr"][:1], "hr": batch["hr"][:1]}
             t1 = time.perf_counter()
-            step()
+            opt.zero_grad()
+            m.training_step(one)["loss"].backward()
+            opt.step()
             d1 = time.perf_counter() - t1
-            out["all_cores"] = {"value": round(n / d1, 3), "cores": avail, "sample": f"1 training step of batch {n} on {avail} threads, {d1:.1f} s"}
+            out["all_cores"] = {"value": round(1 / d1, 3), "cores": avail, "sample": f"1 training step of batch 1 on {avail} threads, {d1:.1f} s"}
         finally:
             torch.set_num_threads(cores)
     if model is not None and lr is not None:
@@ -184,8 +188,8 @@ def trained_parity(A, steps=200):
         loss = m.training_step({"lr": lr_d[idx], "hr": hr_d[idx]}, step)["loss"]
         loss.backward()
         opt.step()
-        first = float(loss) if first is None else first
-        last = float(loss)
+        first = float(loss.detach()) if first is None else first
+        last = float(loss.detach())
     sd = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
     hr_t = smooth_images(4, 192, 99)
     lr_t = F.interpolate(hr_t, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
@@ -382,7 +386,7 @@ def _flavours(A, model_name, batch, patch, feats, dtype):
         kwc = dict(N=n, H=hw, W=hw, Cin=feats, Cout=feats, out=out)
         return f"conv_igemm_kernel 3x3 {feats}->{feats} (fp32 MFMA)", [dict(name="conv_bias_relu", fn=lambda: ops.conv_raw(x, pk, relu=True, **kwc), flops=flops, count=1)]
     pkd = ops.pack_conv(w, None, dt, dgrad=True)
-    if feats == 64 and ops.pair_ok(x, w, w):
+    if feats == 64 and model_name != "srresnet" and ops.pair_ok(x, w, w):      # (SRResNet: a BatchNorm sits between the two convs of a block -- single conv_ws launches)
         # the reference's batch: two convs per launch (csrc/conv_pair.hip); RCAN: the CALayer steps ride on the launches
         w2, b2 = par(feats, feats, 3)
         pk2, pk2d = ops.pack_conv(w2, b2, dt), ops.pack_conv(w2, None, dt, dgrad=True)

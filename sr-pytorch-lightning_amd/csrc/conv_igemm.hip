@@ -1683,7 +1683,7 @@ static bool conv_trunk_layer_ok(const srk_conv_args& a, const srk_conv_args& a0)
 extern "C" int srk_conv_trunk_ok(const srk_conv_args* layers, int nlayers) {
   if (!layers || nlayers < 1) return 0;
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
-  static const bool off = srk_dbg_getenv("SRK_NO_TRUNK") != nullptr;      // diagnostics knob, read once
+  static const bool off = [] { const char* e = srk_dbg_getenv("SRK_NO_TRUNK"); return e && e[0] == '1'; }();      // diagnostics knob (SRK_DEBUG=1), read once
   if (off) return 0;
   // every CU one image at a time: worth it when the batch fills the chip in whole rounds (else the per-layer launches balance better)
   if (layers[0].N < cus || layers[0].N % cus != 0) return 0;

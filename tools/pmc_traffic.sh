@@ -53,8 +53,8 @@ T64 = lambda n: n * P * 64 * 2.0          # one 64-channel 16-bit activation ten
 DOM = {
     ("edsr_baseline", 256): ("conv_trunk_kernel", "conv_trunk_bf16", None, "33 layers per launch: see roofline.in_step.hbm_view (input, output, residual where the flavour has one, sign bits)"),
     ("edsr_baseline", 16): ("conv_pair_kernel", "conv_pair_bf16", 3 * T64(16), "x read, the intermediate and the output written (training keeps the intermediate)"),
-    ("rcan", 16): ("conv_pair_kernel", "conv_pair_bf16", 3 * T64(16), "x read, the intermediate and the output written"),
-    ("srresnet", 16): ("conv_pair_kernel", "conv_pair_bf16", 3 * T64(16), "x read, the intermediate and the output written"),
+    ("rcan", 16): ("conv_pair_kernel", "conv_pair_bf16", 5 * T64(16), "RCAB pair with the neighbouring block's channel attention: t and x of the previous block read, the block input, the intermediate and conv 2's output written"),
+    ("srresnet", 16): ("conv_ws_kernel<0, 2, 4, true, false, 0>", "conv_ws_plain_bf16", 2 * T64(16), "input read, output written (a BatchNorm sits between the convs of a block: single launches)"),
     ("edsr_large", 16): ("conv_ks_kernel<0, false>", "conv_ks_bf16", 2 * 4 * T64(16) + 9 * 256 * 256 * 2, "256-channel input read, output written, weights"),
     ("rdn_b", 16): ("conv_ks_kernel<0, false>", "conv_ks_bf16", (4.5 + 1) * T64(16), "RDN-B dense layers: Cin = 64 + 64 c, c = 0..7 (288 on average) read, 64 channels written"),
     ("wdsr_b", 16): ("pw_fwd_kernel", "pw_fwd_bf16", 16 * P * (128 + 112) * 2.0, "128-channel block input read, 112 (102 used) channels written; the 768-channel tensor never leaves the chip"),
