@@ -114,8 +114,6 @@ class PackGroup:
         self.pw_table = None
         self.proj_entries = {}  # (id(w), dtype) -> [w, packed buffer]  (D-DBPN's projection convs, csrc/proj.hip)
         self.proj_tables = {}   # dtype -> [device table, addresses it was built from]
-        self.hr_entries = {}    # (id(wu), id(wt), dtype) -> dict: the collapsed HR stage's weights (HrTailFn), rebuilt on a second stream at refresh
-        self.hr_stream = None
         self.tiles, self.total_tiles = None, 0
         self.pw_dirty = False
         self.table = None
@@ -194,41 +192,8 @@ class PackGroup:
             self.pw_dirty = False
         L.check(L.load().srk_pw_pack_group(self.pw_table.data_ptr(), len(self.pw_entries), _stream()), "srk_pw_pack_group")
 
-    def lookup_hr(self, key):
-        e = self.hr_entries.get(key)
-        return e if (e is not None and e["epoch"] == self.epoch and self.open) else None
-
-    def add_hr(self, key, params, bufs, fwd, dgrad):
-        """params: (wu, bu, wt, bt) as the model holds them; fwd / dgrad: (PackArgs, Packed) of the collapsed weight's two layouts (persistent buffers)."""
-        self.hr_entries[key] = dict(params=tuple(self._held(t) for t in params), bufs=bufs, fwd=fwd, dgrad=dgrad, epoch=-1, waited=-1)
-
-    def _refresh_hr(self):
-        """`hrtail_collapse` + the two packs of the collapsed weight (27 us at batch 16, parameters only) for every HR stage the model has used, on a SECOND
-        stream: they overlap the head conv and the trunk instead of sitting between the trunk and the 5x5 convolution.  HrTailFn.forward waits for the stream."""
-        main = torch.cuda.current_stream()
-        dev = next(iter(self.hr_entries.values()))["bufs"]["weff"].device
-        key = (dev.index, torch.cuda.is_current_stream_capturing())
-        if self.hr_stream is None or self.hr_stream[0] != key:
-            self.hr_stream = (key, torch.cuda.Stream(device=dev))
-        side = self.hr_stream[1]
-        side.wait_stream(main)                       # the optimizer's update of the parameters; last pass's readers of the buffers
-        with torch.cuda.stream(side):
-            for e in self.hr_entries.values():
-                wu, bu, wt, bt = e["params"]
-                if wu.dtype != torch.float32 or wt.dtype != torch.float32 or not wu.is_contiguous() or not wt.is_contiguous():
-                    continue                         # (HrTailFn.forward makes fp32 copies per call then: no prefetch)
-                a = e["args"]
-                a.wu, a.bu, a.wt, a.bt = wu.data_ptr(), _ptr(bu), wt.data_ptr(), _ptr(bt)
-                st = _stream()
-                L.call("srk_hrtail_collapse", a, st)
-                L.call("srk_pack_conv_weights", e["fwd"][0], st)
-                L.call("srk_pack_conv_weights", e["dgrad"][0], st)
-                e["epoch"] = self.epoch
-
     def refresh(self):
         self.epoch += 1
-        if self.hr_entries and _HR_PREP:
-            self._refresh_hr()
         if self.pw_entries:
             self._refresh_pw()
         if self.proj_entries:
@@ -359,7 +324,6 @@ def pack_conv(w, b, dtype, *, dgrad=False, ps_r=0, cache=True, as_1x1=False, tok
     a = L.PackArgs(w=wf.data_ptr(), bias=_ptr(bf), wpk=p.wpk.data_ptr(), bias_pk=_ptr(p.bias),
                    Cout=cout, Cin=cin, KH=kh, KW=kw, KinP=p.KinP, CoutP=p.CoutP,
                    dgrad=int(dgrad), ps_r=int(ps_r), dtype=_DT[dtype], rows_layout=int(rows))
-    p.args = a               # (a caller that re-packs the same buffers every step re-launches with these: PackGroup._refresh_hr)
     L.call("srk_pack_conv_weights", a, _stream())
     if store is not None:
         store[key] = (ver, p)
@@ -868,7 +832,6 @@ def discard_wgrads():
     nobody flushes).  Call before starting a fresh step."""
     _WQ.jobs, _WQ.rjobs, _WQ.pwjobs, _WQ.armed, _WQ.targets = [], [], [], False, {}
     _WQ.gen += 1
-    _join_side_streams()
 
 
 def flush_wgrads():
@@ -878,9 +841,6 @@ def flush_wgrads():
     rjobs, _WQ.rjobs = _WQ.rjobs, []
     pwjobs, _WQ.pwjobs = _WQ.pwjobs, []
     _WQ.gen += 1
-    if _SIDE.pending:                       # launch groups of this pass on a second stream (HrTailFn): whoever flushes is about to read gradients
-        with torch.cuda.stream(_WQ.stream if _WQ.stream is not None else torch.cuda.current_stream()):
-            _join_side_streams()
     if not jobs and not rjobs and not pwjobs:
         return
     lib = L.load()
@@ -1310,53 +1270,6 @@ def _hr_bufs(o, ci, dev):
                 wcor=torch.empty((4, o, ci), dtype=f32, device=dev), bcor=torch.empty((4, o), dtype=f32, device=dev))
 
 
-_HR_PREP = _knob("SRK_NO_HR_PREP", "0") != "1"        # A/B knob: the collapsed weights rebuilt inside HrTailFn.forward, on the forward's stream
-_HR_SIDE = _knob("SRK_NO_HR_SIDE", "0") != "1"        # A/B knob: the HR stage's parameter-gradient launches on the backward pass's own stream
-_HR_SIDE_MAX_PIXELS = int(_knob("SRK_HR_SIDE_MAX_PIXELS", str(64 * 48 * 48)))     # above this the chip is busy anyway (HBM-bound launches): one stream
-
-
-class _SideWork:
-    """Launch groups issued on a second stream during a backward pass (HrTailFn) and not joined yet: (stream, tensors kept alive)."""
-
-    def __init__(self):
-        self.pending = []
-        self.streams = {}
-
-
-_SIDE = _SideWork()
-
-
-def _join_side_streams():
-    """The current stream waits for every side-stream group of this pass; their tensors may be released afterwards."""
-    if not _SIDE.pending:
-        return
-    cur = torch.cuda.current_stream()
-    for side, _keep in _SIDE.pending:
-        cur.wait_stream(side)
-    _SIDE.pending = []
-
-
-def _hr_side_stream(x, params):
-    """The second stream for HrTailFn's parameter-gradient launches, or None (run them in line): only inside an autograd backward pass whose final
-    callback will join (`_arm_flush`), only for small batches, and only when autograd will ADOPT the returned gradients (a parameter that already has a
-    `.grad` is accumulated into by a node on the main stream, right behind this one)."""
-    if not _HR_SIDE or x.shape[0] * x.shape[1] * x.shape[2] > _HR_SIDE_MAX_PIXELS:
-        return None
-    if any(p is not None and getattr(p, "grad", None) is not None for p in params):
-        return None
-    if any(p is not None and (getattr(p, "_backward_hooks", None) or (getattr(p, "_post_accumulate_grad_hooks", None) and not p.__dict__.get("_srk_flush_aware", False)))
-           for p in params if isinstance(p, torch.Tensor)):
-        return None
-    if not _arm_flush():
-        return None
-    _WQ.stream = torch.cuda.current_stream()          # the stream the join (flush_wgrads) runs on: this backward pass's
-    key = (x.device.index, torch.cuda.is_current_stream_capturing())
-    st = _SIDE.streams.get(key)
-    if st is None:
-        st = _SIDE.streams[key] = torch.cuda.Stream(device=x.device)
-    return st
-
-
 class HrTailFn(torch.autograd.Function):
     """NHWC features -> NCHW fp32 image: conv3x3(Ci -> 4C) -> PixelShuffle(2) -> conv3x3(C -> O) [+ post_add] as ONE linear map.
 
@@ -1384,33 +1297,15 @@ class HrTailFn(torch.autograd.Function):
         dev, f32 = x.device, torch.float32
         wu_, wt_ = _f32c(wu), _f32c(wt)
         bu_, bt_ = (None if bu is None else _f32c(bu)), (None if bt is None else _f32c(bt))
-        grp = _group_for(None) if _HR_PREP else None
-        hkey = (id(wu), id(wt), x.dtype)
-        ent = grp.lookup_hr(hkey) if grp is not None else None
-        pkd = None
-        if ent is not None:
-            # built at the top of this forward on the group's second stream (PackGroup._refresh_hr): wait for it once per pass
-            bufs, pk, pkd = ent["bufs"], ent["fwd"][1], ent["dgrad"][1]
-            if ent["waited"] != grp.epoch:
-                torch.cuda.current_stream().wait_stream(grp.hr_stream[1])
-                ent["waited"] = grp.epoch
-        else:
-            bufs = _hr_bufs(o, ci, dev)
-            cargs = HrTailFn._args(x, wu_, bu_, wt_, bt_, bufs)
-            L.call("srk_hrtail_collapse", cargs, _stream())
-            pk = pack_conv(bufs["weff"], bufs["beff"], x.dtype, cache=False)
-            if grp is not None and wu_ is wu and wt_ is wt and (bu is None or bu_ is bu) and (bt is None or bt_ is bt):
-                # register: from the next forward on the group rebuilds these buffers itself, early and on its own stream
-                pkd = pack_conv(bufs["weff"], None, x.dtype, dgrad=True, cache=False)
-                grp.add_hr(hkey, (wu, bu, wt, bt), bufs, (pk.args, pk), (pkd.args, pkd))
-                grp.hr_entries[hkey]["args"] = cargs
+        bufs = _hr_bufs(o, ci, dev)
+        L.call("srk_hrtail_collapse", HrTailFn._args(x, wu_, bu_, wt_, bt_, bufs), _stream())
+        pk = pack_conv(bufs["weff"], bufs["beff"], x.dtype, cache=False)
         out = torch.empty((n, o, 2 * h, 2 * w), dtype=f32, device=dev)
         conv_raw(x, pk, N=n, H=h, W=w, Cin=ci, Cout=4 * o, out=out, out_mode=L.OUT_PLANAR, ps_r=2, post_add=post_add)
         L.call("srk_hrtail_edge_fwd", HrTailFn._args(x, wu_, bu_, wt_, bt_, bufs, out=out.data_ptr()), _stream())
         ctx.save_for_backward(x, wu_, wt_, *( [bu_] if bu_ is not None else []))
         ctx.has = (bu is not None, bt is not None)
         ctx.bufs = bufs
-        ctx.pkd = pkd
         ctx.wb = (wu, bu, wt, bt)
         return out
 
@@ -1430,31 +1325,12 @@ class HrTailFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[1:5])
         gx = None
         if need_x:
-            pkd = ctx.pkd if ctx.pkd is not None else pack_conv(bufs["weff"], None, x.dtype, dgrad=True, cache=False)
+            pkd = pack_conv(bufs["weff"], None, x.dtype, dgrad=True, cache=False)
             gx = torch.empty_like(x)
             conv_raw(g12, pkd, N=n, H=h, W=w, Cin=g12.shape[3], Cout=ci, out=gx, use_bias=False)
             L.call("srk_hrtail_edge_bwd_x", HrTailFn._args(x, wu_, bu_, wt_, None, bufs, g=g.data_ptr(), dx=gx.data_ptr(), dx_pitch=_pitch(gx)), st)
         gwu = gbu = gwt = gbt = None
-        # The parameter-gradient side of the stage (5x5 weight gradient + finalize, border correlations, their reduce, the chain rule back to the two layers:
-        # five launches, 64 us at batch 16) depends on g and x only -- not on anything the rest of the backward pass produces, and nothing of that pass reads
-        # it.  At small batches the trunk's data-gradient chain behind this node is latency-bound (one conv_pair tile per CU), so these launches run on a
-        # SECOND STREAM beside it and are joined where the step first needs weight gradients (flush_wgrads: the engine's final callback / a bucket hook).
-        side = _hr_side_stream(x, ctx.wb) if need_w else None
         if need_w:
-            main = torch.cuda.current_stream()
-            if side is not None:
-                side.wait_stream(main)                      # (g12 and everything before it)
-            with torch.cuda.stream(side if side is not None else main):
-                gwu, gbu, gwt, gbt = HrTailFn._backward_params(ctx, x, wu_, wt_, bu_, g, g12, bufs, has_bu, has_bt, side)
-        return gx, gwu, gbu, gwt, gbt, None
-
-    @staticmethod
-    def _backward_params(ctx, x, wu_, wt_, bu_, g, g12, bufs, has_bu, has_bt, side):
-        n, h, w, ci = x.shape
-        o, c = wt_.shape[0], wt_.shape[1]
-        dev, f32 = x.device, torch.float32
-        st = _stream()
-        if True:
             r, r0 = wgrad_raw(x, g12, N=n, H=h, W=w, Cin=ci, Cout=g12.shape[3], k=5, w_shape=(4 * o, ci, 5, 5), want_bias=True)
             red = dict(eedge=torch.empty((4, 2 * o, ci, 5), dtype=f32, device=dev), e0=torch.empty((4, 2 * o), dtype=f32, device=dev),
                        ecor=torch.empty((4, o, ci), dtype=f32, device=dev), k0=torch.empty((4, o), dtype=f32, device=dev))
@@ -1471,11 +1347,7 @@ class HrTailFn(torch.autograd.Function):
             gbt = dest(pbt, (o,)) if has_bt else None
             L.call("srk_hrtail_expand", HrTailFn._args(x, wu_, bu_, wt_, None, bufs, r=r.data_ptr(), r0=r0.data_ptr(), dwt=gwt.data_ptr(),
                                                        dbt=_ptr(gbt), dwu=gwu.data_ptr(), dbu=_ptr(gbu), **ptrs), st)
-            if side is not None:
-                # everything these launches touch stays allocated until the join (a block freed on the main stream could be handed out again there
-                # while the side stream still reads it)
-                _SIDE.pending.append((side, [x, wu_, wt_, bu_, g, g12, bufs, r, r0, red, scratch, gwu, gbu, gwt, gbt]))
-        return gwu, gbu, gwt, gbt
+        return gx, gwu, gbu, gwt, gbt, None
 
 
 def hr_tail(x, wu, bu, wt, bt, *, post_add=None):
