@@ -2344,660 +2344,9 @@ def rdb(x, convs, lff, dest=None):
 
 
 # --------------------------------------------------------------------------------------------
-# remaining conv models: strided / transposed / large-kernel convs, BatchNorm, PReLU
+# op families that live in their own modules (round 6): everything they define is part of this namespace, as before
 # --------------------------------------------------------------------------------------------
-def _unfold_raw(x, k, stride, pad):
-    n, h, w, c = x.shape
-    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
-    cols = torch.empty((n, ho, wo, k * k * c), dtype=x.dtype, device=x.device)
-    L.call("srk_unfold_nhwc", L.UnfoldNhwcArgs(x=x.data_ptr(), x_pitch=_pitch(x), x_coff=0, cols=cols.data_ptr(), cols_pitch=k * k * c,
-                                               N=n, H=h, W=w, C=c, K=k, stride=stride, pad=pad, Ho=ho, Wo=wo, dtype=_DT[x.dtype]), _stream())
-    return cols
-
-
-def _fold_raw(cols, c, k, stride, pad, ho, wo, bias=None):
-    n, hi, wi, kkc = cols.shape
-    assert kkc == k * k * c
-    out = torch.empty((n, ho, wo, c), dtype=cols.dtype, device=cols.device)
-    L.call("srk_fold_nhwc", L.FoldNhwcArgs(cols=cols.data_ptr(), cols_pitch=_pitch(cols), bias=_ptr(bias), out=out.data_ptr(), out_pitch=c, out_coff=0,
-                                           N=n, Hi=hi, Wi=wi, C=c, K=k, stride=stride, pad=pad, Ho=ho, Wo=wo, dtype=_DT[cols.dtype]), _stream())
-    return out
-
-
-class UnfoldFn(torch.autograd.Function):
-    """im2col on an NHWC tensor (srk_unfold_nhwc); backward = col2im (srk_fold_nhwc), its adjoint."""
-
-    @staticmethod
-    def forward(ctx, x, k, stride, pad):
-        _need_gpu(x)
-        ctx.cfg = (tuple(x.shape), k, stride, pad)
-        return _unfold_raw(x.contiguous(), k, stride, pad)
-
-    @staticmethod
-    def backward(ctx, g):
-        (n, h, w, c), k, stride, pad = ctx.cfg
-        return _fold_raw(g.contiguous(), c, k, stride, pad, h, w), None, None, None
-
-
-class FoldFn(torch.autograd.Function):
-    """col2im (srk_fold_nhwc) + per-channel bias; backward = im2col of the gradient, bias gradient = its pixel sum."""
-
-    @staticmethod
-    def forward(ctx, cols, bias, c, k, stride, pad, ho, wo):
-        _need_gpu(cols)
-        b32 = None
-        if bias is not None:
-            b32 = _f32c(bias)
-            if b32.numel() != c:
-                b32 = torch.nn.functional.pad(b32, (0, c - b32.numel()))
-        ctx.cfg = (k, stride, pad, None if bias is None else bias.numel())
-        return _fold_raw(cols.contiguous(), c, k, stride, pad, ho, wo, b32)
-
-    @staticmethod
-    def backward(ctx, g):
-        k, stride, pad, nb = ctx.cfg
-        g = g.contiguous()
-        gb = None
-        if nb is not None and ctx.needs_input_grad[1]:
-            gb = chan_sums(g)[0][:nb]
-        return _unfold_raw(g, k, stride, pad), gb, None, None, None, None, None, None
-
-
-def chan_sums(x, y=None, mode=None, shift=None):
-    """Per-channel sums over all pixels of NHWC `x`: (sum x, sum x^2); with y: mode 1 (sum y, sum x*y) or 2 (sum over x <= 0
-    of x*y, 0).  `shift` [C] fp32: x is centred (x - shift[c]) first.  srk_chan_stats partials added in block order
-    (fp32, reproducible)."""
-    _need_gpu(x)
-    c = x.shape[-1]
-    P = x.numel() // c
-    mode = (0 if y is None else 1) if mode is None else mode
-    if P == 0:
-        z = torch.zeros(c, dtype=torch.float32, device=x.device)
-        return z, z.clone()
-    nb = L.load().srk_chan_stats_blocks(P)
-    part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
-    L.call("srk_chan_stats", L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=0), _stream())
-    tot = part.sum(0)
-    return tot[0], tot[1]
-
-
-def _pitch4(t):
-    return _pitch(t) if t.dim() == 4 else t.shape[-1]
-
-
-def _gate_fields(gate):
-    """ChanStatsArgs fields of the optional PReLU input-gradient output: gate = (out tensor, fp32 slope [1] or [C]); or, for mode 3
-    (BatchNorm backward behind a PReLU), gate = ("bn", gate_a, gate_d, slope, partial2)."""
-    if gate is None:
-        return dict(gate_out=0, gate_pitch=0, slope=0, slope_stride=0)
-    if gate[0] == "bn":
-        _, ga, gd, sl, p2 = gate
-        return dict(gate_out=0, gate_pitch=0, slope=sl.data_ptr(), slope_stride=0 if sl.numel() == 1 else 1,
-                    gate_a=ga.data_ptr(), gate_d=gd.data_ptr(), partial2=p2.data_ptr())
-    out, sl = gate
-    return dict(gate_out=out.data_ptr(), gate_pitch=_pitch4(out), slope=sl.data_ptr(), slope_stride=0 if sl.numel() == 1 else 1)
-
-
-def chan_partials(x, y=None, mode=0, shift=None, shift_out=None, gate=None):
-    """The per-block partial sums of srk_chan_stats [blocks][2][C] (see chan_sums), left unsummed for srk_chan_finalize."""
-    _need_gpu(x)
-    c = x.shape[-1]
-    P = x.numel() // c
-    nb = L.load().srk_chan_stats_blocks(P)
-    part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
-    L.call("srk_chan_stats", L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-                                             P=P, C=c, mode=mode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=_ptr(shift_out),
-                                             **_gate_fields(gate)), _stream())
-    return part
-
-
-_COUNTERS = {}
-_FUSE_MAX_BLOCKS = int(_knob("SRK_CHAN_FUSE_MAX_BLOCKS", "160"))
-
-
-def _arrival_counter(device):
-    """One int32 of device memory per call, handed out round-robin from a zeroed pool: srk_chan_stats_finalize's arrival counter (the
-    kernel leaves it 0).  Launches that could overlap (other streams, parallel branches of a replayed graph) are many calls apart."""
-    st = _COUNTERS.get(device)
-    if st is None:
-        st = _COUNTERS[device] = [torch.zeros(4096, dtype=torch.int32, device=device), 0]
-    st[1] = (st[1] + 1) % 4096
-    return st[0].data_ptr() + 4 * st[1]
-
-
-def chan_reduce(x, y, smode, shift, fmode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None,
-                bias=None, running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None, shift_out=None, gate=None,
-                bn_gate=None, total2=False, dslope_acc=None):
-    """chan_finalize(chan_partials(x, y, smode, shift), fmode, rows, ...) as ONE launch (srk_chan_stats_finalize: the block that
-    finishes last does the [C]-sized step)."""
-    _need_gpu(x)
-    c = x.shape[-1]
-    P = x.numel() // c
-    nb = L.load().srk_chan_stats_blocks(P)
-    p2 = None
-    if bn_gate is not None:              # smode 3: (gate_a, gate_d, slope) -> third partial sums (the PReLU slope gradient)
-        p2 = torch.empty((nb, c), dtype=torch.float32, device=x.device)
-        gate = ("bn", bn_gate[0], bn_gate[1], bn_gate[2], p2)
-    if nb > _FUSE_MAX_BLOCKS:            # many blocks: their arrival counts (same-address atomics) would take longer than the launch they save
-        return chan_finalize(chan_partials(x, y, smode, shift, shift_out, gate), fmode, rows, partial2=p2, total2=total2, dslope_acc=dslope_acc, M=M, creal=creal, eps=eps, momentum=momentum, mean=mean, invstd=invstd,
-                             gamma=gamma, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var, total=total,
-                             nbt=nbt, dgamma_acc=dgamma_acc, dbeta_acc=dbeta_acc)
-    part = torch.empty((nb, 2, c), dtype=torch.float32, device=x.device)
-    out = torch.empty((rows, c), dtype=torch.float32, device=x.device)
-    sa = L.ChanStatsArgs(x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-                         P=P, C=c, mode=smode, partial=part.data_ptr(), dtype=_DT[x.dtype], shift=_ptr(shift), shift_out=_ptr(shift_out),
-                         **_gate_fields(gate))
-    fa = L.ChanFinalizeArgs(
-        partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=fmode, total=int(total),
-        M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
-        weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr(),
-        nbt=_ptr(nbt), dgamma_acc=_ptr(dgamma_acc), dbeta_acc=_ptr(dbeta_acc), partial2=_ptr(p2), total2=int(total2), dslope_acc=_ptr(dslope_acc))
-    import ctypes as C
-    L.check(L.load().srk_chan_stats_finalize(C.byref(sa), C.byref(fa), C.c_void_p(_arrival_counter(x.device)), C.c_void_p(_stream())),
-            "srk_chan_stats_finalize")
-    return out
-
-
-def chan_finalize(part, mode, rows, *, M=1.0, creal=None, eps=0.0, momentum=0.0, mean=None, invstd=None, gamma=None, weight=None, bias=None,
-                  running_mean=None, running_var=None, total=False, nbt=None, dgamma_acc=None, dbeta_acc=None, partial2=None, total2=False,
-                  dslope_acc=None):
-    """srk_chan_finalize on the partials of chan_partials: `rows` x [C] fp32 results (include/srk.h lists them per mode)."""
-    nb, _, c = part.shape
-    out = torch.empty((rows, c), dtype=torch.float32, device=part.device)
-    L.call("srk_chan_finalize", L.ChanFinalizeArgs(
-        partial=part.data_ptr(), nblocks=nb, C=c, Creal=c if creal is None else creal, mode=mode, total=int(total),
-        M=float(M), eps=float(eps), momentum=float(momentum), mean=_ptr(mean), invstd=_ptr(invstd), gamma=_ptr(gamma),
-        weight=_ptr(weight), bias=_ptr(bias), running_mean=_ptr(running_mean), running_var=_ptr(running_var), out=out.data_ptr(),
-        nbt=_ptr(nbt), dgamma_acc=_ptr(dgamma_acc), dbeta_acc=_ptr(dbeta_acc), partial2=_ptr(partial2), total2=int(total2),
-        dslope_acc=_ptr(dslope_acc)), _stream())
-    return out
-
-
-def chan_apply(x, *, y=None, z=None, a=None, b=None, d=None, slope=None, post_prelu=False, out=None, gate_a=None, gate_d=None):
-    """out = post((a*x + b*y + d) * gate(z)) per channel (srk_chan_apply).  a/b/d/slope: fp32 [C] (slope may have 1 element).
-    out: a tensor of x's shape to write (a channel-slice view of a wider NHWC buffer is fine), else a fresh one."""
-    _need_gpu(x)
-    c = x.shape[-1]
-    P = x.numel() // c
-    if out is None:
-        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    else:
-        assert tuple(out.shape) == tuple(x.shape) and out.dtype == x.dtype
-    if P == 0:
-        return out
-    sl = None if slope is None else _f32c(slope)
-
-    def vec(v):
-        if v is None:
-            return None
-        v = _f32c(v)
-        return v if v.numel() == c else torch.nn.functional.pad(v, (0, c - v.numel()))
-    a, b, d = vec(a), vec(b), vec(d)
-    if sl is not None and sl.numel() not in (1, c):
-        sl = torch.nn.functional.pad(sl, (0, c - sl.numel()))
-    L.call("srk_chan_apply", L.ChanApplyArgs(
-        x=x.data_ptr(), x_pitch=_pitch4(x), x_coff=0, y=_ptr(y), y_pitch=0 if y is None else _pitch4(y), y_coff=0,
-        z=_ptr(z), z_pitch=0 if z is None else _pitch4(z), z_coff=0, a=_ptr(a), b=_ptr(b), d=_ptr(d),
-        slope=_ptr(sl), slope_stride=0 if (sl is None or sl.numel() == 1) else 1, post_prelu=int(post_prelu),
-        out=out.data_ptr(), out_pitch=_pitch4(out), out_coff=0, P=P, C=c, dtype=_DT[x.dtype], gate_a=_ptr(gate_a), gate_d=_ptr(gate_d)), _stream())
-    return out
-
-
-class PReLUFn(torch.autograd.Function):
-    """nn.PReLU (one shared slope or one per channel) on an NHWC tensor: srk_chan_apply forward, gate + slope-gradient
-    reduction backward (models/srresnet.py:14,20,27; models/ddbpn.py:33,42-53,82-86)."""
-
-    @staticmethod
-    def forward(ctx, x, weight):
-        x = x.contiguous()
-        ctx.save_for_backward(x, weight)
-        ctx.wparam = weight
-        return chan_apply(x, slope=weight, post_prelu=True)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        g = g.contiguous()
-        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if x.numel() == 0:
-            return (torch.empty_like(g) if want_x else None), (torch.zeros_like(weight) if want_w else None)
-        if not want_w:
-            return chan_apply(g, z=x, slope=weight), None
-        # partial sums over x <= 0 of x * g, summed (over the channels too for a single slope) by one small launch; the pass that
-        # takes them writes the input gradient g * (x > 0 ? 1 : slope) from the same read of x and g
-        c = x.shape[-1]
-        gate = gx = None
-        if want_x:
-            sl = _f32c(weight)
-            if sl.numel() not in (1, c):
-                sl = torch.nn.functional.pad(sl, (0, c - sl.numel()))
-            gx = torch.empty_like(g)
-            gate = (gx, sl)
-        one = weight.numel() == 1
-        slot = _grad_slot(ctx.wparam, tuple(weight.shape))      # an existing fp32 .grad: the finalize step adds into it
-        acc = slot[1] if (slot is not None and slot[0] == "acc") else None
-        s = chan_reduce(x, g, 2, None, 4, 1, total=one, creal=None if one else weight.numel(), dgamma_acc=acc, gate=gate)[0]
-        gw = None if acc is not None else (s[:1] if one else s[:weight.numel()])
-        return gx, gw
-
-
-def prelu(x, weight):
-    return PReLUFn.apply(x, weight)
-
-
-class BatchNormFn(torch.autograd.Function):
-    """nn.BatchNorm2d on an NHWC tensor, training (batch statistics, running buffers updated like torch) or eval mode,
-    optionally fused with a residual add: out = gamma*(x - mean)*invstd + beta (+ res).
-    Reference: the `norm` of `ResBlock` / `BasicBlock` (models/common.py:33-56,97-98) in SRResNet (srresnet.py:16-21).
-    Statistics: srk_chan_stats (fp32 sums); apply and backward: srk_chan_apply; [C]-sized vector math stays in torch."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, res, nbt=None, link=None):
-        x = x.contiguous()
-        ctx.params = (weight, bias)
-        ctx.link = link
-        c = weight.numel()
-        cp = x.shape[-1]
-        M = x.numel() // cp
-        if training and M > 0:
-            # ONE pass: sums of the values shifted by the tensor's first pixel K (E[x^2] - mean^2 cancels in fp32 when |mean| >> std,
-            # which formula-filled / badly scaled nets do have; E[(x-K)^2] - (E[x-K])^2 with K from the data does not), and the
-            # [C]-sized arithmetic (mean; variance, running buffers, invstd, scale and shift of the apply pass) in the same launch.
-            w32, b32 = _f32c(weight), _f32c(bias)
-            upd = running_mean is not None and running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
-            k0 = torch.empty(cp, dtype=torch.float32, device=x.device)
-            r = chan_reduce(x, None, 0, None, 1, 5, M=M, creal=c, eps=eps, momentum=momentum, mean=k0, weight=w32, bias=b32,
-                            running_mean=running_mean if upd else None, running_var=running_var if upd else None, nbt=nbt, shift_out=k0)
-            mean = r[4]
-            nbt = None
-            invstd, gamma, a, d = r[0], r[1], r[2], r[3]
-            if running_mean is not None and not upd:        # buffers in another dtype: torch arithmetic
-                var = 1.0 / (invstd * invstd) - eps
-                with torch.no_grad():
-                    running_mean.mul_(1 - momentum).add_(mean[:c].to(running_mean.dtype), alpha=momentum)
-                    running_var.mul_(1 - momentum).add_((var[:c] * (M / max(M - 1, 1))).to(running_var.dtype), alpha=momentum)
-        else:
-            if training:
-                mean, var = torch.zeros(cp, dtype=torch.float32, device=x.device), torch.zeros(cp, dtype=torch.float32, device=x.device)
-            else:
-                mean = torch.nn.functional.pad(running_mean.float(), (0, cp - c))
-                var = torch.nn.functional.pad(running_var.float(), (0, cp - c), value=1.0)
-            invstd = torch.rsqrt(var + eps)
-            gamma = torch.nn.functional.pad(weight.detach().float(), (0, cp - c))
-            beta = torch.nn.functional.pad(bias.detach().float(), (0, cp - c))
-            a = gamma * invstd
-            d = beta - mean * a
-        if nbt is not None:                 # (no batch statistics pass ran: empty batch)
-            nbt.add_(1)
-        out = chan_apply(x, y=res, a=a, d=d)
-        ctx.save_for_backward(x, mean, invstd, gamma)
-        ctx.cfg = (training, c, M, res is not None)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        x, mean, invstd, gamma = ctx.saved_tensors
-        training, c, M, has_res = ctx.cfg
-        g = g.contiguous()
-        if M == 0:
-            z = torch.zeros(c, dtype=torch.float32, device=x.device)
-            return torch.empty_like(g), z, z.clone(), None, None, None, None, None, (g if has_res else None), None, None
-        mean = mean.contiguous()                                         # the sums: sum dy, sum (x - mean)*dy
-        # gamma's / beta's gradients go straight into the parameters' existing fp32 .grad buffers when they have them (the finalize
-        # step adds them there: what autograd's AccumulateGrad would do with one more launch each), else to autograd as tensors
-        wacc, wmode = _pass_slot(ctx.params[0], (c,), x.device) if ctx.needs_input_grad[1] else (None, None)
-        bacc, bmode = _pass_slot(ctx.params[1], (c,), x.device) if ctx.needs_input_grad[2] else (None, None)
-
-        def hand(mode, t, p):           # (a second use of the same module in this pass added into the first use's tensor: nothing to hand over)
-            if mode is None:
-                return None
-            if mode == "new+remember":
-                _remember_pass_grad(p, t)
-            return t
-        if training:
-            # dx = gamma*invstd * (dy - dbeta/M - xhat*dgamma/M),  xhat = (x - mean)*invstd
-            r = chan_reduce(x, g, 1, mean, 2, 5, M=M, creal=c, mean=mean, invstd=invstd.contiguous(), gamma=gamma.contiguous(), dgamma_acc=wacc, dbeta_acc=bacc)
-            dgamma, dbeta = r[0], r[1]
-            gx = chan_apply(g, y=x, a=r[2], b=r[3], d=r[4])
-        else:
-            r = chan_reduce(x, g, 1, mean, 3, 3, M=M, creal=c, invstd=invstd.contiguous(), gamma=gamma.contiguous(), dgamma_acc=wacc, dbeta_acc=bacc)
-            dgamma, dbeta = r[0], r[1]
-            gx = chan_apply(g, a=r[2])
-        gres = g if has_res else None
-        if has_res and ctx.link is not None and ctx.link.armed:         # parked for the block's first conv (ResLink): its data-gradient launch adds it
-            ctx.link.g, gres = g, None
-        return gx, hand(wmode, dgamma[:c], ctx.params[0]), hand(bmode, dbeta[:c], ctx.params[1]), None, None, None, None, None, gres, None, None
-
-
-class BNPReLUFn(torch.autograd.Function):
-    """nn.BatchNorm2d (batch statistics) followed by nn.PReLU -- SRResNet's conv -> norm -> act (srresnet.py:16-21 through
-    common.py:94-100) -- as ONE unit: forward = the statistics launch + one apply launch (the activation rides in it, the BatchNorm's
-    output is never stored); backward = ONE statistics launch over (x, dy) that recomputes the BatchNorm output a x + d for the
-    PReLU's gate and takes the BatchNorm's two sums AND the slope's gradient (srk_chan_stats mode 3), + one apply launch
-    (dx = A dy gate + B x + D).  Five launches per layer instead of seven."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, slope, nbt):
-        x = x.contiguous()
-        c, cp = weight.numel(), x.shape[-1]
-        M = x.numel() // cp
-        w32, b32 = _f32c(weight), _f32c(bias)
-        upd = running_mean is not None and running_mean.dtype == torch.float32 and running_var.dtype == torch.float32
-        k0 = torch.empty(cp, dtype=torch.float32, device=x.device)
-        r = chan_reduce(x, None, 0, None, 1, 5, M=M, creal=c, eps=eps, momentum=momentum, mean=k0, weight=w32, bias=b32,
-                        running_mean=running_mean if upd else None, running_var=running_var if upd else None, nbt=nbt, shift_out=k0)
-        invstd, gamma, a, d, mean = r[0], r[1], r[2], r[3], r[4]
-        if running_mean is not None and not upd:            # buffers in another dtype: torch arithmetic
-            var = 1.0 / (invstd * invstd) - eps
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean[:c].to(running_mean.dtype), alpha=momentum)
-                running_var.mul_(1 - momentum).add_((var[:c] * (M / max(M - 1, 1))).to(running_var.dtype), alpha=momentum)
-        sl = _f32c(slope)
-        if sl.numel() not in (1, cp):
-            sl = torch.nn.functional.pad(sl, (0, cp - sl.numel()))
-        out = chan_apply(x, a=a, d=d, slope=sl, post_prelu=True)
-        ctx.save_for_backward(x, mean, invstd, gamma, a, d, sl)
-        ctx.cfg = (c, M, slope.numel())
-        ctx.params = (weight, bias, slope)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        x, mean, invstd, gamma, a, d, sl = ctx.saved_tensors
-        c, M, ns = ctx.cfg
-        g = g.contiguous()
-
-        dev = x.device
-        wacc, wmode = _pass_slot(ctx.params[0], (c,), dev) if ctx.needs_input_grad[1] else (None, None)
-        bacc, bmode = _pass_slot(ctx.params[1], (c,), dev) if ctx.needs_input_grad[2] else (None, None)
-        sacc, smode = _pass_slot(ctx.params[2], tuple(ctx.params[2].shape), dev) if ctx.needs_input_grad[7] else (None, None)
-        r = chan_reduce(x, g, 3, mean.contiguous(), 2, 6, M=M, creal=c, mean=mean.contiguous(), invstd=invstd.contiguous(), gamma=gamma.contiguous(),
-                        dgamma_acc=wacc, dbeta_acc=bacc, bn_gate=(a.contiguous(), d.contiguous(), sl), total2=ns == 1, dslope_acc=sacc)
-        gx = chan_apply(g, y=x, z=x, a=r[2], b=r[3], d=r[4], slope=sl, gate_a=a.contiguous(), gate_d=d.contiguous())
-
-        def hand(mode, t, p):
-            if mode is None:
-                return None
-            if mode == "new+remember":
-                _remember_pass_grad(p, t)
-            return t
-        gw = hand(wmode, r[0][:c], ctx.params[0])
-        gb = hand(bmode, r[1][:c], ctx.params[1])
-        gs = hand(smode, r[5][:1] if ns == 1 else r[5][:ns], ctx.params[2])
-        return (gx, gw, gb, None, None, None, None, gs, None)
-
-
-_BN_PRELU_FUSED = _knob("SRK_NO_BN_PRELU", "0") != "1"      # A/B knob
-
-
-def batch_norm_prelu(x, bn, slope):
-    """`prelu(batch_norm(x, bn), slope)` -- fused (BNPReLUFn) in training mode with batch statistics and momentum set."""
-    if (_BN_PRELU_FUSED and (bn.training or bn.running_mean is None) and bn.momentum is not None and x.numel() > 0
-            and slope.numel() in (1, bn.weight.numel()) and bn.weight is not None):
-        nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats and bn.num_batches_tracked is not None) else None
-        if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
-            nbt.add_(1)
-            nbt = None
-        return BNPReLUFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, slope, nbt)
-    return prelu(batch_norm(x, bn), slope)
-
-
-def batch_norm(x, bn, res=None, link=None):
-    """`bn`: an nn.BatchNorm2d (parameters, running buffers, training flag, momentum, eps) applied to NHWC `x`.
-    link: a ResLink shared with the conv that consumes `res` (the residual's gradient then rides in that conv's data gradient)."""
-    nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats and bn.num_batches_tracked is not None) else None
-    if bn.momentum is not None:
-        mom = bn.momentum                                   # num_batches_tracked += 1 rides in the statistics launch
-    elif nbt is not None:
-        nbt.add_(1)
-        mom = 1.0 / float(nbt)                              # torch: cumulative moving average (a host read, as in torch)
-        nbt = None
-    else:
-        mom = 0.0
-    use_batch = bn.training or bn.running_mean is None
-    if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
-        nbt.add_(1)
-        nbt = None
-    return BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch, mom, bn.eps, res, nbt, link if res is not None else None)
-
-
-_LK_OFF = _knob("SRK_NO_LK", "0") == "1"        # A/B knob: large kernels through im2col as in round 2
-
-
-def _nhwc_view(x):
-    """`x` itself when it is a dense NHWC tensor or a channel-slice view of one (the kernels take a pixel pitch), else a copy."""
-    try:
-        if x.data_ptr() % 16 == 0 and _pitch(x) % 8 == 0:
-            return x
-    except AssertionError:
-        pass
-    return x.contiguous()
-
-
-_PROJ_OFF = _knob("SRK_NO_PROJ", "0") == "1"    # A/B knob: D-DBPN's projections through im2col / col2im as in round 2
-
-
-def proj_ok(x, w, stride, pad, up):
-    """Whether a D-DBPN projection conv (ddbpn.py:10-24) on NHWC `x` runs on the direct kernels (csrc/proj.hip): scale 4
-    (kernel 8, stride 4, padding 2), 32 channels on both sides, 16-bit storage."""
-    if _PROJ_OFF or x.dtype not in (torch.bfloat16, torch.float16) or x.numel() == 0:
-        return False
-    if tuple(w.shape) != (32, 32, 8, 8) or stride != 4 or pad != 2 or x.shape[3] != 32:
-        return False
-    if not up and (x.shape[1] % 4 or x.shape[2] % 4):
-        return False
-    return x.numel() * (16 if up else 1) * 2 < _ADDR_LIMIT
-
-
-def _proj_launch(x, wpk_half, bias, up, slope=None, want_pre=False):
-    """One srk_proj_up / srk_proj_down launch; with `slope` (fp32 [1] or [32]) the following nn.PReLU rides in the epilogue:
-    returns (activation, stored conv output or None)."""
-    n, h, wd, _ = x.shape
-    lh, lw = (h, wd) if up else (h // 4, wd // 4)
-    shape = (n, 4 * lh, 4 * lw, 32) if up else (n, lh, lw, 32)
-    out = torch.empty(shape, dtype=x.dtype, device=x.device)
-    pre = torch.empty(shape, dtype=x.dtype, device=x.device) if (slope is not None and want_pre) else None
-    L.call("srk_proj_up" if up else "srk_proj_down",
-           L.ProjArgs(x=x.data_ptr(), x_pitch=_pitch(x), out=out.data_ptr(), out_pitch=32, wpk=wpk_half.data_ptr(), bias=_ptr(bias),
-                      N=n, H=lh, W=lw, dtype=_DT[x.dtype], slope=_ptr(slope), slope_stride=0 if (slope is None or slope.numel() == 1) else 1,
-                      pre=_ptr(pre), pre_pitch=32), _stream())
-    return out, pre
-
-
-class ProjFn(torch.autograd.Function):
-    """nn.Conv2d / nn.ConvTranspose2d(32, 32, 8, stride=4, padding=2) [+ the nn.PReLU(32) behind it] on an NHWC 16-bit tensor
-    (ddbpn.py:10-24, 42-53): forward, data gradient and weight gradient on the direct kernels of csrc/proj.hip.  Both weight
-    layouts read as [c_low][c_high][ky][kx] (Conv2d: [out][in], ConvTranspose2d: [in][out]), so `up` alone tells the directions
-    apart.  With `slope` the activation is applied in the conv's epilogue (the stored conv output is kept for the backward:
-    PReLU's input gradient and slope gradient come from one pass over it, srk_chan_stats mode 2 with gate_out)."""
-
-    @staticmethod
-    def forward(ctx, x, w, b, slope, up):
-        _need_gpu(x)
-        x = _nhwc_view(x)
-        half = L.load().srk_proj_pack_bytes() // 2
-        # a model's forward window (forward_scope) packs the projection weights it has seen before in ONE launch; a first use, a
-        # weight that is not a plain fp32 parameter, or a call outside any window packs here
-        group = _group_for(None) if (isinstance(w, torch.nn.Parameter) and w.dtype == torch.float32 and w.is_contiguous()) else None
-        key = (id(w), x.dtype)
-        wpk = group.lookup_proj(key) if group is not None else None
-        ctx.pg = _tok() if wpk is not None else None
-        if wpk is None or wpk.device != x.device:
-            wpk = torch.empty(2 * half, dtype=torch.uint8, device=x.device)
-            L.check(L.load().srk_proj_pack(_f32c(w).data_ptr(), wpk.data_ptr(), _DT[x.dtype], _stream()), "srk_proj_pack")
-            if group is not None:
-                group.add_proj(key, w, wpk)
-                ctx.pg = _tok()
-        sl = None if slope is None else _f32c(slope)
-        need_pre = sl is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3])
-        out, pre = _proj_launch(x, wpk[half:] if up else wpk[:half], None if b is None else _f32c(b), up, sl, need_pre)
-        ctx.save_for_backward(x, wpk, pre, sl)
-        ctx.up, ctx.half = bool(up), half
-        ctx.wparam, ctx.bparam, ctx.sparam = w, b, slope
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        x, wpk, pre, sl = ctx.saved_tensors
-        up, half = ctx.up, ctx.half
-        if ctx.pg is not None and _group_for(ctx.pg) is None:
-            # the group's buffer was re-packed by a later forward window (from possibly updated weights): pack the weights again, here
-            wpk = torch.empty(2 * half, dtype=torch.uint8, device=x.device)
-            L.check(L.load().srk_proj_pack(_f32c(ctx.wparam).data_ptr(), wpk.data_ptr(), _DT[x.dtype], _stream()), "srk_proj_pack")
-        g = _nhwc_view(g)               # (a slice of a SliceBuffer's gradient buffer is read with its pitch: no copy)
-        gs = None
-        if sl is not None:                       # through the PReLU first: g <- g * (pre > 0 ? 1 : slope), slope gradient on the side
-            if ctx.needs_input_grad[3]:
-                one = sl.numel() == 1
-                slot = _grad_slot(ctx.sparam, tuple(ctx.sparam.shape))
-                acc = slot[1] if (slot is not None and slot[0] == "acc") else None
-                gp = torch.empty_like(g)
-                s = chan_reduce(pre, g, 2, None, 4, 1, total=one, creal=None if one else sl.numel(), dgamma_acc=acc, gate=(gp, sl))[0]
-                gs = None if acc is not None else (s[:1] if one else s[:sl.numel()])
-                g = gp
-            else:
-                g = chan_apply(g, z=pre, slope=sl)
-        gx = _proj_launch(g, wpk[:half] if up else wpk[half:], None, not up)[0] if ctx.needs_input_grad[0] else None
-        gw = gb = None
-        want_b = ctx.bparam is not None and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            xh, gl = (g, x) if up else (x, g)
-            n, lh, lw, _ = gl.shape
-
-            def slot_of(p, shape):          # existing fp32 .grad: added into; GradSync's flat-buffer slice: written there; else fresh
-                sl_ = _grad_slot(p, shape)
-                acc_ = sl_[1] if (sl_ is not None and sl_[0] == "acc") else None
-                t = acc_ if acc_ is not None else _grad_target(p, shape, x.device)
-                return (t if t is not None else torch.empty(shape, dtype=torch.float32, device=x.device)), acc_ is not None
-            dw, wacc = slot_of(ctx.wparam, (32, 32, 8, 8))
-            db, bacc = slot_of(ctx.bparam, (32,)) if want_b else (None, False)
-            scratch = torch.empty(L.load().srk_proj_wgrad_scratch_floats(n, lh, lw), dtype=torch.float32, device=x.device)
-            L.call("srk_proj_wgrad", L.ProjWgradArgs(xh=xh.data_ptr(), xh_pitch=_pitch(xh), g=gl.data_ptr(), g_pitch=_pitch(gl),
-                                                     scratch=scratch.data_ptr(), dw=dw.data_ptr(), accumulate=int(wacc),
-                                                     N=n, H=lh, W=lw, dtype=_DT[x.dtype], db=_ptr(db), bias_side=2 if up else 1,
-                                                     db_accumulate=int(bacc)), _stream())
-            gw = None if wacc else dw
-            gb = None if (bacc or not want_b) else db
-        elif want_b:
-            gb = chan_sums(g)[0][:32]
-        return gx, gw, gb, gs, None
-
-
-def proj_prelu(x, w, b, slope, *, up):
-    """D-DBPN's [projection conv, PReLU] pair (ddbpn.py:42-53) on NHWC `x` as ONE forward launch (shapes: see proj_ok)."""
-    return ProjFn.apply(x, w, b, slope, bool(up))
-
-
-def conv_general(x, w, b, *, stride=1, pad=0):
-    """nn.Conv2d with any square kernel / stride / zero padding on NHWC `x`: im2col (srk_unfold_nhwc) + the 1x1 MFMA conv
-    with the OIHW weight presented as a [Cout][K*K*Cin] matrix in (kh, kw, ci) order.  The permute / reshape of the
-    parameter is a view-level torch op, so its gradient flows back to the OIHW parameter through autograd."""
-    cout, cin, k, _ = w.shape
-    cp = x.shape[-1]
-    if proj_ok(x, w, stride, pad, False):             # D-DBPN's down-projection at scale 4: direct kernels (csrc/proj.hip)
-        return ProjFn.apply(x, w, b, None, False)
-    if (stride == 1 and pad == k // 2 and k in (5, 7, 9) and cin == cp == 64 and cout <= 16 and x.dtype in (torch.bfloat16, torch.float16)
-            and x.numel() * 2 < _ADDR_LIMIT and not _LK_OFF):
-        # SRResNet's 9x9 tail conv (srresnet.py:29): the direct large-kernel kernels (csrc/conv_lk.hip), no column tensor
-        return conv(x, w, b)
-    if cp != cin:                                   # zero-padded storage channels: pad the weight's input channels too
-        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cp - cin))
-    wm = w.permute(0, 2, 3, 1).reshape(cout, k * k * cp, 1, 1)
-    cols = UnfoldFn.apply(x, k, stride, pad)
-    return conv(cols, wm, b)
-
-
-def conv_transpose_general(x, w, b, *, stride=1, pad=0):
-    """nn.ConvTranspose2d (weight [Cin][Cout][K][K]) on NHWC `x`: 1x1 MFMA conv to K*K*Cout channels + col2im gather
-    (srk_fold_nhwc) with the bias added once per output element."""
-    cin, cout, k, _ = w.shape
-    n, h, wd, cp = x.shape
-    if proj_ok(x, w, stride, pad, True):              # D-DBPN's up-projection at scale 4: direct kernels (csrc/proj.hip)
-        return ProjFn.apply(x, w, b, None, True)
-    coutp = pad16(cout)
-    if cp != cin:
-        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cp - cin))
-    if coutp != cout:
-        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, coutp - cout))
-    wm = w.permute(2, 3, 1, 0).reshape(k * k * coutp, cp, 1, 1)
-    cols = conv(x, wm, None)
-    ho, wo = (h - 1) * stride - 2 * pad + k, (wd - 1) * stride - 2 * pad + k
-    return FoldFn.apply(cols, b, coutp, k, stride, pad, ho, wo)
-
-
-# --------------------------------------------------------------------------------------------
-# metric core on the device (SURVEY.md 8(f) rank 2)
-# --------------------------------------------------------------------------------------------
-def image_sse(sr, hr, *, luma=False, shave=0):
-    """Per-image sum of squared differences of clamp(sr,0,1) and clamp(hr,0,1) (all channels, or BT.601 luma) with a
-    `shave`-pixel border removed, and the element count per image.  srmodel.py:224-232,582 (piq.psnr core)."""
-    _need_gpu(sr)
-    n, c, h, w = sr.shape
-    s32, h32 = _f32c(sr), _f32c(hr)
-    sse = torch.zeros(n, dtype=torch.float64, device=sr.device)
-    a = L.SseArgs(sr=s32.data_ptr(), hr=h32.data_ptr(), N=n, C=c, H=h, W=w, luma=int(luma), shave=int(shave), sse=sse.data_ptr())
-    L.call("srk_image_sse", a, _stream())
-    count = (h - 2 * shave) * (w - 2 * shave) * (1 if luma else c)
-    return sse, count
-
-
-def psnr(sr, hr, *, luma=False, shave=0, eps=1e-8):
-    """10 log10(1 / (MSE + eps)) per image, batch mean (piq.psnr defaults: data_range 1, EPS 1e-8)."""
-    sse, count = image_sse(sr, hr, luma=luma, shave=shave)
-    return (10.0 * torch.log10(1.0 / (sse / count + eps))).mean().float()
-
-
-def ssim(x, y, *, sigma=1.5, k1=0.01, k2=0.03):
-    """SSIM with piq.ssim's defaults on the device (srk_image_ssim): average-pool by max(1, round(min(H, W) / 256)),
-    separable 11-tap Gaussian, mean of the valid SSIM map per (image, channel), then mean over channels and images.
-    No host synchronisation: the result is a 0-d device tensor."""
-    _need_gpu(x)
-    xs, ys = _f32c(x), _f32c(y)
-    n, c, h, w = xs.shape
-    f = max(1, round(min(h, w) / 256))
-    sums = torch.zeros(n * c, dtype=torch.float64, device=xs.device)
-    a = L.SsimArgs(x=xs.data_ptr(), y=ys.data_ptr(), N=n, C=c, H=h, W=w, pool=f, sigma=float(sigma), k1=float(k1), k2=float(k2),
-                   sums=sums.data_ptr())
-    L.call("srk_image_ssim", a, _stream())
-    count = (h // f - 10) * (w // f - 10)
-    return (sums / count).mean().float()
-
-
-class L1LossFn(torch.autograd.Function):
-    """mean |sr - hr| (F.l1_loss, reference srmodel.py:160-171) as two HIP launches per step instead of torch's
-    sub / abs / mean / sign / mul chain: forward reads both images once and keeps sign(sr - hr) as int8, backward
-    expands the signs into the gradient (no second read of the images, no host sync: gout stays on the device)."""
-
-    @staticmethod
-    def forward(ctx, sr, hr):
-        _need_gpu(sr)
-        s, h = _f32c(sr), _f32c(hr)
-        n = s.numel()
-        sign = torch.empty(n, dtype=torch.int8, device=s.device)
-        nb = L.load().srk_l1_blocks(n)
-        partial = torch.empty(nb, dtype=torch.float64, device=s.device)
-        a = L.L1Args(sr=s.data_ptr(), hr=h.data_ptr(), n=n, sign=sign.data_ptr(), partial=partial.data_ptr(), gout=0, scale=0.0, grad=0)
-        L.call("srk_l1_loss_fwd", a, _stream())
-        ctx.save_for_backward(sign)
-        ctx.shape = tuple(sr.shape)
-        out = torch.empty((), dtype=torch.float32, device=s.device)
-        L.check(L.load().srk_l1_loss_mean(partial.data_ptr(), nb, n, out.data_ptr(), _stream()), "srk_l1_loss_mean")
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        (sign,) = ctx.saved_tensors
-        n = sign.numel()
-        gout = g.detach().float().contiguous()
-        grad = torch.empty(ctx.shape, dtype=torch.float32, device=sign.device)
-        a = L.L1Args(sr=0, hr=0, n=n, sign=sign.data_ptr(), partial=0, gout=gout.data_ptr(), scale=1.0 / n, grad=grad.data_ptr())
-        L.call("srk_l1_loss_bwd", a, _stream())
-        return grad, None
-
-
-def l1_loss(sr, hr):
-    """F.l1_loss(sr, hr) for device tensors (hr needs no gradient)."""
-    if hr.requires_grad or sr.numel() == 0:
-        return torch.nn.functional.l1_loss(sr, hr)
-    return L1LossFn.apply(sr, hr)
+from .ops_norm import *      # noqa: E402,F401,F403  BatchNorm2d, PReLU, per-channel statistics
+from .ops_proj import *      # noqa: E402,F401,F403  unfold / fold, projection and general strided convs
+from .ops_proj import _proj_launch      # noqa: E402,F401  (bench.py / tools/microbench_proj.py time the raw launches)
+from .ops_metrics import *   # noqa: E402,F401,F403  PSNR / SSIM reductions, L1 loss
