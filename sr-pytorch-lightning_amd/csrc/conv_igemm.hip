@@ -26,18 +26,6 @@
 #ifndef SRK_WS_ABLATE
 #define SRK_WS_ABLATE 0        // timing ablations (wrong results): 1 = skip MFMAs, 2 = skip epilogue, 4 = skip halo DMA, 16 = no weight-order rotation
 #endif
-#ifndef SRK_WS_PRIO_M
-#define SRK_WS_PRIO_M 1       // s_setprio of a wave in its MFMA phase / its epilogue phase (A/B builds)
-#endif
-#ifndef SRK_WS_PRIO_E
-#define SRK_WS_PRIO_E 0
-#endif
-#ifndef SRK_TRUNK_PREFETCH
-#define SRK_TRUNK_PREFETCH 0  // conv_trunk_kernel: 1 = the wave group that is idle while the other one stores the layer's last tile fetches the NEXT
-                              // layer's weight slab (conv_ws_body<.., CHAIN>).  Built, bit-identical, measured on one box (tools/microbench_trunk.py,
-                              // two runs each): 42.54 / 42.58 us per convolution with it, 42.36 / 42.40 without -- a layer's prologue is not what bounds the
-                              // chain (the memory system is: DESIGN.md 3.20), and the extra live scalars cost 63 more SGPR spills.  Off.
-#endif
 #ifndef SRK_ST_AUX
 #define SRK_ST_AUX 16         // cache policy of the quad epilogue's stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
@@ -913,13 +901,9 @@ SRK_DEV void grp_barrier(unsigned addr, unsigned target, int lane) {
 // The body of the weight-stationary kernel for ONE contiguous range of tiles [t0, t0 + nt) of channel tile `ctile`: called once per
 // launch by conv_ws_kernel and once per (image, layer) by conv_trunk_kernel (below).  Every wave of the workgroup must call it with the
 // same arguments; on return the last tile's 8 stores per lane may still be in flight.
-// CHAIN (conv_trunk_kernel only): `w_ready` -- this layer's weight slab is already in LDS, fetched by the previous layer's call --, and
-// `next_wpk` -- the next layer's packed weights (or null): the wave group that is idle while the other one finishes the layer's last tile
-// fetches them into the (then unused) weight region, so the next layer starts with its halo tiles only.
-template <int DT, int CBW, int NKS, bool FAST, bool EARLY, int EM, bool CHAIN = false>
+template <int DT, int CBW, int NKS, bool FAST, bool EARLY, int EM>
 SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ctile, int t0, int nt, unsigned x_bytes,
-                          int xs_img, int xs_row, int xs_col, int wtap, const int tid, const bool w_ready = false,
-                          const void* const next_wpk = nullptr) {
+                          int xs_img, int xs_row, int xs_col, int wtap, const int tid) {
   // wtap: 16-byte chunks per tap in the packed weight buffer (8 for Cin = 64; 8*r*r when this launch handles one
   // 64-channel K-block of a wider reduction, a.wpk then points at that block's first chunk)
   // xs_img / xs_row / xs_col: element strides of the input between images, rows and columns of the conv-space grid
@@ -1053,10 +1037,8 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
   // through phase 0, fetches taps 3-8 behind it; group 0 meets it at a workgroup barrier just before the first
   // fragment of tap 3 / tap 6 is read (K-steps 10 / 22), then group 1 loads its own first halo tile.
   constexpr bool STAGED = !EARLY && FAST && CBW == 2 && NKS == 4;
-  const bool have_w = CHAIN && w_ready;                // (compile-time false outside the trunk kernel)
-  const bool staged = STAGED && !have_w;
   const int rot = (STAGED || (dbg & 16)) ? 0 : (int)((blockIdx.x * 11u) % (unsigned)NBLK);
-  if (staged) {
+  if constexpr (STAGED) {
     const int pt0 = t0;                                   // group 0's first tile
     const int tX = pt0 % tilesX, q0 = pt0 / tilesX, tY = q0 % tilesY, n0 = q0 / tilesY;
     const int y0 = tY * 16, x0 = tX * 16;
@@ -1086,25 +1068,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
     if constexpr (EARLY) dma16(wg + off, Wl + (rb << 10));
     else dma16_hidden(wrsrc, (unsigned)(off * sizeof(elem)), (unsigned)__builtin_amdgcn_readfirstlane((int)(wl_lds + (rb << 10))));
   };
-  auto fetch_next_weights = [&]() {               // this wave GROUP's 4 waves: the whole slab of the next layer, in place
-    if constexpr (CHAIN) {
-      const elem* const wn = reinterpret_cast<const elem*>(next_wpk);
-      const i32x4 wnrsrc = make_rsrc4(wn, 0x7fffffffu);
-#pragma unroll 1
-      for (int kk = 0; kk < NBLK / 4; ++kk) {
-        const int blk = kk * 4 + w4;
-        const int i = blk * 64 + lane;
-        const int co = i % TCW, c = (i / TCW) % (2 * NKS), tap = i / (TCW * 2 * NKS);
-        const size_t off = ((size_t)(tap * wtap + c) * a.CoutP + ctile * TCW + co) * CH;
-        if constexpr (EARLY) dma16(wn + off, Wl + (blk << 10));
-        else dma16_hidden(wnrsrc, (unsigned)(off * sizeof(elem)), (unsigned)__builtin_amdgcn_readfirstlane((int)(wl_lds + (blk << 10))));
-      }
-    }
-  };
-  static_assert(!CHAIN || NBLK % 4 == 0, "the slab splits over a group's 4 waves");
-  if (have_w) {
-    // (the slab is in LDS already: conv_trunk_kernel, fetched during the previous layer's last phase)
-  } else if (staged) {
+  if constexpr (STAGED) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) dma_wblock(k * 8 + wave);          // taps 0-2, all 8 waves; taps 3-8: group 1, below
   } else {
@@ -1118,7 +1082,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
   fill_pieces();
   load_bias();
   asm volatile("" ::: "memory");
-  if (!staged && nj > 0) dma_x(0);
+  if (!STAGED && nj > 0) dma_x(0);
 #if SRK_WS_STAMPS
   const unsigned long long tB = __builtin_amdgcn_s_memtime();
 #endif
@@ -1158,7 +1122,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
   // group 0 needs the weights and its halo tile now; group 1 idles through phase 0, so it only has to have landed its
   // share of the weights here (its 10-11 halo pieces are the youngest operations) and waits for its halo tile at the
   // end of phase 0: 41.5 KB less in the all-CUs-at-once prologue burst (~12-14 B/clk/CU)
-  if (staged) {
+  if constexpr (STAGED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of group 0's halo tile and of taps 0-2
   } else {
     if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1175,7 +1139,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
 #if SRK_WS_STAMPS
   const unsigned long long tD = __builtin_amdgcn_s_memtime();
 #endif
-  if (staged) {
+  if constexpr (STAGED) {
     // group 1 (idle through phase 0) fetches taps 3-8: 12 blocks per wave, in tap order
     if (grp == 1) {
 #pragma unroll
@@ -1230,11 +1194,6 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
     const int q = FREE ? p : p - grp;            // this group's own phase counter
     const int j = q >> 1;
     SRK_STAMP(2 * p);
-    if constexpr (CHAIN && !FREE) {
-      // phase nt: the layer's last MFMA phase (tile nt - 1, the other group's) ended at the barrier just passed, that group now stores the tile,
-      // this one has nothing left: it fetches the next layer's weight slab (18 blocks per wave)
-      if (next_wpk && p == nt && grp == (nt & 1)) fetch_next_weights();
-    }
     if (q >= 0 && j < nj) {
       if ((q & 1) == 0) {
         if (dbg & 1) {
@@ -1280,7 +1239,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
         frag(1, fa[1], fb0[1], fb1[1]);
         QuadPre pre;
         if constexpr (EARLY) pre = EM == 3 ? quad_early_setup_bits(a, quad_geo(j), qi, h) : quad_early_setup(a, quad_geo(j), qi);     // behind the first LDS reads: overlaps their latency
-        __builtin_amdgcn_s_setprio(SRK_WS_PRIO_M);
+        __builtin_amdgcn_s_setprio(1);
 #if SRK_WS_STAMPS
         if (p == 2) SRK_STAMP(40);
 #endif
@@ -1295,7 +1254,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
           // 4 reads per wave in one gap oversubscribes the array while the waves run in step
           if constexpr (STAGED) {
             // first tile only: taps 3-5 / 6-8 are needed from K-steps 12 / 24 on, their fragments two steps earlier
-            if (staged && p == 0 && (s == 10 || s == 22)) __builtin_amdgcn_s_barrier();      // group 1 has landed taps 3-5 / 6-8
+            if (p == 0 && (s == 10 || s == 22)) __builtin_amdgcn_s_barrier();      // group 1 has landed taps 3-5 / 6-8
           }
           int q = 0;
           if constexpr (EARLY) {
@@ -1322,7 +1281,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        __builtin_amdgcn_s_setprio(SRK_WS_PRIO_E);
+        __builtin_amdgcn_s_setprio(0);
 #if SRK_WS_STAMPS
         if (p == 2) SRK_STAMP(43);
 #endif
@@ -1399,7 +1358,7 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
         }
       }
     }
-    if (staged) {
+    if constexpr (STAGED) {
       if (q < 0) {                                        // group 1, phase 0: the two staged weight syncs of group 0
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // its 6 blocks of taps 3-5 (taps 6-8 are the 6 younger ones)
         __builtin_amdgcn_s_barrier();
@@ -1412,18 +1371,6 @@ SRK_DEV void conv_ws_body(const srk_conv_args& a, int tilesX, int tilesY, int ct
     SRK_STAMP(2 * p + 1);
     if constexpr (FREE) grp_barrier(my_ctr, 4 * ++gen, lane);
     else __builtin_amdgcn_s_barrier();
-  }
-  if constexpr (CHAIN && FREE) {
-    // free-running groups: the one that does NOT own the layer's last tile waits until the other one has left its last MFMA phase (its
-    // arrival counter: one barrier per phase, group 1 one more before its first), then fetches the next layer's weight slab
-    if (next_wpk && grp == (nt & 1)) {
-      const int o = 1 - grp;
-      const int nj_o = (nt - o + 1) >> 1;
-      const unsigned target = 4u * (unsigned)(o == 0 ? 2 * nj_o - 1 : 2 * nj_o);
-      const unsigned other = lds_addr_of(sync_ctr + o);
-      while (grp_peek(other) < target) __builtin_amdgcn_s_sleep(1);
-      fetch_next_weights();
-    }
   }
 #if SRK_WS_STAMPS
   if (wg_slot) wg_slot[1] = __builtin_amdgcn_s_memrealtime();
@@ -1459,13 +1406,14 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const srk_conv_args a, 
 // memory model: an image's bytes are written and read by ONE CU, whose vector L1 is coherent with its own stores.  (No `buffer_inv sc1`:
 // at agent scope it also drops the XCD's L2 lines, 33 times per image: 46.9 instead of 41.2 us per convolution.)  The table lives in
 // device memory; a layer's arguments are scalar loads.  A layer with KH = 0 is `out = x + res` on the image (the long skip's gradient).
+// (Measured and removed: the wave group that is idle during a layer's last phase fetching the NEXT layer's weight slab -- 42.5 against 42.4 us per
+// convolution, 63 more spilled SGPRs: tools/ubench/trunk_weight_prefetch.patch, profiles/r6_experiments.txt 3.)
 template <int DT>
 __global__ __launch_bounds__(512, 2) void conv_trunk_kernel(const srk_conv_args* __restrict__ tab, int nlayers, int nimages, int tilesX,
                                                              int tilesY, unsigned x_bytes) {
   const int tpi = tilesX * tilesY;
 #pragma unroll 1
   for (int n = (int)blockIdx.x; n < nimages; n += (int)gridDim.x) {
-    bool w_ready = false;
 #pragma unroll 1
     for (int l = 0; l < nlayers; ++l) {
       const srk_conv_args a = tab[l];
@@ -1474,8 +1422,6 @@ __global__ __launch_bounds__(512, 2) void conv_trunk_kernel(const srk_conv_args*
       int tid = (int)threadIdx.x;
       asm volatile("" : "+v"(tid));
       const int xs_col = a.x_pitch, xs_row = a.W * a.x_pitch, xs_img = a.H * a.W * a.x_pitch;
-      // the next layer's weights are fetched while this layer stores its last tile (conv_ws_body, CHAIN)
-      const void* const next_w = (SRK_TRUNK_PREFETCH && l + 1 < nlayers && tab[l + 1].KH != 0 && a.KH != 0) ? tab[l + 1].wpk : nullptr;
       if (a.KH == 0) {
         // pseudo-layer `out = x + res` on this image (the long skip's gradient: the two contributions to the trunk input's gradient,
         // models/edsr.py:46-47 backward): fp32 add of the two 16-bit values, rounded once -- what torch's add does
@@ -1496,12 +1442,11 @@ __global__ __launch_bounds__(512, 2) void conv_trunk_kernel(const srk_conv_args*
           }
           po[i] = uint4{oo[0], oo[1], oo[2], oo[3]};
         }
-      } else if (a.mask_bits) conv_ws_body<DT, 2, 4, true, true, 3, true>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid, w_ready, next_w);
-      else if (a.res) conv_ws_body<DT, 2, 4, true, true, 1, true>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid, w_ready, next_w);
-      else conv_ws_body<DT, 2, 4, true, false, 0, true>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid, w_ready, next_w);
+      } else if (a.mask_bits) conv_ws_body<DT, 2, 4, true, true, 3>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid);
+      else if (a.res) conv_ws_body<DT, 2, 4, true, true, 1>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid);
+      else conv_ws_body<DT, 2, 4, true, false, 0>(a, tilesX, tilesY, 0, n * tpi, tpi, x_bytes, xs_img, xs_row, xs_col, 8, tid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      w_ready = next_w != nullptr;
     }
   }
 }
