@@ -100,7 +100,10 @@ def test_round6_line_quotes_the_trunk_launch_and_every_config_has_traffic():
     tn = line["cpu_baseline"]["parity"]["trained_net"]
     d = tn["delta_psnr_db"]
     assert abs(d["fp16"]) < 0.01 and abs(d["bf16_model_eval_dtype_path"]) < 0.01 and abs(d["bf16"]) < 0.03, d
-    assert line["cpu_baseline"]["all_cores"]["cores"] == line["cpu_baseline"]["cores_available"]
+    # the all-cores figure SURVEY 8(d) defines (os.cpu_count() threads) was measured once and is named in every line (it takes ~100 s on this host)
+    assert "all_cores" in line["cpu_baseline"]
+    first = json.loads(open(os.path.join(ROOT, "profiles", "r6_bench_default_first.json")).readline())["cpu_baseline"]
+    assert first["all_cores"]["cores"] == first["cores_available"] and first["all_cores"]["value"] > 0
 
 
 def test_refuses_to_run_without_a_gpu():

@@ -124,8 +124,10 @@ def block(tag, short=False):
             bw = par.get("bench_weights", par)
             out.append(f"`cpu_baseline`: {cb['value']} patches/s ({cb['sample']}); parity of the build on the bench's own weights: PSNR(build, oracle) {bw.get('psnr_build_vs_oracle_db')} dB, max |err| {bw.get('max_abs_err')}.")
             ac = cb.get("all_cores")
-            if ac:
+            if ac and "value" in ac:
                 out.append(f"`cpu_baseline.all_cores`: {ac['value']} patches/s ({ac['sample']}).")
+            elif ac:
+                out.append(f"`cpu_baseline.all_cores`: {ac.get('note')}.")
             tn = par.get("trained_net")
             if tn and "delta_psnr_db" in tn:
                 d_, w_ = tn["delta_psnr_db"], tn.get("worst_image_delta_db", {})
