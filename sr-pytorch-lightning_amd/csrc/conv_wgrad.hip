@@ -228,8 +228,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const srk_wgrad_args
 // =================================================================================================
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// The 16 x 16-tile form of rounds 1-5 (two buffers, one tile ahead): kept for SMALL problems, where a workgroup walks few tiles and the three-tile fill of the ring
+// below costs more than it returns (same box, patches/s 16-row / 8-row: RCAN batch 16 2,064 / 2,058, EDSR-large batch 16 1,391 / 1,371, EDSR-baseline batch 64 32.4k / 32.2k;
+// batch 256 sustained 48.1k / 49.7k: profiles/r6_experiments.txt 10).  ws_tile_height() picks per launch.
 template <int DT>
-SRK_DEV void wgrad_ws_body(const srk_wgrad_args& a, const int slot, const int cib, const int cob, const int tilesX, const int tilesY,
+SRK_DEV void wgrad_ws_body16(const srk_wgrad_args& a, const int slot, const int cib, const int cob, const int tilesX, const int tilesY,
                            const unsigned x_bytes, const unsigned dy_bytes, const int tq, const int trem, char* const smem) {
   typedef WgCfg<DT, 3> C;
   typedef typename C::Tr Tr;
@@ -423,11 +426,225 @@ SRK_DEV void wgrad_ws_body(const srk_wgrad_args& a, const int slot, const int ci
   }
 }
 
+
+// Round 6: tiles of WS_TH = 8 rows x 16 columns in a ring of FOUR buffers, THREE tiles in flight.  With 16 x 16 tiles the LDS held two (X, dY) pairs: the next
+// tile's 73.5 KB were requested during the first half of a tile and the stream then paused until the next tile began -- on average half a tile's bytes in
+// flight per CU, and the kernel ran at the byte rate that allows (4.7 TB/s chip-wide, profiles/r6_experiments.txt 9; MFMA issue was not the limit: two waves
+// per SIMD changed nothing).  Half-height tiles are 40 KB each (10 x 18 halo pixels + 8 x 16 gradient pixels, the halo image padded to whole 256-lane
+// pieces so that EVERY lane issues the same 10 pieces per tile: out-of-image and past-the-end pieces use out-of-range offsets), four of them fill the 160 KB,
+// and the wait in front of a tile is the constant vmcnt(2 x 10): the two younger tiles stay in flight.  Same MFMAs per pixel; the halo rows cost 10 / 8
+// instead of 18 / 16 of X.  The slabs differ from the 16-row form in summation order only (a tile row is still one K step).
+constexpr int WS_TH = 8;                                 // tile height of the slab-mode 3x3 weight gradient (host: tilesY = ceil(H / WS_TH))
+
 template <int DT>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int ntiles,
+SRK_DEV void wgrad_ws_body8(const srk_wgrad_args& a, const int slot, const int cib, const int cob, const int tilesX, const int tilesY,
+                           const unsigned x_bytes, const unsigned dy_bytes, const int tq, const int trem, char* const smem) {
+  typedef WgCfg<DT, 3> C;
+  typedef typename C::Tr Tr;
+  typedef typename Tr::elem elem;
+  constexpr int CH = C::CH, KS = 3, GT = 256, ESZ = C::ESZ;
+  constexpr int TH = WS_TH, NBUF = 4, AHEAD = NBUF - 1;
+  constexpr int XPIECES = (TH + 2) * C::TIN * 8;       // 16-byte pieces of the halo image: (TH + 2) rows x 18 columns x 8 chunks
+  constexpr int NPK = (XPIECES + GT - 1) / GT;         // 6 halo pieces per lane (the image is padded to NPK * GT pieces)
+  constexpr int NDK = TH * 16 * 8 / GT;                // 4 dY pieces per lane
+  constexpr int PPT = NPK + NDK;                       // vector-memory operations per lane and tile: ALWAYS issued (the counted waits rely on it)
+  constexpr int XS_PAD = NPK * GT * 16, DYS = TH * 16 * 128;
+  constexpr int BUF_BYTES = XS_PAD + DYS;
+  static_assert(NBUF * BUF_BYTES <= 160 * 1024, "the ring must fit the LDS");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = wave >> 1, cbk = wave & 1;
+  const int H = a.H, W = a.W;
+  const int nch_x = a.Cin / CH, nch_d = a.Cout / CH;
+
+  const int t0 = slot * tq + min(slot, trem);
+  const int nt = tq + (slot < trem ? 1 : 0);
+
+  // ---- per-lane DMA constants --------------------------------------------------------------------------
+  const i32x4 xrs = make_rsrc4(a.x, x_bytes), drs = make_rsrc4(a.dy, dy_bytes);
+  const unsigned lds0 = lds_addr_of(smem);
+  int pconst[NPK], pyx[NPK];
+#pragma unroll
+  for (int k = 0; k < NPK; ++k) {
+    const int i = tid + k * GT;
+    const int sl = i & 7, p = i >> 3;
+    const int iy = p / C::TIN, ix = p - iy * C::TIN;
+    const int c = cib * 8 + (sl ^ swz(ix));
+    pconst[k] = (((iy - 1) * W + (ix - 1)) * a.x_pitch + a.x_coff + c * CH) * ESZ;
+    pyx[k] = (i < XPIECES && c < nch_x) ? (((iy - 1) & 0xffff) | ((ix - 1) << 16)) : (int)0x7fff7fff;      // (padding pieces: never inside the image)
+  }
+  // dY piece i = tid + 256k: slot, column and channel chunk do not depend on k, the row advances by 2 per k
+  const int rd = a.dy_ps > 1 ? a.dy_ps : 1;
+  const int d_ix = (tid >> 3) & 15, d_iy0 = tid >> 7;
+  const int d_c = cob * 8 + ((tid & 7) ^ swz(d_ix));
+  const bool d_cok = d_c < nch_d;
+  int dconst, dkstride;
+  {
+    const int Csd = a.Cout / (rd * rd);
+    const int k0 = d_c * CH;
+    const int ij = k0 / Csd, c0 = k0 - ij * Csd;
+    const int si = ij / rd, sj = ij - si * rd;
+    dconst = (((d_iy0 * rd + si) * (W * rd) + d_ix * rd + sj) * a.dy_pitch + a.dy_coff + c0) * ESZ;
+    dkstride = 2 * rd * (W * rd) * a.dy_pitch * ESZ;
+  }
+  // one tile's DMA = 11 halo pieces + 8 dY pieces per lane.  The pieces are issued one or two per K-step from inside
+  // the MFMA loop of the previous tile (an LDS-DMA issue costs 60-100 cycles of the wave's time in front of the loop,
+  // with the matrix pipe idle: one wave per SIMD; between MFMAs most of that hides behind the running MFMA)
+  struct TileAddr { int y0, x0, xbase, dbase; bool colok, live; unsigned Xb; };   // Xb: LDS byte address of the buffer; live: a tile of this workgroup
+  auto tile_addr = [&](int it_, char* Xb) {
+    TileAddr t;
+    t.live = it_ < nt;
+    const int pt = t0 + (t.live ? it_ : 0);
+    const int tX = pt % tilesX;
+    const int q = pt / tilesX;
+    const int tY = q % tilesY, n = q / tilesY;
+    t.y0 = tY * TH; t.x0 = tX * 16;
+    t.xbase = (((n * H + t.y0) * W + t.x0) * a.x_pitch) * ESZ;
+    t.dbase = (((n * H * rd + t.y0 * rd) * (W * rd) + t.x0 * rd) * a.dy_pitch) * ESZ;
+    t.colok = t.live && d_cok && (t.x0 + d_ix < W);
+    t.Xb = lds0 + (unsigned)(Xb - smem);
+    return t;
+  };
+  auto dma_x_piece = [&](const TileAddr& t, int k) {
+    const int gy = t.y0 + (int)(short)(pyx[k] & 0xffff), gx = t.x0 + (pyx[k] >> 16);
+    const bool ok = t.live && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const unsigned voff = ok ? (unsigned)(t.xbase + pconst[k]) : 0x80000000u;
+    dma16_hidden(xrs, voff, __builtin_amdgcn_readfirstlane(t.Xb + ((k * GT + wave * 64) << 4)));
+  };
+  auto dma_d_piece = [&](const TileAddr& t, int k) {
+    const bool ok = t.colok && (t.y0 + d_iy0 + 2 * k < H);
+    const unsigned voff = ok ? (unsigned)(t.dbase + dconst + k * dkstride) : 0x80000000u;
+    dma16_hidden(drs, voff, __builtin_amdgcn_readfirstlane(t.Xb + XS_PAD + ((k * GT + wave * 64) << 4)));
+  };
+  auto dma_tile = [&](int it_, char* Xb) {
+    const TileAddr t = tile_addr(it_, Xb);
+#pragma unroll
+    for (int k = 0; k < NPK; ++k) dma_x_piece(t, k);
+#pragma unroll
+    for (int k = 0; k < NDK; ++k) dma_d_piece(t, k);
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  float bsum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = a.dbp != nullptr && cib == 0;
+  int xoff[KS][2], doff[2];
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) {
+    xoff[kw][0] = tr_lane_off(kw, 0, rb, lane);
+    xoff[kw][1] = tr_lane_off(kw, 1, rb, lane);
+  }
+  doff[0] = tr_lane_off(0, 0, cbk, lane);
+  doff[1] = tr_lane_off(0, 1, cbk, lane);
+
+#pragma unroll
+  for (int k = 0; k < AHEAD; ++k) dma_tile(k, smem + k * BUF_BYTES);      // tiles 0 .. 2 (past-the-end ones as out-of-range pieces)
+#pragma unroll 1
+  for (int it = 0; it < nt; ++it) {
+    char* const Xs = smem + (it & (NBUF - 1)) * BUF_BYTES;
+    char* const Ds = Xs + XS_PAD;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * PPT) : "memory");     // tile `it` landed; the two younger tiles stay in flight
+    __builtin_amdgcn_s_barrier();                         // ... for every wave; the buffer of tile it - 1 is free
+    constexpr bool more = true;                           // (a tile is ALWAYS requested: past the end as out-of-range pieces)
+    const TileAddr nxt = tile_addr(it + AHEAD, smem + ((it + AHEAD) & (NBUF - 1)) * BUF_BYTES);
+
+    if (do_bias) {
+      // bias gradient: lane owns LDS slot (tid&7) of pixels (tid>>3) + 32k; the slot's channel chunk is the same
+      // for all 8 of them (the swizzle depends on the column, and 32 pixels = 2 full rows)
+#pragma unroll
+      for (int k = 0; k < NDK; ++k) {
+        const i32x4 raw = lds_read16(Ds + ((tid + 256 * k) << 4));
+        const uint32_t w4[4] = {(uint32_t)raw.x, (uint32_t)raw.y, (uint32_t)raw.z, (uint32_t)raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bsum8[2 * i] += Tr::to_f32((uint16_t)(w4[i] & 0xffff));
+          bsum8[2 * i + 1] += Tr::to_f32((uint16_t)(w4[i] >> 16));
+        }
+      }
+    }
+    // K loop over the 16 tile rows; the fragments of step y+1 (one new halo row, one dY row) are fetched while
+    // the 9 MFMAs of step y run (4 rotating halo-row slots), sched_barrier keeps the groups apart
+    i32x4 xf[4][KS];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw)
+        xf[rr][kw] = tr_read2(Xs + xoff[kw][0] + rr * (C::PITCH * 128), Xs + xoff[kw][1] + rr * (C::PITCH * 128));
+    i32x4 bf = tr_read2(Ds + doff[0], Ds + doff[1]);
+#pragma unroll
+    for (int y = 0; y < TH; ++y) {
+      i32x4 bfn = bf;
+      if (y + 1 < TH) {
+        const int nr = y + 3;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw)
+          xf[nr & 3][kw] = tr_read2(Xs + xoff[kw][0] + nr * (C::PITCH * 128), Xs + xoff[kw][1] + nr * (C::PITCH * 128));
+        bfn = tr_read2(Ds + doff[0] + (y + 1) * (16 * 128), Ds + doff[1] + (y + 1) * (16 * 128));
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int kh = t / KS, kw = t - kh * KS;
+        acc[t] = Tr::mma(xf[(y + kh) & 3][kw], bf, acc[t]);
+        // next tile's DMA, front-loaded (3 pieces per step in steps 0-5, the rest by step 7): a piece takes 3-5k cycles
+        // to land under load and the whole tile must be there when this loop (5.3k cycles) ends
+        if (t == 1 && y < NPK && more) dma_x_piece(nxt, y);
+        if (t == 5 && y < NDK && more) dma_d_piece(nxt, y);
+      }
+      bf = bfn;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the past-the-end pieces (zero fill) are LDS writes too: done before the buffers are reused
+  // ---- store the workgroup's slab (row-contiguous 128-byte segments per half wave) ------------------------
+  // buffer stores: one 32-bit offset per lane, the (tap, row) part is uniform; rows / columns beyond the real
+  // channel counts get an out-of-range offset (dropped by the hardware) instead of a branch
+  {
+    const int co = cob * 64 + cbk * 32 + (lane & 31);
+    const int hq = lane >> 5;
+    const size_t slab_elems = (size_t)9 * a.Cin * a.Cout;
+    const __amdgpu_buffer_rsrc_t srs =
+        __builtin_amdgcn_make_buffer_rsrc(a.dwp + (size_t)slot * slab_elems, 0, (unsigned)(slab_elems * 4), 0x00020000);
+    const int ci0 = cib * 64 + rb * 32 + 4 * hq;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ci = ci0 + (e & 3) + 8 * (e >> 2);
+        const unsigned voff = (ci < a.Cin && co < a.Cout) ? (unsigned)(((t * a.Cin + ci) * a.Cout + co) * 4) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][e]), srs, voff, 0, 0);
+      }
+    }
+  }
+  if (do_bias) {
+    // fixed-order reduction of the per-lane chunk sums: channel c lives in chunk c>>3, held by the 32 lanes
+    // (hi, q16) with slot (c>>3) ^ swz(q16)
+    float* const bred = reinterpret_cast<float*>(smem);      // [256][8]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bred[tid * 8 + e] = bsum8[e];
+    __syncthreads();
+    if (tid < 64) {
+      const int ch = tid >> 3, e = tid & 7;
+      float t = 0.f;
+      for (int p0 = 0; p0 < 32; ++p0) t += bred[((p0 << 3) + (ch ^ swz(p0 & 15))) * 8 + e];
+      const int c = cob * 64 + tid;
+      if (c < a.Cout) a.dbp[(size_t)slot * a.Cout + c] = t;
+    }
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_ws_kernel(const srk_wgrad_args a, int tilesX, int tilesY, int th,
                                                                 unsigned x_bytes, unsigned dy_bytes, int tq, int trem) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  wgrad_ws_body<DT>(a, blockIdx.x, blockIdx.y, blockIdx.z, tilesX, tilesY, x_bytes, dy_bytes, tq, trem, smem);
+  // th: tile height the host cut the images with (ws_tile_height: 8 = the four-buffer ring, 16 = two buffers); uniform over the launch
+  if (th == WS_TH) wgrad_ws_body8<DT>(a, blockIdx.x, blockIdx.y, blockIdx.z, tilesX, tilesY, x_bytes, dy_bytes, tq, trem, smem);
+  else wgrad_ws_body16<DT>(a, blockIdx.x, blockIdx.y, blockIdx.z, tilesX, tilesY, x_bytes, dy_bytes, tq, trem, smem);
 }
 
 // ---- grouped launch: the weight gradients of MANY convolutions in one dispatch ---------------------------------------------
@@ -443,7 +660,7 @@ struct WgJob {
   unsigned x_bytes, dy_bytes;
   int tq, trem;
   int ncib, ncob;
-  int block0, pad_;
+  int block0, th;           // th: tile height of this launch (all jobs of a launch: ws_tile_height of the largest one)
 };
 
 template <int DT>
@@ -455,7 +672,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_group_kernel(const WgJob
   const int per = j.ncib * j.ncob;
   const int slot = local / per, rem = local - slot * per;
   const int cib = rem / j.ncob, cob = rem - cib * j.ncob;
-  wgrad_ws_body<DT>(j.a, slot, cib, cob, j.tilesX, j.tilesY, j.x_bytes, j.dy_bytes, j.tq, j.trem, smem);
+  if (j.th == WS_TH) wgrad_ws_body8<DT>(j.a, slot, cib, cob, j.tilesX, j.tilesY, j.x_bytes, j.dy_bytes, j.tq, j.trem, smem);
+  else wgrad_ws_body16<DT>(j.a, slot, cib, cob, j.tilesX, j.tilesY, j.x_bytes, j.dy_bytes, j.tq, j.trem, smem);
 }
 
 // =================================================================================================
@@ -735,6 +953,14 @@ static int wgrad1x1_slabs(const srk_wgrad_args& a) {
   return (int)slabs;
 }
 
+// Tile height of a slab-mode 3x3 launch: the 8-row four-buffer ring where a workgroup walks many tiles (>= 1,024 16-row tiles per convolution: batch 256 of
+// 48 x 48), else the 16-row two-buffer form.  SRK_WGRAD_TH=8 / 16 (under SRK_DEBUG=1) forces one (A/B).
+static int ws_tile_height(long long n_images, int H, int W) {
+  static const int forced = [] { const char* e = srk_dbg_getenv("SRK_WGRAD_TH"); return e ? atoi(e) : 0; }();
+  if (forced == 8 || forced == 16) return forced;
+  return n_images * ((H + 15) / 16) * ((W + 15) / 16) >= 1024 ? WS_TH : 16;
+}
+
 static int wgrad_ws_slabs(const srk_wgrad_args& a) {
   if (a.KH == 1 && a.KW == 1) return wgrad1x1_slabs(a);
   if (a.KH > 3) return srk_wgrad_lk_ok(a) ? srk_wgrad_lk_slabs(a) : 0;
@@ -744,7 +970,8 @@ static int wgrad_ws_slabs(const srk_wgrad_args& a) {
   const int rd = a.dy_ps > 1 ? a.dy_ps : 1;
   const long long xb = (long long)a.N * a.H * a.W * a.x_pitch * 2, db = (long long)a.N * a.H * a.W * rd * rd * a.dy_pitch * 2;
   if (xb >= 0x7fff0000LL || db >= 0x7fff0000LL) return 0;
-  const long long ntiles = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+  const int th = ws_tile_height(a.N, a.H, a.W);
+  const long long ntiles = (long long)a.N * ((a.H + th - 1) / th) * ((a.W + 15) / 16);
   const int cib = (a.Cin + 63) / 64, cob = (a.Cout + 63) / 64;
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
   long long slabs = cus / (cib * cob);
@@ -753,22 +980,25 @@ static int wgrad_ws_slabs(const srk_wgrad_args& a) {
   return (int)slabs;
 }
 
+constexpr int WS_LDS_BYTES = 160 * 1024;                 // four (padded halo image, gradient tile) buffers: wgrad_ws_body
+
 template <int DT> int launch_ws(const srk_wgrad_args& a, hipStream_t st, int slabs) {
   typedef WgCfg<DT, 3> C;
-  constexpr int LDS = 2 * (C::XS_BYTES + C::DYS_BYTES);
+  constexpr int LDS = WS_LDS_BYTES;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ws_kernel<DT>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) {
     srk_set_error("srk_conv2d_wgrad(ws): cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
     return (int)attr;
   }
-  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
+  const int th = ws_tile_height(a.N, a.H, a.W);
+  const int tilesX = (a.W + 15) / 16, tilesY = (a.H + th - 1) / th;
   const long long ntiles = (long long)a.N * tilesX * tilesY;
   const int cib = (a.Cin + 63) / 64, cob = (a.Cout + 63) / 64;
   const int rd = a.dy_ps > 1 ? a.dy_ps : 1;
   const unsigned xb = (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2);
   const unsigned db = (unsigned)((long long)a.N * a.H * a.W * rd * rd * a.dy_pitch * 2);
-  hipLaunchKernelGGL((conv_wgrad_ws_kernel<DT>), dim3(slabs, cib, cob), dim3(256), LDS, st, a, tilesX, tilesY, (int)ntiles, xb, db,
+  hipLaunchKernelGGL((conv_wgrad_ws_kernel<DT>), dim3(slabs, cib, cob), dim3(256), LDS, st, a, tilesX, tilesY, th, xb, db,
                      (int)(ntiles / slabs), (int)(ntiles % slabs));
   SRK_LAUNCH_CHECK();
   return 0;
@@ -886,12 +1116,16 @@ extern "C" int srk_wgrad_group_plan(srk_wgrad_args* jobs, int n, float* scratch,
                                     int* nblocks_out, long long* scratch_floats_out) {
   SRK_CHECK_ARG(jobs && n > 0 && nblocks_out && scratch_floats_out, "srk_wgrad_group_plan: null pointer / no jobs");
   static const int cus = [] { int c = srk_device_cus(); return c > 0 ? c : 256; }();
+  // one tile height for the whole launch: the largest job's (jobs of a backward pass share their batch)
+  int th = 16;
+  for (int i = 0; i < n; ++i)
+    if (ws_tile_height(jobs[i].N, jobs[i].H, jobs[i].W) == WS_TH) th = WS_TH;
   long long units = 0, maxnt = 0;
   for (int i = 0; i < n; ++i) {
     const srk_wgrad_args& a = jobs[i];
     SRK_CHECK_ARG(srk_wgrad_group_ok(&a), "srk_wgrad_group_plan: job %d is not a 16-bit 3x3 slab-mode weight gradient", i);
     SRK_CHECK_ARG(a.dtype == jobs[0].dtype, "srk_wgrad_group_plan: job %d has another dtype", i);
-    const long long nt = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+    const long long nt = (long long)a.N * ((a.H + th - 1) / th) * ((a.W + 15) / 16);
     units += nt * ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
     if (nt > maxnt) maxnt = nt;
   }
@@ -901,7 +1135,7 @@ extern "C" int srk_wgrad_group_plan(srk_wgrad_args* jobs, int n, float* scratch,
     long long nb = 0;
     for (int i = 0; i < n; ++i) {
       const srk_wgrad_args& a = jobs[i];
-      const long long nt = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+      const long long nt = (long long)a.N * ((a.H + th - 1) / th) * ((a.W + 15) / 16);
       nb += ((nt + T - 1) / T) * ((a.Cin + 63) / 64) * ((a.Cout + 63) / 64);
     }
     return nb;
@@ -914,18 +1148,18 @@ extern "C" int srk_wgrad_group_plan(srk_wgrad_args* jobs, int n, float* scratch,
     if (t < 1) t = 1;
     if (t > maxnt) t = maxnt;
     const long long nb = blocks_for(t);
-    const double cost = (double)((nb + cus - 1) / cus) * (double)(t + 3);
+    const double cost = (double)((nb + cus - 1) / cus) * (double)(t + (th == WS_TH ? 6 : 3));      // (fill / slab-store overhead: 3 tiles of 16 rows)
     if (cost < best || (cost == best && t > bestT)) { best = cost; bestT = t; }
   };
   consider((units + cus - 1) / cus);
-  for (long long t = 8; t <= maxnt; t = t + 1 + t / 12) consider(t);
+  for (long long t = (th == WS_TH ? 16 : 8); t <= maxnt; t = t + 1 + t / 12) consider(t);
   consider(maxnt);
   if (bestT == 0) bestT = maxnt;
   long long off = 0, nb = 0;
   WgJob* tab = reinterpret_cast<WgJob*>(table_host);
   for (int i = 0; i < n; ++i) {
     srk_wgrad_args& a = jobs[i];
-    const int tilesX = (a.W + 15) / 16, tilesY = (a.H + 15) / 16;
+    const int tilesX = (a.W + 15) / 16, tilesY = (a.H + th - 1) / th;
     const long long nt = (long long)a.N * tilesX * tilesY;
     const int slabs = (int)((nt + bestT - 1) / bestT);
     const int ncib = (a.Cin + 63) / 64, ncob = (a.Cout + 63) / 64;
@@ -946,7 +1180,7 @@ extern "C" int srk_wgrad_group_plan(srk_wgrad_args* jobs, int n, float* scratch,
       j.x_bytes = (unsigned)((long long)a.N * a.H * a.W * a.x_pitch * 2);
       j.dy_bytes = (unsigned)((long long)a.N * a.H * a.W * rd * rd * a.dy_pitch * 2);
       j.tq = (int)(nt / slabs); j.trem = (int)(nt % slabs);
-      j.ncib = ncib; j.ncob = ncob; j.block0 = (int)nb; j.pad_ = 0;
+      j.ncib = ncib; j.ncob = ncob; j.block0 = (int)nb; j.th = th;
     }
     const long long cnt = (long long)slabs * ncib * ncob;
     if (block_job_host)
@@ -963,7 +1197,7 @@ extern "C" int srk_conv2d_wgrad_group(const void* table_dev, const int* block_jo
   SRK_CHECK_ARG(table_dev && block_job_dev && nblocks > 0, "srk_conv2d_wgrad_group: null pointer / no blocks");
   SRK_CHECK_ARG(dtype == SRK_BF16 || dtype == SRK_F16, "srk_conv2d_wgrad_group: 16-bit dtypes only");
   typedef WgCfg<SRK_BF16, 3> C;
-  constexpr int LDS = 2 * (C::XS_BYTES + C::DYS_BYTES);
+  constexpr int LDS = WS_LDS_BYTES;
   static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ws_group_kernel<SRK_BF16>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ws_group_kernel<SRK_F16>),
