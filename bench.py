@@ -128,8 +128,8 @@ def cpu_baseline(model_name, scale, patch, seconds=15.0, max_steps=8, model=None
     out = {"value": round(n * k / dt, 3), "unit": "LR patches/s", "cores": cores, "cores_available": avail, "cpu_model": cpu_model, "kind": "port",
            "sample": f"{k} training steps of batch {n} ({cls} fp32, torch {torch.__version__} CPU, {cores} threads), {dt:.1f} s"}
     # SURVEY.md 8(d) defines the baseline on os.cpu_count() threads; the quoted figure uses min(32, cores) because torch's CPU convs collapse beyond that
-    # on this host: ONE step on all 256 threads takes 107 s at batch 16 (0.15 patches/s) and 96 s at batch 1 (profiles/r6_bench_default_first.json,
-    # r6_bench_default_allcores.json) -- oversubscription, not work.  The all-cores step therefore runs on request only (SRK_BENCH_ALLCORES=1).
+    # on this host: ONE step on all 256 threads takes 107 s at batch 16 (0.15 patches/s) and 96 s at batch 1 (profiles/r6_bench_default_first.json; the
+    # batch-1 figure: profiles/r6_experiments.txt 11) -- oversubscription, not work.  The all-cores step therefore runs on request only (SRK_BENCH_ALLCORES=1).
     out["all_cores"] = {"note": f"not measured in this run (SRK_BENCH_ALLCORES=1 adds one batch-1 step on all {avail} threads: ~96 s on this host); "
                                 "measured once: 0.15 patches/s at batch 16 on 256 threads (profiles/r6_bench_default_first.json)"}
     if avail > cores and os.environ.get("SRK_BENCH_ALLCORES") == "1":
