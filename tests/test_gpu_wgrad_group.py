@@ -4,12 +4,15 @@ launches give (same slab kernel body, different slab partition: sums differ by f
 reference, be bitwise reproducible, and keep autograd's semantics (accumulation into existing .grad, a weight used twice,
 non-leaf weights, hooks)."""
 import ctypes as C
+import os
+import sys
 
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -219,3 +222,68 @@ def test_channel_attention_gradients_are_summed_by_one_deferred_launch(A, monkey
         A.ops.set_defer_wgrad(prev)
     for a, b in zip(ga, [p.grad for p in blocks[0].body[3].parameters()]):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
+
+
+TH_CHILD = r'''
+import json, sys, torch
+sys.path.insert(0, %r)
+import sr_amd as A
+ops = A.ops
+out = {}
+for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+    for (n, h, w, cin, cout) in ((3, 33, 20, 64, 64), (5, 7, 9, 64, 64), (16, 48, 48, 64, 64), (2, 24, 24, 64, 256), (2, 17, 16, 128, 64), (1, 8, 8, 64, 64)):
+        g = torch.Generator().manual_seed(n * 1000 + h)
+        x = (torch.rand(n, h, w, cin, generator=g) - 0.5).to(dt).cuda()
+        dy = (torch.rand(n, h, w, cout, generator=g) - 0.5).to(dt).cuda()
+        ws = [torch.nn.Parameter(torch.zeros(cout, cin, 3, 3, device="cuda")) for _ in range(3)]
+        bs = [torch.nn.Parameter(torch.zeros(cout, device="cuda")) for _ in range(3)]
+        res = []
+        with ops.hold_wgrads():                                   # the grouped launch (three jobs)
+            for wi, bi in zip(ws, bs):
+                res.append(ops.wgrad(x, dy, wparam=wi, bparam=bi, N=n, H=h, W=w, Cin=cin, Cout=cout, k=3, w_shape=(cout, cin, 3, 3)))
+        gw1, gb1 = ops.wgrad_raw(x, dy, N=n, H=h, W=w, Cin=cin, Cout=cout, k=3, w_shape=(cout, cin, 3, 3))      # the single launch
+        torch.cuda.synchronize()
+        ref = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (cout, cin, 3, 3), dy.double().cpu().permute(0, 3, 1, 2), padding=1)
+        bref = dy.double().cpu().sum((0, 1, 2))
+        gw, gb = res[0][0].detach().double().cpu(), res[0][1].detach().double().cpu()
+        out[f"{name}_{n}x{h}x{w}_{cin}_{cout}"] = {
+            "rel": float((gw - ref).norm() / ref.norm()), "brel": float((gb - bref).norm() / bref.norm()),
+            "rel_single": float((gw1.double().cpu() - ref).norm() / ref.norm()), "same_jobs": bool(torch.equal(res[0][0], res[2][0])),
+            "sum": float(gw.sum()), "abs": float(gw.abs().sum())}
+print("RESULT " + json.dumps(out))
+''' % ROOT
+
+
+def _th_run(env_extra):
+    import json as _json
+    import subprocess as _sp
+    env = dict(os.environ, **env_extra)
+    p = _sp.run([sys.executable, "-c", TH_CHILD], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return _json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+def test_both_tile_geometries_of_the_slab_weight_gradient_against_float64():
+    """Round 6: the slab-mode 3x3 weight gradient cuts the images into 8-row tiles (a ring of four buffers, three tiles in flight) where a workgroup walks many
+    tiles, and into 16-row tiles (two buffers) otherwise (csrc/conv_wgrad.hip: ws_tile_height).  Both forms, forced through SRK_WGRAD_TH, on ragged images, one-tile
+    images, 128 input / 256 output channels, grouped and single launch: each within fp32 rounding of the float64 gradient of the rounded operands, and of each other."""
+    r8 = _th_run({"SRK_DEBUG": "1", "SRK_WGRAD_TH": "8"})
+    r16 = _th_run({"SRK_DEBUG": "1", "SRK_WGRAD_TH": "16"})
+    assert set(r8) == set(r16) and len(r8) == 12
+    for k in r8:
+        for r in (r8[k], r16[k]):
+            assert r["rel"] < 5e-5 and r["rel_single"] < 5e-5 and r["brel"] < 5e-5 and r["same_jobs"], (k, r)
+        assert abs(r8[k]["sum"] - r16[k]["sum"]) <= 1e-5 * r16[k]["abs"], k
+
+
+def test_large_batches_take_the_ring_automatically(A):
+    """1,024 16-row tiles per convolution switch the launch to the 8-row ring without any knob: a batch of 1,024 16 x 16 images against float64."""
+    n, h, w, c = 1024, 16, 16, 64
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(n, h, w, c, generator=g) - 0.5).bfloat16().cuda()
+    dy = (torch.rand(n, h, w, c, generator=g) - 0.5).bfloat16().cuda()
+    gw, gb = A.ops.wgrad_raw(x, dy, N=n, H=h, W=w, Cin=c, Cout=c, k=3, w_shape=(c, c, 3, 3))
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu().permute(0, 3, 1, 2), (c, c, 3, 3), dy.double().cpu().permute(0, 3, 1, 2), padding=1)
+    assert float((gw.double().cpu() - ref).norm() / ref.norm()) < 5e-5
+    assert float((gb.double().cpu() - dy.double().cpu().sum((0, 1, 2))).norm() / dy.double().cpu().sum((0, 1, 2)).norm()) < 5e-5
