@@ -276,3 +276,42 @@ def test_trainer_graph_replay_follows_the_eager_loop(model_kw):
     # gradients may part by a few steps' worth; on average the two runs stay together
     for a, b in zip(pg, pe):
         assert float((a - b).abs().max()) <= 9.5e-3 and float((a - b).abs().mean()) <= 3e-4
+
+
+def test_trainer_replays_the_trunk_launch_inside_the_step_graph():
+    """Round 6: at a batch of one image per CU the EDSR body is ONE srk_conv_trunk launch per direction (ops.ResTrunkFn); Trainer.fit captures the step with
+    those launches (their layer tables are written once at capture time: ops.static_tables) and the replays follow the eager loop -- which, with the trunk
+    switched off, is the per-layer path: same losses step for step."""
+    import sr_amd
+    from sr_amd import trainer as T
+    ops = sr_amd.ops
+    n = sr_amd._lib.load().srk_device_cus()
+
+    def batches():
+        for i in range(7):
+            yield T.synthetic_batch(n, 3, 8, 2, 300 + i, "cpu")
+
+    out = []
+    for use_graph, trunk in ((True, True), (False, True), (False, False)):
+        prev = ops._TRUNK_OFF
+        ops._TRUNK_OFF = not trunk
+        used = []
+        real = ops._trunk_launch
+        ops._trunk_launch = lambda layers, d: (used.append(len(layers)), real(layers, d))[1]
+        try:
+            torch.manual_seed(0)
+            m = sr_amd.EDSR(n_feats=64, n_resblocks=2, res_scale=0.1, scale_factor=2, precision="bf16")
+            tr = T.Trainer(device="cuda", use_graph=use_graph)
+            tr.fit(m, batches())
+            torch.cuda.synchronize()
+            out.append((tr.losses, tr.graphed, list(used)))
+        finally:
+            ops._TRUNK_OFF = prev
+            ops._trunk_launch = real
+    (lg, g, ug), (le, _, ue), (lp, _, up) = out
+    assert g is not None and g.graphs is not None and not g.failed, "the step was captured"
+    assert ug and set(ug) == {5, 6} and ue and not up, (ug[:4], ue[:4], up)          # 2 x 2 + 1 layers forward, + the skip's add backward
+    assert len(lg) == len(le) == len(lp) == 7
+    assert le == lp, "trunk launch and per-layer launches: the same bits, so the same losses"
+    np.testing.assert_allclose(lg, le, rtol=2e-3)
+    np.testing.assert_allclose(lg[:3], le[:3], rtol=1e-4)
