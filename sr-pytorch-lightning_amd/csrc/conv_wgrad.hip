@@ -666,9 +666,20 @@ struct WgJob {
 template <int DT>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_ws_group_kernel(const WgJob* __restrict__ jobs, const int* __restrict__ block_job) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int jid = block_job[blockIdx.x];
+  // The (ci block, co block) workgroups of one tile range read the SAME X and dY tiles.  The hardware deals consecutive block ids to the eight XCDs in turn
+  // (each with its own L2), so the logical index is (XCD, slot in the XCD): the ncib x ncob blocks of a range share one L2 (cf. conv_ks.hip).  Any grid size:
+  // XCD x holds ceil((G - x) / 8) blocks.  (SRK_WGRAD_XCD_REMAP=0: A/B builds.)
+#ifndef SRK_WGRAD_XCD_REMAP
+#define SRK_WGRAD_XCD_REMAP 1
+#endif
+  unsigned lb = blockIdx.x;
+  if (SRK_WGRAD_XCD_REMAP) {
+    const unsigned q = gridDim.x >> 3, r = gridDim.x & 7u, x = blockIdx.x & 7u;
+    lb = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
+  }
+  const int jid = block_job[lb];
   const WgJob j = jobs[jid];
-  const int local = (int)blockIdx.x - j.block0;
+  const int local = (int)lb - j.block0;
   const int per = j.ncib * j.ncob;
   const int slot = local / per, rem = local - slot * per;
   const int cib = rem / j.ncob, cob = rem - cib * j.ncob;
